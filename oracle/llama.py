@@ -1,0 +1,139 @@
+"""Oracle: Vicuna / Llama decoder forward with KV cache, torch fp32 CPU.
+
+Test infrastructure only (see oracle/__init__.py).  The arithmetic lives in third-party
+``transformers`` (reference pins 4.41.2, requirements.txt:10; not vendored).  This restates the
+published Llama algorithm as called from revisionllm/model/vtimellm_llama.py:79-90
+(``LlamaForCausalLM.forward(inputs_embeds=...)``), and is pinned by goldens generated through the
+reference's own ``VTimeLLMLlamaForCausalLM`` in the build container (tests/golden/make_goldens.py).
+
+Weights: flat dict with HF state-dict names (``model.layers.{i}.self_attn.q_proj.weight`` ...).
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class LlamaCfg:
+    hidden: int = 4096
+    inter: int = 11008
+    layers: int = 32
+    heads: int = 32
+    vocab: int = 32000
+    eps: float = 1e-5
+    theta: float = 10000.0
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+
+VICUNA_7B = LlamaCfg()
+
+
+def rmsnorm(x, weight, eps):
+    """w * (x * rsqrt(mean(x^2) + eps)), statistics in fp32 (HF LlamaRMSNorm)."""
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    return weight * (xf * torch.rsqrt(var + eps)).to(x.dtype)
+
+
+def rope_cos_sin(position_ids, head_dim, theta):
+    """position_ids [B,S] -> cos, sin [B,S,head_dim]; inv_freq_i = theta^(-2i/head_dim),
+    emb = [pos*inv_freq ; pos*inv_freq] (HF LlamaRotaryEmbedding)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = position_ids[..., None].float() * inv
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """q,k [B,H,S,dh]; cos,sin [B,S,dh]."""
+    c, s = cos[:, None], sin[:, None]
+    return q * c + rotate_half(q) * s, k * c + rotate_half(k) * s
+
+
+class KVCache:
+    """Per-layer list of (k, v) tensors [B,H,S,dh], grown by concatenation."""
+
+    def __init__(self, n_layers):
+        self.k = [None] * n_layers
+        self.v = [None] * n_layers
+
+    def append(self, layer, k, v):
+        if self.k[layer] is None:
+            self.k[layer], self.v[layer] = k, v
+        else:
+            self.k[layer] = torch.cat([self.k[layer], k], dim=2)
+            self.v[layer] = torch.cat([self.v[layer], v], dim=2)
+        return self.k[layer], self.v[layer]
+
+    def seq_len(self):
+        return 0 if self.k[0] is None else self.k[0].shape[2]
+
+
+def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None):
+    """One Llama block: x + Wo(softmax(QK^T/sqrt(dh) + mask) V); then + W_down(silu(W_gate n) * W_up n)."""
+    p = f"model.layers.{i}."
+    B, S, D = h.shape
+    H, dh = cfg.heads, cfg.head_dim
+    n = rmsnorm(h, w[p + "input_layernorm.weight"], cfg.eps)
+    q = F.linear(n, w[p + "self_attn.q_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    k = F.linear(n, w[p + "self_attn.k_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    v = F.linear(n, w[p + "self_attn.v_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
+    q, k = apply_rope(q, k, cos, sin)
+    if cache is not None:
+        k, v = cache.append(i, k, v)
+    s = (q @ k.transpose(2, 3)) * (1.0 / math.sqrt(dh))
+    if attn_bias is not None:
+        s = s + attn_bias
+    pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = (pr @ v).transpose(1, 2).reshape(B, S, D)
+    h = h + F.linear(o, w[p + "self_attn.o_proj.weight"])
+    n = rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.eps)
+    g = F.linear(n, w[p + "mlp.gate_proj.weight"])
+    u = F.linear(n, w[p + "mlp.up_proj.weight"])
+    return h + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+
+
+def _bias_from_mask(attention_mask, q_len, past_len, dtype):
+    """Additive causal + padding bias [B,1,q_len,past_len+q_len] (HF causal-mask semantics):
+    query row r (absolute index past_len+r) sees key c iff c <= past_len+r and attention_mask[b,c]."""
+    B, total = attention_mask.shape
+    assert total == past_len + q_len
+    rows = torch.arange(past_len, past_len + q_len)[:, None]
+    cols = torch.arange(total)[None, :]
+    allowed = (cols <= rows)[None, None] & attention_mask.bool()[:, None, None, :]
+    bias = torch.zeros(B, 1, q_len, total, dtype=dtype)
+    return bias.masked_fill(~allowed, torch.finfo(dtype).min)
+
+
+def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=None, cache: KVCache = None,
+            last_only=False, n_layers=None):
+    """``LlamaForCausalLM.forward(inputs_embeds=...)`` -> logits [B,S,V] (or [B,1,V] if last_only).
+
+    attention_mask [B, past+S] (1 = real token); position_ids [B,S]; cache is updated in place.
+    ``n_layers`` limits the depth (bench cpu_baseline sampling only).
+    """
+    B, S, _ = inputs_embeds.shape
+    past = cache.seq_len() if cache is not None else 0
+    if attention_mask is None:
+        attention_mask = torch.ones(B, past + S, dtype=torch.bool)
+    if position_ids is None:
+        position_ids = torch.arange(past, past + S)[None].expand(B, S)
+    cos, sin = rope_cos_sin(position_ids, cfg.head_dim, cfg.theta)
+    bias = _bias_from_mask(attention_mask, S, past, inputs_embeds.dtype)
+    h = inputs_embeds
+    for i in range(cfg.layers if n_layers is None else n_layers):
+        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache)
+    if last_only:
+        h = h[:, -1:]
+    h = rmsnorm(h, w["model.norm.weight"], cfg.eps)
+    return F.linear(h, w["lm_head.weight"])

@@ -1,0 +1,152 @@
+"""Synthetic (random-init) model specs and inputs of the reference's shapes.
+
+Used by ``bench.py``, ``__graft_entry__.smoke()`` and the tests: there is no network for checkpoints
+or datasets.  Tensor names follow the reference's state dict (HF Llama names for the LLM,
+``revisionllm/model/adapter/transformer.py:60-92`` names for the adapter) so the same spec can fill
+the reference model when goldens are generated, the CPU oracle, and the HIP engine (on device, via
+``rv_init_hash``).  Each spec entry is (name, shape, a, base): values are uniform(base-a, base+a).
+"""
+import math
+import re
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+from . import hashinit
+
+SQRT3 = math.sqrt(3.0)
+
+
+@dataclass(frozen=True)
+class LlamaShape:
+    hidden: int = 4096
+    inter: int = 11008
+    layers: int = 32
+    heads: int = 32
+    vocab: int = 32000
+    eps: float = 1e-5
+    theta: float = 10000.0
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+
+VICUNA_7B = LlamaShape()
+#: small Llama with the 7B head geometry (dH = 128) for full-generate parity tests
+TINY = LlamaShape(hidden=512, inter=1408, layers=3, heads=4, vocab=512)
+
+
+def llama_spec(s: LlamaShape, std: float = 0.02) -> List[Tuple[str, tuple, float, float]]:
+    a = std * SQRT3
+    spec = [("model.embed_tokens.weight", (s.vocab, s.hidden), a, 0.0)]
+    for i in range(s.layers):
+        p = f"model.layers.{i}."
+        spec += [
+            (p + "self_attn.q_proj.weight", (s.hidden, s.hidden), a, 0.0),
+            (p + "self_attn.k_proj.weight", (s.hidden, s.hidden), a, 0.0),
+            (p + "self_attn.v_proj.weight", (s.hidden, s.hidden), a, 0.0),
+            (p + "self_attn.o_proj.weight", (s.hidden, s.hidden), a, 0.0),
+            (p + "mlp.gate_proj.weight", (s.inter, s.hidden), a, 0.0),
+            (p + "mlp.up_proj.weight", (s.inter, s.hidden), a, 0.0),
+            (p + "mlp.down_proj.weight", (s.hidden, s.inter), a, 0.0),
+            (p + "input_layernorm.weight", (s.hidden,), 0.1, 1.0),
+            (p + "post_attention_layernorm.weight", (s.hidden,), 0.1, 1.0),
+        ]
+    spec += [("model.norm.weight", (s.hidden,), 0.1, 1.0), ("lm_head.weight", (s.vocab, s.hidden), a, 0.0)]
+    return spec
+
+
+def _xavier(fan_out, fan_in):
+    return math.sqrt(6.0 / (fan_in + fan_out))
+
+
+def clip_encoder_spec(d=768, ff=2048, hidden=4096, n_layers=2, text=True):
+    """State dict of ``ClipEncoder`` (non-cross_attn).  Matrices are xavier-uniform as in
+    transformer.py:89-92; vectors get small non-trivial values so biases / LayerNorm affine are exercised."""
+    spec = [("global_rep_token", (d,), SQRT3, 0.0), ("global_rep_pos", (d,), SQRT3, 0.0)]
+    stacks = (["t2v_encoder"] if text else []) + ["encoder"]
+    for st in stacks:
+        for l in range(n_layers):
+            p = f"{st}.layers.{l}."
+            spec += [
+                (p + "self_attn.in_proj_weight", (3 * d, d), _xavier(3 * d, d), 0.0),
+                (p + "self_attn.in_proj_bias", (3 * d,), 0.05, 0.0),
+                (p + "self_attn.out_proj.weight", (d, d), _xavier(d, d), 0.0),
+                (p + "self_attn.out_proj.bias", (d,), 0.05, 0.0),
+                (p + "linear1.weight", (ff, d), _xavier(ff, d), 0.0),
+                (p + "linear1.bias", (ff,), 0.05, 0.0),
+                (p + "linear2.weight", (d, ff), _xavier(d, ff), 0.0),
+                (p + "linear2.bias", (d,), 0.05, 0.0),
+                (p + "norm1.weight", (d,), 0.1, 1.0),
+                (p + "norm1.bias", (d,), 0.05, 0.0),
+                (p + "norm2.weight", (d,), 0.1, 1.0),
+                (p + "norm2.bias", (d,), 0.05, 0.0),
+            ]
+    spec += [("mm_projector.weight", (hidden, d), _xavier(hidden, d), 0.0), ("mm_projector.bias", (hidden,), 0.05, 0.0)]
+    return spec
+
+
+def linear_projector_spec(d=768, hidden=4096):
+    return [("weight", (hidden, d), _xavier(hidden, d), 0.0), ("bias", (hidden,), 0.05, 0.0)]
+
+
+def build_numpy(spec, seed: int, prefix: str = "", bf16: bool = False):
+    """Materialise a spec on the host -> {prefix+name: fp32 ndarray}.  ``bf16=True`` rounds every value
+    to a bf16-representable fp32 (what the device holds when the engine stores bf16)."""
+    return {prefix + n: hashinit.make_tensor(prefix + n, shp, seed, a, base, bf16) for n, shp, a, base in spec}
+
+
+def features(name, shape, seed, bf16=False):
+    """Synthetic CLIP features / query features: uniform with unit variance."""
+    return hashinit.make_tensor(name, shape, seed, SQRT3, 0.0, bf16)
+
+
+class FakeTokenizer:
+    """Deterministic stand-in for the sentencepiece tokenizer (none is on disk): one id per
+    whitespace/punctuation-separated piece, BOS prepended, ids in [3, vocab).  Implements the duck-typed
+    surface ``tokenizer_image_token`` / ``inference`` use: ``__call__(text).input_ids``, ``bos_token_id``,
+    ``batch_decode``.  Ids 3..12 decode to the digits 0..9 and a few ids to the answer words so that
+    decoded strings can exercise the answer regexes."""
+
+    _fixed = {**{str(d): 3 + d for d in range(10)}, "From": 13, "to": 14, "Not": 15, "Present": 16,
+              "In": 17, "video": 18, ".": 19, "and": 20}
+
+    def __init__(self, vocab=32000):
+        self.vocab = vocab
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = 1, 2, 0
+        self._inv = {v: k for k, v in self._fixed.items()}
+
+    def _id(self, piece):
+        if piece in self._fixed:
+            return self._fixed[piece]
+        return 21 + hashinit.fnv1a64(piece) % (self.vocab - 21)
+
+    def __call__(self, text):
+        class _Enc:
+            pass
+        e = _Enc()
+        e.input_ids = [self.bos_token_id] + [self._id(p) for p in re.findall(r"\w+|[^\w\s]", text)]
+        return e
+
+    def decode(self, ids, skip_special_tokens=True):
+        out = []
+        for t in (int(x) for x in ids):
+            if skip_special_tokens and t in (0, 1, 2):
+                continue
+            out.append(self._inv.get(t, f"<{t}>"))
+        s = " ".join(out)
+        return re.sub(r" \.", ".", s)
+
+    def batch_decode(self, seqs, skip_special_tokens=True):
+        return [self.decode(s, skip_special_tokens) for s in seqs]
+
+
+def synthetic_prompt_ids(P=72, sentinel_at=40, seed=0, vocab=32000):
+    """fixed synthetic int64[P] in [3, vocab) with BOS=1 at 0 and one -200 at ``sentinel_at``."""
+    h = hashinit.hash_uniform(P, hashinit.tensor_key("prompt_ids", seed), 1.0)
+    ids = (3 + ((h.astype(np.float64) + 1.0) * 0.5 * (vocab - 3)).astype(np.int64)).clip(3, vocab - 1)
+    ids[0] = 1
+    ids[sentinel_at] = -200
+    return ids

@@ -1,0 +1,323 @@
+"""Generate the golden vectors by running the REFERENCE ITSELF (imported from /root/reference).
+
+Run in the build container only:  ``python tests/golden/make_goldens.py``.  Inputs and weights are
+rebuilt on both sides from ``revisionllm_amd.utils.synth`` (hash-seeded), so the fixtures hold only
+the reference's OUTPUTS (plus the small integer/string cases of the driver helpers).  Versions of the
+third-party numerics actually executed are recorded in ``meta.json``.
+"""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from revisionllm_amd.utils import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+SEED = 1234
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrays.items()}, os.path.getsize(path) // 1024, "KiB")
+
+
+def fill(module, weights, prefix=""):
+    sd = module.state_dict()
+    for k in sd:
+        if prefix + k in weights:
+            sd[k].copy_(T(weights[prefix + k]))
+        elif "rotary" in k or "inv_freq" in k:
+            continue
+        else:
+            raise KeyError(k)
+
+
+def g1_pos(M):
+    pe = M["transformer"].PositionEmbeddingSine(768, temperature=10000, normalize=True)
+    out = {}
+    for t in (1, 16, 256, 1024):
+        p = pe(torch.zeros(1, t, 768), torch.ones(1, t))[0]
+        out[f"T{t}"] = p if t <= 16 else p[:: (t // 16)]
+        out[f"T{t}_sum"] = p.double().sum()
+    save("g1_sine_pos", **out)
+
+
+def make_clip_encoder(M, text=True, feature="cls", hierarchy=True, seed=SEED):
+    enc = M["transformer"].ClipEncoder(hidden_size=4096, clip_adapter_text=text, cross_attn=False,
+                                       hierarchy=hierarchy, clip_adapter_feature=feature).eval()
+    w = synth.build_numpy(synth.clip_encoder_spec(text=text), seed, prefix="mm_projector.")
+    fill(enc, w, "mm_projector.")
+    return enc
+
+
+def g2_layers(M):
+    enc = make_clip_encoder(M)
+    B, Tn, Lq = 2, 16, 5
+    src = T(synth.features("g2.src", (B, Tn, 768), SEED))
+    txt = T(synth.features("g2.txt", (B, Lq, 768), SEED))
+    mask_text = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]], dtype=torch.float32)
+    pos = enc.position_embedding(src, torch.ones(B, Tn))
+    # self layer on [CLS;frames], seq-first as the reference runs it
+    x = torch.cat([enc.global_rep_token.view(1, 1, -1).expand(B, 1, -1), src], 1).permute(1, 0, 2)
+    pm = torch.cat([enc.global_rep_pos.view(1, 1, -1).expand(B, 1, -1), pos], 1).permute(1, 0, 2)
+    y_self, _ = enc.encoder.layers[0](x, src_key_padding_mask=torch.zeros(B, Tn + 1, dtype=torch.bool), pos=pm)
+    # t2v layer
+    src_t2v = torch.cat([x, txt.permute(1, 0, 2)], 0)
+    pos_t2v = torch.cat([pm, torch.zeros(Lq, B, 768)], 0)
+    mask = torch.cat([torch.ones(B, Tn + 1, dtype=torch.bool), mask_text.bool()], 1)
+    y_t2v = enc.t2v_encoder.layers[0](src_t2v, src_key_padding_mask=~mask, pos=pos_t2v, video_length=Tn)
+    save("g2_layers", mask_text=mask_text, self_out=y_self.permute(1, 0, 2), t2v_out=y_t2v.permute(1, 0, 2)[:, 1:Tn + 1])
+
+
+def g3_clip_encoder(M):
+    out = {}
+    for text in (True, False):
+        for feature, hierarchy in (("cls", True), ("temporal", False), ("alternate", False)):
+            for Tn in (16, 256):
+                enc = make_clip_encoder(M, text=text, feature=feature, hierarchy=hierarchy)
+                B, Lq = 2, 7
+                src = T(synth.features(f"g3.src.{Tn}", (B, Tn, 768), SEED))
+                txt = T(synth.features("g3.txt", (B, Lq, 768), SEED))
+                mt = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]], dtype=torch.float32)
+                for it in ((0, 1) if feature == "alternate" else (None,)):
+                    y = enc(src, txt if text else None, mt if text else None, it)
+                    key = f"text{int(text)}_{feature}_T{Tn}" + ("" if it is None else f"_it{it}")
+                    if y.shape[1] > 1:  # temporal output: keep a few rows
+                        y = y[:, :: max(1, y.shape[1] // 8)]
+                    out[key] = y
+    save("g3_clip_encoder", **out)
+
+
+def tiny_model(M, shape, args, seed=SEED):
+    L = M["llama"]
+    cfg = L.VTimeLLMConfig(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
+                           num_attention_heads=shape.heads, num_key_value_heads=shape.heads, vocab_size=shape.vocab,
+                           max_position_embeddings=2048, rms_norm_eps=shape.eps, rope_theta=shape.theta,
+                           pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")
+    model = L.VTimeLLMLlamaForCausalLM(cfg).eval()
+    model.get_model().initialize_vision_modules(args)
+    w = synth.build_numpy(synth.llama_spec(shape), seed)
+    if args.clip_adapter:
+        w.update(synth.build_numpy(synth.clip_encoder_spec(hidden=shape.hidden, text=args.clip_adapter_text), seed,
+                                   prefix="model.mm_projector."))
+    else:
+        w.update(synth.build_numpy(synth.linear_projector_spec(hidden=shape.hidden), seed, prefix="model.mm_projector."))
+    fill(model, w)
+    return model.eval()
+
+
+def ns(**kw):
+    d = dict(clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None,
+             clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True, adapter_input_dim=768)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def g4_splice(M):
+    out = {}
+    shape = synth.LlamaShape(hidden=64, inter=128, layers=1, heads=1, vocab=128)
+    # hierarchy (stage-2): one row, 6 video tokens
+    m = tiny_model(M, shape, ns())
+    ids = T(np.array([[1, 5, 6, -200, 7, 8, 9]], dtype=np.int64))
+    feat = T(synth.features("g4.h", (1, 6, 8, 768), SEED))
+    q = (T(synth.features("g4.q", (1, 4, 768), SEED)), torch.ones(1, 4))
+    r = m.prepare_inputs_labels_for_multimodal(ids, None, torch.ones_like(ids), None, None, feat, q, None, None, None)
+    out["hier_embeds"], out["hier_mask"], out["hier_pos"] = r[4], r[2], torch.zeros(0) if r[1] is None else r[1]
+    # sparse stage-1 (cls, non-hierarchy), batch 3 with one padded row
+    m = tiny_model(M, shape, ns(hierarchy=False))
+    ids = T(np.array([[1, 5, -200, 7, 8, 9], [1, 5, -200, 7, 8, 0], [1, -200, 6, 7, 0, 0]], dtype=np.int64))
+    am = (ids != 0).long()
+    feat = T(synth.features("g4.s", (3, 8, 768), SEED))
+    q = (T(synth.features("g4.q3", (3, 4, 768), SEED)), torch.ones(3, 4))
+    pos_in = torch.arange(6)[None].expand(3, 6)
+    r = m.prepare_inputs_labels_for_multimodal(ids, pos_in, am, None, None, feat, q, None, None, None)
+    out["sparse_embeds"], out["sparse_mask"], out["sparse_pos"] = r[4], r[2], r[1]
+    # dense Linear projector, batch 2
+    m = tiny_model(M, shape, ns(clip_adapter=False, clip_adapter_text=False, hierarchy=False))
+    ids = T(np.array([[1, 5, 6, -200, 7, 8], [1, 5, 6, -200, 7, 8]], dtype=np.int64))
+    feat = T(synth.features("g4.d", (2, 10, 768), SEED))
+    r = m.prepare_inputs_labels_for_multimodal(ids, pos_in[:2], torch.ones_like(ids), None, None, feat, None, None, None, None)
+    out["dense_embeds"], out["dense_mask"], out["dense_pos"] = r[4], r[2], r[1]
+    save("g4_splice", **out)
+
+
+def g5_tiny_generate(M):
+    """Full generate through the reference model + inference(): stage-2 hierarchy and stage-1 dense."""
+    shape = synth.TINY
+    out = {}
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    prompt_ids = M["mm_utils"].tokenizer_image_token(
+        M["conversation"].conv_templates["v1"].copy().system + " USER: <video>\nDuring which video can we see a man? ASSISTANT:",
+        tok, return_tensors="pt")
+    out["prompt_ids"] = prompt_ids
+    for tag, args, feat_shape, B in (("hier", ns(), (1, 12, 32, 768), 1), ("dense", ns(clip_adapter=False, clip_adapter_text=False, hierarchy=False), (2, 24, 768), 2)):
+        m = tiny_model(M, shape, args)
+        feat = T(synth.features(f"g5.{tag}", feat_shape, SEED))
+        q = (T(synth.features("g5.q", (B, 6, 768), SEED)), torch.ones(B, 6)) if args.clip_adapter else None
+        ids = prompt_ids[None].repeat(B, 1)
+        # greedy, fixed 6 new tokens (eos suppressed by setting eos to an unreachable id)
+        m.generation_config.eos_token_id = None
+        g = m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=6, use_cache=True,
+                       output_scores=True, output_logits=True, return_dict_in_generate=True)
+        out[f"{tag}_greedy_seq"] = g["sequences"]
+        out[f"{tag}_greedy_logits"] = torch.stack(g["logits"], 0)       # [G,B,V]
+        # prefill logits for every position
+        o = m(input_ids=ids, images=feat, query_feats=q, attention_mask=torch.ones_like(ids))
+        out[f"{tag}_prefill_logits"] = o.logits
+        # sampling chain as inference.py:45-59 runs it (T=0.05) with top_k=50 / top_p=0.6 from generation config
+        torch.manual_seed(7)
+        m.generation_config.top_k, m.generation_config.top_p = 50, 0.6
+        g = m.generate(ids, images=feat, query_feats=q, do_sample=True, temperature=0.05, num_beams=1, max_new_tokens=4,
+                       use_cache=True, output_scores=True, output_logits=True, return_dict_in_generate=True)
+        out[f"{tag}_sample_seq"] = g["sequences"]
+        out[f"{tag}_sample_logits"] = torch.stack(g["logits"], 0)
+        out[f"{tag}_sample_scores"] = torch.stack(g["scores"], 0)
+        ent = M["entropy"].get_entropy_statistics(torch.cat([a[:, None] for a in g["scores"]], 1), 0, g["scores"][0].shape[1])
+        out[f"{tag}_sample_entropy"] = ent
+    # inference() end to end on the hierarchy model, greedy patched in via generation_config is not possible
+    # (inference hard-codes do_sample=True), so run it seeded and store the decoded text + sequences.
+    m = tiny_model(M, shape, ns())
+    m.generation_config.eos_token_id = None
+    m.generation_config.top_k, m.generation_config.top_p = 50, 1.0
+    feat = T(synth.features("g5.hier", (1, 12, 32, 768), SEED))
+    q = (T(synth.features("g5.q", (1, 6, 768), SEED)), torch.ones(1, 6))
+    torch.manual_seed(11)
+    m.generation_config.max_new_tokens = None
+    import unittest.mock as mock
+    real_generate = m.generate
+
+    def short_generate(*a, **kw):
+        kw["max_new_tokens"] = 5
+        kw["output_hidden_states"] = False
+        return real_generate(*a, **kw)
+
+    with mock.patch.object(m, "generate", short_generate):
+        text, mo = M["inference"].inference(m, feat, q, "<video>\nDuring which video can we see a man?", tok, return_list=True)
+    out["inference_seq"] = mo["sequences"]
+    out["inference_scores"] = torch.stack(mo["scores"], 0)
+    save("g5_tiny_generate", **out)
+    with open(os.path.join(HERE, "g5_text.json"), "w") as f:
+        json.dump({"inference_text": text}, f)
+
+
+def g6_7b_layer(M):
+    """One 7B-shaped decoder layer (D=4096, F=11008, H=32) through the reference model: prefill S=165
+    (65 text + 100 video tokens) + 2 decode steps; vocab shrunk to 1024 to keep lm_head small."""
+    shape = synth.LlamaShape(layers=1, vocab=1024)
+    m = tiny_model(M, shape, ns())
+    P = 66
+    ids = T(synth.synthetic_prompt_ids(P, 40, SEED, vocab=shape.vocab))[None]
+    feat = T(synth.features("g6.feat", (1, 100, 16, 768), SEED))
+    q = (T(synth.features("g6.q", (1, 8, 768), SEED)), torch.ones(1, 8))
+    m.generation_config.eos_token_id = None
+    g = m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=3, use_cache=True,
+                   output_logits=True, return_dict_in_generate=True, output_hidden_states=True)
+    hs = g["hidden_states"]
+    save("g6_7b_layer", seq=g["sequences"], logits=torch.stack(g["logits"], 0),
+         prefill_hidden_in=hs[0][0][0, ::16, ::64], prefill_hidden_out=hs[0][1][0, ::16, ::64],
+         decode1_hidden_out=hs[1][1][0, :, ::64])
+
+
+def g7_scores(M):
+    logits = T(synth.features("g7.logits", (3, 5, 2000), SEED)) * 4.0
+    ent = M["entropy"].get_entropy_statistics(logits, 0, logits.shape[2])
+    ent1 = M["entropy"].get_entropy_statistics(logits[:, :1], 0, logits.shape[2])
+    feat = T(synth.features("g7.feat", (1, 40, 768), SEED))
+    qc = T(synth.features("g7.qcls", (768,), SEED))
+    f = feat / feat.norm(dim=1, keepdim=True)
+    pooled = M["similarity"]._topk_pooling(qc[None], f, 3)
+    cos = torch.einsum("bd,d->b", pooled[:, 0], qc)
+    pf = feat[0, 5:19]
+    pf = pf / pf.norm(dim=0, keepdim=True)
+    pooled1 = M["similarity"]._topk_pooling(qc[None], pf[None], 3)[0]
+    cos1 = torch.einsum("bd,d->b", pooled1, qc)
+    save("g7_scores", entropy=ent, entropy_g1=ent1, pooled=pooled, cos_stage2=cos, cos_stage1=cos1,
+         cos_stage1_mean=torch.einsum("bd,d->b", pf, qc).mean())
+
+
+def g9_driver(M):
+    """Integer / string helpers of the drivers, captured from the reference functions."""
+    e2, neg = M["e2e2"], M["negative"]
+    cases = {}
+    cases["gt_windows"] = [[list(a), b] for a, b in (e2.get_ground_truth_windows(1000, 1010, 6000),
+                                                     e2.get_ground_truth_windows(0.0, 3.2, 95.5),
+                                                     e2.get_ground_truth_windows(5399.1, 5400.0, 5400.0))]
+    rng = np.random.RandomState(0)
+    s2 = []
+    for W, batch in ((100, 100), (33, 33), (143, 100), (290, 100)):
+        starts, idxs, zooms, answers = [], [], [], []
+        import math
+        for z in (4, 2, 1):
+            b = batch // z
+            for i in range(math.ceil(W / b)):
+                start = i * b
+                end = min(start + b, W)
+                if end - start < b:
+                    start = end - b
+                starts.append(start)
+                idxs.append(rng.permutation(b).tolist())
+                zooms.append(z)
+                answers.append(["In video %d." % rng.randint(0, 100), "Not Present", "From %d to %d." % (rng.randint(0, 99), 99),
+                                "video 7"][rng.randint(0, 4)])
+        gw = list(range(W))
+        gt, _ = e2.get_ground_truth_windows(1000, 1400, 6000)
+        frames, hit = e2.iou(answers, gt, 250, batch, starts, [torch.tensor(i) for i in idxs], True, zooms, gw)
+        s2.append(dict(W=W, batch=batch, starts=starts, indexes=idxs, zooms=zooms, answers=answers, gt=gt,
+                       frames={str(k): list(v) for k, v in frames.items()}, hit=hit))
+    cases["stage2"] = s2
+    outs = ["From 12 to 45.", "Not Present", "From 249 to 249.", "From 7 to 7.", "From 3 and 9.", "garbage", "From 100 to 180."]
+    frames, ious, keep = neg.iou(outs, (0.1, 0.2), 250, 2000, [.5, .6, .7, .8, .9, 1.0, 1.1], False)
+    cases["stage1"] = dict(outputs=outs, gt=[0.1, 0.2], frames={str(k): list(v) for k, v in frames.items()}, ious=ious, keep=keep)
+    # tokenizer_image_token on the fake tokenizer
+    tok = synth.FakeTokenizer()
+    conv = M["conversation"].conv_templates["v1"].copy()
+    conv.append_message(conv.roles[0], "<video>\nDuring which video can we see a man?")
+    conv.append_message(conv.roles[1], None)
+    p = conv.get_prompt()
+    cases["prompt"] = p
+    cases["prompt_ids"] = M["mm_utils"].tokenizer_image_token(p, tok)
+    conv = M["conversation"].conv_templates["v1"].copy()
+    conv.append_message(conv.roles[0], "<video>\nDuring which video can we see a man?<memory>")
+    conv.append_message(conv.roles[1], None)
+    cases["prompt_mem_ids"] = M["mm_utils"].tokenizer_image_token(conv.get_prompt(), tok)
+    cases["sep2"] = conv.sep2
+    # window cutting: restated from e2e2.py:262-277 is pure numpy; capture np.linspace results for pins
+    with open(os.path.join(HERE, "g9_driver.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote g9_driver.json")
+
+
+def main():
+    M = ref_import.install()
+    for k, v in M.items():
+        if isinstance(v, Exception):
+            raise RuntimeError(f"reference module {k} failed to import: {v!r}")
+    import transformers
+    only = set(sys.argv[1:])
+    groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
+                  g7=g7_scores, g9=g9_driver)
+    for k, fn in groups.items():
+        if only and k not in only:
+            continue
+        fn(M)
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "transformers": transformers.__version__, "numpy": np.__version__,
+                   "seed": SEED, "reference": "Tanveer81/ReVisionLLM @ /root/reference (2025-11-28)",
+                   "dtype": "float32 cpu", "attn_implementation": "eager"}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
