@@ -1,0 +1,143 @@
+/*
+ * revision_hip.h - C ABI of librevision_hip.so: the MI355X (gfx950) implementation of ReVisionLLM's
+ * recursive temporal-grounding inference path.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python API
+ *   revisionllm/model/builder.py:21-67   load_pretrained_model
+ *   revisionllm/inference.py:28-75       inference  (-> model.generate, inference.py:45-59)
+ *   revisionllm/mm_utils.py:22-75        tokenizer_image_token
+ * which revisionllm_amd/ keeps verbatim.  This header is the build-defined boundary directly beneath
+ * that API: what a maintainer binds (ctypes) in place of the torch modules the
+ * reference calls.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a caller-owned DEVICE pointer unless marked host;
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises;
+ *   - the library allocates nothing on the device: workspaces are caller-provided, sizes come from
+ *     the *_ws_bytes queries; rv_ctx only stores pointers + configuration;
+ *   - return 0 on success, negative rv_status on error; rv_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - dtypes: RV_BF16 activations/weights, RV_F32 residual streams, statistics and logits.
+ */
+#ifndef REVISION_HIP_H
+#define REVISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_ABI_VERSION 1
+
+typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
+typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
+typedef enum { RV_ACT_NONE = 0, RV_ACT_RELU = 1, RV_ACT_SILU_MUL = 2 } rv_act;
+/* ClipEncoder output selection, revisionllm/model/adapter/transformer.py:134-145 */
+typedef enum { RV_FEAT_CLS = 0, RV_FEAT_ALL = 2 } rv_feature;
+
+typedef struct rv_ctx rv_ctx;
+
+typedef struct rv_config {
+    /* LLM (HF LlamaConfig of Vicuna-7B-v1.5: 4096/11008/32/32/32000, eps 1e-5, theta 1e4) */
+    int32_t hidden, inter, layers, heads, vocab;
+    float rms_eps, rope_theta;
+    /* adapter (revisionllm/model/adapter/transformer.py:61-62: 768, 8 heads, 2+2 layers, ff 2048) */
+    int32_t adapter_dim, adapter_heads, adapter_ff, adapter_layers;
+    int32_t adapter_text; /* clip_adapter_text: run the two text->video layers */
+} rv_config;
+
+int rv_abi_version(void);
+int rv_last_error(char* buf, size_t n);
+
+/* ---- context + weights ------------------------------------------------------------------- */
+int rv_ctx_create(const rv_config* cfg, rv_ctx** out);
+void rv_ctx_destroy(rv_ctx* ctx);
+/* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout"):
+ *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows); llm.L{i}.wo [D,D];
+ *   llm.L{i}.wgu [2F,D] bf16, gate/up interleaved in 16-row blocks; llm.L{i}.wdown [D,F];
+ *   llm.L{i}.norm1 / norm2 [D] f32; llm.norm [D] f32; llm.lm_head [V,D] bf16;
+ *   adp.cls_token / adp.cls_pos [768] f32; adp.{t2v,enc}.{l}.{w_in[2304,768],w_out,w1,w2} bf16,
+ *   adp.{..}.{b_in,b_out,b1,b2,ln1_w,ln1_b,ln2_w,ln2_b} f32; adp.proj_w [D,768] bf16; adp.proj_b [D] f32;
+ *   proj.w [D,768] bf16; proj.b [D] f32   (dense nn.Linear projector, vtimellm_arch.py:42)
+ * Replaces model.load_state_dict (builder.py:16,35). */
+int rv_weights_bind(rv_ctx* ctx, const char* name, const void* dptr, int dtype, int64_t numel);
+
+/* ---- synthetic weights: w[i] = base + float(int(splitmix64(i + key) >> 40) - 2^23) * step ---- */
+int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, float base, void* stream);
+
+/* ---- building blocks (exported for the unit parity tests; the engine calls the same kernels) -- */
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]     (nn.Linear semantics)
+ * A, W bf16 row-major (lda/ldw in elements), bias f32 or NULL, residual f32 (ldr) or NULL,
+ * out dtype RV_BF16 or RV_F32 (ldc).  RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and
+ * the output has N/2 columns.  K % 64 == 0.  M <= 16 takes the weight-streaming (decode) kernel. */
+int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+            int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
+/* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
+ * x f32 [rows,d]; any of y_f32 / y_bf16 / y_pos_bf16 may be NULL; y_pos = bf16(y + pos[row % period]). */
+int rv_layernorm(const float* x, const float* w, const float* b, float* y_f32, void* y_bf16, void* y_pos_bf16,
+                 const float* pos, int64_t period, int64_t rows, int32_t d, void* stream);
+/* y = w * x * rsqrt(mean(x^2) + eps) (HF LlamaRMSNorm); x f32 [rows,d] -> y bf16 */
+int rv_rmsnorm(const float* x, const float* w, void* y_bf16, int64_t rows, int32_t d, float eps, void* stream);
+/* pos[t, j], t = 0..T-1 (frame t+1): transformer.py:35-57 with normalize=True, scale 2*pi */
+int rv_sine_pos(float* pos, int32_t T, int32_t d, void* stream);
+/* softmax(Q K^T * scale + mask) V for head dims 96 / 128.
+ * q [B,Lq,H,dh] bf16 (q_row_stride, q_batch_stride in elements; heads contiguous dh chunks);
+ * k [.. Lk ..] bf16 (k_row_stride, k_batch_stride, k_head_stride); vt = V^T [dh, Lk] per (b,h)
+ * (vt_batch_stride, vt_head_stride, vt_d_stride); out [B,Lq,H*dh] bf16 (o_row_stride, o_batch_stride).
+ * causal: query i (absolute position q_pos0 + i) sees keys <= its position.
+ * key_pad: u8 [B/kv_batch_div,Lk] (1 = ignore) or NULL (nn.MultiheadAttention key_padding_mask,
+ * transformer.py:293-294).  Query batch b reads K/V batch b / kv_batch_div (one text for v segments).
+ * V^T rows (vt_d_stride) must be padded with finite values to a multiple of 32 keys. */
+int rv_attention(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k, int64_t k_row_stride,
+                 int64_t k_batch_stride, int64_t k_head_stride, const void* vt, int64_t vt_batch_stride,
+                 int64_t vt_head_stride, int64_t vt_d_stride, void* out, int64_t o_row_stride, int64_t o_batch_stride,
+                 const uint8_t* key_pad, int32_t B, int32_t H, int32_t dh, int32_t Lq, int32_t Lk, int32_t causal,
+                 int32_t q_pos0, int32_t kv_batch_div, float scale, void* stream);
+
+/* ---- adapter ---------------------------------------------------------------------------- */
+/* nn.Linear(768, D) projector on [rows,768] bf16 -> [rows,D] (vtimellm_arch.py:42,125). out f32 or bf16. */
+int rv_project_dense(rv_ctx* ctx, const void* x_bf16, void* y, int out_dtype, int64_t rows, void* stream);
+/* ClipEncoder.forward (transformer.py:94-145) on N independent sequences.
+ * x [N,T,768] bf16; txt [Nq,Lq,768] bf16 and txt_mask u8 [Nq,Lq] (1 = valid) with sequence n using text
+ * row n / (N/Nq) (hierarchy: '(b v) t d', vtimellm_arch.py:115-121); ignored when adapter_text == 0.
+ * out f32: RV_FEAT_CLS [N,D]; RV_FEAT_ALL [N,T+1,D] (row 0 = CLS; the 'temporal' feature is rows 1..T,
+ * sliced by the caller). */
+size_t rv_clip_encoder_ws_bytes(const rv_ctx* ctx, int32_t N, int32_t T, int32_t Nq, int32_t Lq);
+int rv_clip_encoder(rv_ctx* ctx, const void* x, const void* txt, const uint8_t* txt_mask, int32_t N, int32_t T,
+                    int32_t Nq, int32_t Lq, int32_t feature, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- LLM -------------------------------------------------------------------------------- */
+/* Embedding gather + video-row splice (vtimellm_arch.py:149-238). map i32 [rows]: v >= 0 -> token id
+ * (row of llm.embed), v < 0 -> video row -(v+1) of video_rows f32 [*,D].  h f32 [rows,D]. */
+int rv_splice_embed(rv_ctx* ctx, const int32_t* map, const float* video_rows, float* h, int64_t rows, void* stream);
+/* KV cache for B rows, Smax positions: K [L,B,H,Smax,dh] and V^T [L,B,H,dh,Smax], bf16. */
+size_t rv_kv_bytes(const rv_ctx* ctx, int32_t B, int32_t Smax);
+size_t rv_llm_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t S);
+/* 32x Llama block over h f32 [B,S,D] (clobbered), positions pos0..pos0+S-1, causal, appends to the cache;
+ * logits f32 [B,V] of the LAST position only (LlamaForCausalLM.forward via vtimellm_llama.py:79-90).
+ * S > 1: prefill (pos0 = 0); S == 1: one KV-cached decode step at position pos0 (vtimellm_arch.py:88-100). */
+int rv_llm_forward(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ---- token selection + scores ----------------------------------------------------------- */
+/* HF warper chain temperature -> top-k -> top-p, inverse-CDF draw with caller uniforms (or argmax when
+ * do_sample == 0), plus the entropy of the processed and of the raw distribution
+ * (vtimellm_llama.py:312-338; funs_get_feature_X.py:131-132).  logits f32 [B,V].
+ * out_topk_idx i32 / out_topk_val f32 [B,top_k_cap]: kept candidates in descending order (processed
+ * scores), n_keep i32 [B].  top_k <= 64. */
+int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
+              int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
+              int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream);
+/* get_entropy_statistics (funs_get_feature_X.py:120-146): logits f32 [B,G,V] -> [B,4] = max,min,mean,std. */
+int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream);
+/* Stage-2 cosine score (eval_nlq_retrieval_e2e2.py:380-386): feat bf16/f32 [n,T,768]; per segment:
+ * column-normalise over frames, top-k frames by <f,q>, sum, dot q.  out f32 [n]. */
+int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
+                   float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVISION_HIP_H */

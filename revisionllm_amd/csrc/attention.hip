@@ -1,0 +1,134 @@
+// softmax(Q K^T * scale + mask) V with MFMA 16x16x32, head dims 96 (adapter, nn.MultiheadAttention) and
+// 128 (Llama).  One wave = 16 query rows of one (batch, head); keys are walked 32 at a time with an
+// online softmax.  Both products use swapped operands so that every per-query quantity is lane-local:
+//   S^T[key][q] = K . Q^T     lane (q = lane & 15, g = lane >> 4) holds keys {g*4+r} and {16+g*4+r}
+//   O^T[d][q]   = V^T . P^T   the same 8 scores ARE the lane's B fragment (the sum over keys is
+//                             permutation invariant), V^T rows give the A fragment as two 8-byte loads
+// so there is no LDS traffic and no cross-lane movement besides two shuffles for the row max.  V is
+// kept transposed in memory ([dh][keys]: the KV cache is written that way, the adapter transposes once).
+// K / V^T tiles come straight from L2 (a head's K/V is <= 64 KB at the path's sequence lengths).
+#include "kernels.h"
+
+namespace {
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    constexpr int NC = DH / 32, ND = DH / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= a.Lq) return;
+    const int kb_ = b / a.kv_div;
+
+    const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+    bf16x8 qf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qf[c] = *(const bf16x8*)(qp + c * 32);
+
+    const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * 4;
+    const uint8_t* pad = a.key_pad ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
+
+    f32x4 o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qpos = a.q_pos0 + q0 + fr;
+    const int kend = a.causal ? min(a.Lk, a.q_pos0 + q0 + 16) : a.Lk;
+
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = min(k0 + t * 16 + fr, a.Lk - 1);
+            const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + c * 32), qf[c], s[t], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + g * 4 + r;
+                bool dead = key >= a.Lk || (a.causal && key > qpos);
+                if (pad && key < a.Lk) dead = dead || pad[key];
+                const float v = dead ? -INFINITY : s[t][r] * a.scale;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
+        float psum = 0.f;
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[t][r] - m_use);
+                p[t * 4 + r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        union { bf16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const bf16_t* vp = vbase + (int64_t)dt * 16 * a.vt_ds + k0;
+            union { bf16x8 v; u32x2 h2[2]; } vf;
+            vf.h2[0] = *(const u32x2*)(vp);
+            vf.h2[1] = *(const u32x2*)(vp + 16);
+            o[dt] *= alpha;
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q0 + fr >= a.Lq) return;
+    const float inv = 1.0f / l_run;
+    bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+        *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+}
+
+}  // namespace
+
+int k_attention(const AttnArgs& a, hipStream_t st) {
+    RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");
+    RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
+    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
+                 "attention: stride alignment");
+    RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
+    dim3 grid((unsigned)cdiv(a.Lq, 64), (unsigned)a.H, (unsigned)a.B);
+    if (a.dh == 96)
+        hipLaunchKernelGGL(attn_kernel<96>, grid, dim3(256), 0, st, a);
+    else if (a.dh == 128)
+        hipLaunchKernelGGL(attn_kernel<128>, grid, dim3(256), 0, st, a);
+    else {
+        rv_set_error("attention: head dim %d unsupported (96, 128)", a.dh);
+        return RV_ERR_ARG;
+    }
+    RV_CHECK_LAUNCH("attention");
+    return RV_OK;
+}
+
+extern "C" int rv_attention(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k, int64_t k_row_stride,
+                            int64_t k_batch_stride, int64_t k_head_stride, const void* vt, int64_t vt_batch_stride,
+                            int64_t vt_head_stride, int64_t vt_d_stride, void* out, int64_t o_row_stride, int64_t o_batch_stride,
+                            const uint8_t* key_pad, int32_t B, int32_t H, int32_t dh, int32_t Lq, int32_t Lk, int32_t causal,
+                            int32_t q_pos0, int32_t kv_batch_div, float scale, void* stream) {
+    AttnArgs a{q, q_row_stride, q_batch_stride, k, k_row_stride, k_batch_stride, k_head_stride, vt, vt_batch_stride,
+               vt_head_stride, vt_d_stride, out, o_row_stride, o_batch_stride, key_pad, B, H, dh, Lq, Lk, causal, q_pos0,
+               kv_batch_div, scale};
+    return k_attention(a, as_stream(stream));
+}

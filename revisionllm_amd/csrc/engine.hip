@@ -1,0 +1,376 @@
+// Host-side orchestration of the grounding path: context / weight table, the sparse adapter
+// (ClipEncoder), the dense projector, splice, and the Llama forward (prefill and KV-cached decode).
+// Everything here only enqueues kernels on the caller's stream; there is no device allocation,
+// no synchronisation and no global state besides the thread-local error string.
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+struct Tensor {
+    const void* p = nullptr;
+    int dtype = 0;
+    int64_t numel = 0;
+};
+
+struct AdapterLayer {
+    const bf16_t *w_in, *w_out, *w1, *w2;
+    const float *b_in, *b_out, *b1, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+struct LlmLayer {
+    const bf16_t *wqkv, *wo, *wgu, *wdown;
+    const float *norm1, *norm2;
+};
+
+struct rv_ctx {
+    rv_config cfg;
+    std::unordered_map<std::string, Tensor> w;
+    // resolved views (rebuilt lazily after every bind)
+    bool resolved_adapter = false, resolved_llm = false, resolved_proj = false;
+    std::vector<AdapterLayer> t2v, enc;
+    const float *cls_token = nullptr, *cls_pos = nullptr, *adp_proj_b = nullptr, *proj_b = nullptr;
+    const bf16_t *adp_proj_w = nullptr, *proj_w = nullptr;
+    std::vector<LlmLayer> layers;
+    const bf16_t *embed = nullptr, *lm_head = nullptr;
+    const float* final_norm = nullptr;
+};
+
+namespace {
+
+int find(const rv_ctx* c, const std::string& name, int dtype, int64_t numel, const void** out) {
+    auto it = c->w.find(name);
+    if (it == c->w.end()) {
+        rv_set_error("weight '%s' is not bound", name.c_str());
+        return RV_ERR_UNBOUND;
+    }
+    if (it->second.dtype != dtype || it->second.numel != numel) {
+        rv_set_error("weight '%s': expected dtype %d numel %lld, bound dtype %d numel %lld", name.c_str(), dtype,
+                     (long long)numel, it->second.dtype, (long long)it->second.numel);
+        return RV_ERR_ARG;
+    }
+    *out = it->second.p;
+    return RV_OK;
+}
+
+#define FIND(name, dt, n, dst)                                              \
+    do {                                                                    \
+        const void* p_;                                                     \
+        int rc_ = find(c, name, dt, n, &p_);                                \
+        if (rc_) return rc_;                                                \
+        dst = (decltype(dst))p_;                                            \
+    } while (0)
+
+int resolve_adapter(rv_ctx* c) {
+    if (c->resolved_adapter) return RV_OK;
+    const rv_config& g = c->cfg;
+    const int64_t d = g.adapter_dim, ff = g.adapter_ff, D = g.hidden;
+    FIND("adp.cls_token", RV_F32, d, c->cls_token);
+    FIND("adp.cls_pos", RV_F32, d, c->cls_pos);
+    FIND("adp.proj_w", RV_BF16, D * d, c->adp_proj_w);
+    FIND("adp.proj_b", RV_F32, D, c->adp_proj_b);
+    for (int stack = 0; stack < 2; ++stack) {
+        std::vector<AdapterLayer>& v = stack == 0 ? c->t2v : c->enc;
+        v.clear();
+        if (stack == 0 && !g.adapter_text) continue;
+        for (int l = 0; l < g.adapter_layers; ++l) {
+            const std::string p = std::string("adp.") + (stack == 0 ? "t2v." : "enc.") + std::to_string(l) + ".";
+            AdapterLayer L;
+            FIND(p + "w_in", RV_BF16, 3 * d * d, L.w_in);
+            FIND(p + "b_in", RV_F32, 3 * d, L.b_in);
+            FIND(p + "w_out", RV_BF16, d * d, L.w_out);
+            FIND(p + "b_out", RV_F32, d, L.b_out);
+            FIND(p + "w1", RV_BF16, ff * d, L.w1);
+            FIND(p + "b1", RV_F32, ff, L.b1);
+            FIND(p + "w2", RV_BF16, d * ff, L.w2);
+            FIND(p + "b2", RV_F32, d, L.b2);
+            FIND(p + "ln1_w", RV_F32, d, L.ln1_w);
+            FIND(p + "ln1_b", RV_F32, d, L.ln1_b);
+            FIND(p + "ln2_w", RV_F32, d, L.ln2_w);
+            FIND(p + "ln2_b", RV_F32, d, L.ln2_b);
+            v.push_back(L);
+        }
+    }
+    c->resolved_adapter = true;
+    return RV_OK;
+}
+
+int resolve_proj(rv_ctx* c) {
+    if (c->resolved_proj) return RV_OK;
+    FIND("proj.w", RV_BF16, (int64_t)c->cfg.hidden * c->cfg.adapter_dim, c->proj_w);
+    FIND("proj.b", RV_F32, c->cfg.hidden, c->proj_b);
+    c->resolved_proj = true;
+    return RV_OK;
+}
+
+int resolve_llm(rv_ctx* c) {
+    if (c->resolved_llm) return RV_OK;
+    const rv_config& g = c->cfg;
+    const int64_t D = g.hidden, F = g.inter, V = g.vocab;
+    FIND("llm.embed", RV_BF16, V * D, c->embed);
+    FIND("llm.lm_head", RV_BF16, V * D, c->lm_head);
+    FIND("llm.norm", RV_F32, D, c->final_norm);
+    c->layers.clear();
+    for (int l = 0; l < g.layers; ++l) {
+        const std::string p = "llm.L" + std::to_string(l) + ".";
+        LlmLayer L;
+        FIND(p + "wqkv", RV_BF16, 3 * D * D, L.wqkv);
+        FIND(p + "wo", RV_BF16, D * D, L.wo);
+        FIND(p + "wgu", RV_BF16, 2 * F * D, L.wgu);
+        FIND(p + "wdown", RV_BF16, D * F, L.wdown);
+        FIND(p + "norm1", RV_F32, D, L.norm1);
+        FIND(p + "norm2", RV_F32, D, L.norm2);
+        c->layers.push_back(L);
+    }
+    c->resolved_llm = true;
+    return RV_OK;
+}
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+    void* take(size_t bytes) {
+        void* r = base ? base + off : nullptr;
+        off += al(bytes);
+        return r;
+    }
+};
+
+__global__ void invert_mask_kernel(const uint8_t* __restrict__ valid, uint8_t* __restrict__ pad, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pad[i] = valid[i] ? 0 : 1;
+}
+
+struct ClipWs {
+    float *pm, *x32, *y32;
+    bf16_t *x16, *xp16, *qk16, *vv16, *vt16, *a16, *h16, *tk16, *tv16, *tvt16;
+    uint8_t* pad;
+    int Lpad, Lqpad;
+    size_t bytes;
+};
+
+ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, int Lq) {
+    const int64_t d = c->cfg.adapter_dim, ff = c->cfg.adapter_ff, H = c->cfg.adapter_heads;
+    const int64_t R1 = (int64_t)N * (T + 1);
+    ClipWs w;
+    w.Lpad = ((T + 1 + 31) / 32) * 32;
+    w.Lqpad = ((Lq + 31) / 32) * 32;
+    Carver k(ws, cap);
+    w.pm = (float*)k.take((size_t)(T + 1) * d * 4);
+    w.x32 = (float*)k.take((size_t)R1 * d * 4);
+    w.y32 = (float*)k.take((size_t)R1 * d * 4);
+    w.x16 = (bf16_t*)k.take((size_t)R1 * d * 2);
+    w.xp16 = (bf16_t*)k.take((size_t)R1 * d * 2);
+    w.qk16 = (bf16_t*)k.take((size_t)R1 * 2 * d * 2);
+    w.vv16 = (bf16_t*)k.take((size_t)R1 * d * 2);
+    w.vt16 = (bf16_t*)k.take((size_t)N * d * w.Lpad * 2);
+    w.a16 = (bf16_t*)k.take((size_t)R1 * d * 2);
+    w.h16 = (bf16_t*)k.take((size_t)R1 * ff * 2);
+    const int64_t RT = (int64_t)(Nq > 0 ? Nq : 1) * (Lq > 0 ? Lq : 1);
+    w.tk16 = (bf16_t*)k.take((size_t)RT * d * 2);
+    w.tv16 = (bf16_t*)k.take((size_t)RT * d * 2);
+    w.tvt16 = (bf16_t*)k.take((size_t)(Nq > 0 ? Nq : 1) * d * w.Lqpad * 2);
+    w.pad = (uint8_t*)k.take((size_t)RT);
+    (void)H;
+    w.bytes = k.off;
+    return w;
+}
+
+#define RV_TRY(expr)            \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__) return rc__;  \
+    } while (0)
+
+}  // namespace
+
+extern "C" int rv_ctx_create(const rv_config* cfg, rv_ctx** out) {
+    RV_CHECK_ARG(cfg && out, "rv_ctx_create: null argument");
+    RV_CHECK_ARG(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0, "rv_ctx_create: bad hidden/heads");
+    RV_CHECK_ARG(cfg->hidden / cfg->heads == 128, "rv_ctx_create: LLM head dim must be 128 (got %d)", cfg->hidden / cfg->heads);
+    RV_CHECK_ARG(cfg->hidden % 128 == 0 && cfg->inter % 128 == 0, "rv_ctx_create: hidden and inter must be multiples of 128");
+    RV_CHECK_ARG(cfg->adapter_dim == 768 && cfg->adapter_heads == 8, "rv_ctx_create: adapter must be 768-d with 8 heads");
+    RV_CHECK_ARG(cfg->adapter_ff % 128 == 0 && cfg->adapter_layers >= 1, "rv_ctx_create: bad adapter ff/layers");
+    rv_ctx* c = new rv_ctx();
+    c->cfg = *cfg;
+    *out = c;
+    return RV_OK;
+}
+
+extern "C" void rv_ctx_destroy(rv_ctx* ctx) { delete ctx; }
+
+extern "C" int rv_weights_bind(rv_ctx* c, const char* name, const void* dptr, int dtype, int64_t numel) {
+    RV_CHECK_ARG(c && name && dptr && numel > 0, "rv_weights_bind: bad arguments");
+    RV_CHECK_ARG(((uintptr_t)dptr & 15) == 0, "rv_weights_bind: '%s' must be 16-byte aligned", name);
+    c->w[name] = Tensor{dptr, dtype, numel};
+    c->resolved_adapter = c->resolved_llm = c->resolved_proj = false;
+    return RV_OK;
+}
+
+extern "C" int rv_project_dense(rv_ctx* c, const void* x_bf16, void* y, int out_dtype, int64_t rows, void* stream) {
+    RV_CHECK_ARG(c && x_bf16 && y && rows > 0, "rv_project_dense: bad arguments");
+    RV_TRY(resolve_proj(c));
+    const int64_t d = c->cfg.adapter_dim, D = c->cfg.hidden;
+    return rv_gemm_impl(x_bf16, d, c->proj_w, d, c->proj_b, nullptr, 0, y, D, out_dtype, RV_ACT_NONE, rows, D, d, as_stream(stream));
+}
+
+extern "C" size_t rv_clip_encoder_ws_bytes(const rv_ctx* c, int32_t N, int32_t T, int32_t Nq, int32_t Lq) {
+    if (!c || N <= 0 || T <= 0) return 0;
+    return carve_clip(c, nullptr, 0, N, T, Nq, Lq).bytes;
+}
+
+extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const uint8_t* txt_mask, int32_t N, int32_t T,
+                               int32_t Nq, int32_t Lq, int32_t feature, float* out, void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && x && out && ws, "rv_clip_encoder: null argument");
+    RV_CHECK_ARG(N > 0 && T > 0, "rv_clip_encoder: empty input N=%d T=%d", N, T);
+    RV_CHECK_ARG(feature == RV_FEAT_CLS || feature == RV_FEAT_ALL, "rv_clip_encoder: feature must be CLS or ALL");
+    RV_TRY(resolve_adapter(c));
+    const bool text = c->cfg.adapter_text != 0;
+    if (text) {
+        RV_CHECK_ARG(txt && txt_mask && Nq > 0 && Lq > 0, "rv_clip_encoder: text features required (clip_adapter_text)");
+        RV_CHECK_ARG(N % Nq == 0, "rv_clip_encoder: N=%d must be a multiple of Nq=%d", N, Nq);
+    }
+    hipStream_t st = as_stream(stream);
+    const ClipWs w = carve_clip(c, ws, ws_bytes, N, T, text ? Nq : 0, text ? Lq : 0);
+    if (w.bytes > ws_bytes) {
+        rv_set_error("rv_clip_encoder: workspace %zu < required %zu", ws_bytes, w.bytes);
+        return RV_ERR_WORKSPACE;
+    }
+    const int64_t d = c->cfg.adapter_dim, ff = c->cfg.adapter_ff, D = c->cfg.hidden;
+    const int H = c->cfg.adapter_heads, dh = (int)(d / H);
+    const float scale = 1.0f / sqrtf((float)dh);
+    const int64_t R0 = (int64_t)N * T, R1 = (int64_t)N * (T + 1);
+
+    // position table: row 0 = learned CLS position, rows 1..T = sine embedding (transformer.py:109-116)
+    RV_TRY(k_copy_f32(c->cls_pos, w.pm, d, st));
+    RV_TRY(k_sine_pos(w.pm + d, T, (int)d, st));
+
+    if (text) {
+        const int64_t RT = (int64_t)Nq * Lq;
+        hipLaunchKernelGGL(invert_mask_kernel, dim3((unsigned)cdiv(RT, 256)), dim3(256), 0, st, txt_mask, w.pad, (int)RT);
+        RV_CHECK_LAUNCH("invert_mask");
+        float* v32 = w.x32;
+        bf16_t* vp16 = w.xp16;
+        RV_TRY(k_frames_in(x, w.pm + d, v32, vp16, R0, T, (int)d, st));
+        for (size_t l = 0; l < c->t2v.size(); ++l) {
+            const AdapterLayer& L = c->t2v[l];
+            bf16_t* q16 = w.qk16;
+            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, L.b_in, nullptr, 0, q16, d, RV_BF16, RV_ACT_NONE, R0, d, d, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, L.b_in + d, nullptr, 0, w.tk16, d, RV_BF16, RV_ACT_NONE, RT, d, d, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_BF16, RV_ACT_NONE, RT, d, d, st));
+            RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
+            AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
+                       w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
+            RV_TRY(k_attention(a, st));
+            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, st));
+            RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R0, ff, d, st));
+            RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, st));
+            RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, v32, nullptr, vp16, w.pm + d, T, R0, (int)d, st));
+        }
+        // X = [CLS ; frames]; y32 is free, use it as the staging copy of the frames
+        RV_TRY(k_copy_f32(v32, w.y32, R0 * d, st));
+        RV_TRY(k_build_x(nullptr, w.y32, c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
+    } else {
+        RV_TRY(k_build_x(x, nullptr, c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
+    }
+
+    for (size_t l = 0; l < c->enc.size(); ++l) {
+        const AdapterLayer& L = c->enc[l];
+        RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_BF16, RV_ACT_NONE, R1, 2 * d, d, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, st));
+        RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));
+        AttnArgs a{w.qk16, 2 * d, (int64_t)(T + 1) * 2 * d, w.qk16 + d, 2 * d, (int64_t)(T + 1) * 2 * d, dh, w.vt16,
+                   (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, (int64_t)(T + 1) * d, nullptr, N, H, dh, T + 1,
+                   T + 1, 0, 0, 1, scale};
+        RV_TRY(k_attention(a, st));
+        RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, L.b_out, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, d, st));
+        RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, w.x32, w.x16, nullptr, nullptr, 0, R1, (int)d, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R1, ff, d, st));
+        RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, L.b2, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, ff, st));
+        RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, w.x32, w.x16, w.xp16, w.pm, T + 1, R1, (int)d, st));
+    }
+    if (feature == RV_FEAT_CLS)
+        return rv_gemm_impl(w.x16, (int64_t)(T + 1) * d, c->adp_proj_w, d, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D,
+                            d, st);
+    return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, R1, D, d, st);
+}
+
+extern "C" int rv_splice_embed(rv_ctx* c, const int32_t* map, const float* video_rows, float* h, int64_t rows, void* stream) {
+    RV_CHECK_ARG(c && map && h && rows > 0, "rv_splice_embed: bad arguments");
+    RV_TRY(resolve_llm(c));
+    return k_splice_embed(map, c->embed, video_rows, h, rows, c->cfg.hidden, as_stream(stream));
+}
+
+extern "C" size_t rv_kv_bytes(const rv_ctx* c, int32_t B, int32_t Smax) {
+    if (!c || B <= 0 || Smax <= 0) return 0;
+    return (size_t)2 * c->cfg.layers * B * c->cfg.hidden * (size_t)Smax * 2;
+}
+
+namespace {
+struct LlmWs {
+    bf16_t *xn16, *q16, *a16, *act16, *xl16;
+    float* qkv32;
+    size_t bytes;
+};
+LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
+    const int64_t M = (int64_t)B * S, D = c->cfg.hidden, F = c->cfg.inter;
+    Carver k(ws, cap);
+    LlmWs w;
+    w.xn16 = (bf16_t*)k.take((size_t)M * D * 2);
+    w.qkv32 = (float*)k.take((size_t)M * 3 * D * 4);
+    w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
+    w.a16 = (bf16_t*)k.take((size_t)M * D * 2);
+    w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
+    w.xl16 = (bf16_t*)k.take((size_t)B * D * 2);
+    w.bytes = k.off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
+    if (!c || B <= 0 || S <= 0) return 0;
+    return carve_llm(c, nullptr, 0, B, S).bytes;
+}
+
+extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
+                              void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_forward: null argument");
+    RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_forward: empty problem");
+    RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_forward: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
+    RV_TRY(resolve_llm(c));
+    const LlmWs w = carve_llm(c, ws, ws_bytes, B, S);
+    if (w.bytes > ws_bytes) {
+        rv_set_error("rv_llm_forward: workspace %zu < required %zu", ws_bytes, w.bytes);
+        return RV_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const rv_config& g = c->cfg;
+    const int64_t D = g.hidden, F = g.inter, V = g.vocab, M = (int64_t)B * S;
+    const int H = g.heads, dh = (int)(D / H);
+    const int64_t per_layer = (int64_t)B * D * Smax;  // elements of one layer's K (= V^T)
+    bf16_t* kbase = (bf16_t*)kv;
+    bf16_t* vbase = kbase + (int64_t)g.layers * per_layer;
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int l = 0; l < g.layers; ++l) {
+        const LlmLayer& L = c->layers[l];
+        bf16_t* kc = kbase + l * per_layer;
+        bf16_t* vtc = vbase + l * per_layer;
+        RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, st));
+        RV_TRY(k_rope_kv(w.qkv32, w.q16, kc, vtc, M, S, pos0, H, dh, Smax, g.rope_theta, st));
+        AttnArgs a{w.q16, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                   (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
+        RV_TRY(k_attention(a, st));
+        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, st));
+        RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, st));
+        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, st));
+    }
+    // final norm + lm_head on the last position of every row only
+    RV_TRY(k_rmsnorm(h + (int64_t)(S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
+    return rv_gemm_impl(w.xl16, D, c->lm_head, D, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, st);
+}

@@ -1,0 +1,313 @@
+// nn.Linear on gfx950: C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, bf16 operands, fp32 accumulate.
+//
+// Two kernels behind rv_gemm():
+//   gemm_tile   M > 16: 128x128x64 tiles, 4 waves (2x2, 64x64 each, 4x4 MFMA 16x16x32 fragments),
+//               operands staged HBM -> LDS with 16-byte global_load_lds (LDS-DMA, no VGPR round trip),
+//               double-buffered; the LDS image is XOR-swizzled through the per-lane SOURCE address
+//               (LDS-DMA destinations are lane-linear) so ds_read_b128 fragment reads are conflict-free.
+//   gemv_stream M <= 16 (KV-cached decode): weight-streaming; W fragments go HBM -> VGPR directly
+//               (each weight byte is used once, an LDS round trip is pure overhead), 8 waves split K,
+//               cross-wave reduction in LDS.  HBM-bound: algorithmic bytes = N*K*2.
+// Both compute D^T = W . A^T ("swapped" MFMA operands): a lane then owns 4 consecutive output columns of
+// one row, so bias/residual/stores are 8/16-byte vectors and the SiLU(gate)*up epilogue is lane-local
+// (gate/up rows are interleaved in 16-row blocks in the packed weight).
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+// Stage one 128x64 bf16 operand tile: wave w loads rows [32w, 32w+32), 8 rows (8 x 128 B) per instruction.
+// LDS slot (row, c') holds global 16-byte chunk c = c' ^ ((row >> 1) & 7).
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int row0, int row_max, int k0,
+                                           char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max - 1;
+        const bf16_t* g = base + (int64_t)grow * ld + k0 + c * 8;
+        glds16(g, lds + (wave * 32 + i * 8) * (BK * 2));
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
+    return *(const bf16x8*)(lds + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int OUT_BF16, int ACT>
+__global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                 int64_t ldw, const float* __restrict__ bias, const float* res,
+                                                 int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K,
+                                                 int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> tile.  Blocks land on XCD (id % 8); when possible give each XCD whole W column-panels so the
+    // tiles_m blocks sharing a W panel hit the same L2.
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        if ((tiles_n & 7) == 0) {
+            const int xcd = b & 7, idx = b >> 3;
+            tn = (idx / tiles_m) * 8 + xcd;
+            tm = idx % tiles_m;
+        } else {
+            tm = b % tiles_m;
+            tn = b / tiles_m;
+        }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+
+    f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = K / BK;
+    // LDS: buffer b holds the A tile at b*2*TILE_BYTES and the W tile right behind it
+    stage_tile(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    __syncthreads();  // (hipcc drains vmcnt before the barrier while LDS-DMA is in flight)
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        char* const a_cur = smem + cur * (2 * TILE_BYTES);
+        char* const b_cur = a_cur + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* const a_nxt = smem + (cur ^ 1) * (2 * TILE_BYTES);
+            stage_tile(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
+            stage_tile(W, ldw, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = read_frag(b_cur, wc * 64 + i * 16 + fr, ks * 4 + kg);
+                af[i] = read_frag(a_cur, wr * 64 + i * 16 + fr, ks * 4 + kg);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane owns row m = ..+fr, columns n = ..+kg*4 .. +3 of each 16x16 fragment
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + mi * 16 + fr;
+        if (m >= M) continue;
+        if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int n = n0 + wc * 64 + ni * 16;  // packed (interleaved) column of the gate block
+                if (n >= N) continue;
+                const int no = (n >> 1) + kg * 4;      // output column
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_BF16) {
+                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = p;
+                } else {
+                    *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+                if (n >= N) continue;
+                f32x4 v = acc[ni][mi];
+                if (bias) v += *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (OUT_BF16) {
+                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = p;
+                } else {
+                    *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-streaming kernel for M <= 16 rows (decode).  Block = 8 waves = NT 16-row weight tiles; wave w
+// takes k-blocks (128 wide) w, w+8, ...  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and
+// x[r][k] for k = kb*128 + j*32 + kg*8 .. +8, j = 0..3 - the native 16x16x32 operand layout, so no
+// cross-lane movement at all.  Every weight byte is read exactly once.
+template <int NT, int OUT_BF16, int ACT>
+__global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
+                                                   int64_t ldw, const float* __restrict__ bias, const float* res,
+                                                   int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float red[8 * NT * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NT);
+    const int nkb = K >> 7;
+
+    const int xr = fr < M ? fr : M - 1;
+    const bf16_t* xp = X + (int64_t)xr * lda + kg * 8;
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int n = n0 + t * 16 + fr;
+        n = n < N ? n : N - 1;
+        wp[t] = W + (int64_t)n * ldw + kg * 8;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int kb = wave; kb < nkb; kb += 8) {
+        const int k = kb << 7;
+        bf16x8 wf[NT][4], xf[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + k + j * 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + k + j * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], xf[j], acc[t], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
+    }
+    const int b = fr;  // batch row
+    if (b >= M) return;
+    if (ACT == RV_ACT_SILU_MUL) {
+        const int no = blockIdx.x * 16 + kg * 4;
+        if (n0 >= N) return;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
+        if (OUT_BF16) {
+            u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + no) = p;
+        } else {
+            *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 16 + kg * 4;
+            if (n >= N) continue;
+            f32x4 v = s[t];
+            if (bias) v += *(const f32x4*)(bias + n);
+            if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (res) v += *(const f32x4*)(res + (int64_t)b * ldr + n);
+            if (OUT_BF16) {
+                u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + n) = p;
+            } else {
+                *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
+            }
+        }
+    }
+}
+
+template <int OUT_BF16, int ACT>
+void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+                 int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
+    const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
+    hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
+                       C, ldc, M, N, K, tiles_m, tiles_n);
+}
+
+template <int OUT_BF16, int ACT>
+void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+                 int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
+    if constexpr (ACT == RV_ACT_SILU_MUL) {
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K);
+    } else if (N >= 16384) {
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K);
+    } else {
+        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K);
+    }
+}
+
+}  // namespace
+
+int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K,
+                 hipStream_t st) {
+    RV_CHECK_ARG(A && W && C, "rv_gemm: null operand");
+    RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
+                 (long long)K);
+    RV_CHECK_ARG(K % 64 == 0, "rv_gemm: K=%lld must be a multiple of 64", (long long)K);
+    RV_CHECK_ARG(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "rv_gemm: alignment (N%%4, lda%%8, ldw%%8, ldc%%4)");
+    RV_CHECK_ARG(out_dtype == RV_BF16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
+    RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_SILU_MUL, "rv_gemm: bad activation %d", act);
+    RV_CHECK_ARG(act != RV_ACT_SILU_MUL || (N % 32 == 0 && !bias && !residual),
+                 "rv_gemm: SILU_MUL needs N%%32==0 and no bias/residual");
+    RV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "rv_gemm: dims exceed int32");
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* w = (const bf16_t*)W;
+    const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
+#define RV_DISPATCH(OB, AC)                                                                                  \
+    do {                                                                                                     \
+        if (gemv)                                                                                            \
+            launch_gemv<OB, AC>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st);    \
+        else                                                                                                 \
+            launch_tile<OB, AC>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st);    \
+    } while (0)
+    const int ob = out_dtype == RV_BF16;
+    if (ob && act == RV_ACT_NONE) RV_DISPATCH(1, RV_ACT_NONE);
+    else if (ob && act == RV_ACT_RELU) RV_DISPATCH(1, RV_ACT_RELU);
+    else if (ob && act == RV_ACT_SILU_MUL) RV_DISPATCH(1, RV_ACT_SILU_MUL);
+    else if (!ob && act == RV_ACT_NONE) RV_DISPATCH(0, RV_ACT_NONE);
+    else if (!ob && act == RV_ACT_RELU) RV_DISPATCH(0, RV_ACT_RELU);
+    else RV_DISPATCH(0, RV_ACT_SILU_MUL);
+#undef RV_DISPATCH
+    RV_CHECK_LAUNCH("rv_gemm");
+    return RV_OK;
+}
+
+extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                       int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K,
+                       void* stream) {
+    return rv_gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, as_stream(stream));
+}

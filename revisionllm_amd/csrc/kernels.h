@@ -1,0 +1,29 @@
+// Internal (non-exported) launch wrappers shared between the .hip translation units.
+#pragma once
+#include "common.h"
+
+int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, hipStream_t st);
+int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
+                int64_t period, int64_t rows, int d, hipStream_t st);
+int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);
+int k_sine_pos(float* pos, int T, int d, hipStream_t st);
+int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
+int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
+              int64_t N, int T, int d, hipStream_t st);
+int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
+int k_rope_kv(const float* qkv, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh, int Smax,
+              float theta, hipStream_t st);
+int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st);
+
+struct AttnArgs {
+    const void* q; int64_t q_rs, q_bs;
+    const void* k; int64_t k_rs, k_bs, k_hs;
+    const void* vt; int64_t vt_bs, vt_hs, vt_ds;
+    void* out; int64_t o_rs, o_bs;
+    const uint8_t* key_pad;  // [B / kv_div, Lk], 1 = ignore
+    int B, H, dh, Lq, Lk, causal, q_pos0, kv_div;
+    float scale;
+};
+int k_attention(const AttnArgs& a, hipStream_t st);

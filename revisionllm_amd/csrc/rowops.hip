@@ -1,0 +1,303 @@
+// Row-wise / elementwise kernels of the grounding path (all HBM-bound, 16-byte vector accesses):
+// LayerNorm, RMSNorm, sine position table, adapter row assembly, V transposes, RoPE + KV-cache append,
+// embedding gather + video-row splice.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- LayerNorm (nn.LayerNorm: biased variance, eps 1e-5), one wave per row, row held in registers ----
+template <int NV>  // d = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y32,
+                                                        bf16_t* __restrict__ y16, bf16_t* __restrict__ yp16,
+                                                        const float* __restrict__ pos, int64_t period, int64_t rows) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    const float* pr = pos ? pos + (row % period) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 ww = *(const f32x4*)(w + c), bb = *(const f32x4*)(b + c);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
+        if (y32) *(f32x4*)(y32 + row * D + c) = y;
+        if (y16) *(u32x2*)(y16 + row * D + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        if (yp16) {
+            const f32x4 p = *(const f32x4*)(pr + c);
+            *(u32x2*)(yp16 + row * D + c) = u32x2{pack_bf16x2(y[0] + p[0], y[1] + p[1]), pack_bf16x2(y[2] + p[2], y[3] + p[3])};
+        }
+    }
+}
+
+// ---- RMSNorm (HF LlamaRMSNorm), one wave per row, two passes (second pass served by L1/L2) ----
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
+                                                      const float* __restrict__ w, bf16_t* __restrict__ y, int64_t rows,
+                                                      int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_row_stride;
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float r = rsqrtf(wave_sum(s) / (float)d + eps);
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
+        *(u32x2*)(y + row * d + c) =
+            u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
+    }
+}
+
+// ---- sine position table: pos[t][j], frame t+1 of T (transformer.py:35-57) ----
+__global__ void sine_pos_kernel(float* __restrict__ pos, int T, int d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * d) return;
+    const int t = (int)(i / d), j = (int)(i % d);
+    const float x = (float)(t + 1) / ((float)T + 1e-6f) * 6.283185307179586f;
+    const float dim = powf(10000.0f, (float)(2 * (j / 2)) / (float)d);
+    const float a = x / dim;
+    pos[i] = (j & 1) ? cosf(a) : sinf(a);
+}
+
+// ---- adapter row assembly -------------------------------------------------------------------------
+// frames: x bf16 [N*T,768] -> v32 (f32), vp16 = bf16(x + pos[t])           (text->video layer input)
+__global__ void frames_in_kernel(const bf16_t* __restrict__ x, const float* __restrict__ pos, float* __restrict__ v32,
+                                 bf16_t* __restrict__ vp16, int64_t rows, int T, int d) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * d) return;
+    const int64_t row = i / d;
+    const int c = (int)(i % d);
+    const u32x2 raw = *(const u32x2*)(x + i);
+    const float f0 = __uint_as_float(raw[0] << 16), f1 = __uint_as_float(raw[0] & 0xffff0000u);
+    const float f2 = __uint_as_float(raw[1] << 16), f3 = __uint_as_float(raw[1] & 0xffff0000u);
+    *(f32x4*)(v32 + i) = f32x4{f0, f1, f2, f3};
+    const f32x4 p = *(const f32x4*)(pos + (row % T) * d + c);
+    *(u32x2*)(vp16 + i) = u32x2{pack_bf16x2(f0 + p[0], f1 + p[1]), pack_bf16x2(f2 + p[2], f3 + p[3])};
+}
+
+// X = [cls ; frames] per sequence: src is either bf16 features (src16) or f32 frames (src32), [N,T,768];
+// writes x32, x16 = bf16(X), xp16 = bf16(X + pm[row]) with pm [T+1,768] (row 0 = cls_pos).
+__global__ void build_x_kernel(const bf16_t* __restrict__ src16, const float* __restrict__ src32,
+                               const float* __restrict__ cls, const float* __restrict__ pm, float* __restrict__ x32,
+                               bf16_t* __restrict__ x16, bf16_t* __restrict__ xp16, int64_t N, int T, int d) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= N * (T + 1) * d) return;
+    const int64_t row = i / d;
+    const int c = (int)(i % d);
+    const int64_t n = row / (T + 1);
+    const int t = (int)(row % (T + 1));
+    f32x4 v;
+    if (t == 0) {
+        v = *(const f32x4*)(cls + c);
+    } else if (src32) {
+        v = *(const f32x4*)(src32 + (n * T + (t - 1)) * d + c);
+    } else {
+        const u32x2 raw = *(const u32x2*)(src16 + (n * T + (t - 1)) * d + c);
+        v = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
+                  __uint_as_float(raw[1] & 0xffff0000u)};
+    }
+    *(f32x4*)(x32 + i) = v;
+    *(u32x2*)(x16 + i) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    const f32x4 p = *(const f32x4*)(pm + (int64_t)t * d + c);
+    *(u32x2*)(xp16 + i) = u32x2{pack_bf16x2(v[0] + p[0], v[1] + p[1]), pack_bf16x2(v[2] + p[2], v[3] + p[3])};
+}
+
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---- V [Nb, L, H*DH] bf16 (row stride ld) -> V^T [Nb, H, DH, Lpad] bf16, zero padded to Lpad ----
+template <int DH>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, int64_t ld, bf16_t* __restrict__ vt,
+                                                          int L, int Lpad, int H) {
+    __shared__ bf16_t tile[64][DH + 2];
+    const int l0 = blockIdx.x * 64, h = blockIdx.y;
+    const int64_t nb = blockIdx.z;
+    for (int i = threadIdx.x; i < 64 * (DH / 2); i += 256) {
+        const int r = i / (DH / 2), c2 = i % (DH / 2);
+        uint32_t val = 0;
+        if (l0 + r < L) val = *(const uint32_t*)(v + (nb * L + l0 + r) * ld + h * DH + c2 * 2);
+        tile[r][c2 * 2] = (bf16_t)(val & 0xffff);
+        tile[r][c2 * 2 + 1] = (bf16_t)(val >> 16);
+    }
+    __syncthreads();
+    bf16_t* o = vt + ((nb * H + h) * DH) * (int64_t)Lpad;
+    for (int i = threadIdx.x; i < DH * 32; i += 256) {
+        const int d = i / 32, l2 = i % 32;
+        if (l0 + l2 * 2 < Lpad) {
+            const uint32_t p = (uint32_t)tile[l2 * 2][d] | ((uint32_t)tile[l2 * 2 + 1][d] << 16);
+            *(uint32_t*)(o + (int64_t)d * Lpad + l0 + l2 * 2) = p;
+        }
+    }
+}
+
+// ---- RoPE (rotate_half) + KV-cache append.  qkv f32 [M,3D]; row m = b*S + s at position pos0 + s. ----
+// q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated; v -> vtc [B,H,dh,Smax] (transposed).
+__global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ q16,
+                                                      bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc, int S, int pos0,
+                                                      int H, int dh, int Smax, float theta) {
+    const int64_t m = blockIdx.x;
+    const int b = (int)(m / S), s = (int)(m % S);
+    const int pos = pos0 + s;
+    const int D = H * dh, half = dh / 2;
+    const float* row = qkv + m * 3 * (int64_t)D;
+    for (int i = threadIdx.x; i < H * half; i += 256) {
+        const int h = i / half, j = i % half;
+        const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)dh);
+        const float ang = (float)pos * inv;
+        const float c = cosf(ang), sn = sinf(ang);
+        const float q1 = row[h * dh + j], q2 = row[h * dh + j + half];
+        q16[m * D + h * dh + j] = f32_to_bf16(q1 * c - q2 * sn);
+        q16[m * D + h * dh + j + half] = f32_to_bf16(q2 * c + q1 * sn);
+        const float k1 = row[D + h * dh + j], k2 = row[D + h * dh + j + half];
+        bf16_t* kr = kc + (((int64_t)b * H + h) * Smax + pos) * dh;
+        kr[j] = f32_to_bf16(k1 * c - k2 * sn);
+        kr[j + half] = f32_to_bf16(k2 * c + k1 * sn);
+    }
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const int h = i / dh, d = i % dh;
+        vtc[(((int64_t)b * H + h) * dh + d) * Smax + pos] = f32_to_bf16(row[2 * D + i]);
+    }
+}
+
+// ---- embedding gather + video-row splice -> f32 residual stream ----
+__global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __restrict__ map, const bf16_t* __restrict__ embed,
+                                                           const float* __restrict__ video, float* __restrict__ h, int D) {
+    const int64_t r = blockIdx.x;
+    const int src = map[r];
+    float* o = h + r * D;
+    if (src >= 0) {
+        const bf16_t* e = embed + (int64_t)src * D;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+            const u32x2 raw = *(const u32x2*)(e + c);
+            *(f32x4*)(o + c) = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+                                     __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+        }
+    } else {
+        const float* v = video + (int64_t)(-(src + 1)) * D;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) *(f32x4*)(o + c) = *(const f32x4*)(v + c);
+    }
+}
+
+}  // namespace
+
+int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
+                int64_t period, int64_t rows, int d, hipStream_t st) {
+    RV_CHECK_ARG(x && w && b && rows >= 0, "layernorm: bad arguments");
+    RV_CHECK_ARG(!yp16 || (pos && period > 0), "layernorm: y_pos needs pos table and period");
+    if (rows == 0) return RV_OK;
+    const unsigned blocks = (unsigned)cdiv(rows, 4);
+    if (d == 768)
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+    else if (d == 4096)
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+    else if (d == 256)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+    else if (d == 512)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+    else {
+        rv_set_error("layernorm: unsupported width %d (256, 512, 768, 4096)", d);
+        return RV_ERR_ARG;
+    }
+    RV_CHECK_LAUNCH("layernorm");
+    return RV_OK;
+}
+
+int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st) {
+    RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm: bad arguments");
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+    RV_CHECK_LAUNCH("rmsnorm");
+    return RV_OK;
+}
+
+int k_sine_pos(float* pos, int T, int d, hipStream_t st) {
+    RV_CHECK_ARG(pos && T > 0 && d > 0, "sine_pos: bad arguments");
+    hipLaunchKernelGGL(sine_pos_kernel, dim3((unsigned)cdiv((int64_t)T * d, 256)), dim3(256), 0, st, pos, T, d);
+    RV_CHECK_LAUNCH("sine_pos");
+    return RV_OK;
+}
+
+int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st) {
+    hipLaunchKernelGGL(frames_in_kernel, dim3((unsigned)cdiv(rows * d / 4, 256)), dim3(256), 0, st, (const bf16_t*)x16, pos, v32,
+                       (bf16_t*)vp16, rows, T, d);
+    RV_CHECK_LAUNCH("frames_in");
+    return RV_OK;
+}
+
+int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
+              int64_t N, int T, int d, hipStream_t st) {
+    hipLaunchKernelGGL(build_x_kernel, dim3((unsigned)cdiv(N * (T + 1) * d / 4, 256)), dim3(256), 0, st, (const bf16_t*)src16,
+                       src32, cls, pm, x32, (bf16_t*)x16, (bf16_t*)xp16, N, T, d);
+    RV_CHECK_LAUNCH("build_x");
+    return RV_OK;
+}
+
+int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+    RV_CHECK_LAUNCH("copy_f32");
+    return RV_OK;
+}
+
+int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st) {
+    RV_CHECK_ARG(Lpad % 2 == 0 && Lpad >= L, "transpose_v: bad Lpad");
+    dim3 grid((unsigned)cdiv(Lpad, 64), (unsigned)H, (unsigned)Nb);
+    if (dh == 96)
+        hipLaunchKernelGGL(transpose_v_kernel<96>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+    else if (dh == 128)
+        hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+    else {
+        rv_set_error("transpose_v: head dim %d unsupported", dh);
+        return RV_ERR_ARG;
+    }
+    RV_CHECK_LAUNCH("transpose_v");
+    return RV_OK;
+}
+
+int k_rope_kv(const float* qkv, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh, int Smax,
+              float theta, hipStream_t st) {
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (bf16_t*)q16, (bf16_t*)kc, (bf16_t*)vtc, S, pos0, H,
+                       dh, Smax, theta);
+    RV_CHECK_LAUNCH("rope_kv");
+    return RV_OK;
+}
+
+int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st) {
+    hipLaunchKernelGGL(splice_embed_kernel, dim3((unsigned)rows), dim3(256), 0, st, map, (const bf16_t*)embed, video, h, D);
+    RV_CHECK_LAUNCH("splice_embed");
+    return RV_OK;
+}
+
+extern "C" int rv_layernorm(const float* x, const float* w, const float* b, float* y_f32, void* y_bf16, void* y_pos_bf16,
+                            const float* pos, int64_t period, int64_t rows, int32_t d, void* stream) {
+    return k_layernorm(x, w, b, y_f32, y_bf16, y_pos_bf16, pos, period, rows, d, as_stream(stream));
+}
+extern "C" int rv_rmsnorm(const float* x, const float* w, void* y_bf16, int64_t rows, int32_t d, float eps, void* stream) {
+    return k_rmsnorm(x, d, w, y_bf16, rows, d, eps, as_stream(stream));
+}
+extern "C" int rv_sine_pos(float* pos, int32_t T, int32_t d, void* stream) { return k_sine_pos(pos, T, d, as_stream(stream)); }

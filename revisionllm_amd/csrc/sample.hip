@@ -1,0 +1,293 @@
+// Token selection and segment scores, fused on the device so the decode loop needs no [B,V] host round trip:
+//   rv_sample         HF warper chain (temperature -> top-k -> top-p), inverse-CDF draw / argmax, plus the
+//                     entropy of the processed and of the raw next-token distribution
+//   rv_entropy_stats  get_entropy_statistics (funs_get_feature_X.py:120-146) over stacked per-step scores
+//   rv_topk_cosine    column-normalised top-k pooled cosine score (eval_nlq_retrieval_e2e2.py:380-386)
+#include "kernels.h"
+
+namespace {
+
+constexpr int TPB = 1024;   // threads per row
+constexpr int ITEMS = 32;   // V <= 32768
+constexpr int KCAP = 64;
+
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // larger value, then smaller index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax b{__shfl_xor(a.v, o, 64), __shfl_xor(a.i, o, 64)};
+        a = better(a, b);
+    }
+    return a;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {  // sh: 16 floats; all threads get the result
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) t += sh[w];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) t = fmaxf(t, sh[w]);
+    return t;
+}
+
+// entropy of softmax(x) with the reference's formula H = -sum p*log(p + 1e-10); -inf entries give p = 0
+__device__ float block_entropy(const float* x, int V, float* sh) {
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += TPB) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, sh);
+    float z = 0.f;
+    for (int i = threadIdx.x; i < V; i += TPB) z += expf(x[i] - mx);
+    z = block_sum(z, sh);
+    const float iz = 1.0f / z;
+    float hsum = 0.f;
+    for (int i = threadIdx.x; i < V; i += TPB) {
+        const float p = expf(x[i] - mx) * iz;
+        hsum += p * logf(p + 1e-10f);
+    }
+    return -block_sum(hsum, sh);
+}
+
+__global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ logits, int V, const float* __restrict__ uniforms,
+                                                     int do_sample, float temperature, int top_k, float top_p,
+                                                     int32_t* __restrict__ out_tok, float* __restrict__ out_hp,
+                                                     float* __restrict__ out_hr, int32_t* __restrict__ out_idx,
+                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nkeep) {
+    __shared__ float sh[16];
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    __shared__ float topv[KCAP];
+    __shared__ int topi[KCAP];
+    __shared__ int win;
+    __shared__ float e[KCAP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (int64_t)b * V;
+
+    const float h_raw = block_entropy(x, V, sh);
+    if (tid == 0) out_hr[b] = h_raw;
+
+    float v[ITEMS];
+    const float inv_t = do_sample ? 1.0f / temperature : 1.0f;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = tid + j * TPB;
+        v[j] = i < V ? x[i] * inv_t : -INFINITY;
+    }
+    const int K = do_sample ? top_k : 1;
+    for (int r = 0; r < K; ++r) {
+        ArgMax m{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) m = better(m, ArgMax{v[j], tid + j * TPB});
+        m = wave_argmax(m);
+        if (lane == 0) {
+            wv[wave] = m.v;
+            wi[wave] = m.i;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            ArgMax t = tid < TPB / 64 ? ArgMax{wv[tid], wi[tid]} : ArgMax{-INFINITY, 0x7fffffff};
+            t = wave_argmax(t);
+            if (tid == 0) {
+                topv[r] = t.v;
+                topi[r] = t.i;
+                win = t.i;
+            }
+        }
+        __syncthreads();
+        const int w = win;
+        if ((w % TPB) == tid) {
+            const int jj = w / TPB;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (j == jj) v[j] = -INFINITY;
+        }
+    }
+    if (!do_sample) {
+        if (tid == 0) {
+            out_tok[b] = topi[0];
+            out_hp[b] = h_raw;
+            out_nkeep[b] = 0;
+        }
+        return;
+    }
+    if (tid == 0) {
+        // sequential, in the order HF's TopPLogitsWarper accumulates (ascending probability)
+        const float mx = topv[0];
+        float z = 0.f;
+        for (int i = 0; i < K; ++i) {
+            e[i] = expf(topv[i] - mx);
+            z += e[i];
+        }
+        int keep = K;
+        if (top_p < 1.0f) {
+            float cum = 0.f;
+            keep = 1;
+            for (int i = K - 1; i >= 1; --i) {
+                cum += e[i] / z;
+                if (cum > 1.0f - top_p) {
+                    keep = i + 1;
+                    break;
+                }
+            }
+        }
+        float z2 = 0.f;
+        for (int i = 0; i < keep; ++i) z2 += e[i];
+        float hp = 0.f, cum = 0.f;
+        const float u = uniforms ? uniforms[b] : 0.f;
+        int pos = 0;
+        for (int i = 0; i < keep; ++i) {
+            const float p = e[i] / z2;
+            hp += p * logf(p + 1e-10f);
+            cum += p;
+            if (cum <= u) pos = i + 1;
+        }
+        pos = pos < keep - 1 ? pos : keep - 1;
+        out_tok[b] = topi[pos];
+        out_hp[b] = -hp;
+        out_nkeep[b] = keep;
+    }
+    if (tid < KCAP) {
+        out_idx[b * KCAP + tid] = tid < K ? topi[tid] : -1;
+        out_val[b * KCAP + tid] = tid < K ? topv[tid] : -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void entropy_stats_kernel(const float* __restrict__ logits, int G, int V, float* __restrict__ out) {
+    __shared__ float sh[16];
+    extern __shared__ float hs[];  // G entropies
+    const int b = blockIdx.x;
+    for (int g = 0; g < G; ++g) {
+        const float h = block_entropy(logits + ((int64_t)b * G + g) * V, V, sh);
+        if (threadIdx.x == 0) hs[g] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = -INFINITY, mn = INFINITY, s = 0.f;
+        for (int g = 0; g < G; ++g) {
+            mx = fmaxf(mx, hs[g]);
+            mn = fminf(mn, hs[g]);
+            s += hs[g];
+        }
+        const float mean = s / (float)G;
+        float q = 0.f;
+        for (int g = 0; g < G; ++g) q += (hs[g] - mean) * (hs[g] - mean);
+        out[b * 4 + 0] = mx;
+        out[b * 4 + 1] = mn;
+        out[b * 4 + 2] = mean;
+        out[b * 4 + 3] = G > 1 ? sqrtf(q / (float)(G - 1)) : __int_as_float(0x7fc00000);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// one block per segment: column norms over frames, sims[t] = <f_t / norm, q>, sum of the k largest (k <= 0: mean)
+template <typename T>
+__global__ __launch_bounds__(256) void topk_cosine_kernel(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
+                                                          int k, float* __restrict__ out) {
+    extern __shared__ float smem[];
+    float* qn = smem;        // [d]
+    float* sims = smem + d;  // [Tn]
+    const T* f = feat + (int64_t)blockIdx.x * Tn * d;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            const float v = ld<T>(f + (int64_t)t * d + c);
+            s += v * v;
+        }
+        qn[c] = q[c] / sqrtf(s);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < Tn; t += 4) {
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s += ld<T>(f + (int64_t)t * d + c) * qn[c];
+        s = wave_sum(s);
+        if (lane == 0) sims[t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        if (k <= 0) {
+            for (int t = 0; t < Tn; ++t) acc += sims[t];
+            acc /= (float)Tn;
+        } else {
+            for (int r = 0; r < k && r < Tn; ++r) {
+                int bi = 0;
+                float bv = -INFINITY;
+                for (int t = 0; t < Tn; ++t)
+                    if (sims[t] > bv) {
+                        bv = sims[t];
+                        bi = t;
+                    }
+                acc += bv;
+                sims[bi] = -INFINITY;
+            }
+        }
+        out[blockIdx.x] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
+                         int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
+                         int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream) {
+    RV_CHECK_ARG(logits && out_tokens && out_entropy_proc && out_entropy_raw && out_nkeep, "rv_sample: null output");
+    RV_CHECK_ARG(B > 0 && V > 0 && V <= TPB * ITEMS, "rv_sample: V=%d exceeds %d", V, TPB * ITEMS);
+    if (do_sample) {
+        RV_CHECK_ARG(top_k >= 1 && top_k <= KCAP, "rv_sample: top_k=%d must be in [1,%d] when sampling", top_k, KCAP);
+        RV_CHECK_ARG(temperature > 0.f && top_p > 0.f, "rv_sample: temperature and top_p must be positive");
+        RV_CHECK_ARG(out_topk_idx && out_topk_val, "rv_sample: candidate outputs required when sampling");
+    }
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(TPB), 0, as_stream(stream), logits, V, uniforms, do_sample, temperature, top_k,
+                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep);
+    RV_CHECK_LAUNCH("rv_sample");
+    return RV_OK;
+}
+
+extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream) {
+    RV_CHECK_ARG(logits && out && B > 0 && G > 0 && V > 0, "rv_entropy_stats: bad arguments");
+    RV_CHECK_ARG(G <= 8192, "rv_entropy_stats: G=%d too large", G);
+    hipLaunchKernelGGL(entropy_stats_kernel, dim3(B), dim3(TPB), G * sizeof(float), as_stream(stream), logits, G, V, out);
+    RV_CHECK_LAUNCH("rv_entropy_stats");
+    return RV_OK;
+}
+
+extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
+                              float* out, void* stream) {
+    RV_CHECK_ARG(feat && q_cls && out && n > 0 && T > 0 && d > 0, "rv_topk_cosine: bad arguments");
+    RV_CHECK_ARG((size_t)(d + T) * 4 <= 64 * 1024, "rv_topk_cosine: d + T too large for LDS");
+    const size_t sm = (size_t)(d + T) * sizeof(float);
+    if (feat_dtype == RV_BF16)
+        hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(256), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+    else if (feat_dtype == RV_F32)
+        hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(256), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
+    else {
+        rv_set_error("rv_topk_cosine: dtype must be f32 or bf16");
+        return RV_ERR_ARG;
+    }
+    RV_CHECK_LAUNCH("rv_topk_cosine");
+    return RV_OK;
+}

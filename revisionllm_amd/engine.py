@@ -1,0 +1,201 @@
+"""Python owner of an ``rv_ctx``: packs / binds weights, owns workspaces and KV caches (torch device tensors),
+and exposes the high-level entry points of the C ABI.
+
+Weight packing (build-defined layout): q/k/v rows fused into ``wqkv`` [3D,D]; gate/up rows
+interleaved in 16-row blocks into ``wgu`` [2F,D] (so SiLU(gate)*up is a lane-local GEMM epilogue); matrices
+bf16, vectors f32.  LoRA never exists here: the builder merges it before packing (builder.py:53-60).
+"""
+import ctypes as C
+
+import torch
+
+from . import hip, ops
+from .utils import synth
+
+
+def _dev_f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _dev_bf16(t, device):
+    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+class Engine:
+    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, adapter_text=True, device="cuda:0", adapter_dim=768,
+                 adapter_heads=8, adapter_ff=2048, adapter_layers=2):
+        if not torch.cuda.is_available():
+            raise hip.HipLibraryError("no GPU visible: revisionllm_amd runs only on the HIP device path")
+        self.lib = hip.lib()
+        self.shape = shape
+        self.device = torch.device(device)
+        self.adapter_text = bool(adapter_text)
+        self.adapter_dim, self.adapter_ff, self.adapter_layers = adapter_dim, adapter_ff, adapter_layers
+        cfg = hip.RvConfig(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta,
+                           adapter_dim, adapter_heads, adapter_ff, adapter_layers, int(adapter_text))
+        self._ctx = C.c_void_p()
+        hip.check(self.lib.rv_ctx_create(C.byref(cfg), C.byref(self._ctx)), "rv_ctx_create")
+        self._keep = {}      # name -> tensor (keeps device memory alive while bound)
+        self._ws = {}        # workspace cache
+        self.has_llm = self.has_clip = self.has_linear = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                self.lib.rv_ctx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def bind(self, name, t):
+        assert t.is_cuda and t.is_contiguous()
+        self._keep[name] = t
+        hip.check(self.lib.rv_weights_bind(self._ctx, name.encode(), hip.ptr(t), hip.dtype_code(t), t.numel()),
+                  f"rv_weights_bind({name})")
+
+    def weight(self, name):
+        return self._keep[name]
+
+    def load_llm(self, get):
+        """``get(hf_name) -> tensor`` (any device / float dtype), HF Llama names.  Packs layer by layer."""
+        s, dev = self.shape, self.device
+        self.bind("llm.embed", _dev_bf16(get("model.embed_tokens.weight"), dev))
+        self.bind("llm.lm_head", _dev_bf16(get("lm_head.weight"), dev))
+        self.bind("llm.norm", _dev_f32(get("model.norm.weight"), dev))
+        for i in range(s.layers):
+            p = f"model.layers.{i}."
+            q, k, v = (_dev_bf16(get(p + f"self_attn.{n}_proj.weight"), dev) for n in "qkv")
+            self.bind(f"llm.L{i}.wqkv", torch.cat([q, k, v], dim=0).contiguous())
+            del q, k, v
+            self.bind(f"llm.L{i}.wo", _dev_bf16(get(p + "self_attn.o_proj.weight"), dev))
+            g = _dev_bf16(get(p + "mlp.gate_proj.weight"), dev)
+            u = _dev_bf16(get(p + "mlp.up_proj.weight"), dev)
+            self.bind(f"llm.L{i}.wgu", pack_gate_up(g, u))
+            del g, u
+            self.bind(f"llm.L{i}.wdown", _dev_bf16(get(p + "mlp.down_proj.weight"), dev))
+            self.bind(f"llm.L{i}.norm1", _dev_f32(get(p + "input_layernorm.weight"), dev))
+            self.bind(f"llm.L{i}.norm2", _dev_f32(get(p + "post_attention_layernorm.weight"), dev))
+        self.has_llm = True
+
+    def load_clip_adapter(self, get):
+        """``get(name)`` with ClipEncoder state-dict names (transformer.py:60-92), e.g. 'encoder.layers.0.linear1.weight'."""
+        dev = self.device
+        self.bind("adp.cls_token", _dev_f32(get("global_rep_token"), dev))
+        self.bind("adp.cls_pos", _dev_f32(get("global_rep_pos"), dev))
+        self.bind("adp.proj_w", _dev_bf16(get("mm_projector.weight"), dev))
+        self.bind("adp.proj_b", _dev_f32(get("mm_projector.bias"), dev))
+        stacks = ([("t2v_encoder", "t2v")] if self.adapter_text else []) + [("encoder", "enc")]
+        for ref, tag in stacks:
+            for l in range(self.adapter_layers):
+                r, o = f"{ref}.layers.{l}.", f"adp.{tag}.{l}."
+                self.bind(o + "w_in", _dev_bf16(get(r + "self_attn.in_proj_weight"), dev))
+                self.bind(o + "b_in", _dev_f32(get(r + "self_attn.in_proj_bias"), dev))
+                self.bind(o + "w_out", _dev_bf16(get(r + "self_attn.out_proj.weight"), dev))
+                self.bind(o + "b_out", _dev_f32(get(r + "self_attn.out_proj.bias"), dev))
+                self.bind(o + "w1", _dev_bf16(get(r + "linear1.weight"), dev))
+                self.bind(o + "b1", _dev_f32(get(r + "linear1.bias"), dev))
+                self.bind(o + "w2", _dev_bf16(get(r + "linear2.weight"), dev))
+                self.bind(o + "b2", _dev_f32(get(r + "linear2.bias"), dev))
+                for n in ("1", "2"):
+                    self.bind(o + f"ln{n}_w", _dev_f32(get(r + f"norm{n}.weight"), dev))
+                    self.bind(o + f"ln{n}_b", _dev_f32(get(r + f"norm{n}.bias"), dev))
+        self.has_clip = True
+
+    def load_linear_projector(self, get):
+        self.bind("proj.w", _dev_bf16(get("weight"), self.device))
+        self.bind("proj.b", _dev_f32(get("bias"), self.device))
+        self.has_linear = True
+
+    # ---- synthetic weights generated on the device (bench / smoke / tests) -----------------------
+    def _synth_get(self, spec, seed, prefix):
+        table = {n: (shp, a, base) for n, shp, a, base in spec}
+
+        def get(name):
+            shp, a, base = table[name]
+            t = torch.empty(shp, dtype=torch.float32, device=self.device)
+            return ops.init_hash_(t, prefix + name, seed, a, base)
+        return get
+
+    def init_synthetic(self, seed=0, llm=True, clip=True, linear=False, llm_prefix="", clip_prefix="model.mm_projector.",
+                       linear_prefix="model.mm_projector."):
+        """Random-init weights of the reference's shapes, bit-identical to ``synth.build_numpy`` on the host."""
+        if llm:
+            self.load_llm(self._synth_get(synth.llama_spec(self.shape), seed, llm_prefix))
+        if clip:
+            self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text), seed,
+                                                   clip_prefix))
+        if linear:
+            self.load_linear_projector(self._synth_get(synth.linear_projector_spec(hidden=self.shape.hidden), seed, linear_prefix))
+        return self
+
+    # ---- workspaces ------------------------------------------------------------------------------
+    def _workspace(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    # ---- adapter ---------------------------------------------------------------------------------
+    def project_dense(self, x, out_dtype=torch.float32):
+        """nn.Linear(768, D) on [..., 768] bf16 -> [..., D]."""
+        lead = x.shape[:-1]
+        x2 = _dev_bf16(x, self.device).reshape(-1, x.shape[-1])
+        y = torch.empty(x2.shape[0], self.shape.hidden, dtype=out_dtype, device=self.device)
+        hip.check(self.lib.rv_project_dense(self._ctx, hip.ptr(x2), hip.ptr(y), hip.dtype_code(y), x2.shape[0], hip.stream()),
+                  "rv_project_dense")
+        return y.reshape(*lead, self.shape.hidden)
+
+    def clip_encoder(self, x, txt=None, txt_mask=None, feature="cls"):
+        """x [N,T,768]; txt [Nq,Lq,768], txt_mask [Nq,Lq] (1 = valid) -> f32 [N,D] ('cls') or [N,T+1,D] ('all')."""
+        N, T, _ = x.shape
+        x = _dev_bf16(x, self.device)
+        if self.adapter_text:
+            txt = _dev_bf16(txt, self.device)
+            Nq, Lq = txt.shape[0], txt.shape[1]
+            m = (txt_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+        else:
+            txt, m, Nq, Lq = None, None, 0, 0
+        feat = hip.RV_FEAT_CLS if feature == "cls" else hip.RV_FEAT_ALL
+        D = self.shape.hidden
+        out = torch.empty((N, D) if feat == hip.RV_FEAT_CLS else (N, T + 1, D), dtype=torch.float32, device=self.device)
+        nbytes = self.lib.rv_clip_encoder_ws_bytes(self._ctx, N, T, Nq, Lq)
+        ws = self._workspace("clip", nbytes)
+        hip.check(self.lib.rv_clip_encoder(self._ctx, hip.ptr(x), hip.ptr(txt), hip.ptr(m), N, T, Nq, Lq, feat, hip.ptr(out),
+                                           hip.ptr(ws), ws.numel(), hip.stream()), "rv_clip_encoder")
+        return out
+
+    # ---- LLM -------------------------------------------------------------------------------------
+    def splice_embed(self, row_map, video_rows):
+        """row_map i32 [B,S] (>=0 token id, <0 video row -(v+1)); video_rows f32 [R,D] -> h f32 [B,S,D]."""
+        B, S = row_map.shape
+        h = torch.empty(B, S, self.shape.hidden, dtype=torch.float32, device=self.device)
+        rm = row_map.to(device=self.device, dtype=torch.int32).contiguous()
+        vr = _dev_f32(video_rows, self.device) if video_rows is not None else None
+        hip.check(self.lib.rv_splice_embed(self._ctx, hip.ptr(rm), hip.ptr(vr), hip.ptr(h), B * S, hip.stream()), "rv_splice_embed")
+        return h
+
+    def new_kv(self, B, Smax):
+        Smax = (Smax + 31) // 32 * 32
+        nbytes = self.lib.rv_kv_bytes(self._ctx, B, Smax)
+        return torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device), Smax
+
+    def llm_forward(self, h, pos0, kv, Smax, logits=None):
+        """h f32 [B,S,D] (clobbered) -> logits f32 [B,V] of the last position; appends K/V at pos0..pos0+S-1."""
+        B, S, _ = h.shape
+        assert h.dtype == torch.float32 and h.is_contiguous()
+        if logits is None:
+            logits = torch.empty(B, self.shape.vocab, dtype=torch.float32, device=self.device)
+        nbytes = self.lib.rv_llm_ws_bytes(self._ctx, B, S)
+        ws = self._workspace("llm", nbytes)
+        hip.check(self.lib.rv_llm_forward(self._ctx, hip.ptr(h), B, S, pos0, hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws),
+                                          ws.numel(), hip.stream()), "rv_llm_forward")
+        return logits
+
+
+def pack_gate_up(gate, up):
+    """[F,D] x2 -> [2F,D] with 16-row blocks alternating gate / up."""
+    F, D = gate.shape
+    assert F % 16 == 0
+    return torch.stack([gate.view(F // 16, 16, D), up.view(F // 16, 16, D)], dim=1).reshape(2 * F, D).contiguous()

@@ -1,0 +1,110 @@
+"""Functional wrappers over the C ABI building blocks (used by the engine, the scoring helpers and the tests).
+
+Every function takes / returns torch DEVICE tensors and enqueues on torch's current stream.
+"""
+import math
+
+import torch
+
+from . import hip
+from .utils import hashinit
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def init_hash_(t, name, seed, a, base=0.0, offset=0):
+    """Fill ``t`` in place with the hash-seeded uniform(base-a, base+a) stream of tensor ``name``."""
+    key = (hashinit.tensor_key(name, seed) + offset) & 0xFFFFFFFFFFFFFFFF
+    hip.check(hip.lib().rv_init_hash(hip.ptr(t), hip.dtype_code(t), t.numel(), key, float(hashinit.step_for(a)), float(base),
+                                     hip.stream()), "rv_init_hash")
+    return t
+
+
+def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None):
+    """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16."""
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    hip.check(hip.lib().rv_gemm(hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), hip.ptr(bias), hip.ptr(residual),
+                                residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0),
+                                hip.dtype_code(out), act, M, N, K, hip.stream()), "rv_gemm")
+    return out
+
+
+def layernorm(x, w, b, pos=None, period=0, want=("f32", "bf16")):
+    rows, d = x.shape
+    y32 = torch.empty_like(x) if "f32" in want else None
+    y16 = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if "bf16" in want else None
+    yp = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if pos is not None else None
+    hip.check(hip.lib().rv_layernorm(hip.ptr(_c(x)), hip.ptr(w), hip.ptr(b), hip.ptr(y32), hip.ptr(y16), hip.ptr(yp),
+                                     hip.ptr(pos), period, rows, d, hip.stream()), "rv_layernorm")
+    return y32, y16, yp
+
+
+def rmsnorm(x, w, eps):
+    rows, d = x.shape
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device)
+    hip.check(hip.lib().rv_rmsnorm(hip.ptr(_c(x)), hip.ptr(w), hip.ptr(y), rows, d, eps, hip.stream()), "rv_rmsnorm")
+    return y
+
+
+def sine_pos(T, d=768, device="cuda"):
+    pos = torch.empty(T, d, dtype=torch.float32, device=device)
+    hip.check(hip.lib().rv_sine_pos(hip.ptr(pos), T, d, hip.stream()), "rv_sine_pos")
+    return pos
+
+
+def attention(q, k, v, causal=False, key_pad=None, q_pos0=0, scale=None):
+    """q [B,Lq,H,dh], k/v [Bk,Lk,H,dh] bf16 (B % Bk == 0) -> [B,Lq,H*dh] bf16.  Transposes V itself
+    (test / convenience entry; the engine keeps V^T resident)."""
+    B, Lq, H, dh = q.shape
+    Bk, Lk = k.shape[0], k.shape[1]
+    Lpad = (Lk + 31) // 32 * 32
+    vt = torch.zeros(Bk, H, dh, Lpad, dtype=torch.bfloat16, device=q.device)
+    vt[..., :Lk] = v.permute(0, 2, 3, 1)
+    q, k = _c(q), _c(k)
+    out = torch.empty(B, Lq, H * dh, dtype=torch.bfloat16, device=q.device)
+    pad = _c(key_pad.to(torch.uint8)) if key_pad is not None else None
+    hip.check(hip.lib().rv_attention(hip.ptr(q), H * dh, Lq * H * dh, hip.ptr(k), H * dh, Lk * H * dh, dh, hip.ptr(vt),
+                                     H * dh * Lpad, dh * Lpad, Lpad, hip.ptr(out), H * dh, Lq * H * dh, hip.ptr(pad), B, H, dh,
+                                     Lq, Lk, int(causal), q_pos0, B // Bk, scale if scale is not None else 1.0 / math.sqrt(dh),
+                                     hip.stream()), "rv_attention")
+    return out
+
+
+def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0):
+    """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B])."""
+    B, V = logits.shape
+    dev = logits.device
+    o = dict(tokens=torch.empty(B, dtype=torch.int32, device=dev), entropy_proc=torch.empty(B, dtype=torch.float32, device=dev),
+             entropy_raw=torch.empty(B, dtype=torch.float32, device=dev),
+             topk_idx=torch.full((B, hip.TOPK_CAP), -1, dtype=torch.int32, device=dev),
+             topk_val=torch.full((B, hip.TOPK_CAP), float("-inf"), dtype=torch.float32, device=dev),
+             n_keep=torch.zeros(B, dtype=torch.int32, device=dev))
+    hip.check(hip.lib().rv_sample(hip.ptr(_c(logits)), B, V, hip.ptr(uniforms), int(do_sample), float(temperature), int(top_k),
+                                  float(top_p if top_p is not None else 1.0), hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
+                                  hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]),
+                                  hip.stream()), "rv_sample")
+    return o
+
+
+def entropy_stats(logits):
+    """get_entropy_statistics on the device: logits f32 [B,G,V] -> [B,4] (max, min, mean, std)."""
+    B, G, V = logits.shape
+    out = torch.empty(B, 4, dtype=torch.float32, device=logits.device)
+    hip.check(hip.lib().rv_entropy_stats(hip.ptr(_c(logits.float())), B, G, V, hip.ptr(out), hip.stream()), "rv_entropy_stats")
+    return out
+
+
+def topk_cosine(feat, q_cls, k=3):
+    """feat [n,T,d] (bf16 or f32), q_cls [d] -> f32 [n]: column-normalise over frames, sum of the k best <f_t, q> (k<=0: mean)."""
+    n, T, d = feat.shape
+    out = torch.empty(n, dtype=torch.float32, device=feat.device)
+    hip.check(hip.lib().rv_topk_cosine(hip.ptr(_c(feat)), hip.dtype_code(feat), hip.ptr(_c(q_cls.float())), n, T, d, k, hip.ptr(out),
+                                       hip.stream()), "rv_topk_cosine")
+    return out

@@ -6,7 +6,7 @@ GPU; instead every element is a pure function of (tensor name, global seed, flat
 
     h   = splitmix64(index + key)                 key = fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15)
     v   = int(h >> 40) - 2**23                    exact 24-bit signed integer
-    w   = base + float32(v) * step                two correctly-rounded fp32 ops (no FMA)
+    w   = float32(float64(v) * step + base)       product exact in double, one rounding to fp32
 
 which gives uniform(base - a, base + a) with step = a * 2**-23.  ``csrc/init.hip`` (rv_init_hash)
 computes the same thing on the GPU, so a 7B-parameter model is filled in HBM in milliseconds and the
@@ -51,8 +51,7 @@ def hash_uniform(n: int, key: int, a: float, base: float = 0.0, offset: int = 0,
             idx = np.arange(offset + s, offset + e, dtype=np.uint64) + np.uint64(key)
             h = _splitmix64(idx)
             v = (h >> np.uint64(40)).astype(np.int64) - np.int64(1 << 23)
-            w = v.astype(np.float32) * step
-            out[s:e] = w + b if base != 0.0 else w
+            out[s:e] = (v.astype(np.float64) * np.float64(step) + np.float64(b)).astype(np.float32)
     return out
 
 

@@ -1,0 +1,284 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Both sides see identical (bf16-representable) weights and inputs, so differences come only
+from bf16 activation rounding between kernels and fp32 accumulation order.  Tolerances are stated per test:
+  f32 outputs of a single kernel ........ 2e-5 relative (max-norm)
+  bf16 outputs / chained bf16 kernels ... 1.5e-2 relative (bf16 eps = 3.9e-3)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import SEED, T, clip_weights, feats, linear_weights, llama_weights, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 1.5e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from revisionllm_amd import hip
+    hip.lib()  # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def test_abi_version(dev):
+    from revisionllm_amd import hip
+    assert hip.lib().rv_abi_version() == 1
+
+
+def test_init_hash_bit_exact(dev):
+    from revisionllm_amd import ops
+    from revisionllm_amd.utils import hashinit
+    for n, a, base in ((1000, 0.02, 0.0), (70001, 0.1, 1.0)):
+        ref = hashinit.hash_uniform(n, hashinit.tensor_key("x.y", 3), a, base)
+        t = ops.init_hash_(torch.empty(n, device=dev), "x.y", 3, a, base)
+        assert np.array_equal(t.cpu().numpy(), ref)
+        tb = ops.init_hash_(torch.empty(n, dtype=torch.bfloat16, device=dev), "x.y", 3, a, base)
+        assert np.array_equal(tb.float().cpu().numpy(), hashinit.round_bf16(ref))
+    # offset form used for sub-blocks
+    ref = hashinit.hash_uniform(500, hashinit.tensor_key("x.y", 3), 0.02, 0.0, offset=123)
+    t = ops.init_hash_(torch.empty(500, device=dev), "x.y", 3, 0.02, 0.0, offset=123)
+    assert np.array_equal(t.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (130, 512, 1408), (1190, 4096, 512), (257, 2304, 768), (1, 4096, 4096),
+                                    (7, 1024, 11008), (16, 32000, 512), (17, 768, 2048), (100, 4096, 768)])
+@pytest.mark.parametrize("out", ["bf16", "f32"])
+def test_gemm(dev, M, N, K, out):
+    from revisionllm_amd import hip, ops
+    a = feats(f"gemm.a.{M}.{K}", (M, K), bf16=True)
+    w = feats(f"gemm.w.{N}.{K}", (N, K), bf16=True) * (1.0 / math.sqrt(K))
+    w = bf(w).float()
+    bias = feats(f"gemm.b.{N}", (N,))
+    res = feats(f"gemm.r.{M}.{N}", (M, N))
+    od = torch.bfloat16 if out == "bf16" else torch.float32
+    tol = BF16_TOL if out == "bf16" else F32_TOL * 5
+    ad, wd = bf(a).to(dev), bf(w).to(dev)
+    ref0 = a.double() @ w.double().t()
+    y = ops.gemm(ad, wd, out_dtype=od)
+    assert rel_err(y.float().cpu(), ref0) < tol
+    y = ops.gemm(ad, wd, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU)
+    ref = torch.relu(ref0 + bias.double()) + res.double()
+    assert rel_err(y.float().cpu(), ref) < tol
+    if N % 32 == 0:
+        y = ops.gemm(ad, wd, out_dtype=od, act=hip.RV_ACT_SILU_MUL)
+        r3 = ref0.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
+        assert rel_err(y.float().cpu(), ref) < tol
+
+
+def test_gemm_strided_rows_and_inplace_residual(dev):
+    from revisionllm_amd import ops
+    x = bf(feats("gemm.s", (20, 5, 768), bf16=True)).to(dev)
+    w = bf(feats("gemm.sw", (4096, 768), bf16=True) * 0.03).to(dev)
+    y = ops.gemm(x[:, 0], w, out_dtype=torch.float32)      # row stride 5*768 (CLS selection)
+    assert rel_err(y.cpu(), x[:, 0].float().cpu() @ w.float().cpu().t()) < 1e-4
+    h = feats("gemm.h", (20, 4096)).to(dev)
+    h0 = h.clone()
+    ops.gemm(x[:, 1].contiguous(), w, residual=h, out_dtype=torch.float32, out=h)  # C aliases the residual
+    assert rel_err(h.cpu(), h0.cpu() + x[:, 1].float().cpu() @ w.float().cpu().t()) < 1e-4
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from revisionllm_amd import hip, ops
+    a = torch.zeros(4, 100, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(8, 100, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(hip.HipLibraryError, match="multiple of 64"):
+        ops.gemm(a, w)
+
+
+def test_layernorm_rmsnorm_sinepos(dev):
+    from oracle import adapter, llama
+    from revisionllm_amd import ops
+    x = feats("ln.x", (37, 768)) * 3 + 0.5
+    w, b = feats("ln.w", (768,)) * 0.1 + 1, feats("ln.b", (768,)) * 0.05
+    pos = feats("ln.pos", (5, 768))
+    y32, y16, yp = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), pos=pos.to(dev), period=5)
+    ref = torch.nn.functional.layer_norm(x, (768,), w, b, 1e-5)
+    assert rel_err(y32.cpu(), ref) < F32_TOL
+    assert rel_err(y16.float().cpu(), ref) < BF16_TOL
+    refp = ref + pos[torch.arange(37) % 5]
+    assert rel_err(yp.float().cpu(), refp) < BF16_TOL
+    for d in (512, 4096):
+        x = feats(f"rms.x{d}", (9, d)) * 2
+        w = feats(f"rms.w{d}", (d,)) * 0.1 + 1
+        y = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+        assert rel_err(y.float().cpu(), llama.rmsnorm(x, w, 1e-5)) < BF16_TOL
+    for Tn in (1, 16, 256, 1024):
+        p = ops.sine_pos(Tn, 768, dev)
+        assert (p.cpu() - adapter.sine_pos_embed(Tn)).abs().max() < 2e-5
+
+
+def _ref_attn(q, k, v, causal, pad, q_pos0, kv_div):
+    B, Lq, H, dh = q.shape
+    k = k.repeat_interleave(kv_div, 0)
+    v = v.repeat_interleave(kv_div, 0)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) / math.sqrt(dh)
+    if pad is not None:
+        s = s.masked_fill(pad.repeat_interleave(kv_div, 0)[:, None, None, :].bool(), float("-inf"))
+    if causal:
+        qi = torch.arange(Lq)[:, None] + q_pos0
+        s = s.masked_fill((torch.arange(k.shape[1])[None, :] > qi)[None, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v.double()).reshape(B, Lq, H * dh)
+
+
+@pytest.mark.parametrize("case", ["self96", "cross96", "causal128", "decode128", "long96"])
+def test_attention(dev, case):
+    from revisionllm_amd import ops
+    cfg = {"self96": (3, 3, 257, 257, 8, 96, False, False, 0), "cross96": (6, 2, 50, 13, 8, 96, False, True, 0),
+           "causal128": (2, 2, 171, 171, 4, 128, True, False, 0), "decode128": (3, 3, 1, 173, 4, 128, True, False, 172),
+           "long96": (1, 1, 1025, 1025, 8, 96, False, False, 0)}[case]
+    B, Bk, Lq, Lk, H, dh, causal, use_pad, q_pos0 = cfg
+    q = feats(f"at.q.{case}", (B, Lq, H, dh), bf16=True)
+    k = feats(f"at.k.{case}", (Bk, Lk, H, dh), bf16=True)
+    v = feats(f"at.v.{case}", (Bk, Lk, H, dh), bf16=True)
+    pad = None
+    if use_pad:
+        pad = torch.zeros(Bk, Lk, dtype=torch.uint8)
+        pad[1, 9:] = 1
+    y = ops.attention(bf(q).to(dev), bf(k).to(dev), bf(v).to(dev), causal=causal, key_pad=pad.to(dev) if pad is not None else None,
+                      q_pos0=q_pos0)
+    ref = _ref_attn(q, k, v, causal, pad, q_pos0, B // Bk)
+    assert rel_err(y.float().cpu(), ref) < BF16_TOL
+
+
+def test_project_dense(dev):
+    from oracle import adapter
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    eng = engine.Engine(synth.LlamaShape(layers=0), device=dev)
+    eng.init_synthetic(seed=SEED, llm=False, clip=False, linear=True)
+    w = linear_weights(bf16=True)
+    x = feats("pd.x", (3, 256, 768), bf16=True)
+    y = eng.project_dense(x)
+    ref = adapter.dense_projector(x, w["weight"], w["bias"])
+    assert rel_err(y.cpu(), ref) < 1e-4
+    assert rel_err(eng.project_dense(x, torch.bfloat16).float().cpu(), ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("text", [True, False])
+@pytest.mark.parametrize("Tn", [16, 256])
+def test_clip_encoder(dev, text, Tn):
+    """Full sparse adapter (2 T2V + 2 self layers + projector), N=4 sequences sharing 2 texts."""
+    from oracle import adapter
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    eng = engine.Engine(synth.LlamaShape(layers=0), adapter_text=text, device=dev)
+    eng.init_synthetic(seed=SEED, llm=False, clip=True, clip_prefix="mm_projector.")
+    w = clip_weights(text=text, bf16=True)
+    # vectors stay fp32 on the device; rebuild them un-rounded for the oracle
+    w32 = clip_weights(text=text, bf16=False)
+    for k_ in w:
+        if w[k_].dim() == 1:
+            w[k_] = w32[k_]
+    N, Nq, Lq = 4, 2, 7
+    x = feats(f"ce.x.{Tn}", (N, Tn, 768), bf16=True)
+    txt = feats("ce.txt", (Nq, Lq, 768), bf16=True)
+    mask = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]], dtype=torch.float32)
+    y = eng.clip_encoder(x, txt, mask, "cls")
+    qf = txt.repeat_interleave(N // Nq, 0)
+    qm = mask.repeat_interleave(N // Nq, 0)
+    ref = adapter.clip_encoder(x, w, qf if text else None, qm if text else None, text, "cls", True)[:, 0]
+    assert rel_err(y.cpu(), ref) < 2e-2
+    yall = eng.clip_encoder(x, txt, mask, "all")
+    refall = adapter.clip_encoder(x, w, qf if text else None, qm if text else None, text, "all", False)
+    assert rel_err(yall.cpu(), refall) < 2e-2
+    assert rel_err(yall[:, 0].cpu(), y.cpu()) < 1e-6
+
+
+def _tiny_engine(dev, text=True):
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    eng = engine.Engine(synth.TINY, adapter_text=text, device=dev)
+    eng.init_synthetic(seed=SEED, llm=True, clip=True)
+    return eng
+
+
+def test_llm_prefill_and_decode(dev):
+    """TINY Llama (3 layers, dH=128): prefill logits, then 3 KV-cached decode steps, vs the oracle."""
+    from oracle import llama
+    from revisionllm_amd.utils import synth
+    eng = _tiny_engine(dev)
+    shape = synth.TINY
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    w = llama_weights(shape, bf16=True)
+    w32 = llama_weights(shape, bf16=False)
+    for k_ in w:
+        if "norm" in k_:
+            w[k_] = w32[k_]
+    B, S = 3, 45
+    ids = torch.from_numpy(np.stack([synth.synthetic_prompt_ids(S, 5, s, vocab=shape.vocab) for s in range(B)]))
+    ids[:, 5] = 7
+    emb = w["model.embed_tokens.weight"][ids]
+    cache = llama.KVCache(cfg.layers)
+    ref = llama.forward(emb, w, cfg, cache=cache)[:, -1]
+    kv, Smax = eng.new_kv(B, 64)
+    h = eng.splice_embed(ids.int(), None)
+    assert rel_err(h.cpu(), emb) < 1e-6
+    logits = eng.llm_forward(h, 0, kv, Smax)
+    assert rel_err(logits.cpu(), ref) < 2e-2
+    for step in range(3):
+        nxt = ref.argmax(-1)
+        e1 = w["model.embed_tokens.weight"][nxt][:, None]
+        ref = llama.forward(e1, w, cfg, cache=cache)[:, -1]
+        h1 = eng.splice_embed(nxt.int()[:, None], None)
+        logits = eng.llm_forward(h1, S + step, kv, Smax)
+        assert rel_err(logits.cpu(), ref) < 2e-2, step
+
+
+def test_sample_and_scores(dev):
+    from oracle import sampling, scores
+    from revisionllm_amd import ops
+    logits = feats("smp.logits", (5, 32000)) * 1.3
+    u = torch.tensor([0.0, 0.3, 0.55, 0.9, 0.999])
+    for (temp, k, p) in ((0.05, 50, 0.6), (1.0, 50, 1.0), (0.7, 20, 0.9), (2.0, 64, 0.3)):
+        o = ops.sample(logits.to(dev), u.to(dev), True, temp, k, p)
+        sc = sampling.process_logits(logits, temp, k, p)
+        tok = sampling.select_token(sc, u)
+        assert (o["tokens"].cpu().long() == tok).all(), (temp, k, p)
+        keep = torch.isfinite(sc).sum(-1)
+        assert (o["n_keep"].cpu().long() == keep).all()
+        ent = scores.entropy_statistics(sc[:, None])[:, 0]
+        assert torch.allclose(o["entropy_proc"].cpu(), ent, rtol=1e-4, atol=1e-6)
+        raw = scores.entropy_statistics(logits[:, None])[:, 0]
+        assert torch.allclose(o["entropy_raw"].cpu(), raw, rtol=1e-5)
+        for b in range(5):
+            n = int(keep[b])
+            idx = o["topk_idx"][b, :n].cpu().long()
+            assert torch.allclose(o["topk_val"][b, :n].cpu(), sc[b, idx], rtol=1e-6)
+    o = ops.sample(logits.to(dev), None, False)
+    assert (o["tokens"].cpu().long() == logits.argmax(-1)).all()
+    # max / min / mean to 1e-5 relative; std is a difference of nearly equal entropies (H ~ 10, std ~ 5e-4),
+    # so it is only compared to 2e-5 ABSOLUTE (= 2e-6 of H, fp32 resolution of the inputs)
+    st = ops.entropy_stats((logits.view(1, 5, 32000) * 0.5).to(dev))
+    ref = scores.entropy_statistics(logits.view(1, 5, 32000) * 0.5)
+    assert torch.allclose(st[:, :3].cpu(), ref[:, :3], rtol=1e-5) and abs(float(st[0, 3]) - float(ref[0, 3])) < 2e-5
+    sc = sampling.process_logits(logits, 0.05, 50, 0.6)
+    st = ops.entropy_stats(sc.view(1, 5, 32000).to(dev))
+    assert torch.allclose(st.cpu(), scores.entropy_statistics(sc.view(1, 5, 32000)), rtol=1e-4, atol=2e-5)
+    st1 = ops.entropy_stats(logits[:1, None].to(dev))
+    assert torch.isnan(st1[0, 3])
+
+
+def test_topk_cosine(dev):
+    from oracle import scores
+    from revisionllm_amd import ops
+    feat = feats("tc.feat", (4, 250, 768), bf16=True)
+    q = feats("tc.q", (768,))
+    y = ops.topk_cosine(bf(feat).to(dev), q.to(dev), 3)
+    ref = torch.stack([scores.stage2_cosine(feat[i:i + 1], q)[0] for i in range(4)])
+    assert rel_err(y.cpu(), ref) < 1e-4
+    y = ops.topk_cosine(feat[0, 5:19][None].to(dev), q.to(dev), 3)
+    assert rel_err(y.cpu(), scores.stage1_cosine(feat[0, 5:19], q)) < 1e-4
+    y = ops.topk_cosine(feat[0, 5:19][None].to(dev), q.to(dev), 0)
+    assert rel_err(y.cpu(), scores.stage1_cosine(feat[0, 5:19], q, topk_pool=False)) < 1e-4
