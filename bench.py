@@ -1,0 +1,246 @@
+"""Benchmark of the hot path: video-segments/sec on the stage-2 100-segment recursion at Vicuna-7B scale.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``)
+
+One "step" = one stage-2 recursion (zoom levels 4/2/1) of one query over this rank's 100 windows
+[100 x 256 x 768] of synthetic CLIP features with random-init Vicuna-7B-shaped weights (hash-seeded, generated in
+HBM), sampling at T = 0.05, decode length forced to G = 8 (eos disabled: random-init models never emit EOS).
+N ranks process a 100*N-window video: windows block-partitioned, CLS rows and proposals exchanged by RCCL
+all-gathers (weak scaling: per-GPU work fixed).  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, timed with HIP events on
+the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--windows", type=int, default=100, help="windows (segments) per GPU")
+    p.add_argument("--frames", type=int, default=256)
+    p.add_argument("--lq", type=int, default=16)
+    p.add_argument("--decode-steps", type=int, default=8)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-layers", type=int, default=2, help="decoder layers executed by the CPU baseline sample")
+    p.add_argument("--cpu-segments", type=int, default=8, help="segments encoded by the CPU baseline sample")
+    return p.parse_args()
+
+
+def event_time_ms(fn, iters, warm=3):
+    """Average duration of ``fn`` (one kernel launch) with HIP events on torch's current stream = the launch stream."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def roofline_legs(model, n_calls, S):
+    """Time the path's two heavy kernels in isolation on the shapes the recursion launches them with."""
+    from revisionllm_amd import hip, ops
+    eng, s = model.engine, model.shape
+    dev = eng.device
+    M = n_calls * S
+    legs = {}
+    # (1) prefill gate/up GEMM + SiLU*mul epilogue: [M,4096] x [22016,4096]^T  (MFMA-bound)
+    x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
+    w = eng.weight("llm.L0.wgu")
+    out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
+    ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out), 20)
+    flops = 2.0 * M * s.hidden * 2 * s.inter
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile<bf16,SILU_MUL>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops)
+    # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
+    #     256 MB infinity cache cannot serve the weights
+    xs = torch.randn(n_calls, s.hidden, device=dev).to(torch.bfloat16)
+    outs = torch.empty(n_calls, s.inter, dtype=torch.bfloat16, device=dev)
+    ws = [eng.weight(f"llm.L{i}.wgu") for i in range(s.layers)]
+    state = {"i": 0}
+
+    def gemv():
+        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs)
+        state["i"] += 1
+    ms = event_time_ms(gemv, 64, warm=4)
+    nbytes = 2.0 * s.hidden * 2 * s.inter
+    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,bf16,SILU_MUL>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
+                                      peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes)
+    return legs
+
+
+def cpu_baseline(args, n_calls, P):
+    """Torch-fp32 CPU oracle on a bounded sample of the same workload, extrapolated linearly:
+    adapter on ``cpu_segments`` of 100 segments; one LLM call (prefill S + G decode steps) through ``cpu_layers`` of 32
+    layers + lm_head.  recursion time = adapter(100 segs) x 7 calls' worth (the reference re-encodes per call)
+    + 7 x call time."""
+    import numpy as np
+
+    from oracle import adapter as o_adapter
+    from oracle import llama as o_llama
+    from oracle import sampling as o_sampling
+    from revisionllm_amd.utils import synth
+    torch.set_grad_enabled(False)
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    T = lambda a: torch.from_numpy(a)
+    seed, W, Tn, L = args.seed, args.windows, args.frames, args.cpu_layers
+    shape = synth.LlamaShape(layers=L)
+    cfg = o_llama.LlamaCfg(layers=L)
+    w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), seed).items()}
+    wa = {k[len("model.mm_projector."):]: T(v) for k, v in
+          synth.build_numpy(synth.clip_encoder_spec(), seed, prefix="model.mm_projector.").items()}
+    ns = args.cpu_segments
+    feat = T(synth.features("bench.feat.r0", (ns, Tn, 768), seed))
+    q = (T(synth.features("bench.q", (1, args.lq, 768), seed)), torch.ones(1, args.lq))
+    qf, qm = q[0].expand(ns, -1, -1), q[1].expand(ns, -1)
+    o_adapter.clip_encoder(feat[:2], wa, qf[:2], qm[:2])  # warm-up
+    t0 = time.perf_counter()
+    o_adapter.clip_encoder(feat, wa, qf, qm)
+    t_adapter_seg = (time.perf_counter() - t0) / ns
+    # one call: 100 video tokens (already encoded rows stand in), prompt P, G forced decode steps
+    ids = T(synth.synthetic_prompt_ids(P, 40, seed))[None]
+    rows = torch.randn(1, W, shape.hidden) * 0.02
+    emb, mask, pos, _ = __import__("oracle.splice", fromlist=["splice"]).splice(ids, list(rows), w["model.embed_tokens.weight"])
+    t0 = time.perf_counter()
+    cache = o_llama.KVCache(L)
+    logits = o_llama.forward(emb, w, cfg, mask, pos, cache, last_only=True)[:, -1]
+    t_prefill = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.decode_steps - 1):
+        nxt = o_sampling.select_token(o_sampling.process_logits(logits, 0.05, 50, 1.0), torch.tensor([0.5]))
+        e1 = w["model.embed_tokens.weight"][nxt][:, None]
+        logits = o_llama.forward(e1, w, cfg, cache=cache)[:, -1]
+    t_decode = time.perf_counter() - t0
+    # scale the layer-proportional part to 32 layers (lm_head / embedding time is small and left unscaled)
+    scale = 32.0 / L
+    t_call = (t_prefill + t_decode) * scale
+    t_recursion = n_calls * (W * t_adapter_seg + t_call)
+    return dict(value=W / t_recursion, unit="segments/s", cores=cores, kind="port",
+                sample=(f"torch-fp32 oracle: ClipEncoder on {ns} of {W} segments ({t_adapter_seg*1e3:.0f} ms/segment), one LLM call "
+                        f"(prefill S={emb.shape[1]} {t_prefill:.2f}s + {args.decode_steps - 1} decode steps {t_decode:.2f}s) through "
+                        f"{L} of 32 layers, scaled x{scale:.0f}; recursion = {n_calls} calls x (100 segment encodings + call) "
+                        f"= {t_recursion:.1f}s as the reference executes it"))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from revisionllm_amd import ops, parallel
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+
+    model = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device=dev)
+    model.get_model().initialize_vision_modules(SimpleNamespace(
+        clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
+        adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
+    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True)
+    model.generation_config.eos_token_id = None     # forced decode length
+    tok = synth.FakeTokenizer()
+
+    Wl, Tn = args.windows, args.frames
+    W = Wl * world
+    feats = ops.init_hash_(torch.empty(Wl, Tn, 768, dtype=torch.bfloat16, device=dev), f"bench.feat.r{rank}", args.seed, synth.SQRT3)
+    qf = ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), "bench.q", args.seed, synth.SQRT3)
+    qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "bench.qcls", args.seed, synth.SQRT3)
+    plan = stage2.plan_groups(W, 100)
+    gen = torch.Generator().manual_seed(args.seed)
+    perms = stage2.make_perms(plan, gen)
+    sentence = "a person opens the door and walks into the kitchen"
+    stages = parallel.HipStages(model, tok)
+
+    def step():
+        return parallel.run_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms,
+                                          max_new_tokens=args.decode_steps)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rec = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ids1, _ = __import__("revisionllm_amd.inference", fromlist=["_prompt_ids"])._prompt_ids(
+            "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence), tok, 1)
+        P = ids1.shape[1]
+        S = P - 1 + 100
+        n_calls_rank = len(parallel.deal(len(plan), 0, world))
+        legs = roofline_legs(model, n_calls_rank, S)
+        dom = max(legs.values(), key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * args.decode_steps))
+        out = {
+            "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
+            "value": W * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
+                       "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
+                       "prefill_len": int(S), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
+                       "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
+                       "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},
+            "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+                         "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": None,
+                         "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"],
+                         "other": {k: {"achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
+                                       "avg_launch_ms": v["ms"]} for k, v in legs.items()}},
+            "answers_sample": rec["answers"][:2],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, len(plan), int(P))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

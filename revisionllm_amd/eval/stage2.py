@@ -1,0 +1,281 @@
+"""Stage-2 hierarchical retrieval driver: the recursion over windows and zoom levels.
+
+Counterpart of ``eval()`` in revisionllm/eval/eval_nlq_retrieval_e2e2.py:262-417 for one query.  Two modes that
+produce the same records:
+
+``reference``  one ``inference()`` call per (level, group), exactly as the reference loops (e2e2.py:337-353);
+``batched``    results-preserving restructuring for the GPU: every window's CLS token is a pure function
+               of (window, query), so it is encoded ONCE (the reference re-encodes it zoom x per call and again at
+               every level); the per-call video rows are then gathered / repeated from that table and all calls of
+               the recursion run as ONE batched generate (decode streams the 13 GB of weights once per step for
+               all calls instead of once per call).
+
+Index arithmetic (windows, groups, answer -> window) is integer host work and is checked bit-exactly against
+the reference's own functions (tests/golden/g9_driver.json).
+"""
+import json
+import math
+import re
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..inference import _decode, _prompt_ids, inference
+from ..model.adapter import pad_sequences_1d
+
+QUERY_TEMPLATE = "During which video can we see {}?"  # e2e2.py:325
+
+
+def cut_windows(ctx_l, debug_window=125, feature_fps=5, stride=5, num_frames=250):
+    """Overlapping windows of ``debug_window*feature_fps`` frames every ``clip_length//stride`` (e2e2.py:262-277).
+    -> (times [(start, end)], frame indices int32 [W, num_frames])."""
+    clip_length = debug_window * feature_fps
+    num_window = math.ceil(ctx_l / (clip_length // stride)) - 1
+    times, idx = [], []
+    for i in range(num_window):
+        start = max(i * clip_length // stride, 0)
+        end = min(i * clip_length // stride + clip_length, ctx_l - 1)
+        if end - start < clip_length:
+            start = end - clip_length
+        times.append((start, end))
+        idx.append(np.linspace(start, end, num_frames, dtype=np.int32))
+    return times, (np.stack(idx) if idx else np.zeros((0, num_frames), np.int32))
+
+
+def plan_groups(W, batch, zooms=(4, 2, 1)):
+    """[(zoom, start, end)] in the order the reference visits them (e2e2.py:337-346); the last group of a level is
+    shifted back so that it also holds ``batch // zoom`` windows."""
+    plan = []
+    for z in zooms:
+        b = batch // z
+        for g in range(math.ceil(W / b)):
+            start = g * b
+            end = min(start + b, W)
+            if end - start < b:
+                start = end - b
+            plan.append((z, start, end))
+    return plan
+
+
+def get_ground_truth_windows(start, end, duration):
+    """e2e2.py:161-170."""
+    clip_len = 0.2
+    start, end = start / clip_len, end / clip_len
+    size = int(900 / 2)
+    ids = list(range(math.floor(start / size), math.ceil(end / size) + 1))
+    return ids, math.ceil(duration / clip_len / size) + 1
+
+
+def answer_to_window(output, zoom, index, start, grounding_windows):
+    """First integer in the answer -> // zoom -> un-shuffle -> + start -> clamp -> window id (e2e2.py:113-123)."""
+    m = re.search(r"(\d+)", output)
+    if not m:
+        return None
+    n = int(m.group(1)) // zoom
+    if n < len(index):
+        n = int(index[n])
+    n = min(len(grounding_windows) - 1, max(0, start + n))
+    return grounding_windows[n]
+
+
+def iou(outputs, gt, num_frames_clip, num_frames_video, starts, indexes, single, hierarchy_zooms, grounding_windows):
+    """Same signature / result as the reference's ``iou`` (e2e2.py:109-139): ({call: (from, to)}, [hit])."""
+    clip_frames, frames = {}, []
+    for i, output in enumerate(outputs):
+        w = answer_to_window(output, hierarchy_zooms[i], indexes[i], starts[i], grounding_windows)
+        if w is None:
+            continue
+        f, t = max(0, w - 1), min(num_frames_video, w + 1)
+        clip_frames[i] = (int(f), int(t))
+        frames.append((f, t))
+    s, e = min(gt), max(gt)
+    inter = [max(0, min(t, e) - max(f, s)) for f, t in frames]
+    return clip_frames, [1] if sum(inter) > 0 else [0]
+
+
+def write_log(log_path, video_id, task, query_id, answer, info=None):
+    """JSONL record (e2e2.py:142-152)."""
+    log = {"video_id": video_id, "task": task, "query_id": query_id, "answer": answer}
+    if info is not None:
+        log["info"] = info
+    with open(log_path, "a") as f:
+        f.write(json.dumps(log) + "\n")
+
+
+def _proposal_rows(answer0, n_group_rows, zooms_so_far, indexes, starts, i_inner, grounding_windows, single=True):
+    """Rows of the CURRENT group tensor whose cosine score the reference logs for one call, INCLUDING its quirks
+    (e2e2.py:360-379): zoom / permutation / start are looked up with the group index of the current LEVEL (``i``),
+    not the global call index, and the resulting window ids are used to index the shuffled, zoom-repeated group
+    tensor.  Returns None when nothing parses (the reference then logs a single 0)."""
+    m = None
+    if not single:
+        m = re.search(r"(\d+) (to|and) (\d+)", answer0)
+    if not m:
+        m = re.search(r"(\d+)", answer0)
+    if not m:
+        return None
+    n = int(m.group(1)) // zooms_so_far[i_inner]
+    if n < len(indexes[i_inner]):
+        n = int(indexes[i_inner][n])
+    n = min(len(grounding_windows) - 1, max(0, starts[i_inner] + n))
+    w = grounding_windows[n]
+    return list(range(max(0, w - 1), min(w + 1, n_group_rows - 1)))
+
+
+def _steps_until_eos(new_tokens, eos):
+    """Number of steps a batch-1 generate would have produced for each row (up to and including EOS)."""
+    G = new_tokens.shape[1]
+    if eos is None:
+        return [G] * new_tokens.shape[0]
+    out = []
+    for row in new_tokens.tolist():
+        out.append(row.index(eos) + 1 if eos in row else G)
+    return out
+
+
+# ---- the four device stages of the batched recursion (each is what a rank runs on its shard) -----------------
+
+def encode_windows(model, features, query_feats):
+    """CLS row of every window for one query: [W,T,768] -> f32 [W,D].  Each (window, query) is encoded once."""
+    mask = torch.ones(1, query_feats.shape[0])
+    return model.engine.clip_encoder(features, query_feats[None], mask, "cls")
+
+
+def window_cosine(features, query_cls, k=3):
+    """Cosine score of every window (e2e2.py:380-386 for one group row): f32 [W]."""
+    return ops.topk_cosine(features, query_cls, min(features.shape[1], k))
+
+
+def build_call_rows(cls, plan, perms):
+    """Video rows of every call: cls[start:end][perm].repeat_interleave(zoom)  (e2e2.py:345-352 applied to CLS rows)."""
+    rows = []
+    for (z, start, end), idx in zip(plan, perms):
+        r = cls[start:end][idx.to(cls.device)]
+        rows.append(r.repeat_interleave(z, 0) if z > 1 else r)
+    return rows
+
+
+def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
+    """Run the LLM for the given call indices.  Calls with the same number of video rows have equal prompt lengths and
+    run as one batched generate.  -> {call: (new_token_ids list, max_entropy, mean_entropy)} with the statistics taken
+    over the steps a batch-1 generate would have produced."""
+    ids1, _ = _prompt_ids(query, tokenizer, 1)
+    eos = model.generation_config.eos_token_id
+    by_rows = {}
+    for c in calls:
+        by_rows.setdefault(rows[c].shape[0], []).append(c)
+    res = {}
+    for n_rows, cs in by_rows.items():
+        for c0 in range(0, len(cs), max_calls_per_generate):
+            sel = cs[c0:c0 + max_calls_per_generate]
+            ids = ids1.repeat(len(sel), 1)
+            u = None if uniforms is None else uniforms[:, sel]
+            out = model.generate(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows, do_sample=True,
+                                 temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens, output_scores=False,
+                                 return_dict_in_generate=True, uniforms=u)
+            new = out["sequences"][:, ids.shape[1]:].cpu()
+            ent = out["entropy"].cpu()
+            for j, (c, g) in enumerate(zip(sel, _steps_until_eos(new, eos))):
+                e = ent[j, :g]
+                res[c] = (new[j, :g].tolist(), float(e.max()), float(e.mean()))
+    return res
+
+
+def assemble(plan, perms, call_results, cos, tokenizer, zooms, grounding_windows, single=True):
+    """Host epilogue: decode answers, invert the entropies, look up the (quirky) cosine proposals."""
+    stop_str = "</s>"
+    answers, max_ent, mean_ent, score_cos, starts, indexes, hz = [], [], [], [], [], [], []
+    i_call = 0
+    for z in zooms:
+        level = [p for p in plan if p[0] == z]
+        for i, (_, start, end) in enumerate(level):
+            idx = perms[i_call]
+            toks, emax, emean = call_results[i_call]
+            text = tokenizer.batch_decode([toks], skip_special_tokens=True)[0].strip()
+            if text.endswith(stop_str):
+                text = text[:-len(stop_str)]
+            text = text.strip()
+            starts.append(start)
+            indexes.append(idx)
+            hz.append(z)
+            answers.append(text)
+            max_ent.append(1 / emax)
+            mean_ent.append(1 / emean)
+            n_rows = (end - start) * z
+            prop = _proposal_rows(text, n_rows, hz, indexes, starts, i, grounding_windows, single)
+            if prop is None:
+                score_cos.append(0)
+            else:  # group row n holds window start + perm[n // zoom] of THIS call
+                score_cos.extend(float(cos[start + int(idx[n // z])]) for n in prop)
+            i_call += 1
+    return dict(answers=answers, starts=starts, indexes=indexes, hierarchy_zooms=hz, max_entropy=max_ent,
+                mean_entropy=mean_ent, score_cos=score_cos, grounding_windows=grounding_windows, plan=plan)
+
+
+def make_perms(plan, generator=None):
+    """One permutation per call, like ``torch.randperm(feat.size(1))`` at e2e2.py:348 (global RNG unless a generator is given)."""
+    return [torch.randperm(end - start, generator=generator) for _, start, end in plan]
+
+
+def run_query(model, tokenizer, features, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1), perms=None,
+              mode="batched", grounding_windows=None, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, single=True):
+    """One query of the stage-2 recursion.  features [W,T,768] (device), query_feats [Lq,768], query_cls [768].
+
+    ``perms``: one permutation per call (length batch//zoom); default ``torch.randperm`` like e2e2.py:348.
+    ``uniforms`` [G, n_calls]: host-supplied sampling draws (default: torch.rand on the device).
+    Returns the fields the reference logs (e2e2.py:411-417) + the per-call bookkeeping.
+    """
+    W = features.shape[0]
+    if grounding_windows is None:
+        grounding_windows = list(range(W))
+    zooms = tuple(zooms)
+    plan = plan_groups(W, batch, zooms)
+    perms = [torch.as_tensor(p).long() for p in (perms if perms is not None else make_perms(plan))]
+    query = "<video>\n" + QUERY_TEMPLATE.format(sentence)
+
+    if mode == "batched":
+        cls = encode_windows(model, features, query_feats)
+        cos = window_cosine(features, query_cls).cpu()
+        rows = build_call_rows(cls, plan, perms)
+        res = generate_calls(model, tokenizer, query, rows, list(range(len(plan))), uniforms, max_new_tokens, max_calls_per_generate)
+        return assemble(plan, perms, res, cos, tokenizer, zooms, grounding_windows, single)
+    if mode != "reference":
+        raise ValueError(f"mode must be 'reference' or 'batched', got {mode!r}")
+
+    # reference mode: one inference() per (level, group), adapter re-run inside every call (e2e2.py:337-386)
+    qf = pad_sequences_1d(query_feats[None], dtype=query_feats.dtype, device=query_feats.device)
+    answers, max_ent, mean_ent, score_cos, starts, indexes, hz = [], [], [], [], [], [], []
+    i_call = 0
+    for z in zooms:
+        level = [p for p in plan if p[0] == z]
+        for i, (_, start, end) in enumerate(level):
+            idx = perms[i_call]
+            feat = features[start:end][None][:, idx.to(features.device)]
+            if z > 1:
+                feat = feat.repeat_interleave(z, 1)
+            starts.append(start)
+            indexes.append(idx)
+            ans, out = inference(model, feat, qf, query, tokenizer, return_list=True)
+            answers.extend(ans)
+            hz.append(z)
+            st = ops.entropy_stats(torch.stack(out["scores"], 1))
+            max_ent.extend(1 / float(e[0]) for e in st)
+            mean_ent.extend(1 / float(e[2]) for e in st)
+            prop = _proposal_rows(ans[0], feat.shape[1], hz, indexes, starts, i, grounding_windows, single)
+            if prop is None:
+                score_cos.append(0)
+            elif prop:
+                sc = ops.topk_cosine(feat[0, prop[0]:prop[-1] + 1], query_cls, min(feat.shape[2], 3))
+                score_cos.extend(float(x) for x in sc.tolist())
+            i_call += 1
+    return dict(answers=answers, starts=starts, indexes=indexes, hierarchy_zooms=hz, max_entropy=max_ent,
+                mean_entropy=mean_ent, score_cos=score_cos, grounding_windows=grounding_windows, plan=plan)
+
+
+def log_record(res, timestamps, batch, num_frames=250, single=True):
+    """The ``info`` dict of the JSONL record (e2e2.py:399-417); ``num_frames_video = args.batch`` as in the reference."""
+    frames, ious = iou(res["answers"], timestamps, num_frames, batch, res["starts"], res["indexes"], single,
+                       res["hierarchy_zooms"], res["grounding_windows"])
+    return {"gt": timestamps, "frames": frames, "iou": ious, "score_cos": res["score_cos"], "mean_entropy": res["mean_entropy"],
+            "max_entropy": res["max_entropy"], "hierarchy_zooms": res["hierarchy_zooms"]}

@@ -1,0 +1,293 @@
+"""The model object of the kept API: what ``load_pretrained_model`` returns and ``inference()`` drives.
+
+Surface follows revisionllm/model/vtimellm_llama.py:23-110 + vtimellm_arch.py:10-147 as far as the inference
+path touches it: ``generate(input_ids, images=, query_feats=, ...)``, ``get_model()`` (-> ``mm_projector``,
+``initialize_vision_modules``, ``config``, adapter flags), ``bfloat16()/cuda()/to()/eval()``, ``device``.
+All arithmetic runs in the HIP engine (revisionllm_amd/engine.py); this file is host orchestration:
+adapter dispatch, building the splice map, the token loop, EOS bookkeeping and output assembly.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from .. import hip, ops
+from ..constants import IMAGE_TOKEN_INDEX, MEMORY_TOKEN_INDEX
+from ..engine import Engine
+from ..utils import synth
+
+
+class GenerateOutput(dict):
+    """dict with attribute access, standing in for HF's ``GenerateDecoderOnlyOutput`` (``out['sequences']``,
+    ``out['scores']`` are what the drivers read: inference.py:62, eval_nlq_retrieval_e2e2.py:356)."""
+    __getattr__ = dict.get
+
+
+class GenerationConfig(SimpleNamespace):
+    pass
+
+
+class _Projector:
+    """Stand-in for ``model.get_model().mm_projector``: callable like the torch module it replaces."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __call__(self, images, query_feats=None, query_mask=None, iteration_step=None):
+        o = self._o
+        if not o.clip_adapter:
+            return o.engine.project_dense(images)
+        feature = "cls" if (o.hierarchy or o.clip_adapter_feature == "cls") else "all"
+        y = o.engine.clip_encoder(images, query_feats, query_mask, feature)
+        if feature == "cls":
+            return y[:, None]
+        return y[:, 1:] if o.clip_adapter_feature == "temporal" else y
+
+
+class _Inner:
+    """``model.get_model()``: adapter topology flags + ``initialize_vision_modules`` (vtimellm_arch.py:12-73)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self.config = owner.config
+        self.clip_adapter = False
+        self.clip_adapter_text = False
+        self.clip_adapter_feature = "cls"
+        self.hierarchy = False
+        self.pretrain_clip_adapter = None
+        self.mm_projector = None
+
+    @property
+    def engine(self):
+        return self._owner.engine
+
+    def initialize_vision_modules(self, model_args, state_dict=None):
+        """Select the adapter topology from the duck-typed args namespace (same fields as the reference reads)
+        and bind its weights.  ``state_dict`` (adapter-relative names) overrides the ``pretrain_*`` files."""
+        from . import builder
+        a = model_args
+        assert not getattr(a, "clip_adapter", False) or not getattr(a, "cross_attn", False), \
+            "both clip_adapter and cross_attn cannot be true"
+        if getattr(a, "cross_attn", False):
+            raise NotImplementedError("the separate cross_attn module (chapters variant, vtimellm_arch.py:52-71) is not built yet")
+        self.clip_adapter = bool(getattr(a, "clip_adapter", False))
+        self.clip_adapter_text = bool(getattr(a, "clip_adapter_text", False))
+        self.clip_adapter_feature = getattr(a, "clip_adapter_feature", "cls")
+        if not isinstance(self.clip_adapter_feature, str):  # e2e2.py:72 declares it type=bool
+            self.clip_adapter_feature = "cls"
+        self.hierarchy = bool(getattr(a, "hierarchy", False))
+        self.pretrain_clip_adapter = getattr(a, "pretrain_clip_adapter", None)
+        if self.clip_adapter_feature == "alternate":
+            raise NotImplementedError("clip_adapter_feature='alternate' needs iteration_step (training-time only)")
+        eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text)
+        if state_dict is None:
+            path = self.pretrain_clip_adapter if self.clip_adapter else getattr(a, "pretrain_mm_mlp_adapter", None)
+            if path is not None:
+                state_dict = builder.remap_projector_keys(torch.load(path, map_location="cpu"), clip=self.clip_adapter)
+        if state_dict is not None:
+            if self.clip_adapter:
+                eng.load_clip_adapter(lambda n: state_dict[n])
+            else:
+                eng.load_linear_projector(lambda n: state_dict[n])
+        self.mm_projector = _Projector(self)
+
+
+class ReVisionLlamaForCausalLM:
+    """Drop-in for ``VTimeLLMLlamaForCausalLM`` on the inference path."""
+
+    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, device="cuda:0", max_sequence_length=None):
+        self.shape = shape
+        self.config = SimpleNamespace(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
+                                      num_attention_heads=shape.heads, vocab_size=shape.vocab, rms_norm_eps=shape.eps,
+                                      rope_theta=shape.theta, model_type="VTimeLLM", pad_token_id=0, bos_token_id=1, eos_token_id=2)
+        if max_sequence_length is not None:
+            self.config.max_sequence_length = max_sequence_length
+        self.generation_config = GenerationConfig(top_k=50, top_p=1.0, temperature=1.0, eos_token_id=2, pad_token_id=0)
+        self._device = torch.device(device)
+        self.engine = None
+        self.model = _Inner(self)
+        self.scores_mode = "processed"  # what transformers>=4.39 returns; "raw" = the override's intent (vtimellm_llama.py:321)
+        self.dtype = torch.bfloat16
+        self.uniform_fn = None  # optional (step, B) -> uniforms hook for reproducible sampling through inference()
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _ensure_engine(self, adapter_text=None):
+        if self.engine is None:
+            self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device)
+        elif adapter_text is not None and bool(adapter_text) != self.engine.adapter_text:
+            raise RuntimeError("adapter topology was already fixed for this model")
+        return self.engine
+
+    def get_model(self):
+        return self.model
+
+    @property
+    def device(self):
+        return self._device
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def bfloat16(self):
+        return self
+
+    def half(self):
+        return self
+
+    def float(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        """Weights live in HBM as bf16 with fp32 accumulation / residual stream; dtype moves are accepted and ignored."""
+        return self
+
+    # ---- adapter dispatch (vtimellm_arch.py:102-147) ---------------------------------------------
+    def encode_images(self, images, query_feats):
+        """-> (video_rows f32 [R,D], rows_per_sample).  hierarchy: [b,v,t,d] -> v rows per sample;
+        ClipEncoder: [b,t,d] -> 1 (cls) / t (temporal) rows; Linear: [b,t,d] -> t rows."""
+        m = self.model
+        eng = self.engine
+        if isinstance(images, (list, tuple)):
+            images = torch.cat(list(images), dim=0)
+        if not m.clip_adapter:
+            y = eng.project_dense(images)
+            return y.reshape(-1, self.shape.hidden), images.shape[1]
+        qf, qm = (query_feats[0], query_feats[1]) if query_feats is not None else (None, None)
+        if m.hierarchy:
+            b, v, t, d = images.shape
+            y = eng.clip_encoder(images.reshape(b * v, t, d), qf, qm, "cls")
+            return y, v
+        if m.clip_adapter_feature == "temporal":
+            y = eng.clip_encoder(images, qf, qm, "all")[:, 1:]
+            return y.reshape(-1, self.shape.hidden), images.shape[1]
+        return eng.clip_encoder(images, qf, qm, "cls"), 1
+
+    @staticmethod
+    def build_row_map(input_ids, rows_per_sample, attention_mask=None):
+        """Splice plan (vtimellm_arch.py:149-238): int32 [B,S]; >= 0 token id, < 0 -> video row -(v+1).
+        Sample b consumes video rows [b*rows_per_sample, (b+1)*rows_per_sample) at its -200 slot."""
+        ids = input_ids.cpu().tolist()
+        mask = attention_mask.cpu().tolist() if attention_mask is not None else None
+        out = []
+        for b, row in enumerate(ids):
+            if mask is not None:
+                row = [t for t, m in zip(row, mask[b]) if m]
+            if MEMORY_TOKEN_INDEX in row:
+                raise NotImplementedError("visual_memory / <memory> prompts (training-time streaming memory) are not built")
+            r, used = [], 0
+            for t in row:
+                if t == IMAGE_TOKEN_INDEX:
+                    if used:
+                        raise NotImplementedError("more than one <video> per sample")
+                    r.extend(-(b * rows_per_sample + i + 1) for i in range(rows_per_sample))
+                    used = 1
+                else:
+                    r.append(t)
+            out.append(r)
+        if len({len(r) for r in out}) != 1:
+            raise NotImplementedError("ragged batches: every row of a generate() call must have the same length "
+                                      "(inference() repeats one prompt, inference.py:36)")
+        return torch.tensor(out, dtype=torch.int32)
+
+    # ---- generate ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids, images=None, query_feats=None, do_sample=False, temperature=None, num_beams=1,
+                 max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
+                 return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
+                 attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None, **kwargs):
+        """Prefill + KV-cached sampling loop (inference.py:45-59 kwargs).
+
+        Extra, build-defined kwargs: ``uniforms`` [G,B] (host-supplied draws for reproducible sampling; default
+        ``torch.rand`` on the device), ``forced_tokens`` [G,B] (teacher forcing for parity tests),
+        ``video_rows`` / ``rows_per_sample`` (pre-encoded adapter output, used by the batched recursion).
+        ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
+        """
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not on the grounding path (num_beams=1, inference.py:51)")
+        if visual_memory is not None or prefix_memory is not None:
+            raise NotImplementedError("visual_memory / prefix_memory (streaming-memory variant) are not built")
+        eng = self._ensure_engine()
+        gc = self.generation_config
+        temperature = gc.temperature if temperature is None else temperature
+        top_k = gc.top_k if top_k is None else top_k
+        top_p = gc.top_p if top_p is None else top_p
+        max_new_tokens = 20 if max_new_tokens is None else max_new_tokens
+        eos, pad = gc.eos_token_id, gc.pad_token_id
+        dev = eng.device
+
+        if video_rows is None:
+            if images is None:
+                video_rows, rows_per_sample = None, 0
+            else:
+                video_rows, rows_per_sample = self.encode_images(images, query_feats)
+        row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
+        B, S = row_map.shape
+        h = eng.splice_embed(row_map, video_rows)
+
+        cap = min(max_new_tokens, 64)
+        kv, Smax = eng.new_kv(B, S + cap)
+        logits = eng.llm_forward(h, 0, kv, Smax)
+
+        seqs = input_ids.to(dev).long()
+        unfinished = torch.ones(B, dtype=torch.long, device=dev)
+        raw_steps, score_steps, ent_p, ent_r, new_tokens = [], [], [], [], []
+        pos = S
+        for step in range(max_new_tokens):
+            if do_sample:
+                if uniforms is not None:
+                    u = uniforms[step].to(dev).float().contiguous()
+                elif self.uniform_fn is not None:
+                    u = self.uniform_fn(step, B).to(dev).float().contiguous()
+                else:
+                    u = torch.rand(B, device=dev)
+                o = ops.sample(logits, u, True, temperature, top_k, top_p)
+            else:
+                o = ops.sample(logits, None, False)
+            nxt = o["tokens"].long() if forced_tokens is None else forced_tokens[step].to(dev).long()
+            ent_p.append(o["entropy_proc"])
+            ent_r.append(o["entropy_raw"])
+            if output_logits or (output_scores and (not do_sample or self.scores_mode == "raw")):
+                raw_steps.append(logits.clone())
+            if output_scores and do_sample and self.scores_mode == "processed":
+                V = logits.shape[1]
+                sc = torch.full((B, V + 1), float("-inf"), device=dev)      # column V swallows the dropped candidates
+                keep = torch.arange(hip.TOPK_CAP, device=dev)[None] < o["n_keep"][:, None]
+                idx = torch.where(keep, o["topk_idx"], torch.full_like(o["topk_idx"], V)).long()
+                score_steps.append(sc.scatter(1, idx, o["topk_val"])[:, :V].contiguous())
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+            new_tokens.append(nxt)
+            if eos is not None:
+                unfinished = unfinished * (nxt != eos).long()
+            if step == max_new_tokens - 1 or int(unfinished.max()) == 0:
+                break
+            if pos + 1 > Smax:
+                kv, Smax = self._grow_kv(kv, B, Smax, min(S + max_new_tokens, Smax * 2))
+            h1 = eng.splice_embed(nxt.int()[:, None], None)
+            logits = eng.llm_forward(h1, pos, kv, Smax)
+            pos += 1
+
+        seqs = torch.cat([seqs, torch.stack(new_tokens, dim=1)], dim=1)
+        if not return_dict_in_generate:
+            return seqs
+        out = GenerateOutput(sequences=seqs, entropy=torch.stack(ent_p, 1), entropy_raw=torch.stack(ent_r, 1))
+        if output_scores:
+            out["scores"] = tuple(score_steps) if (do_sample and self.scores_mode == "processed") else tuple(raw_steps)
+        if output_logits:
+            out["logits"] = tuple(raw_steps)
+        return out
+
+    def _grow_kv(self, kv, B, Smax, new_smax):
+        s = self.shape
+        new, new_smax = self.engine.new_kv(B, new_smax)
+        half_old, half_new = kv.numel() // 2, new.numel() // 2
+        k_old = kv[:half_old].view(s.layers, B, s.heads, Smax, s.head_dim)
+        v_old = kv[half_old:].view(s.layers, B, s.heads, s.head_dim, Smax)
+        new[:half_new].view(s.layers, B, s.heads, new_smax, s.head_dim)[:, :, :, :Smax] = k_old
+        new[half_new:].view(s.layers, B, s.heads, s.head_dim, new_smax)[..., :Smax] = v_old
+        return new, new_smax
+
+
+#: the reference's class name, so ``from revisionllm.model import VTimeLLMLlamaForCausalLM`` keeps working
+VTimeLLMLlamaForCausalLM = ReVisionLlamaForCausalLM

@@ -1,0 +1,126 @@
+"""Segment-parallel stage-2 recursion: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The path shards naturally: adapter encodings are independent per (segment, query) and LLM calls are
+independent of each other.  Two real exchange steps, both tiny and latency-bound (so plain all-gathers, no ring
+tuning): (1) all-gather of the per-window CLS rows [W/R, D] (+ the [W/R] cosine scores) so every rank can build
+any call's video rows, (2) all-gather of the per-call proposals (token ids + entropy statistics).  Weights are
+replicated.  Every rank ends with the identical record, bit-for-bit equal to the 1-rank result because each CLS
+row and each call is computed by exactly one rank with the same kernels.
+
+The compute stages are injectable (``stages=``) so the sharding / gather logic is covered by world_size-2 gloo
+tests on CPU with stand-in stages; the defaults are the HIP stages of revisionllm_amd.eval.stage2.
+"""
+import torch
+import torch.distributed as dist
+
+from .eval import stage2
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block partition of ``n`` items: rank r owns [lo, hi); sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def deal(n_items, rank, world):
+    """Round-robin deal of call indices (keeps the zoom levels, which have different costs, spread over ranks)."""
+    return list(range(rank, n_items, world))
+
+
+def allgather_rows(local, n_total, group=None):
+    """All-gather a block-partitioned [n_local, ...] tensor into [n_total, ...] (blocks padded to equal size)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    per = -(-n_total // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        parts.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def allgather_calls(results, n_calls, max_tokens, device, group=None):
+    """All-gather {call: (tokens, ent_max, ent_mean)} dealt round-robin -> the full dict on every rank.
+    Wire format per call: int32 [2 + max_tokens] = (call id, n_tokens, tokens...) and f32 [2]."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return dict(results)
+    per = -(-n_calls // world)
+    tok = torch.full((per, 2 + max_tokens), -1, dtype=torch.int32, device=device)
+    ent = torch.zeros((per, 2), dtype=torch.float32, device=device)
+    for j, (c, (t, emax, emean)) in enumerate(sorted(results.items())):
+        if len(t) > max_tokens:
+            raise ValueError(f"call {c} generated {len(t)} tokens > wire capacity {max_tokens}")
+        tok[j, 0], tok[j, 1] = c, len(t)
+        tok[j, 2:2 + len(t)] = torch.tensor(t, dtype=torch.int32)
+        ent[j, 0], ent[j, 1] = emax, emean
+    tok_all = torch.empty((world * per, 2 + max_tokens), dtype=torch.int32, device=device)
+    ent_all = torch.empty((world * per, 2), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(tok_all, tok, group=group)
+    dist.all_gather_into_tensor(ent_all, ent, group=group)
+    tok_all, ent_all = tok_all.cpu(), ent_all.cpu()
+    out = {}
+    for j in range(tok_all.shape[0]):
+        c = int(tok_all[j, 0])
+        if c >= 0:
+            n = int(tok_all[j, 1])
+            out[c] = (tok_all[j, 2:2 + n].tolist(), float(ent_all[j, 0]), float(ent_all[j, 1]))
+    return out
+
+
+class HipStages:
+    """The device stages of the recursion on the HIP engine (revisionllm_amd.eval.stage2)."""
+
+    def __init__(self, model, tokenizer):
+        self.model, self.tokenizer = model, tokenizer
+
+    def encode(self, features, query_feats):
+        return stage2.encode_windows(self.model, features, query_feats)
+
+    def cosine(self, features, query_cls):
+        return stage2.window_cosine(features, query_cls)
+
+    def generate(self, query, rows, calls, uniforms, max_new_tokens):
+        return stage2.generate_calls(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens)
+
+
+def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
+                      perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Stage-2 recursion over ``W`` windows with the windows block-partitioned over the ranks of ``group``.
+
+    ``features_local`` [hi-lo, T, 768] are this rank's windows (``shard_bounds(W, rank, world)``).  ``perms`` and
+    ``uniforms`` must be identical on all ranks (derive them from a shared seed).  Returns the same record as
+    ``stage2.run_query`` on every rank.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(W, rank, world)
+    assert features_local.shape[0] == hi - lo, f"rank {rank} must hold windows [{lo},{hi})"
+    zooms = tuple(zooms)
+    plan = stage2.plan_groups(W, batch, zooms)
+    if perms is None:
+        raise ValueError("perms must be given (identical on all ranks); use stage2.make_perms with a seeded generator")
+    perms = [torch.as_tensor(p).long() for p in perms]
+    if grounding_windows is None:
+        grounding_windows = list(range(W))
+    query = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
+
+    cls_local = stages.encode(features_local, query_feats)
+    cos_local = stages.cosine(features_local, query_cls)
+    if world > 1:
+        cls = allgather_rows(cls_local, W, group)          # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
+        cos = allgather_rows(cos_local[:, None], W, group)[:, 0]
+    else:
+        cls, cos = cls_local, cos_local
+    rows = stage2.build_call_rows(cls, plan, perms)
+    mine = deal(len(plan), rank, world)
+    res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
+    if world > 1:
+        res = allgather_calls(res, len(plan), max_new_tokens, cls.device, group)   # exchange 2: proposals
+    return stage2.assemble(plan, perms, res, cos.cpu(), tokenizer, zooms, grounding_windows, single)
