@@ -11,14 +11,17 @@
 
 namespace {
 
-template <int DH>
+// SPLIT (Lq <= 16, i.e. KV-cached decode): the block's 4 waves share the same 16 queries and take key blocks
+// w, w+4, ...; their (m, l, O) partials are merged through LDS.  A decode step is pure latency (one wave would
+// walk all keys serially), so this cuts it ~4x.
+template <int DH, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int NC = DH / 32, ND = DH / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = SPLIT ? blockIdx.x * 16 : blockIdx.x * 64 + wave * 16;
     if (q0 >= a.Lq) return;
     const int kb_ = b / a.kv_div;
 
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int qpos = a.q_pos0 + q0 + fr;
     const int kend = a.causal ? min(a.Lk, a.q_pos0 + q0 + 16) : a.Lk;
 
-    for (int k0 = 0; k0 < kend; k0 += 32) {
+    for (int k0 = SPLIT ? wave * 32 : 0; k0 < kend; k0 += SPLIT ? 128 : 32) {
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -93,6 +96,42 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
+    if constexpr (SPLIT) {
+        __shared__ float sm_m[4][16], sm_l[4][16];
+        __shared__ __attribute__((aligned(16))) float sm_o[4][16][DH + 4];
+        if (g == 0) {
+            sm_m[wave][fr] = m_run;
+            sm_l[wave][fr] = l_run;
+        }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) *(f32x4*)&sm_o[wave][fr][dt * 16 + g * 4] = o[dt];
+        __syncthreads();
+        // 256 threads: thread t -> query t / 16, d-chunk (t % 16) * (DH / 16)
+        const int q = threadIdx.x >> 4, dc = (threadIdx.x & 15) * (DH / 16);
+        if (q0 + q >= a.Lq) return;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm_m[w][q]);
+        float sc[4], lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sc[w] = sm_m[w][q] == -INFINITY ? 0.f : __expf(sm_m[w][q] - mm);
+            lt += sm_l[w][q] * sc[w];
+        }
+        const float inv = 1.0f / lt;
+        bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + q) * a.o_rs + h * DH + dc;
+#pragma unroll
+        for (int j = 0; j < DH / 16; j += 2) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                v0 += sm_o[w][q][dc + j] * sc[w];
+                v1 += sm_o[w][q][dc + j + 1] * sc[w];
+            }
+            *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
+        }
+        return;
+    }
     if (q0 + fr >= a.Lq) return;
     const float inv = 1.0f / l_run;
     bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
@@ -109,11 +148,16 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
-    dim3 grid((unsigned)cdiv(a.Lq, 64), (unsigned)a.H, (unsigned)a.B);
-    if (a.dh == 96)
-        hipLaunchKernelGGL(attn_kernel<96>, grid, dim3(256), 0, st, a);
+    const bool split = a.Lq <= 16;
+    dim3 grid((unsigned)cdiv(a.Lq, split ? 16 : 64), (unsigned)a.H, (unsigned)a.B);
+    if (a.dh == 96 && !split)
+        hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a);
+    else if (a.dh == 96)
+        hipLaunchKernelGGL((attn_kernel<96, true>), grid, dim3(256), 0, st, a);
+    else if (a.dh == 128 && !split)
+        hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, st, a);
     else if (a.dh == 128)
-        hipLaunchKernelGGL(attn_kernel<128>, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, st, a);
     else {
         rv_set_error("attention: head dim %d unsupported (96, 128)", a.dh);
         return RV_ERR_ARG;

@@ -313,7 +313,7 @@ extern "C" size_t rv_kv_bytes(const rv_ctx* c, int32_t B, int32_t Smax) {
 namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
-    float* qkv32;
+    float *qkv32, *cs;
     size_t bytes;
 };
 LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
@@ -326,6 +326,7 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.a16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)B * D * 2);
+    w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.bytes = k.off;
     return w;
 }
@@ -355,13 +356,14 @@ extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t
     bf16_t* kbase = (bf16_t*)kv;
     bf16_t* vbase = kbase + (int64_t)g.layers * per_layer;
     const float scale = 1.0f / sqrtf((float)dh);
+    RV_TRY(k_rope_table(w.cs, S, pos0, dh, g.rope_theta, st));
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
         RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, st));
-        RV_TRY(k_rope_kv(w.qkv32, w.q16, kc, vtc, M, S, pos0, H, dh, Smax, g.rope_theta, st));
+        RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, M, S, pos0, H, dh, Smax, st));
         AttnArgs a{w.q16, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                    (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
         RV_TRY(k_attention(a, st));

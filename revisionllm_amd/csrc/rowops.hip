@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// ---- RMSNorm (HF LlamaRMSNorm), one wave per row, two passes (second pass served by L1/L2) ----
+// ---- RMSNorm (HF LlamaRMSNorm), one wave per row.  NV > 0: row (NV*256 wide) held in registers, all loads issued
+// up front (decode calls have a handful of rows, so the kernel is pure latency); NV == 0: generic two-pass loop ----
+template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
                                                       const float* __restrict__ w, bf16_t* __restrict__ y, int64_t rows,
                                                       int d, float eps) {
@@ -59,16 +61,33 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * x_row_stride;
-    float s = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c);
-        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    }
-    const float r = rsqrtf(wave_sum(s) / (float)d + eps);
-    for (int c = lane * 4; c < d; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
-        *(u32x2*)(y + row * d + c) =
-            u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
+    if constexpr (NV > 0) {
+        f32x4 v[NV], ww[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+            ww[i] = *(const f32x4*)(w + i * 256 + lane * 4);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        const float r = rsqrtf(wave_sum(s) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *(u32x2*)(y + row * d + i * 256 + lane * 4) = u32x2{pack_bf16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)),
+                                                                 pack_bf16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
+    } else {
+        float s = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            const f32x4 v = *(const f32x4*)(xr + c);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        const float r = rsqrtf(wave_sum(s) / (float)d + eps);
+        for (int c = lane * 4; c < d; c += 256) {
+            const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
+            *(u32x2*)(y + row * d + c) =
+                u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
+        }
     }
 }
 
@@ -157,20 +176,31 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }
 
 // ---- RoPE (rotate_half) + KV-cache append.  qkv f32 [M,3D]; row m = b*S + s at position pos0 + s. ----
+// cs: (cos, sin) table [S][dh/2] for positions pos0..pos0+S-1, built once per forward (shared by all layers).
+__global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int dh, float theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dh / 2;
+    if (i >= S * half) return;
+    const int s = i / half, j = i % half;
+    const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)dh);
+    const float ang = (float)(pos0 + s) * inv;
+    cs[i] = make_float2(cosf(ang), sinf(ang));
+}
+
 // q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated; v -> vtc [B,H,dh,Smax] (transposed).
-__global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ q16,
-                                                      bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc, int S, int pos0,
-                                                      int H, int dh, int Smax, float theta) {
+__global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ qkv, const float2* __restrict__ cs,
+                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc,
+                                                      bf16_t* __restrict__ vtc, int S, int pos0, int H, int dh, int Smax) {
     const int64_t m = blockIdx.x;
     const int b = (int)(m / S), s = (int)(m % S);
     const int pos = pos0 + s;
     const int D = H * dh, half = dh / 2;
     const float* row = qkv + m * 3 * (int64_t)D;
+    const float2* csr = cs + (int64_t)s * half;
     for (int i = threadIdx.x; i < H * half; i += 256) {
         const int h = i / half, j = i % half;
-        const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)dh);
-        const float ang = (float)pos * inv;
-        const float c = cosf(ang), sn = sinf(ang);
+        const float2 t = csr[j];
+        const float c = t.x, sn = t.y;
         const float q1 = row[h * dh + j], q2 = row[h * dh + j + half];
         q16[m * D + h * dh + j] = f32_to_bf16(q1 * c - q2 * sn);
         q16[m * D + h * dh + j + half] = f32_to_bf16(q2 * c + q1 * sn);
@@ -231,7 +261,13 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st) {
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm: bad arguments");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+    const dim3 grid((unsigned)cdiv(rows, 4));
+    if (d == 4096)
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+    else if (d == 512)
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
     RV_CHECK_LAUNCH("rmsnorm");
     return RV_OK;
 }
@@ -279,10 +315,16 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
     return RV_OK;
 }
 
-int k_rope_kv(const float* qkv, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh, int Smax,
-              float theta, hipStream_t st) {
-    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (bf16_t*)q16, (bf16_t*)kc, (bf16_t*)vtc, S, pos0, H,
-                       dh, Smax, theta);
+int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)cdiv((int64_t)S * (dh / 2), 256)), dim3(256), 0, st, (float2*)cs, S, pos0, dh, theta);
+    RV_CHECK_LAUNCH("rope_table");
+    return RV_OK;
+}
+
+int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
+              int Smax, hipStream_t st) {
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc,
+                       (bf16_t*)vtc, S, pos0, H, dh, Smax);
     RV_CHECK_LAUNCH("rope_kv");
     return RV_OK;
 }

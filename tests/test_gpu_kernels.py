@@ -132,12 +132,13 @@ def _ref_attn(q, k, v, causal, pad, q_pos0, kv_div):
     return torch.einsum("bhqk,bkhd->bqhd", p, v.double()).reshape(B, Lq, H * dh)
 
 
-@pytest.mark.parametrize("case", ["self96", "cross96", "causal128", "decode128", "long96"])
+@pytest.mark.parametrize("case", ["self96", "cross96", "causal128", "decode128", "long96", "split96", "split128"])
 def test_attention(dev, case):
     from revisionllm_amd import ops
     cfg = {"self96": (3, 3, 257, 257, 8, 96, False, False, 0), "cross96": (6, 2, 50, 13, 8, 96, False, True, 0),
            "causal128": (2, 2, 171, 171, 4, 128, True, False, 0), "decode128": (3, 3, 1, 173, 4, 128, True, False, 172),
-           "long96": (1, 1, 1025, 1025, 8, 96, False, False, 0)}[case]
+           "long96": (1, 1, 1025, 1025, 8, 96, False, False, 0), "split96": (4, 2, 9, 77, 8, 96, False, True, 0),
+           "split128": (2, 2, 16, 300, 4, 128, True, False, 284)}[case]
     B, Bk, Lq, Lk, H, dh, causal, use_pad, q_pos0 = cfg
     q = feats(f"at.q.{case}", (B, Lq, H, dh), bf16=True)
     k = feats(f"at.k.{case}", (Bk, Lk, H, dh), bf16=True)

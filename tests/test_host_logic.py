@@ -1,0 +1,141 @@
+"""CPU tests of the host side of the kept API: prompt / tokenisation, driver index arithmetic (bit-exact against the
+reference's own functions via tests/golden/g9_driver.json), checkpoint-loader key rules and LoRA merge, the splice
+plan, and that the C-ABI library loads and exports every symbol the header declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recursion
+from revisionllm_amd import hip, mm_utils
+from revisionllm_amd.conversation import SeparatorStyle, conv_templates
+from revisionllm_amd.eval import stage2
+from revisionllm_amd.model import builder
+from revisionllm_amd.model.adapter import pad_sequences_1d
+from revisionllm_amd.model.revision_llama import ReVisionLlamaForCausalLM
+from revisionllm_amd.utils import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_prompt_and_tokenizer_image_token(golden):
+    c = golden.json("g9_driver")
+    tok = synth.FakeTokenizer()
+    conv = conv_templates["v1"].copy()
+    conv.append_message(conv.roles[0], "<video>\nDuring which video can we see a man?")
+    conv.append_message(conv.roles[1], None)
+    assert conv.get_prompt() == c["prompt"]
+    assert conv.sep_style == SeparatorStyle.TWO and conv.sep2 == c["sep2"]
+    ids = mm_utils.tokenizer_image_token(conv.get_prompt(), tok)
+    assert ids == c["prompt_ids"] and ids.count(-200) == 1 and ids[0] == 1 and ids.count(1) == 1
+    conv = conv_templates["v1"].copy()
+    conv.append_message(conv.roles[0], "<video>\nDuring which video can we see a man?<memory>")
+    conv.append_message(conv.roles[1], None)
+    mem = mm_utils.tokenizer_image_token(conv.get_prompt(), tok)
+    assert mem == c["prompt_mem_ids"] and mem.count(-300) == 1
+    t = mm_utils.tokenizer_image_token(conv_templates["v1"].system + " <video> x", tok, return_tensors="pt")
+    assert t.dtype == torch.int64
+    with pytest.raises(ValueError):
+        mm_utils.tokenizer_image_token("a <video> b", tok, return_tensors="np")
+    # templates are not mutated by use
+    assert conv_templates["v1"].messages == []
+
+
+def test_stage2_index_math_matches_reference(golden):
+    c = golden.json("g9_driver")
+    got = [stage2.get_ground_truth_windows(1000, 1010, 6000), stage2.get_ground_truth_windows(0.0, 3.2, 95.5),
+           stage2.get_ground_truth_windows(5399.1, 5400.0, 5400.0)]
+    assert [[list(a), b] for a, b in got] == c["gt_windows"]
+    for s in c["stage2"]:
+        plan = stage2.plan_groups(s["W"], s["batch"])
+        assert [p[1] for p in plan] == s["starts"] and [p[0] for p in plan] == s["zooms"]
+        assert all(e - st == s["batch"] // z for z, st, e in plan)
+        frames, hit = stage2.iou(s["answers"], s["gt"], 250, s["batch"], s["starts"], s["indexes"], True, s["zooms"],
+                                 list(range(s["W"])))
+        assert {str(k): list(v) for k, v in frames.items()} == s["frames"] and hit == s["hit"]
+
+
+def test_cut_windows():
+    for ctx_l in (626, 1000, 5400, 18000, 36123):
+        times, idx = stage2.cut_windows(ctx_l)
+        t2, i2 = recursion.stage2_windows(ctx_l)
+        assert times == t2 and (idx == np.stack(i2)).all() and idx.dtype == np.int32
+        assert idx.min() >= 0 and idx.max() <= ctx_l - 1 and idx.shape[1] == 250
+    assert stage2.cut_windows(100)[1].shape[0] == 0        # shorter than one stride: no window (empty input)
+
+
+def test_pad_sequences_1d():
+    a, m = pad_sequences_1d([torch.ones(3, 4), torch.ones(1, 4)], dtype=torch.float32)
+    assert a.shape == (2, 3, 4) and m.tolist() == [[1, 1, 1], [1, 0, 0]] and a[1, 1:].abs().sum() == 0
+    a, m = pad_sequences_1d([[1, 2, 3], [4]], dtype=np.float32)
+    assert a.shape == (2, 3) and m.dtype == np.float32
+    a, m = pad_sequences_1d([torch.ones(2, 4)], dtype=torch.float32, fixed_length=5)
+    assert a.shape == (1, 5, 4) and m.sum() == 2
+
+
+def test_row_map():
+    ids = torch.tensor([[1, 5, -200, 7], [1, 6, -200, 8]])
+    m = ReVisionLlamaForCausalLM.build_row_map(ids, 3)
+    assert m.tolist() == [[1, 5, -1, -2, -3, 7], [1, 6, -4, -5, -6, 8]] and m.dtype == torch.int32
+    with pytest.raises(NotImplementedError, match="ragged"):
+        ReVisionLlamaForCausalLM.build_row_map(torch.tensor([[1, 5, -200, 7], [1, 6, 9, 8]]), 3)
+    m = ReVisionLlamaForCausalLM.build_row_map(torch.tensor([[1, 5, -200, 0]]), 2, attention_mask=torch.tensor([[1, 1, 1, 0]]))
+    assert m.tolist() == [[1, 5, -1, -2]]
+
+
+def test_loader_key_rules_and_lora_merge():
+    sd = {"base_model.model.model.mm_projector.encoder.layers.0.linear1.weight": 1, "base_model.model.lm_head.weight": 2}
+    out = builder.strip_trainable_prefixes(sd)
+    assert set(out) == {"model.mm_projector.encoder.layers.0.linear1.weight", "lm_head.weight"}
+    w = {"model.mm_projector.encoder.layers.0.linear1.weight": 1, "model.mm_projector.mm_projector.weight": 2,
+         "model.mm_projector.global_rep_token": 3}
+    r = builder.remap_projector_keys(w, clip=True)
+    assert set(r) == {"encoder.layers.0.linear1.weight", "mm_projector.weight", "global_rep_token"}
+    r = builder.remap_projector_keys({"model.mm_projector.weight": 1, "model.mm_projector.bias": 2, "other": 3}, clip=False)
+    assert set(r) == {"weight", "bias"}
+    torch.manual_seed(0)
+    base = {"model.layers.0.self_attn.q_proj.weight": torch.randn(8, 8)}
+    w0 = base["model.layers.0.self_attn.q_proj.weight"].clone()
+    A, B = torch.randn(2, 8), torch.randn(8, 2)
+    lora = {"base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight": A,
+            "base_model.model.model.layers.0.self_attn.q_proj.lora_B.default.weight": B}
+    builder.merge_lora(base, lora, alpha=128, r=64)
+    assert torch.allclose(base["model.layers.0.self_attn.q_proj.weight"], w0 + 2.0 * B @ A, atol=1e-6)
+    with pytest.raises(KeyError):
+        builder.merge_lora({}, lora, 1, 1)
+
+
+def test_abi_exports_every_declared_symbol():
+    """include/revision_hip.h <-> the built library <-> the ctypes table must agree (loads on CPU, no compute)."""
+    header = open(os.path.join(ROOT, "include", "revision_hip.h")).read()
+    declared = set(re.findall(r"\b(rv_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    if not os.path.exists(hip.LIB_PATH):
+        from revisionllm_amd import build
+        build.build_library()
+    h = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(h, name), name
+    assert hip.lib().rv_abi_version() == 1
+    # argument validation runs on the host before any launch
+    assert hip.lib().rv_gemm(None, 0, None, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None) < 0
+    assert "null operand" in hip.last_error()
+
+
+def test_product_has_no_cpu_fallback():
+    from revisionllm_amd import ops
+    with pytest.raises(hip.HipLibraryError, match="no CPU path|device tensors"):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+    if not torch.cuda.is_available():
+        from revisionllm_amd.engine import Engine
+        with pytest.raises(hip.HipLibraryError, match="no GPU"):
+            Engine(synth.TINY)
+    # the product never imports the oracle
+    import subprocess
+    import sys
+    code = "import sys; import revisionllm_amd, revisionllm_amd.parallel, revisionllm_amd.eval.stage2, revisionllm_amd.inference; " \
+           "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
