@@ -69,7 +69,7 @@ def roofline_legs(model, n_calls, S):
     x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
     w = eng.weight("llm.L0.wgu")
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
-    ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out), 20)
+    ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
     legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile<bf16,SILU_MUL>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
                                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops)
@@ -81,7 +81,7 @@ def roofline_legs(model, n_calls, S):
     state = {"i": 0}
 
     def gemv():
-        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs)
+        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True)
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter

@@ -34,6 +34,7 @@ extern "C" {
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
 typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
 typedef enum { RV_ACT_NONE = 0, RV_ACT_RELU = 1, RV_ACT_SILU_MUL = 2 } rv_act;
+typedef enum { RV_W_ROWMAJOR = 0, RV_W_PACKED = 1 } rv_wlayout;
 /* ClipEncoder output selection, revisionllm/model/adapter/transformer.py:134-145 */
 typedef enum { RV_FEAT_CLS = 0, RV_FEAT_ALL = 2 } rv_feature;
 
@@ -54,7 +55,8 @@ int rv_last_error(char* buf, size_t n);
 /* ---- context + weights ------------------------------------------------------------------- */
 int rv_ctx_create(const rv_config* cfg, rv_ctx** out);
 void rv_ctx_destroy(rv_ctx* ctx);
-/* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout"):
+/* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout").  Every bf16 MATRIX
+ * except llm.embed is fragment-packed (rv_gemm w_layout 1); vectors are plain f32:
  *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows); llm.L{i}.wo [D,D];
  *   llm.L{i}.wgu [2F,D] bf16, gate/up interleaved in 16-row blocks; llm.L{i}.wdown [D,F];
  *   llm.L{i}.norm1 / norm2 [D] f32; llm.norm [D] f32; llm.lm_head [V,D] bf16;
@@ -69,10 +71,13 @@ int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, floa
 
 /* ---- building blocks (exported for the unit parity tests; the engine calls the same kernels) -- */
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]     (nn.Linear semantics)
- * A, W bf16 row-major (lda/ldw in elements), bias f32 or NULL, residual f32 (ldr) or NULL,
- * out dtype RV_BF16 or RV_F32 (ldc).  RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and
- * the output has N/2 columns.  K % 64 == 0.  M <= 16 takes the weight-streaming (decode) kernel. */
-int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+ * A bf16 row-major (lda in elements).  W bf16: w_layout 0 = row-major [N,K] (ldw), w_layout 1 = fragment-packed
+ * (RV_W_PACKED, what rv_weights_bind expects for every matrix):
+ *     Wp[(((n>>4)*(K/32) + (k>>5))*64 + (n&15) + 16*((k>>3)&3))*8 + (k&7)]      (N % 16 == 0)
+ * bias f32 or NULL, residual f32 (ldr) or NULL (may alias C), out dtype RV_BF16 or RV_F32 (ldc).
+ * RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and the output has N/2 columns.  K % 64 == 0.
+ * M <= 16 takes the weight-streaming (decode) kernel. */
+int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
 /* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
  * x f32 [rows,d]; any of y_f32 / y_bf16 / y_pos_bf16 may be NULL; y_pos = bf16(y + pos[row % period]). */

@@ -8,6 +8,13 @@
 //   gemv_stream M <= 16 (KV-cached decode): weight-streaming; W fragments go HBM -> VGPR directly
 //               (each weight byte is used once, an LDS round trip is pure overhead), 8 waves split K,
 //               cross-wave reduction in LDS.  HBM-bound: algorithmic bytes = N*K*2.
+// Weight layout.  W may be row-major [N,K] (w_layout 0) or FRAGMENT-PACKED (w_layout 1, what the engine binds):
+//   Wp[(((n>>4) * (K/32) + (k>>5)) * 64 + lane) * 8 + (k&7)],  lane = (n&15) + 16*((k>>3)&3)
+// i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block in exactly the lane order the
+// 16x16x32 MFMA wants.  A wave-wide 16-byte load then reads 1 KiB of consecutive HBM (8 full 128-B lines) - the
+// decode kernel streams weights perfectly coalesced - and the prefill kernel's LDS-DMA drops fragments into LDS
+// already in read order (conflict-free ds_read_b128, no swizzle).  Row blocks of 16 stay contiguous, so row-range
+// views (q/k/v slices of in_proj) are plain pointer offsets.
 // Both compute D^T = W . A^T ("swapped" MFMA operands): a lane then owns 4 consecutive output columns of
 // one row, so bias/residual/stores are 8/16-byte vectors and the SiLU(gate)*up epilogue is lane-local
 // (gate/up rows are interleaved in 16-row blocks in the packed weight).
@@ -46,7 +53,25 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk)
     return *(const bf16x8*)(lds + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int OUT_BF16, int ACT>
+// Packed W: the 128x64 tile is 8 n-tiles x 2 k-fragments = 16 fragments of 1 KiB; wave w moves fragments 4w..4w+3,
+// LDS image = fragment f at f*1024 (lane-linear inside), f = ntl*2 + kbl.
+__device__ __forceinline__ void stage_tile_packed(const bf16_t* __restrict__ Wp, int K, int n0, int N, int k0, char* lds,
+                                                  int wave, int lane) {
+    const int kfr = K >> 5, nt_max = (N >> 4) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = wave * 4 + i;
+        int nt = (n0 >> 4) + (f >> 1);
+        nt = nt < nt_max ? nt : nt_max;
+        const bf16_t* g = Wp + (((int64_t)nt * kfr + (k0 >> 5) + (f & 1)) * 64 + lane) * 8;
+        glds16(g, lds + f * 1024);
+    }
+}
+__device__ __forceinline__ bf16x8 read_frag_packed(const char* lds, int ntl, int ks, int lane) {
+    return *(const bf16x8*)(lds + (ntl * 2 + ks) * 1024 + lane * 16);
+}
+
+template <int OUT_BF16, int ACT, int WP>
 __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                  int64_t ldw, const float* __restrict__ bias, const float* res,
                                                  int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K,
@@ -81,7 +106,8 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
     const int nt = K / BK;
     // LDS: buffer b holds the A tile at b*2*TILE_BYTES and the W tile right behind it
     stage_tile(A, lda, m0, M, 0, smem, wave, lane);
-    stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    if (WP) stage_tile_packed(W, K, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    else stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
     __syncthreads();  // (hipcc drains vmcnt before the barrier while LDS-DMA is in flight)
 
     for (int t = 0; t < nt; ++t) {
@@ -91,14 +117,15 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
         if (t + 1 < nt) {
             char* const a_nxt = smem + (cur ^ 1) * (2 * TILE_BYTES);
             stage_tile(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
-            stage_tile(W, ldw, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
+            if (WP) stage_tile_packed(W, K, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
+            else stage_tile(W, ldw, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[4], af[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                wf[i] = read_frag(b_cur, wc * 64 + i * 16 + fr, ks * 4 + kg);
+                wf[i] = WP ? read_frag_packed(b_cur, wc * 4 + i, ks, lane) : read_frag(b_cur, wc * 64 + i * 16 + fr, ks * 4 + kg);
                 af[i] = read_frag(a_cur, wr * 64 + i * 16 + fr, ks * 4 + kg);
             }
 #pragma unroll
@@ -155,11 +182,23 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Weight-streaming kernel for M <= 16 rows (decode).  Block = 8 waves = NT 16-row weight tiles; wave w
-// takes k-blocks (128 wide) w, w+8, ...  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and
-// x[r][k] for k = kb*128 + j*32 + kg*8 .. +8, j = 0..3 - the native 16x16x32 operand layout, so no
-// cross-lane movement at all.  Every weight byte is read exactly once.
-template <int NT, int OUT_BF16, int ACT>
+// Weight-streaming kernel for M <= 16 rows (decode).  Block = 8 waves = NT 16-row weight tiles; wave w takes
+// k-blocks (128 wide) w, w+8, ... two at a time, so 8*NT independent 1-KiB weight loads are in flight per wave
+// before the first MFMA.  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and x[r][k] for
+// k = kb*128 + j*32 + kg*8 .. +8, j = 0..3 - the native 16x16x32 operand layout, no cross-lane movement.
+// Every weight byte is read exactly once (non-temporal: it will not be re-used before the next step).
+template <int NT, int WP>
+__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* xp, int kb, bf16x8 (&wf)[NT][4], bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + (WP ? (kb * 4 + j) * 512 : kb * 128 + j * 32)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + kb * 128 + j * 32);
+}
+
+template <int NT, int OUT_BF16, int ACT, int WP>
 __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
                                                    int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K) {
@@ -175,28 +214,41 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     const bf16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int n = n0 + t * 16 + fr;
-        n = n < N ? n : N - 1;
-        wp[t] = W + (int64_t)n * ldw + kg * 8;
+        if (WP) {
+            int nt = (n0 >> 4) + t;
+            nt = nt < (N >> 4) ? nt : (N >> 4) - 1;
+            wp[t] = W + (int64_t)nt * (K >> 5) * 512 + lane * 8;
+        } else {
+            int n = n0 + t * 16 + fr;
+            n = n < N ? n : N - 1;
+            wp[t] = W + (int64_t)n * ldw + kg * 8;
+        }
     }
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int kb = wave; kb < nkb; kb += 8) {
-        const int k = kb << 7;
-        bf16x8 wf[NT][4], xf[4];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + k + j * 32));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + k + j * 32);
+    int kb = wave;
+    for (; kb + 8 < nkb; kb += 16) {
+        bf16x8 wf0[NT][4], wf1[NT][4], xf0[4], xf1[4];
+        gemv_load<NT, WP>(wp, xp, kb, wf0, xf0);
+        gemv_load<NT, WP>(wp, xp, kb + 8, wf1, xf1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], xf[j], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[t][j], xf0[j], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[t][j], xf1[j], acc[t], 0, 0, 0);
+    }
+    if (kb < nkb) {
+        bf16x8 wf0[NT][4], xf0[4];
+        gemv_load<NT, WP>(wp, xp, kb, wf0, xf0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[t][j], xf0[j], acc[t], 0, 0, 0);
     }
 
 #pragma unroll
@@ -246,39 +298,41 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     }
 }
 
-template <int OUT_BF16, int ACT>
+template <int OUT_BF16, int ACT, int WP>
 void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
+    hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT, WP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
                        C, ldc, M, N, K, tiles_m, tiles_n);
 }
 
-template <int OUT_BF16, int ACT>
+template <int OUT_BF16, int ACT, int WP>
 void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     if constexpr (ACT == RV_ACT_SILU_MUL) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K);
     } else if (N >= 16384) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K);
     } else {
-        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K);
     }
 }
 
 }  // namespace
 
-int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
-                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K,
-                 hipStream_t st) {
+int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
+                 const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
+                 int64_t K, hipStream_t st) {
     RV_CHECK_ARG(A && W && C, "rv_gemm: null operand");
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
     RV_CHECK_ARG(K % 64 == 0, "rv_gemm: K=%lld must be a multiple of 64", (long long)K);
-    RV_CHECK_ARG(N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "rv_gemm: alignment (N%%4, lda%%8, ldw%%8, ldc%%4)");
+    RV_CHECK_ARG(N % 4 == 0 && lda % 8 == 0 && ldc % 4 == 0, "rv_gemm: alignment (N%%4, lda%%8, ldc%%4)");
+    RV_CHECK_ARG(w_layout == 0 || w_layout == 1, "rv_gemm: w_layout must be 0 (row-major) or 1 (fragment-packed)");
+    RV_CHECK_ARG(w_layout == 1 ? (N % 16 == 0) : (ldw % 8 == 0), "rv_gemm: packed W needs N%%16==0; row-major W needs ldw%%8==0");
     RV_CHECK_ARG(out_dtype == RV_BF16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
     RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_SILU_MUL, "rv_gemm: bad activation %d", act);
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || (N % 32 == 0 && !bias && !residual),
@@ -287,12 +341,17 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const f
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
-#define RV_DISPATCH(OB, AC)                                                                                  \
+#define RV_DISPATCH2(OB, AC, WP)                                                                            \
     do {                                                                                                     \
         if (gemv)                                                                                            \
-            launch_gemv<OB, AC>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st);    \
+            launch_gemv<OB, AC, WP>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st); \
         else                                                                                                 \
-            launch_tile<OB, AC>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st);    \
+            launch_tile<OB, AC, WP>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st); \
+    } while (0)
+#define RV_DISPATCH(OB, AC)             \
+    do {                                \
+        if (w_layout) RV_DISPATCH2(OB, AC, 1); \
+        else RV_DISPATCH2(OB, AC, 0);   \
     } while (0)
     const int ob = out_dtype == RV_BF16;
     if (ob && act == RV_ACT_NONE) RV_DISPATCH(1, RV_ACT_NONE);
@@ -301,13 +360,14 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const f
     else if (!ob && act == RV_ACT_NONE) RV_DISPATCH(0, RV_ACT_NONE);
     else if (!ob && act == RV_ACT_RELU) RV_DISPATCH(0, RV_ACT_RELU);
     else RV_DISPATCH(0, RV_ACT_SILU_MUL);
+#undef RV_DISPATCH2
 #undef RV_DISPATCH
     RV_CHECK_LAUNCH("rv_gemm");
     return RV_OK;
 }
 
-extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
-                       int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K,
-                       void* stream) {
-    return rv_gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, as_stream(stream));
+extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
+                       const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
+                       int64_t K, void* stream) {
+    return rv_gemm_impl(A, lda, W, ldw, w_layout, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, as_stream(stream));
 }

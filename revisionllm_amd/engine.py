@@ -2,8 +2,10 @@
 and exposes the high-level entry points of the C ABI.
 
 Weight packing (build-defined layout): q/k/v rows fused into ``wqkv`` [3D,D]; gate/up rows
-interleaved in 16-row blocks into ``wgu`` [2F,D] (so SiLU(gate)*up is a lane-local GEMM epilogue); matrices
-bf16, vectors f32.  LoRA never exists here: the builder merges it before packing (builder.py:53-60).
+interleaved in 16-row blocks into ``wgu`` [2F,D] (so SiLU(gate)*up is a lane-local GEMM epilogue); every matrix
+is then stored FRAGMENT-PACKED (ops.pack_fragments: each 16x32 MFMA operand fragment one contiguous 1 KiB block),
+which makes the decode weight stream perfectly coalesced and the prefill LDS image conflict-free; the embedding
+table stays row-major (it is gathered by row); vectors are f32.  LoRA never exists here: the builder merges it before packing (builder.py:53-60).
 """
 import ctypes as C
 
@@ -19,6 +21,11 @@ def _dev_f32(t, device):
 
 def _dev_bf16(t, device):
     return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _dev_packed(t, device):
+    """bf16 on the device in the fragment-packed GEMM layout."""
+    return ops.pack_fragments(_dev_bf16(t, device))
 
 
 class Engine:
@@ -61,19 +68,19 @@ class Engine:
         """``get(hf_name) -> tensor`` (any device / float dtype), HF Llama names.  Packs layer by layer."""
         s, dev = self.shape, self.device
         self.bind("llm.embed", _dev_bf16(get("model.embed_tokens.weight"), dev))
-        self.bind("llm.lm_head", _dev_bf16(get("lm_head.weight"), dev))
+        self.bind("llm.lm_head", _dev_packed(get("lm_head.weight"), dev))
         self.bind("llm.norm", _dev_f32(get("model.norm.weight"), dev))
         for i in range(s.layers):
             p = f"model.layers.{i}."
             q, k, v = (_dev_bf16(get(p + f"self_attn.{n}_proj.weight"), dev) for n in "qkv")
-            self.bind(f"llm.L{i}.wqkv", torch.cat([q, k, v], dim=0).contiguous())
+            self.bind(f"llm.L{i}.wqkv", ops.pack_fragments(torch.cat([q, k, v], dim=0).contiguous()))
             del q, k, v
-            self.bind(f"llm.L{i}.wo", _dev_bf16(get(p + "self_attn.o_proj.weight"), dev))
+            self.bind(f"llm.L{i}.wo", _dev_packed(get(p + "self_attn.o_proj.weight"), dev))
             g = _dev_bf16(get(p + "mlp.gate_proj.weight"), dev)
             u = _dev_bf16(get(p + "mlp.up_proj.weight"), dev)
-            self.bind(f"llm.L{i}.wgu", pack_gate_up(g, u))
+            self.bind(f"llm.L{i}.wgu", ops.pack_fragments(pack_gate_up(g, u)))
             del g, u
-            self.bind(f"llm.L{i}.wdown", _dev_bf16(get(p + "mlp.down_proj.weight"), dev))
+            self.bind(f"llm.L{i}.wdown", _dev_packed(get(p + "mlp.down_proj.weight"), dev))
             self.bind(f"llm.L{i}.norm1", _dev_f32(get(p + "input_layernorm.weight"), dev))
             self.bind(f"llm.L{i}.norm2", _dev_f32(get(p + "post_attention_layernorm.weight"), dev))
         self.has_llm = True
@@ -83,19 +90,19 @@ class Engine:
         dev = self.device
         self.bind("adp.cls_token", _dev_f32(get("global_rep_token"), dev))
         self.bind("adp.cls_pos", _dev_f32(get("global_rep_pos"), dev))
-        self.bind("adp.proj_w", _dev_bf16(get("mm_projector.weight"), dev))
+        self.bind("adp.proj_w", _dev_packed(get("mm_projector.weight"), dev))
         self.bind("adp.proj_b", _dev_f32(get("mm_projector.bias"), dev))
         stacks = ([("t2v_encoder", "t2v")] if self.adapter_text else []) + [("encoder", "enc")]
         for ref, tag in stacks:
             for l in range(self.adapter_layers):
                 r, o = f"{ref}.layers.{l}.", f"adp.{tag}.{l}."
-                self.bind(o + "w_in", _dev_bf16(get(r + "self_attn.in_proj_weight"), dev))
+                self.bind(o + "w_in", _dev_packed(get(r + "self_attn.in_proj_weight"), dev))
                 self.bind(o + "b_in", _dev_f32(get(r + "self_attn.in_proj_bias"), dev))
-                self.bind(o + "w_out", _dev_bf16(get(r + "self_attn.out_proj.weight"), dev))
+                self.bind(o + "w_out", _dev_packed(get(r + "self_attn.out_proj.weight"), dev))
                 self.bind(o + "b_out", _dev_f32(get(r + "self_attn.out_proj.bias"), dev))
-                self.bind(o + "w1", _dev_bf16(get(r + "linear1.weight"), dev))
+                self.bind(o + "w1", _dev_packed(get(r + "linear1.weight"), dev))
                 self.bind(o + "b1", _dev_f32(get(r + "linear1.bias"), dev))
-                self.bind(o + "w2", _dev_bf16(get(r + "linear2.weight"), dev))
+                self.bind(o + "w2", _dev_packed(get(r + "linear2.weight"), dev))
                 self.bind(o + "b2", _dev_f32(get(r + "linear2.bias"), dev))
                 for n in ("1", "2"):
                     self.bind(o + f"ln{n}_w", _dev_f32(get(r + f"norm{n}.weight"), dev))
@@ -103,7 +110,7 @@ class Engine:
         self.has_clip = True
 
     def load_linear_projector(self, get):
-        self.bind("proj.w", _dev_bf16(get("weight"), self.device))
+        self.bind("proj.w", _dev_packed(get("weight"), self.device))
         self.bind("proj.b", _dev_f32(get("bias"), self.device))
         self.has_linear = True
 

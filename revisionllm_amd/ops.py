@@ -22,15 +22,23 @@ def init_hash_(t, name, seed, a, base=0.0, offset=0):
     return t
 
 
-def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None):
-    """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16."""
+def pack_fragments(w):
+    """Row-major [N,K] bf16 -> fragment-packed (same shape / numel): every 16x32 MFMA operand fragment becomes one
+    contiguous 1 KiB block in lane order (lane = (n&15) + 16*((k>>3)&3), 8 bf16 per lane).  See include/revision_hip.h."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
+def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None, w_packed=False):
+    """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16 row-major or fragment-packed."""
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
     if out is None:
         out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
-    hip.check(hip.lib().rv_gemm(hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), hip.ptr(bias), hip.ptr(residual),
+    hip.check(hip.lib().rv_gemm(hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), int(w_packed), hip.ptr(bias), hip.ptr(residual),
                                 residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0),
                                 hip.dtype_code(out), act, M, N, K, hip.stream()), "rv_gemm")
     return out

@@ -66,11 +66,16 @@ def test_gemm(dev, M, N, K, out):
     ref0 = a.double() @ w.double().t()
     y = ops.gemm(ad, wd, out_dtype=od)
     assert rel_err(y.float().cpu(), ref0) < tol
+    wpk = ops.pack_fragments(wd) if N % 16 == 0 else None          # fragment-packed layout (what the engine binds)
+    if wpk is not None:
+        yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True)
+        assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
     y = ops.gemm(ad, wd, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU)
     ref = torch.relu(ref0 + bias.double()) + res.double()
     assert rel_err(y.float().cpu(), ref) < tol
     if N % 32 == 0:
         y = ops.gemm(ad, wd, out_dtype=od, act=hip.RV_ACT_SILU_MUL)
+        assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True), y)
         r3 = ref0.view(M, N // 32, 2, 16)
         ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
         assert rel_err(y.float().cpu(), ref) < tol
