@@ -42,15 +42,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int kend = a.causal ? min(a.Lk, a.q_pos0 + q0 + 16) : a.Lk;
 
     for (int k0 = SPLIT ? wave * 32 : 0; k0 < kend; k0 += SPLIT ? 128 : 32) {
-        f32x4 s[2];
+        // issue every load of this key block up front (K rows and V^T rows are independent of the softmax), so the
+        // block costs one memory round trip instead of two
+        bf16x8 kf[2][NC];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = min(k0 + t * 16 + fr, a.Lk - 1);
             const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
+        }
+        union VF { bf16x8 v; u32x2 h2[2]; };
+        VF vf[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const bf16_t* vp = vbase + (int64_t)dt * 16 * a.vt_ds + k0;
+            vf[dt].h2[0] = *(const u32x2*)(vp);
+            vf[dt].h2[1] = *(const u32x2*)(vp + 16);
+        }
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + c * 32), qf[c], s[t], 0, 0, 0);
+            for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s[t], 0, 0, 0);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -86,12 +101,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
-            const bf16_t* vp = vbase + (int64_t)dt * 16 * a.vt_ds + k0;
-            union { bf16x8 v; u32x2 h2[2]; } vf;
-            vf.h2[0] = *(const u32x2*)(vp);
-            vf.h2[1] = *(const u32x2*)(vp + 16);
             o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt].v, pf.v, o[dt], 0, 0, 0);
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);

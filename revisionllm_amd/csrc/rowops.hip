@@ -187,31 +187,57 @@ __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int 
     cs[i] = make_float2(cosf(ang), sinf(ang));
 }
 
-// q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated; v -> vtc [B,H,dh,Smax] (transposed).
-__global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ qkv, const float2* __restrict__ cs,
-                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc,
-                                                      bf16_t* __restrict__ vtc, int S, int pos0, int H, int dh, int Smax) {
+// q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated.  One thread = 4 consecutive pair indices j (float4
+// loads of both halves, 8-byte bf16 stores).  V is handled by v_cache_kernel below.
+__global__ __launch_bounds__(256) void rope_qk_kernel(const float* __restrict__ qkv, const float2* __restrict__ cs,
+                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc, int S, int pos0,
+                                                      int H, int dh, int Smax) {
     const int64_t m = blockIdx.x;
     const int b = (int)(m / S), s = (int)(m % S);
     const int pos = pos0 + s;
-    const int D = H * dh, half = dh / 2;
+    const int D = H * dh, half = dh / 2, q4 = half / 4;
     const float* row = qkv + m * 3 * (int64_t)D;
     const float2* csr = cs + (int64_t)s * half;
-    for (int i = threadIdx.x; i < H * half; i += 256) {
-        const int h = i / half, j = i % half;
-        const float2 t = csr[j];
-        const float c = t.x, sn = t.y;
-        const float q1 = row[h * dh + j], q2 = row[h * dh + j + half];
-        q16[m * D + h * dh + j] = f32_to_bf16(q1 * c - q2 * sn);
-        q16[m * D + h * dh + j + half] = f32_to_bf16(q2 * c + q1 * sn);
-        const float k1 = row[D + h * dh + j], k2 = row[D + h * dh + j + half];
-        bf16_t* kr = kc + (((int64_t)b * H + h) * Smax + pos) * dh;
-        kr[j] = f32_to_bf16(k1 * c - k2 * sn);
-        kr[j + half] = f32_to_bf16(k2 * c + k1 * sn);
+    for (int i = threadIdx.x; i < 2 * H * q4; i += 256) {
+        const int which = i / (H * q4);          // 0 = q, 1 = k
+        const int r = i % (H * q4);
+        const int h = r / q4, j = (r % q4) * 4;
+        const float* src = row + which * D + h * dh + j;
+        const f32x4 x1 = *(const f32x4*)src, x2 = *(const f32x4*)(src + half);
+        float o1[4], o2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 t = csr[j + e];
+            o1[e] = x1[e] * t.x - x2[e] * t.y;
+            o2[e] = x2[e] * t.x + x1[e] * t.y;
+        }
+        bf16_t* dst = which == 0 ? q16 + m * D + h * dh + j : kc + (((int64_t)b * H + h) * Smax + pos) * dh + j;
+        *(u32x2*)dst = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+        *(u32x2*)(dst + half) = u32x2{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
     }
-    for (int i = threadIdx.x; i < D; i += 256) {
-        const int h = i / dh, d = i % dh;
-        vtc[(((int64_t)b * H + h) * dh + d) * Smax + pos] = f32_to_bf16(row[2 * D + i]);
+}
+
+// V rows of qkv f32 [M,3D] -> vtc [B,H,dh,Smax] bf16 (transposed cache).  Block = (64 positions, head, batch):
+// coalesced reads of 64 x dh floats through LDS, then 128-byte row writes along the position axis.
+template <int DH>
+__global__ __launch_bounds__(256) void v_cache_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ vtc, int S, int pos0,
+                                                      int H, int Smax) {
+    __shared__ bf16_t tile[64][DH + 2];
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * DH;
+    for (int i = threadIdx.x; i < 64 * (DH / 4); i += 256) {
+        const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s0 + r < S) v = *(const f32x4*)(qkv + ((int64_t)b * S + s0 + r) * 3 * D + 2 * D + h * DH + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][c + e] = f32_to_bf16(v[e]);
+    }
+    __syncthreads();
+    bf16_t* o = vtc + (((int64_t)b * H + h) * DH) * Smax + pos0 + s0;
+    const int n = min(64, S - s0);
+    for (int i = threadIdx.x; i < DH * 64; i += 256) {
+        const int d = i / 64, l = i % 64;
+        if (l < n) o[(int64_t)d * Smax + l] = tile[l][d];
     }
 }
 
@@ -323,9 +349,14 @@ int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st
 
 int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
               int Smax, hipStream_t st) {
-    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc,
-                       (bf16_t*)vtc, S, pos0, H, dh, Smax);
-    RV_CHECK_LAUNCH("rope_kv");
+    RV_CHECK_ARG(dh == 128, "rope_kv: head dim must be 128");
+    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc, S,
+                       pos0, H, dh, Smax);
+    RV_CHECK_LAUNCH("rope_qk");
+    const int B = (int)(M / S);
+    hipLaunchKernelGGL(v_cache_kernel<128>, dim3((unsigned)cdiv(S, 64), (unsigned)H, (unsigned)B), dim3(256), 0, st, qkv,
+                       (bf16_t*)vtc, S, pos0, H, Smax);
+    RV_CHECK_LAUNCH("v_cache");
     return RV_OK;
 }
 

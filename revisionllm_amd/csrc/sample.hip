@@ -202,25 +202,32 @@ __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
-// one block per segment: column norms over frames, sims[t] = <f_t / norm, q>, sum of the k largest (k <= 0: mean)
+// one block (1024 threads) per segment: column norms over frames, sims[t] = <f_t / norm, q>, sum of the k largest
+// (k <= 0: mean).  Phase 1 splits the frames over 4 thread groups per column block to keep ~T/4 loads per thread.
 template <typename T>
-__global__ __launch_bounds__(256) void topk_cosine_kernel(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
-                                                          int k, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
+                                                           int k, float* __restrict__ out) {
     extern __shared__ float smem[];
-    float* qn = smem;        // [d]
-    float* sims = smem + d;  // [Tn]
+    float* qn = smem;            // [d] q / column norm
+    float* psum = smem + d;      // [4][d] partial sums of squares (summed in fixed order: deterministic)
+    float* sims = smem + 5 * d;  // [Tn]
     const T* f = feat + (int64_t)blockIdx.x * Tn * d;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        float s = 0.f;
-        for (int t = 0; t < Tn; ++t) {
-            const float v = ld<T>(f + (int64_t)t * d + c);
-            s += v * v;
+    {
+        const int part = threadIdx.x >> 8, c0 = threadIdx.x & 255;   // 4 frame partitions x 256 column lanes
+        for (int c = c0; c < d; c += 256) {
+            float s = 0.f;
+            for (int t = part; t < Tn; t += 4) {
+                const float v = ld<T>(f + (int64_t)t * d + c);
+                s += v * v;
+            }
+            psum[part * d + c] = s;
         }
-        qn[c] = q[c] / sqrtf(s);
     }
     __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 1024) qn[c] = q[c] / sqrtf((psum[c] + psum[d + c]) + (psum[2 * d + c] + psum[3 * d + c]));
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = wave; t < Tn; t += 4) {
+    for (int t = wave; t < Tn; t += 16) {
         float s = 0.f;
         for (int c = lane; c < d; c += 64) s += ld<T>(f + (int64_t)t * d + c) * qn[c];
         s = wave_sum(s);
@@ -278,12 +285,12 @@ extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32
 extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
                               float* out, void* stream) {
     RV_CHECK_ARG(feat && q_cls && out && n > 0 && T > 0 && d > 0, "rv_topk_cosine: bad arguments");
-    RV_CHECK_ARG((size_t)(d + T) * 4 <= 64 * 1024, "rv_topk_cosine: d + T too large for LDS");
-    const size_t sm = (size_t)(d + T) * sizeof(float);
+    RV_CHECK_ARG((size_t)(5 * d + T) * 4 <= 64 * 1024, "rv_topk_cosine: 5*d + T too large for LDS");
+    const size_t sm = (size_t)(5 * d + T) * sizeof(float);
     if (feat_dtype == RV_BF16)
-        hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(256), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+        hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(1024), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
     else if (feat_dtype == RV_F32)
-        hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(256), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
+        hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(1024), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
     else {
         rv_set_error("rv_topk_cosine: dtype must be f32 or bf16");
         return RV_ERR_ARG;
