@@ -39,8 +39,8 @@ def parse():
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-layers", type=int, default=2, help="decoder layers executed by the CPU baseline sample")
-    p.add_argument("--cpu-segments", type=int, default=8, help="segments encoded by the CPU baseline sample")
+    p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
+    p.add_argument("--cpu-segments", type=int, default=16, help="segments encoded by the CPU baseline sample")
     return p.parse_args()
 
 
@@ -108,7 +108,6 @@ def cpu_baseline(args, n_calls, P):
         cores = psutil.cpu_count(logical=False) or cores
     except Exception:
         pass
-    torch.set_num_threads(cores)
     T = lambda a: torch.from_numpy(a)
     seed, W, Tn, L = args.seed, args.windows, args.frames, args.cpu_layers
     shape = synth.LlamaShape(layers=L)
@@ -120,28 +119,38 @@ def cpu_baseline(args, n_calls, P):
     feat = T(synth.features("bench.feat.r0", (ns, Tn, 768), seed))
     q = (T(synth.features("bench.q", (1, args.lq, 768), seed)), torch.ones(1, args.lq))
     qf, qm = q[0].expand(ns, -1, -1), q[1].expand(ns, -1)
-    o_adapter.clip_encoder(feat[:2], wa, qf[:2], qm[:2])  # warm-up
-    t0 = time.perf_counter()
-    o_adapter.clip_encoder(feat, wa, qf, qm)
-    t_adapter_seg = (time.perf_counter() - t0) / ns
-    # one call: 100 video tokens (already encoded rows stand in), prompt P, G forced decode steps
     ids = T(synth.synthetic_prompt_ids(P, 40, seed))[None]
     rows = torch.randn(1, W, shape.hidden) * 0.02
     emb, mask, pos, _ = __import__("oracle.splice", fromlist=["splice"]).splice(ids, list(rows), w["model.embed_tokens.weight"])
-    t0 = time.perf_counter()
-    cache = o_llama.KVCache(L)
-    logits = o_llama.forward(emb, w, cfg, mask, pos, cache, last_only=True)[:, -1]
-    t_prefill = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for _ in range(args.decode_steps - 1):
-        nxt = o_sampling.select_token(o_sampling.process_logits(logits, 0.05, 50, 1.0), torch.tensor([0.5]))
-        e1 = w["model.embed_tokens.weight"][nxt][:, None]
-        logits = o_llama.forward(e1, w, cfg, cache=cache)[:, -1]
-    t_decode = time.perf_counter() - t0
+
+    def sample_once():
+        t0 = time.perf_counter()
+        o_adapter.clip_encoder(feat, wa, qf, qm)
+        ta = (time.perf_counter() - t0) / ns
+        t0 = time.perf_counter()
+        cache = o_llama.KVCache(L)
+        logits = o_llama.forward(emb, w, cfg, mask, pos, cache, last_only=True)[:, -1]
+        tp = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.decode_steps - 1):
+            nxt = o_sampling.select_token(o_sampling.process_logits(logits, 0.05, 50, 1.0), torch.tensor([0.5]))
+            e1 = w["model.embed_tokens.weight"][nxt][:, None]
+            logits = o_llama.forward(e1, w, cfg, cache=cache)[:, -1]
+        return ta, tp, time.perf_counter() - t0
+
+    # the reference leaves torch at its default thread count (= all cores); small decode GEMVs can be faster with
+    # fewer threads, so time both settings (each after a warm-up pass) and report the faster one
+    best = None
+    for nthreads in sorted({cores, min(cores, 32)}, reverse=True):
+        torch.set_num_threads(nthreads)
+        sample_once()
+        ta, tp, td = sample_once()
+        total = n_calls * (W * ta + (tp + td) * 32.0 / L)
+        if best is None or total < best[0]:
+            best = (total, nthreads, ta, tp, td)
+    t_recursion, cores, t_adapter_seg, t_prefill, t_decode = best
     # scale the layer-proportional part to 32 layers (lm_head / embedding time is small and left unscaled)
     scale = 32.0 / L
-    t_call = (t_prefill + t_decode) * scale
-    t_recursion = n_calls * (W * t_adapter_seg + t_call)
     return dict(value=W / t_recursion, unit="segments/s", cores=cores, kind="port",
                 sample=(f"torch-fp32 oracle: ClipEncoder on {ns} of {W} segments ({t_adapter_seg*1e3:.0f} ms/segment), one LLM call "
                         f"(prefill S={emb.shape[1]} {t_prefill:.2f}s + {args.decode_steps - 1} decode steps {t_decode:.2f}s) through "
@@ -183,7 +192,9 @@ def main():
     plan = stage2.plan_groups(W, 100)
     gen = torch.Generator().manual_seed(args.seed)
     perms = stage2.make_perms(plan, gen)
-    sentence = "a person opens the door and walks into the kitchen"
+    # 20 words: with the v1 template the prompt is P = 72 ids, i.e. prefill length S = 171 per call
+    sentence = ("a person opens the door and walks into the kitchen while another person is sitting at the table "
+                "reading a newspaper and then both of them leave the room together")
     stages = parallel.HipStages(model, tok)
 
     def step():

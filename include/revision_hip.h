@@ -76,9 +76,16 @@ int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, floa
  *     Wp[(((n>>4)*(K/32) + (k>>5))*64 + (n&15) + 16*((k>>3)&3))*8 + (k&7)]      (N % 16 == 0)
  * bias f32 or NULL, residual f32 (ldr) or NULL (may alias C), out dtype RV_BF16 or RV_F32 (ldc).
  * RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and the output has N/2 columns.  K % 64 == 0.
- * M <= 16 takes the weight-streaming (decode) kernel. */
+ * M <= 16 takes the weight-streaming (decode) kernel.  ws / ws_bytes: optional workspace of rv_gemm_ws_bytes() bytes
+ * enabling the persistent stream-K kernel (packed W, N % 256 == 0); its first 4 KiB (hand-off flags) must be zero
+ * before the first use and are left zero by every call.  NULL -> plain output-tiled kernel. */
+size_t rv_gemm_ws_bytes(void);
+/* Tuning knob (process-wide): 0 = output-tiled GEMM only (default); stream-K workgroup geometry 4 = 128x128 tiles, two
+ * 4-wave workgroups per CU; 8 = 128x256 tiles, one 8-wave workgroup per CU with a 3-stage LDS ring. */
+void rv_set_gemm_geometry(int32_t waves);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
-            int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
+            int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
+            size_t ws_bytes, void* stream);
 /* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
  * x f32 [rows,d]; any of y_f32 / y_bf16 / y_pos_bf16 may be NULL; y_pos = bf16(y + pos[row % period]). */
 int rv_layernorm(const float* x, const float* w, const float* b, float* y_f32, void* y_bf16, void* y_pos_bf16,

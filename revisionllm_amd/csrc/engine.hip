@@ -148,6 +148,8 @@ struct ClipWs {
     float *pm, *x32, *y32;
     bf16_t *x16, *xp16, *qk16, *vv16, *vt16, *a16, *h16, *tk16, *tv16, *tvt16;
     uint8_t* pad;
+    void* sk;  // stream-K GEMM workspace (flags must be zero: the engine's Python owner allocates it zeroed)
+    size_t sk_bytes;
     int Lpad, Lqpad;
     size_t bytes;
 };
@@ -159,6 +161,8 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
     w.Lpad = ((T + 1 + 31) / 32) * 32;
     w.Lqpad = ((Lq + 31) / 32) * 32;
     Carver k(ws, cap);
+    w.sk_bytes = gemm_sk_ws_bytes();
+    w.sk = k.take(w.sk_bytes);
     w.pm = (float*)k.take((size_t)(T + 1) * d * 4);
     w.x32 = (float*)k.take((size_t)R1 * d * 4);
     w.y32 = (float*)k.take((size_t)R1 * d * 4);
@@ -214,7 +218,7 @@ extern "C" int rv_project_dense(rv_ctx* c, const void* x_bf16, void* y, int out_
     RV_CHECK_ARG(c && x_bf16 && y && rows > 0, "rv_project_dense: bad arguments");
     RV_TRY(resolve_proj(c));
     const int64_t d = c->cfg.adapter_dim, D = c->cfg.hidden;
-    return rv_gemm_impl(x_bf16, d, c->proj_w, d, 1, c->proj_b, nullptr, 0, y, D, out_dtype, RV_ACT_NONE, rows, D, d, as_stream(stream));
+    return rv_gemm_impl(x_bf16, d, c->proj_w, d, 1, c->proj_b, nullptr, 0, y, D, out_dtype, RV_ACT_NONE, rows, D, d, nullptr, 0, as_stream(stream));
 }
 
 extern "C" size_t rv_clip_encoder_ws_bytes(const rv_ctx* c, int32_t N, int32_t T, int32_t Nq, int32_t Lq) {
@@ -258,17 +262,17 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         for (size_t l = 0; l < c->t2v.size(); ++l) {
             const AdapterLayer& L = c->t2v[l];
             bf16_t* q16 = w.qk16;
-            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_BF16, RV_ACT_NONE, R0, d, d, st));
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_BF16, RV_ACT_NONE, RT, d, d, st));
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_BF16, RV_ACT_NONE, RT, d, d, st));
+            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_BF16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_BF16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_BF16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
             AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
                        w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
             RV_TRY(k_attention(a, st));
-            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, st));
+            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
-            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R0, ff, d, st));
-            RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, v32, nullptr, vp16, w.pm + d, T, R0, (int)d, st));
         }
         // X = [CLS ; frames]; y32 is free, use it as the staging copy of the frames
@@ -280,23 +284,23 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
 
     for (size_t l = 0; l < c->enc.size(); ++l) {
         const AdapterLayer& L = c->enc[l];
-        RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_BF16, RV_ACT_NONE, R1, 2 * d, d, st));
-        RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, st));
+        RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_BF16, RV_ACT_NONE, R1, 2 * d, d, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));
         AttnArgs a{w.qk16, 2 * d, (int64_t)(T + 1) * 2 * d, w.qk16 + d, 2 * d, (int64_t)(T + 1) * 2 * d, dh, w.vt16,
                    (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, (int64_t)(T + 1) * d, nullptr, N, H, dh, T + 1,
                    T + 1, 0, 0, 1, scale};
         RV_TRY(k_attention(a, st));
-        RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, d, st));
+        RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, w.x32, w.x16, nullptr, nullptr, 0, R1, (int)d, st));
-        RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R1, ff, d, st));
-        RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, ff, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, ff, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, w.x32, w.x16, w.xp16, w.pm, T + 1, R1, (int)d, st));
     }
     if (feature == RV_FEAT_CLS)
         return rv_gemm_impl(w.x16, (int64_t)(T + 1) * d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D,
-                            d, st);
-    return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, R1, D, d, st);
+                            d, w.sk, w.sk_bytes, st);
+    return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, R1, D, d, w.sk, w.sk_bytes, st);
 }
 
 extern "C" int rv_splice_embed(rv_ctx* c, const int32_t* map, const float* video_rows, float* h, int64_t rows, void* stream) {
@@ -314,12 +318,16 @@ namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
     float *qkv32, *cs;
+    void* sk;
+    size_t sk_bytes;
     size_t bytes;
 };
 LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     const int64_t M = (int64_t)B * S, D = c->cfg.hidden, F = c->cfg.inter;
     Carver k(ws, cap);
     LlmWs w;
+    w.sk_bytes = gemm_sk_ws_bytes();
+    w.sk = k.take(w.sk_bytes);
     w.xn16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.qkv32 = (float*)k.take((size_t)M * 3 * D * 4);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
@@ -362,17 +370,17 @@ extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, w.sk, w.sk_bytes, st));
         RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, M, S, pos0, H, dh, Smax, st));
         AttnArgs a{w.q16, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                    (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
         RV_TRY(k_attention(a, st));
-        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, st));
+        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st));
         RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, st));
-        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st));
     }
     // final norm + lm_head on the last position of every row only
     RV_TRY(k_rmsnorm(h + (int64_t)(S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
-    return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, st);
+    return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st);
 }

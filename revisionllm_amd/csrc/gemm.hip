@@ -18,7 +18,7 @@
 // Both compute D^T = W . A^T ("swapped" MFMA operands): a lane then owns 4 consecutive output columns of
 // one row, so bias/residual/stores are 8/16-byte vectors and the SiLU(gate)*up epilogue is lane-local
 // (gate/up rows are interleaved in 16-row blocks in the packed weight).
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -325,7 +325,7 @@ void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, hipStream_t st) {
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st) {
     RV_CHECK_ARG(A && W && C, "rv_gemm: null operand");
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -341,6 +341,8 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
+    if (!gemv && ws && ws_bytes >= gemm_sk_ws_bytes() && gemm_sk_supported(w_layout, M, N, K))
+        return gemm_sk_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, st);
 #define RV_DISPATCH2(OB, AC, WP)                                                                            \
     do {                                                                                                     \
         if (gemv)                                                                                            \
@@ -366,8 +368,11 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     return RV_OK;
 }
 
+extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_sk_ws_bytes(); }
+
 extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                        const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                       int64_t K, void* stream) {
-    return rv_gemm_impl(A, lda, W, ldw, w_layout, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, as_stream(stream));
+                       int64_t K, void* ws, size_t ws_bytes, void* stream) {
+    return rv_gemm_impl(A, lda, W, ldw, w_layout, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, ws_bytes,
+                        as_stream(stream));
 }

@@ -2,9 +2,14 @@
 #pragma once
 #include "common.h"
 
+// ws: optional zero-initialised stream-K workspace (>= gemm_sk_ws_bytes()); NULL -> plain tiled kernel
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, hipStream_t st);
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_sk_ws_bytes();
+bool gemm_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
+int gemm_sk_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
+                   int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
                 int64_t period, int64_t rows, int d, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);

@@ -140,7 +140,7 @@ class Engine:
     def _workspace(self, key, nbytes):
         t = self._ws.get(key)
         if t is None or t.numel() < nbytes:
-            t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            t = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)  # zero: stream-K flags
             self._ws[key] = t
         return t
 

@@ -196,12 +196,16 @@ class ReVisionLlamaForCausalLM:
     def generate(self, input_ids, images=None, query_feats=None, do_sample=False, temperature=None, num_beams=1,
                  max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
                  return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
-                 attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None, **kwargs):
+                 attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
+                 share_prefix=False, **kwargs):
         """Prefill + KV-cached sampling loop (inference.py:45-59 kwargs).
 
         Extra, build-defined kwargs: ``uniforms`` [G,B] (host-supplied draws for reproducible sampling; default
         ``torch.rand`` on the device), ``forced_tokens`` [G,B] (teacher forcing for parity tests),
-        ``video_rows`` / ``rows_per_sample`` (pre-encoded adapter output, used by the batched recursion).
+        ``video_rows`` / ``rows_per_sample`` (pre-encoded adapter output, used by the batched recursion),
+        ``share_prefix`` (prefill the text prefix common to all rows once and broadcast its K/V; bit-identical results.
+        Off by default: as a separate M = P0 pass it streams all weights a second time, which costs more than it saves
+        until the prefix rows are folded into the main prefill batch).
         ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
         """
         if num_beams != 1:
@@ -224,11 +228,20 @@ class ReVisionLlamaForCausalLM:
                 video_rows, rows_per_sample = self.encode_images(images, query_feats)
         row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
         B, S = row_map.shape
-        h = eng.splice_embed(row_map, video_rows)
-
         cap = min(max_new_tokens, 64)
         kv, Smax = eng.new_kv(B, S + cap)
-        logits = eng.llm_forward(h, 0, kv, Smax)
+        P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
+        if P0 >= 16:
+            # every row starts with the same P0 text tokens (inference() repeats one prompt): under causal attention their
+            # hidden states and K/V are identical for all rows, so prefill them once and broadcast the cache
+            kv1, smax1 = eng.new_kv(1, P0)
+            eng.llm_forward(eng.splice_embed(row_map[:1, :P0], None), 0, kv1, smax1)
+            self._broadcast_prefix(kv1, smax1, kv, Smax, B, P0)
+            h = eng.splice_embed(row_map[:, P0:].contiguous(), video_rows)
+            logits = eng.llm_forward(h, P0, kv, Smax)
+        else:
+            h = eng.splice_embed(row_map, video_rows)
+            logits = eng.llm_forward(h, 0, kv, Smax)
 
         seqs = input_ids.to(dev).long()
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
@@ -277,6 +290,21 @@ class ReVisionLlamaForCausalLM:
         if output_logits:
             out["logits"] = tuple(raw_steps)
         return out
+
+    @staticmethod
+    def _common_text_prefix(row_map):
+        """Number of leading positions that hold the same token id (not a video row) in every row."""
+        same = (row_map == row_map[:1]).all(dim=0) & (row_map[0] >= 0)
+        bad = (~same).nonzero()
+        return int(bad[0]) if bad.numel() else row_map.shape[1]
+
+    def _broadcast_prefix(self, kv1, smax1, kv, Smax, B, P0):
+        s = self.shape
+        h1, hB = kv1.numel() // 2, kv.numel() // 2
+        kv[:hB].view(s.layers, B, s.heads, Smax, s.head_dim)[:, :, :, :P0] = \
+            kv1[:h1].view(s.layers, 1, s.heads, smax1, s.head_dim)[:, :, :, :P0]
+        kv[hB:].view(s.layers, B, s.heads, s.head_dim, Smax)[..., :P0] = \
+            kv1[h1:].view(s.layers, 1, s.heads, s.head_dim, smax1)[..., :P0]
 
     def _grow_kv(self, kv, B, Smax, new_smax):
         s = self.shape

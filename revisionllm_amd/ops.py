@@ -30,17 +30,31 @@ def pack_fragments(w):
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
-def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None, w_packed=False):
-    """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16 row-major or fragment-packed."""
+_SK_WS = {}
+
+
+def stream_k_workspace(device):
+    """Zero-initialised stream-K workspace for stand-alone rv_gemm calls (cached per device)."""
+    key = str(device)
+    if key not in _SK_WS:
+        _SK_WS[key] = torch.zeros(hip.lib().rv_gemm_ws_bytes(), dtype=torch.uint8, device=device)
+    return _SK_WS[key]
+
+
+def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None, w_packed=False, stream_k=None):
+    """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16 row-major or fragment-packed.
+    ``stream_k`` (default: on for packed W) hands the library a workspace so it may pick the persistent stream-K kernel."""
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
     if out is None:
         out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    ws = stream_k_workspace(a.device) if (w_packed if stream_k is None else stream_k) else None
     hip.check(hip.lib().rv_gemm(hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), int(w_packed), hip.ptr(bias), hip.ptr(residual),
                                 residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0),
-                                hip.dtype_code(out), act, M, N, K, hip.stream()), "rv_gemm")
+                                hip.dtype_code(out), act, M, N, K, hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream()),
+              "rv_gemm")
     return out
 
 

@@ -51,7 +51,8 @@ def test_init_hash_bit_exact(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 768, 768), (130, 512, 1408), (1190, 4096, 512), (257, 2304, 768), (1, 4096, 4096),
-                                    (7, 1024, 11008), (16, 32000, 512), (17, 768, 2048), (100, 4096, 768)])
+                                    (7, 1024, 11008), (16, 32000, 512), (17, 768, 2048), (100, 4096, 768), (1197, 4096, 4096),
+                                    (1057, 22016, 1024), (5000, 1536, 768), (129, 256, 11008)])
 @pytest.mark.parametrize("out", ["bf16", "f32"])
 def test_gemm(dev, M, N, K, out):
     from revisionllm_amd import hip, ops
@@ -68,17 +69,26 @@ def test_gemm(dev, M, N, K, out):
     assert rel_err(y.float().cpu(), ref0) < tol
     wpk = ops.pack_fragments(wd) if N % 16 == 0 else None          # fragment-packed layout (what the engine binds)
     if wpk is not None:
-        yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True)
+        yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False)
         assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
+        for geo in (4, 8):                                           # opt-in persistent stream-K kernels
+            hip.lib().rv_set_gemm_geometry(geo)
+            ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True)
+            assert rel_err(ys.float().cpu(), ref0) < tol
+            assert torch.equal(ys, ops.gemm(ad, wpk, out_dtype=od, w_packed=True))   # deterministic split-k summation
+        hip.lib().rv_set_gemm_geometry(0)
     y = ops.gemm(ad, wd, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU)
     ref = torch.relu(ref0 + bias.double()) + res.double()
     assert rel_err(y.float().cpu(), ref) < tol
     if N % 32 == 0:
         y = ops.gemm(ad, wd, out_dtype=od, act=hip.RV_ACT_SILU_MUL)
-        assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True), y)
+        assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=False), y)
         r3 = ref0.view(M, N // 32, 2, 16)
         ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
         assert rel_err(y.float().cpu(), ref) < tol
+        hip.lib().rv_set_gemm_geometry(8)
+        assert rel_err(ops.gemm(ad, wpk, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True).float().cpu(), ref) < tol
+        hip.lib().rv_set_gemm_geometry(0)
 
 
 def test_gemm_strided_rows_and_inplace_residual(dev):

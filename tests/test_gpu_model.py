@@ -152,6 +152,22 @@ def test_inference_api_end_to_end():
     assert len(outs) == 3 and all(isinstance(o, str) for o in outs)
 
 
+def test_shared_prefix_prefill_is_exact():
+    """Prefilling the common text prefix once and broadcasting its K/V gives bit-identical logits."""
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = _model(shape, _args())
+    ids = T(synth.synthetic_prompt_ids(60, 33, SEED, vocab=shape.vocab))[None].repeat(3, 1)
+    feat = feats("sp.feat", (3, 7, 16, 768), bf16=True)
+    q = (feats("sp.q", (3, 4, 768), bf16=True), torch.ones(3, 4))
+    kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
+    a = m.generate(ids, share_prefix=True, **kw)
+    b = m.generate(ids, share_prefix=False, **kw)
+    assert m._common_text_prefix(m.build_row_map(ids, 7)) == 33
+    assert torch.equal(a["sequences"], b["sequences"])
+    assert torch.equal(torch.stack(a["logits"]), torch.stack(b["logits"]))
+
+
 def test_kv_cache_growth_matches_oracle():
     """Generate past the initial KV allocation (64 steps) and check the last logits against the oracle."""
     from oracle import llama, sampling

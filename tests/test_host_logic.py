@@ -121,7 +121,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(h, name), name
     assert hip.lib().rv_abi_version() == 1
     # argument validation runs on the host before any launch
-    assert hip.lib().rv_gemm(None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None) < 0
+    assert hip.lib().rv_gemm(None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None, 0, None) < 0
     assert "null operand" in hip.last_error()
 
 

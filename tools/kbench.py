@@ -26,7 +26,9 @@ def main():
     which = set(sys.argv[1:]) or {"gemm", "gemv", "attn"}
     dev = torch.device("cuda:0")
     D, F, V = 4096, 11008, 32000
-    if "gemm" in which:
+    for geo in ((4, 8) if "gemm" in which else ()):
+        hip.lib().rv_set_gemm_geometry(geo)
+        print(f"--- stream-K geometry: {geo} waves per workgroup")
         for M in (1057, 1190):
             for name, N, K, act, od in (("qkv", 3 * D, D, 0, torch.float32), ("o", D, D, 0, torch.float32),
                                         ("gateup", 2 * F, D, 2, torch.bfloat16), ("down", D, F, 0, torch.float32)):
@@ -35,7 +37,8 @@ def main():
                 res = torch.randn(M, N, device=dev) if name in ("o", "down") else None
                 out = torch.empty(M, N // 2 if act == 2 else N, dtype=od, device=dev)
                 us = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True))
-                print(f"gemm {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
+                us0 = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True, stream_k=False))
+                print(f"gemm {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s   (tiled: {us0:7.1f} us)")
         for name, M, N, K, act in (("adp.qk", 25700, 1536, 768, 0), ("adp.v", 25700, 768, 768, 0), ("adp.ffn1", 25700, 2048, 768, 1),
                                    ("adp.ffn2", 25700, 768, 2048, 0)):
             x = torch.randn(M, K, device=dev).to(torch.bfloat16)
