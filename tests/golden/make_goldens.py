@@ -300,6 +300,66 @@ def g9_driver(M):
     print("wrote g9_driver.json")
 
 
+def _synthetic_logs():
+    """Deterministic stage-1 / stage-2 JSONL logs (data fixtures for the metric merge)."""
+    rng = np.random.RandomState(7)
+    g, r, r2 = [], [], []
+    for q in range(40):
+        n1 = int(rng.randint(6, 40))
+        answers, ious = [], []
+        for _ in range(n1):
+            k = rng.rand()
+            if k < 0.5:
+                answers.append("Not Present")
+            elif k < 0.55:
+                answers.append("From 249 to 249.")
+            else:
+                a = int(rng.randint(0, 200))
+                answers.append(f"From {a} to {a + int(rng.randint(1, 48))}.")
+                ious.append(round(float(rng.rand() ** 2), 2))
+        scores = [round(float(rng.randn()), 4) for _ in ious]
+        g.append({"video_id": f"v{q % 5}", "task": "grounding", "query_id": f"q{q}", "answer": answers,
+                  "info": {"iou": ious, "scores": scores}})
+        for dst, ncalls in ((r, 7), (r2, 9)):
+            if dst is r and q % 11 == 10:
+                continue   # a query missing from the first retrieval run
+            frames = {}
+            for c in range(ncalls):
+                if rng.rand() < 0.8:
+                    w = int(rng.randint(0, int(n1 / 0.4) + 3))
+                    frames[str(c)] = [max(0, w - 1), w + 1]
+            ent = [round(float(rng.rand() + 0.1), 4) for _ in range(ncalls)]
+            dst.append({"video_id": f"v{q % 5}", "task": "grounding", "query_id": f"q{q}", "answer": ["In video 3."] * ncalls,
+                        "info": {"gt": [1, 2], "frames": frames, "iou": [int(rng.rand() < 0.5)], "score_cos": [0.1] * len(frames),
+                                 "mean_entropy": ent, "max_entropy": ent, "hierarchy_zooms": [4] * ncalls}})
+    return g, r, r2
+
+
+def g10_metrics(M):
+    """Run the reference's metric_retrieval_forward.py (its merge lives in __main__) on the synthetic logs."""
+    import subprocess
+    import tempfile
+    g, r, r2 = _synthetic_logs()
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, logs in (("g", g), ("r", r), ("r2", r2)):
+            os.makedirs(os.path.join(td, name))
+            with open(os.path.join(td, name, "predictions_streaming_0.txt"), "w") as f:
+                for x in logs:
+                    f.write(json.dumps(x) + "\n")
+        script = os.path.join(ref_import.REF_ROOT, "revisionllm", "eval", "metric_retrieval_forward.py")
+        for tag, extra in (("two_runs", ["--retrieval_path2", os.path.join(td, "r2")]),):
+            p = subprocess.run([sys.executable, script, "--grounding_path", os.path.join(td, "g"), "--retrieval_path",
+                                os.path.join(td, "r")] + extra, capture_output=True, text=True, cwd=td)
+            assert p.returncode == 0, p.stderr
+            with open(os.path.join(td, "g", "result_retrieval.txt")) as f:
+                out[tag] = json.load(f)
+            out[tag + "_selected_fraction"] = float(p.stdout.split("\n")[2])
+    with open(os.path.join(HERE, "g10_metrics.json"), "w") as f:
+        json.dump({"grounding": g, "retrieval": r, "retrieval2": r2, "expected": out}, f)
+    print("wrote g10_metrics.json", {k: (len(v) if isinstance(v, dict) else v) for k, v in out.items()})
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -308,7 +368,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g9=g9_driver)
+                  g7=g7_scores, g9=g9_driver, g10=g10_metrics)
     for k, fn in groups.items():
         if only and k not in only:
             continue

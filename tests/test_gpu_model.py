@@ -6,6 +6,7 @@ weights.  Tolerances:
   token ids .............................. exact under teacher forcing wherever the oracle's top-2 margin > tolerance
   entropy-derived scores ................. 2e-3 relative
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -210,3 +211,75 @@ def test_stage2_batched_equals_reference_mode():
     assert len(a["score_cos"]) == len(b["score_cos"]) and np.allclose(a["score_cos"], b["score_cos"], rtol=1e-5, atol=1e-6)
     rec = stage2.log_record(b, stage2.get_ground_truth_windows(10, 40, 6000)[0], batch)
     assert set(rec) == {"gt", "frames", "iou", "score_cos", "mean_entropy", "max_entropy", "hierarchy_zooms"}
+
+
+def test_load_pretrained_model_with_lora_checkpoint(tmp_path, monkeypatch):
+    """f-3: HF checkpoint dir + stage-2 LoRA dir (adapter_model + non_lora_trainables.bin) -> ``load_pretrained_model``
+    (builder.py:21-67) -> generate; logits match the oracle run on the merged weights."""
+    import json
+
+    import transformers
+    from safetensors.torch import save_file
+
+    from oracle import llama, sampling
+    from revisionllm_amd.model import builder
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    base = {k: T(v).to(torch.float16) for k, v in synth.build_numpy(synth.llama_spec(shape), SEED).items()}
+    os.makedirs(tmp_path / "base")
+    save_file(base, str(tmp_path / "base" / "model.safetensors"))
+    json.dump({"hidden_size": shape.hidden, "intermediate_size": shape.inter, "num_hidden_layers": shape.layers,
+               "num_attention_heads": shape.heads, "vocab_size": shape.vocab, "rms_norm_eps": shape.eps, "rope_theta": shape.theta},
+              open(tmp_path / "base" / "config.json", "w"))
+    json.dump({"top_p": 0.6, "temperature": 0.9, "eos_token_id": 2, "pad_token_id": 0}, open(tmp_path / "base" / "generation_config.json", "w"))
+    lora = tmp_path / "stage2"
+    os.makedirs(lora)
+    r, alpha = 8, 16
+    lw = {}
+    for i in range(shape.layers):
+        for proj in ("q_proj", "v_proj"):
+            lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_A.weight"] = feats(f"lora.A.{i}.{proj}", (r, shape.hidden)) * 0.05
+            lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_B.weight"] = feats(f"lora.B.{i}.{proj}", (shape.hidden, r)) * 0.05
+    save_file(lw, str(lora / "adapter_model.safetensors"))
+    json.dump({"r": r, "lora_alpha": alpha}, open(lora / "adapter_config.json", "w"))
+    clip = synth.build_numpy(synth.clip_encoder_spec(hidden=shape.hidden), SEED, prefix="base_model.model.model.mm_projector.")
+    torch.save({k: T(v) for k, v in clip.items()}, lora / "non_lora_trainables.bin")
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", lambda *a, **k: synth.FakeTokenizer(vocab=shape.vocab))
+    args = _args(model_base=str(tmp_path / "base"))
+    tok, m, ctx_len = builder.load_pretrained_model(args, str(lora), None)
+    assert ctx_len == 2048 and m.generation_config.top_p == 0.6 and m.generation_config.top_k == 50
+    m = m.bfloat16().cuda()
+    m.generation_config.eos_token_id = None
+    ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None]
+    feat = feats("ld.feat", (1, 6, 16, 768), bf16=True)
+    q = (feats("ld.q", (1, 4, 768), bf16=True), torch.ones(1, 4))
+    out = m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
+    # oracle: merge in fp32 from the fp16 base (as the builder does), then round to bf16 like the engine
+    w = {k: v.float() for k, v in base.items()}
+    for i in range(shape.layers):
+        for proj in ("q_proj", "v_proj"):
+            n = f"model.layers.{i}.self_attn.{proj}.weight"
+            A = lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_A.weight"]
+            Bm = lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_B.weight"]
+            w[n] = (w[n] + (alpha / r) * (Bm @ A)).to(torch.float16).float()
+    w = {k: (v if "norm" in k else v.to(torch.bfloat16).float()) for k, v in w.items()}
+    wa = {k[len("base_model.model.model.mm_projector."):]: (T(v) if v.ndim == 1 else T(v).to(torch.bfloat16).float()) for k, v in clip.items()}
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), max_new_tokens=3, eos_token_id=-1,
+                          forced_tokens=out["sequences"][:, ids.shape[1]:].t().cpu())
+    assert rel_err(torch.stack(out["logits"]).cpu(), torch.stack(o["logits"])) < 3e-2
+
+
+def test_stage1_driver_runs():
+    from revisionllm_amd.eval import stage1
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = _model(shape, _args(clip_adapter=False, clip_adapter_text=False, hierarchy=False))
+    m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
+    real = m.generate
+    m.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    feat = feats("s1.feat", (5, 24, 768), bf16=True).to(torch.bfloat16).cuda()
+    answers, info = stage1.run_query(m, tok, feat, None, feats("s1.qc", (768,)).cuda(), "a man", (10.0, 20.0), 600.0, batch=2,
+                                     num_frames=24)
+    assert len(answers) == 5 and set(info) == {"iou", "scores"} and len(info["iou"]) == len(info["scores"])

@@ -1,0 +1,96 @@
+"""SURVEY section 8(f) "next" rows on the CPU: metric merge + R@k/mIoU against the reference script's own output (f-1),
+the feature-store reader formats (f-2), checkpoint-loader key rules through synthetic checkpoint directories (f-3),
+and the stage-1 driver's window / IoU helpers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recursion
+from revisionllm_amd.data.feature_store import FeatureStore
+from revisionllm_amd.eval import metrics, stage1
+from revisionllm_amd.model import builder
+
+
+def test_f1_metric_merge_matches_reference_script(golden, tmp_path):
+    g = golden.json("g10_metrics")
+    merged, frac = metrics.merge_stage1_stage2(json.loads(json.dumps(g["grounding"])), g["retrieval"], g["retrieval2"])
+    got = metrics.grounding_metrics_stream(merged)
+    exp = g["expected"]["two_runs"]
+    assert set(got) == set(exp)
+    for k in exp:
+        assert got[k] == pytest.approx(exp[k], abs=1e-9), k
+    assert frac == pytest.approx(g["expected"]["two_runs_selected_fraction"], abs=1e-12)
+    # CLI + shard files
+    for name, logs in (("g", g["grounding"]), ("r", g["retrieval"]), ("r2", g["retrieval2"])):
+        os.makedirs(tmp_path / name)
+        with open(tmp_path / name / "predictions_streaming_0.txt", "w") as f:
+            for x in logs:
+                f.write(json.dumps(x) + "\n")
+    out = metrics.main(["--grounding_path", str(tmp_path / "g"), "--retrieval_path", str(tmp_path / "r"), "--retrieval_path2",
+                        str(tmp_path / "r2")])
+    assert out["mIoU"] == pytest.approx(exp["mIoU"], abs=1e-9)
+    assert json.load(open(tmp_path / "g" / "result_retrieval.txt"))["R1@0.5"] == pytest.approx(exp["R1@0.5"], abs=1e-9)
+
+
+def test_f1_metrics_edge_cases():
+    assert metrics.grounding_metrics_stream([]) is None
+    m = metrics.grounding_metrics_stream([{"info": {"iou": [0.2, 0.8], "scores": [0.1, 0.9]}}, {"info": {"iou": [], "scores": []}}])
+    assert m["mIoU"] == pytest.approx(40.0) and m["R1@0.5"] == pytest.approx(50.0) and m["R5@0.9"] == 0
+
+
+def test_f2_feature_store_formats(tmp_path):
+    feats = np.random.RandomState(0).randn(700, 768).astype(np.float16)
+    np.save(tmp_path / "movie1.npy", feats)
+    np.savez_compressed(tmp_path / "movie2.npz", memory_global=feats[:10])
+    os.makedirs(tmp_path / "q")
+    np.savez_compressed(tmp_path / "q" / "q7.npz", token_features=feats[:5], cls_features=feats[5])
+    fs = FeatureStore(str(tmp_path), q_feat_dir=str(tmp_path / "q"))
+    assert np.array_equal(fs.video("movie1"), feats) and fs.video("movie2").shape == (10, 768)
+    tok, cls = fs.query("q7")
+    assert tok.shape == (5, 768) and cls.shape == (768,)
+    assert FeatureStore(str(tmp_path)).query("q7") == (None, None)
+    with pytest.raises((ImportError, Exception)):
+        FeatureStore(str(tmp_path), vis_feat_storage="lmdb")
+
+
+def test_f3_checkpoint_dirs_roundtrip(tmp_path):
+    """HF-style checkpoint + LoRA directory -> merged host state dict (what finalize() packs into HBM)."""
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    base = {"model.layers.0.self_attn.q_proj.weight": torch.randn(16, 16, dtype=torch.float16),
+            "model.layers.0.mlp.up_proj.weight": torch.randn(32, 16, dtype=torch.float16), "lm_head.weight": torch.randn(8, 16, dtype=torch.float16)}
+    os.makedirs(tmp_path / "base")
+    save_file(base, str(tmp_path / "base" / "model-00001-of-00001.safetensors"))
+    sd = builder.read_hf_checkpoint(str(tmp_path / "base"))
+    assert set(sd) == set(base)
+    lora = tmp_path / "stage2"
+    os.makedirs(lora)
+    A, B = torch.randn(4, 16), torch.randn(16, 4)
+    save_file({"base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight": A,
+               "base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight": B}, str(lora / "adapter_model.safetensors"))
+    json.dump({"r": 64, "lora_alpha": 128, "target_modules": ["q_proj"]}, open(lora / "adapter_config.json", "w"))
+    torch.save({"base_model.model.model.mm_projector.mm_projector.weight": torch.ones(4, 3),
+                "base_model.model.model.mm_projector.global_rep_token": torch.zeros(3)}, lora / "non_lora_trainables.bin")
+    w0 = sd["model.layers.0.self_attn.q_proj.weight"].float().clone()
+    merged, extra = builder.apply_lora_dir(sd, str(lora))
+    assert torch.allclose(merged["model.layers.0.self_attn.q_proj.weight"].float(), w0 + 2.0 * (B @ A), atol=2e-2)
+    assert merged["model.layers.0.self_attn.q_proj.weight"].dtype == torch.float16
+    assert set(extra) == {"model.mm_projector.mm_projector.weight", "model.mm_projector.global_rep_token"}
+    assert "model.mm_projector.global_rep_token" in merged
+    shape = builder.shape_from_config({"hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
+                                       "num_attention_heads": 32, "vocab_size": 32000, "rms_norm_eps": 1e-5})
+    assert shape.head_dim == 128 and shape.theta == 10000.0
+    with pytest.raises(FileNotFoundError):
+        builder.read_hf_checkpoint(str(tmp_path / "stage2" / "nothing"))
+
+
+def test_stage1_windows_and_iou(golden):
+    for ctx_l in (700, 5400, 20001):
+        assert (stage1.cut_windows(ctx_l) == np.stack(recursion.stage1_windows(ctx_l)[1])).all()
+    assert stage1.cut_windows(300).shape[0] == 0
+    s1 = golden.json("g9_driver")["stage1"]
+    frames, ious, keep = stage1.iou(s1["outputs"], tuple(s1["gt"]), 250, 2000, [.5, .6, .7, .8, .9, 1.0, 1.1])
+    assert {str(k): list(v) for k, v in frames.items()} == s1["frames"] and ious == s1["ious"] and keep == s1["keep"]
