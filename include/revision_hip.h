@@ -133,6 +133,15 @@ size_t rv_llm_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t S);
 int rv_llm_forward(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Prefill of B sequences that start with the same P0 tokens (inference() repeats one prompt, inference.py:36): under
+ * causal attention the prefix rows are identical for every sequence, so they are computed once.
+ * h f32 [P0 + B*S, D]: the P0 shared rows (positions 0..P0-1) followed by S rows per sequence (positions P0..P0+S-1).
+ * The prefix K/V are written into all B caches; logits f32 [B,V] of each sequence's last position.  Results are
+ * bit-identical to rv_llm_forward on the B full sequences. */
+size_t rv_llm_prefill_shared_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t P0, int32_t S);
+int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t Smax, float* logits,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- token selection + scores ----------------------------------------------------------- */
 /* HF warper chain temperature -> top-k -> top-p, inverse-CDF draw with caller uniforms (or argmax when
  * do_sample == 0), plus the entropy of the processed and of the raw distribution

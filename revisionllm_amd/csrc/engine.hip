@@ -333,7 +333,7 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.a16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
-    w.xl16 = (bf16_t*)k.take((size_t)B * D * 2);
+    w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.bytes = k.off;
     return w;
@@ -342,45 +342,76 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
 
 extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
     if (!c || B <= 0 || S <= 0) return 0;
-    return carve_llm(c, nullptr, 0, B, S).bytes;
+    return carve_llm(c, nullptr, 0, 1, B * S).bytes;
 }
 
-extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
-                              void* ws, size_t ws_bytes, void* stream) {
-    RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_forward: null argument");
-    RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_forward: empty problem");
-    RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_forward: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
+namespace {
+// Rows of h: [P0 shared-prefix rows (positions 0..P0-1)] then B sequences of S rows (positions pos0..pos0+S-1, with
+// pos0 == P0 when P0 > 0).  P0 == 0 is the plain prefill / decode step.
+int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
     RV_TRY(resolve_llm(c));
-    const LlmWs w = carve_llm(c, ws, ws_bytes, B, S);
+    const rv_config& g = c->cfg;
+    const int64_t D = g.hidden, F = g.inter, V = g.vocab, M = (int64_t)B * S + P0;
+    const LlmWs w = carve_llm(c, ws, ws_bytes, 1, (int)M);
     if (w.bytes > ws_bytes) {
         rv_set_error("rv_llm_forward: workspace %zu < required %zu", ws_bytes, w.bytes);
         return RV_ERR_WORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
-    const rv_config& g = c->cfg;
-    const int64_t D = g.hidden, F = g.inter, V = g.vocab, M = (int64_t)B * S;
     const int H = g.heads, dh = (int)(D / H);
     const int64_t per_layer = (int64_t)B * D * Smax;  // elements of one layer's K (= V^T)
     bf16_t* kbase = (bf16_t*)kv;
     bf16_t* vbase = kbase + (int64_t)g.layers * per_layer;
     const float scale = 1.0f / sqrtf((float)dh);
-    RV_TRY(k_rope_table(w.cs, S, pos0, dh, g.rope_theta, st));
+    // (cos, sin) table for positions [P0 ? 0 : pos0, pos0 + S)
+    const int tab0 = P0 > 0 ? 0 : pos0;
+    RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
         RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, w.sk, w.sk_bytes, st));
-        RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, M, S, pos0, H, dh, Smax, st));
-        AttnArgs a{w.q16, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                   (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
+        if (P0 > 0) {
+            RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, P0, P0, 0, H, dh, Smax, B, st));
+            AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                        (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+            RV_TRY(k_attention(ap, st));
+        }
+        const int64_t r0 = P0;  // first row of the per-sequence part
+        RV_TRY(k_rope_kv(w.qkv32 + r0 * 3 * D, w.cs + (int64_t)(pos0 - tab0) * dh, w.q16 + r0 * D, kc, vtc, (int64_t)B * S, S, pos0, H,
+                         dh, Smax, 0, st));
+        AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                   (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
         RV_TRY(k_attention(a, st));
         RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st));
         RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
         RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st));
         RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st));
     }
-    // final norm + lm_head on the last position of every row only
-    RV_TRY(k_rmsnorm(h + (int64_t)(S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
+    // final norm + lm_head on the last position of every sequence only
+    RV_TRY(k_rmsnorm(h + ((int64_t)P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
     return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st);
+}
+}  // namespace
+
+extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
+                              void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_forward: null argument");
+    RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_forward: empty problem");
+    RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_forward: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
+    return llm_forward_impl(c, h, B, S, pos0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" size_t rv_llm_prefill_shared_ws_bytes(const rv_ctx* c, int32_t B, int32_t P0, int32_t S) {
+    if (!c || B <= 0 || S <= 0 || P0 < 0) return 0;
+    return carve_llm(c, nullptr, 0, 1, B * S + P0).bytes;
+}
+
+extern "C" int rv_llm_prefill_shared(rv_ctx* c, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t Smax, float* logits,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_prefill_shared: null argument");
+    RV_CHECK_ARG(B > 0 && S > 0 && P0 > 0, "rv_llm_prefill_shared: empty problem");
+    RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_shared: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
+    return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));
 }

@@ -21,7 +21,7 @@ int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st);
 int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
-              int Smax, hipStream_t st);
+              int Smax, int nb_bcast, hipStream_t st);
 int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st);
 
 struct AttnArgs {

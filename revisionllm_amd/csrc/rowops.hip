@@ -190,8 +190,10 @@ __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int 
 // q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated.  One thread = 4 consecutive pair indices j (float4
 // loads of both halves, 8-byte bf16 stores).  V is handled by v_cache_kernel below.
 __global__ __launch_bounds__(256) void rope_qk_kernel(const float* __restrict__ qkv, const float2* __restrict__ cs,
-                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc, int S, int pos0,
-                                                      int H, int dh, int Smax) {
+                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc,
+                                                      bf16_t* __restrict__ vtc_decode, int S, int pos0, int H, int dh, int Smax,
+                                                      int nb_bcast) {
+    // nb_bcast > 0: the rows are a prefix shared by nb_bcast sequences - K is written into every one of their caches
     const int64_t m = blockIdx.x;
     const int b = (int)(m / S), s = (int)(m % S);
     const int pos = pos0 + s;
@@ -211,9 +213,26 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(const float* __restrict__ 
             o1[e] = x1[e] * t.x - x2[e] * t.y;
             o2[e] = x2[e] * t.x + x1[e] * t.y;
         }
-        bf16_t* dst = which == 0 ? q16 + m * D + h * dh + j : kc + (((int64_t)b * H + h) * Smax + pos) * dh + j;
-        *(u32x2*)dst = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
-        *(u32x2*)(dst + half) = u32x2{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+        const u32x2 lo = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+        const u32x2 hi = u32x2{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+        if (which == 0) {
+            bf16_t* dst = q16 + m * D + h * dh + j;
+            *(u32x2*)dst = lo;
+            *(u32x2*)(dst + half) = hi;
+        } else {
+            const int b0 = nb_bcast > 0 ? 0 : b, b1 = nb_bcast > 0 ? nb_bcast : b + 1;
+            for (int bb = b0; bb < b1; ++bb) {
+                bf16_t* dst = kc + (((int64_t)bb * H + h) * Smax + pos) * dh + j;
+                *(u32x2*)dst = lo;
+                *(u32x2*)(dst + half) = hi;
+            }
+        }
+    }
+    if (vtc_decode) {  // decode step (S == 1): append V^T here too instead of launching the tiled transpose
+        for (int i = threadIdx.x; i < D; i += 256) {
+            const int h = i / dh, d = i % dh;
+            vtc_decode[(((int64_t)b * H + h) * dh + d) * Smax + pos] = f32_to_bf16(row[2 * D + i]);
+        }
     }
 }
 
@@ -221,9 +240,10 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(const float* __restrict__ 
 // coalesced reads of 64 x dh floats through LDS, then 128-byte row writes along the position axis.
 template <int DH>
 __global__ __launch_bounds__(256) void v_cache_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ vtc, int S, int pos0,
-                                                      int H, int Smax) {
+                                                      int H, int Smax, int bcast) {
     __shared__ bf16_t tile[64][DH + 2];
-    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y;
+    const int bd = blockIdx.z, b = bcast ? 0 : bd;   // destination cache / source sequence
     const int D = H * DH;
     for (int i = threadIdx.x; i < 64 * (DH / 4); i += 256) {
         const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(256) void v_cache_kernel(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) tile[r][c + e] = f32_to_bf16(v[e]);
     }
     __syncthreads();
-    bf16_t* o = vtc + (((int64_t)b * H + h) * DH) * Smax + pos0 + s0;
+    bf16_t* o = vtc + (((int64_t)bd * H + h) * DH) * Smax + pos0 + s0;
     const int n = min(64, S - s0);
     for (int i = threadIdx.x; i < DH * 64; i += 256) {
         const int d = i / 64, l = i % 64;
@@ -348,14 +368,17 @@ int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st
 }
 
 int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
-              int Smax, hipStream_t st) {
+              int Smax, int nb_bcast, hipStream_t st) {
     RV_CHECK_ARG(dh == 128, "rope_kv: head dim must be 128");
-    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc, S,
-                       pos0, H, dh, Smax);
+    RV_CHECK_ARG(nb_bcast == 0 || M == S, "rope_kv: a broadcast prefix is a single sequence");
+    const bool fuse_v = S == 1 && nb_bcast == 0;
+    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc,
+                       fuse_v ? (bf16_t*)vtc : nullptr, S, pos0, H, dh, Smax, nb_bcast);
     RV_CHECK_LAUNCH("rope_qk");
-    const int B = (int)(M / S);
+    if (fuse_v) return RV_OK;
+    const int B = nb_bcast > 0 ? nb_bcast : (int)(M / S);
     hipLaunchKernelGGL(v_cache_kernel<128>, dim3((unsigned)cdiv(S, 64), (unsigned)H, (unsigned)B), dim3(256), 0, st, qkv,
-                       (bf16_t*)vtc, S, pos0, H, Smax);
+                       (bf16_t*)vtc, S, pos0, H, Smax, nb_bcast > 0 ? 1 : 0);
     RV_CHECK_LAUNCH("v_cache");
     return RV_OK;
 }

@@ -71,11 +71,8 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
                                                      float* __restrict__ out_hr, int32_t* __restrict__ out_idx,
                                                      float* __restrict__ out_val, int32_t* __restrict__ out_nkeep) {
     __shared__ float sh[16];
-    __shared__ float wv[16];
-    __shared__ int wi[16];
     __shared__ float topv[KCAP];
     __shared__ int topi[KCAP];
-    __shared__ int win;
     __shared__ float e[KCAP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (int64_t)b * V;
@@ -91,34 +88,129 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         v[j] = i < V ? x[i] * inv_t : -INFINITY;
     }
     const int K = do_sample ? top_k : 1;
-    for (int r = 0; r < K; ++r) {
-        ArgMax m{-INFINITY, 0x7fffffff};
+    // ---- top-K selection: radix select on order-preserving integer keys (2 bits per round, pure register counting +
+    // one block reduction per round), then the <= K survivors are rank-sorted by (score desc, index asc).
+    __shared__ int cnt_sh[16][4];
+    __shared__ int n_list, n_eq_taken;
+    __shared__ unsigned list_key[KCAP];
+    __shared__ int list_idx[KCAP];
+    unsigned key[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) m = better(m, ArgMax{v[j], tid + j * TPB});
-        m = wave_argmax(m);
-        if (lane == 0) {
-            wv[wave] = m.v;
-            wi[wave] = m.i;
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned u = __float_as_uint(v[j]);
+        key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        if (tid + j * TPB >= V) key[j] = 0u;   // below every real score (-inf maps to 0x007fffff)
+    }
+    unsigned prefix = 0u;   // bits of the K-th largest key decided so far
+    int need = K;           // how many of the keys matching the prefix are still wanted
+    for (int shift = 30; shift >= 0; shift -= 2) {
+        const unsigned himask = shift == 30 ? 0u : (0xffffffffu << (shift + 2));
+        int c1 = 0, c2 = 0, c3 = 0;   // keys (matching the prefix) whose next 2 bits are >= 1, >= 2, >= 3
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool m = (key[j] & himask) == prefix;
+            const unsigned d = (key[j] >> shift) & 3u;
+            c1 += (m && d >= 1u);
+            c2 += (m && d >= 2u);
+            c3 += (m && d >= 3u);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c1 += __shfl_xor(c1, o, 64);
+            c2 += __shfl_xor(c2, o, 64);
+            c3 += __shfl_xor(c3, o, 64);
         }
         __syncthreads();
-        if (tid < 64) {
-            ArgMax t = tid < TPB / 64 ? ArgMax{wv[tid], wi[tid]} : ArgMax{-INFINITY, 0x7fffffff};
-            t = wave_argmax(t);
-            if (tid == 0) {
-                topv[r] = t.v;
-                topi[r] = t.i;
-                win = t.i;
+        if (lane == 0) {
+            cnt_sh[wave][1] = c1;
+            cnt_sh[wave][2] = c2;
+            cnt_sh[wave][3] = c3;
+        }
+        __syncthreads();
+        int t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) {
+            t1 += cnt_sh[w][1];
+            t2 += cnt_sh[w][2];
+            t3 += cnt_sh[w][3];
+        }
+        // digit of the need-th largest key among the matching ones
+        unsigned dsel;
+        if (t3 >= need) dsel = 3u;
+        else if (t2 >= need) { dsel = 2u; need -= t3; }
+        else if (t1 >= need) { dsel = 1u; need -= t2; }
+        else { dsel = 0u; need -= t1; }
+        prefix |= dsel << shift;
+    }
+    // prefix = K-th largest key; `need` of the keys equal to it are wanted (the ones with the smallest indices)
+    if (tid == 0) {
+        n_list = 0;
+        n_eq_taken = 0;
+    }
+    __syncthreads();
+    int n_eq_local = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) n_eq_local += (key[j] == prefix);
+    const int n_eq_total = (int)(block_sum((float)n_eq_local, sh) + 0.5f);   // <= 32768: exact in fp32
+    const bool take_all_eq = n_eq_total == need;   // the usual case: no tie straddles the K-th place
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (key[j] > prefix || (take_all_eq && key[j] == prefix)) {
+            const int p = atomicAdd(&n_list, 1);
+            if (p < KCAP) {
+                list_key[p] = key[j];
+                list_idx[p] = tid + j * TPB;
             }
         }
-        __syncthreads();
-        const int w = win;
-        if ((w % TPB) == tid) {
-            const int jj = w / TPB;
+    }
+    __syncthreads();
+    if (!take_all_eq) {
+        // ties at the K-th value: keep the `need` smallest indices.  Walk the index space in ascending order: item j of
+        // every thread covers indices [j*TPB, (j+1)*TPB) in (wave, lane) order.
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool eq = key[j] == prefix;
+            const unsigned long long bal = __ballot(eq);
+            if (lane == 0) cnt_sh[wave][0] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-                if (j == jj) v[j] = -INFINITY;
+            for (int w = 0; w < TPB / 64; ++w) {
+                before += w < wave ? cnt_sh[w][0] : 0;
+                total += cnt_sh[w][0];
+            }
+            const int taken = n_eq_taken;
+            if (eq) {
+                const int r = taken + before + __popcll(bal & ((1ull << lane) - 1ull));
+                if (r < need) {
+                    const int p = (K - need) + r;
+                    list_key[p] = key[j];
+                    list_idx[p] = tid + j * TPB;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) n_eq_taken = taken + total;
+            __syncthreads();
+            if (n_eq_taken >= need) break;
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        // rank sort of the K candidates: (key desc, index asc)
+        const unsigned kk = tid < K ? list_key[tid] : 0u;
+        const int ii = tid < K ? list_idx[tid] : 0x7fffffff;
+        int rank = 0;
+        for (int q = 0; q < K; ++q) {
+            const unsigned kq = list_key[q];
+            const int iq = list_idx[q];
+            rank += (kq > kk) || (kq == kk && iq < ii);
+        }
+        if (tid < K) {
+            const unsigned u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
+            topv[rank] = __uint_as_float(u);
+            topi[rank] = ii;
         }
     }
+    __syncthreads();
     if (!do_sample) {
         if (tid == 0) {
             out_tok[b] = topi[0];

@@ -201,6 +201,18 @@ class Engine:
         return logits
 
 
+    def llm_prefill_shared(self, h, B, P0, kv, Smax, logits=None):
+        """h f32 [P0 + B*S, D] (shared prefix rows first, then S rows per sequence) -> logits f32 [B,V]."""
+        assert h.dtype == torch.float32 and h.is_contiguous() and (h.shape[0] - P0) % B == 0
+        S = (h.shape[0] - P0) // B
+        if logits is None:
+            logits = torch.empty(B, self.shape.vocab, dtype=torch.float32, device=self.device)
+        ws = self._workspace("llm", self.lib.rv_llm_prefill_shared_ws_bytes(self._ctx, B, P0, S))
+        hip.check(self.lib.rv_llm_prefill_shared(self._ctx, hip.ptr(h), B, P0, S, hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws),
+                                                 ws.numel(), hip.stream()), "rv_llm_prefill_shared")
+        return logits
+
+
 def pack_gate_up(gate, up):
     """[F,D] x2 -> [2F,D] with 16-row blocks alternating gate / up."""
     F, D = gate.shape

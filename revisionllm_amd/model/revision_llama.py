@@ -197,15 +197,13 @@ class ReVisionLlamaForCausalLM:
                  max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
                  return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
                  attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
-                 share_prefix=False, **kwargs):
+                 share_prefix=True, **kwargs):
         """Prefill + KV-cached sampling loop (inference.py:45-59 kwargs).
 
         Extra, build-defined kwargs: ``uniforms`` [G,B] (host-supplied draws for reproducible sampling; default
         ``torch.rand`` on the device), ``forced_tokens`` [G,B] (teacher forcing for parity tests),
         ``video_rows`` / ``rows_per_sample`` (pre-encoded adapter output, used by the batched recursion),
-        ``share_prefix`` (prefill the text prefix common to all rows once and broadcast its K/V; bit-identical results.
-        Off by default: as a separate M = P0 pass it streams all weights a second time, which costs more than it saves
-        until the prefix rows are folded into the main prefill batch).
+        ``share_prefix`` (the text prefix common to all rows goes through the prefill once; bit-identical results).
         ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
         """
         if num_beams != 1:
@@ -233,12 +231,11 @@ class ReVisionLlamaForCausalLM:
         P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
         if P0 >= 16:
             # every row starts with the same P0 text tokens (inference() repeats one prompt): under causal attention their
-            # hidden states and K/V are identical for all rows, so prefill them once and broadcast the cache
-            kv1, smax1 = eng.new_kv(1, P0)
-            eng.llm_forward(eng.splice_embed(row_map[:1, :P0], None), 0, kv1, smax1)
-            self._broadcast_prefix(kv1, smax1, kv, Smax, B, P0)
-            h = eng.splice_embed(row_map[:, P0:].contiguous(), video_rows)
-            logits = eng.llm_forward(h, P0, kv, Smax)
+            # hidden states and K/V are identical for all rows, so they ride through the prefill once (rows of the
+            # GEMM batch: [P0 shared ; B x (S - P0)]) and their K/V are written into every row's cache
+            flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
+            h = eng.splice_embed(flat, video_rows)[0]
+            logits = eng.llm_prefill_shared(h, B, P0, kv, Smax)
         else:
             h = eng.splice_embed(row_map, video_rows)
             logits = eng.llm_forward(h, 0, kv, Smax)
@@ -297,14 +294,6 @@ class ReVisionLlamaForCausalLM:
         same = (row_map == row_map[:1]).all(dim=0) & (row_map[0] >= 0)
         bad = (~same).nonzero()
         return int(bad[0]) if bad.numel() else row_map.shape[1]
-
-    def _broadcast_prefix(self, kv1, smax1, kv, Smax, B, P0):
-        s = self.shape
-        h1, hB = kv1.numel() // 2, kv.numel() // 2
-        kv[:hB].view(s.layers, B, s.heads, Smax, s.head_dim)[:, :, :, :P0] = \
-            kv1[:h1].view(s.layers, 1, s.heads, smax1, s.head_dim)[:, :, :, :P0]
-        kv[hB:].view(s.layers, B, s.heads, s.head_dim, Smax)[..., :P0] = \
-            kv1[h1:].view(s.layers, 1, s.heads, s.head_dim, smax1)[..., :P0]
 
     def _grow_kv(self, kv, B, Smax, new_smax):
         s = self.shape

@@ -274,6 +274,15 @@ def test_sample_and_scores(dev):
             assert torch.allclose(o["topk_val"][b, :n].cpu(), sc[b, idx], rtol=1e-6)
     o = ops.sample(logits.to(dev), None, False)
     assert (o["tokens"].cpu().long() == logits.argmax(-1)).all()
+    # ties: quantised logits produce many equal scores, some straddling the K-th place (lowest index must win)
+    lt = (logits * 2).round() / 2
+    lt[4, :] = 1.25                      # a fully tied row
+    lt[4, 100] = 3.0
+    for (temp, k, p) in ((1.0, 50, 1.0), (0.5, 7, 0.95), (1.0, 64, 0.7)):
+        o = ops.sample(lt.to(dev), u.to(dev), True, temp, k, p)
+        srt = torch.sort(lt / temp, descending=True, stable=True, dim=-1)
+        assert (o["topk_idx"][:, :k].cpu().long() == srt.indices[:, :k]).all(), (temp, k, p)
+        assert torch.allclose(o["topk_val"][:, :k].cpu(), srt.values[:, :k], rtol=1e-6)
     # max / min / mean to 1e-5 relative; std is a difference of nearly equal entropies (H ~ 10, std ~ 5e-4),
     # so it is only compared to 2e-5 ABSOLUTE (= 2e-6 of H, fp32 resolution of the inputs)
     st = ops.entropy_stats((logits.view(1, 5, 32000) * 0.5).to(dev))

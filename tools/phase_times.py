@@ -39,6 +39,9 @@ def main():
     kv, Smax = eng.new_kv(B, S + 64)
     h0 = torch.randn(B, S, 4096, device=dev) * 0.02
     print(f"prefill B={B} S={S}        : {ev(lambda: eng.llm_forward(h0.clone(), 0, kv, Smax)):8.3f} ms")
+    P0 = 37
+    hs = torch.randn(P0 + B * (S - P0), 4096, device=dev) * 0.02
+    print(f"prefill shared P0={P0}       : {ev(lambda: eng.llm_prefill_shared(hs.clone(), B, P0, kv, Smax)):8.3f} ms")
     h1 = torch.randn(B, 1, 4096, device=dev) * 0.02
     print(f"decode step B={B}          : {ev(lambda: eng.llm_forward(h1.clone(), S, kv, Smax), n=20):8.3f} ms")
     logits = torch.randn(B, 32000, device=dev)
