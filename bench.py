@@ -58,12 +58,12 @@ def event_time_ms(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def roofline_legs(model, n_calls, S):
-    """Time the path's two heavy kernels in isolation on the shapes the recursion launches them with."""
+def roofline_legs(model, n_calls, M):
+    """Time the path's two heavy kernels in isolation on the shapes the recursion launches them with
+    (M = rows of the prefill GEMM batch: shared prompt prefix once + the rest of every call)."""
     from revisionllm_amd import hip, ops
     eng, s = model.engine, model.shape
     dev = eng.device
-    M = n_calls * S
     legs = {}
     # (1) prefill gate/up GEMM + SiLU*mul epilogue: [M,4096] x [22016,4096]^T  (MFMA-bound)
     x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
@@ -71,8 +71,9 @@ def roofline_legs(model, n_calls, S):
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
     ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
-    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile<bf16,SILU_MUL>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
-                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops)
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops,
+                                       grid_threads=((M + 127) // 128) * (2 * s.inter // 128) * 256)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
     #     256 MB infinity cache cannot serve the weights
     xs = torch.randn(n_calls, s.hidden, device=dev).to(torch.bfloat16)
@@ -85,9 +86,22 @@ def roofline_legs(model, n_calls, S):
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
-    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,bf16,SILU_MUL>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
-                                      peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes)
+    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
+                                      peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
     return legs
+
+
+def pmc_traffic(kernel, grid_threads):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE; tools/pmc_summary.py).  None if no summary matches."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    want = kernel.replace(" ", "")
+    for row in json.load(open(path))["kernels"]:
+        if row["kernel"].replace(" ", "") == want and row["grid_threads"] == grid_threads:
+            return row["traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(args, n_calls, P):
@@ -164,10 +178,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    backend = os.environ.get("REVISION_DIST_BACKEND", "nccl")   # "gloo": plumbing smoke test with several ranks on one GPU
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -226,8 +245,12 @@ def main():
         P = ids1.shape[1]
         S = P - 1 + 100
         n_calls_rank = len(parallel.deal(len(plan), 0, world))
-        legs = roofline_legs(model, n_calls_rank, S)
-        dom = max(legs.values(), key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * args.decode_steps))
+        row_map = model.build_row_map(ids1.repeat(n_calls_rank, 1), 100)
+        P0 = model._common_text_prefix(row_map) if n_calls_rank > 1 else 0
+        M_prefill = P0 + n_calls_rank * (S - P0)
+        legs = roofline_legs(model, n_calls_rank, M_prefill)
+        dom = max(legs.values(), key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (args.decode_steps - 1)))
+        traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         out = {
             "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
             "value": W * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -235,11 +258,11 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
                        "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
-                       "prefill_len": int(S), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
+                       "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
                        "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
                        "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                         "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": None,
+                         "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,
                          "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"],
                          "other": {k: {"achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
                                        "avg_launch_ms": v["ms"]} for k, v in legs.items()}},

@@ -188,6 +188,136 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Deep-pipeline variant of the tiled kernel (packed W only): 128x128x32 steps in a 4-stage LDS ring (4 x 16 KiB, so two
+// workgroups still fit per CU) with a COUNTED vmcnt: three stages (96 KiB per CU with two workgroups) stay in flight
+// across the single raw s_barrier per step, instead of one 32 KiB stage.  At the path's prefill shapes one 64-deep
+// K-step is ~0.2 us of MFMA work - less than a memory round trip - so the 2-stage kernel is latency-bound
+// (in-flight bytes per CU x 1/latency ~ 0.9 PF/s); this variant raises the bytes in flight by 1.5x.
+// A rows are 64 B here; chunk c of row r lives in LDS slot c ^ ((r >> 2) & 2), which makes every ds_read_b128 lane
+// group hit 16 distinct 16-byte slots.
+constexpr int P4_BK = 32, P4_STAGES = 4, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
+
+__device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int N,
+                                              int K, int m0, int n0, int k0, char* slot, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r16 = (wave * 2 + i) * 16;
+        const int row = r16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 2);
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        glds16(A + (int64_t)grow * lda + k0 + c * 8, slot + r16 * (P4_BK * 2));
+    }
+    const int kfr = K >> 5, nt_max = (N >> 4) - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = wave * 2 + i;
+        int nt = (n0 >> 4) + f;
+        nt = nt < nt_max ? nt : nt_max;
+        glds16(Wp + (((int64_t)nt * kfr + (k0 >> 5)) * 64 + lane) * 8, slot + P4_A_BYTES + f * 1024);
+    }
+}
+
+template <int OUT_BF16, int ACT>
+__global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[P4_STAGES * P4_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        const int tiles_n8 = tiles_n & ~7;
+        if (b < tiles_n8 * tiles_m) {
+            const int xcd = b & 7, idx = b >> 3;
+            tn = (idx / tiles_m) * 8 + xcd;
+            tm = idx % tiles_m;
+        } else {
+            const int r = b - tiles_n8 * tiles_m;
+            tm = r % tiles_m;
+            tn = tiles_n8 + r / tiles_m;
+        }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nks = K / P4_BK;
+    p4_stage_load(A, lda, W, M, N, K, m0, n0, 0, smem, wave, lane);
+    if (nks > 1) p4_stage_load(A, lda, W, M, N, K, m0, n0, P4_BK, smem + P4_STAGE, wave, lane);
+    if (nks > 2) p4_stage_load(A, lda, W, M, N, K, m0, n0, 2 * P4_BK, smem + 2 * P4_STAGE, wave, lane);
+    int slot = 0;
+    for (int i = 0; i < nks; ++i) {
+        // stage i must have landed; up to two later stages (4 loads per lane each) stay in flight across the barrier
+        const int later = nks - 1 - i;
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + 3 < nks) {
+            const int s3 = (slot + 3) & 3;   // the slot read in step i-1: every wave is past it after this barrier
+            p4_stage_load(A, lda, W, M, N, K, m0, n0, (i + 3) * P4_BK, smem + s3 * P4_STAGE, wave, lane);
+        }
+        const char* a_s = smem + slot * P4_STAGE;
+        const char* w_s = a_s + P4_A_BYTES;
+        bf16x8 wf[4], af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wf[q] = *(const bf16x8*)(w_s + (wc * 4 + q) * 1024 + lane * 16);
+            const int row = wr * 64 + q * 16 + fr;
+            af[q] = *(const bf16x8*)(a_s + row * (P4_BK * 2) + ((kg ^ ((row >> 2) & 2)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        slot = (slot + 1) & 3;
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + mi * 16 + fr;
+        if (m >= M) continue;
+        if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int n = n0 + wc * 64 + ni * 16;
+                if (n >= N) continue;
+                const int no = (n >> 1) + kg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+                if (n >= N) continue;
+                f32x4 v = acc[ni][mi];
+                if (bias) v += *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight-streaming kernel for M <= 16 rows (decode).  Block = 8 waves = NT 16-row weight tiles; wave w takes
 // k-blocks (128 wide) w, w+8, ... two at a time, so 8*NT independent 1-KiB weight loads are in flight per wave
 // before the first MFMA.  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and x[r][k] for
@@ -304,10 +434,17 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     }
 }
 
+int g_tile_variant = 1;  // 1 (default) = 128x128x32 4-stage counted-vmcnt ring (packed W only); 0 = 128x128x64 2-stage
+
 template <int OUT_BF16, int ACT, int WP>
 void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
+    if (WP && g_tile_variant == 1) {
+        hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
+                           ldc, M, N, K, tiles_m, tiles_n);
+        return;
+    }
     hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT, WP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
                        C, ldc, M, N, K, tiles_m, tiles_n);
 }
@@ -373,6 +510,8 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_LAUNCH("rv_gemm");
     return RV_OK;
 }
+
+extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = v == 1 ? 1 : 0; }
 
 extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_sk_ws_bytes(); }
 

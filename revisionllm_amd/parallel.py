@@ -28,6 +28,19 @@ def deal(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _all_gather_cat(padded, group):
+    """all_gather of equal-sized blocks, concatenated on dim 0.  RCCL: one all_gather_into_tensor; other backends (gloo in
+    the CPU tests) use the list form."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world * padded.shape[0],) + tuple(padded.shape[1:]), dtype=padded.dtype, device=padded.device)
+        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+        return out
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded.contiguous(), group=group)
+    return torch.cat(parts, 0)
+
+
 def allgather_rows(local, n_total, group=None):
     """All-gather a block-partitioned [n_local, ...] tensor into [n_total, ...] (blocks padded to equal size)."""
     world = dist.get_world_size(group)
@@ -36,8 +49,7 @@ def allgather_rows(local, n_total, group=None):
     per = -(-n_total // world)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    out = _all_gather_cat(pad, group)
     parts = []
     for r in range(world):
         lo, hi = shard_bounds(n_total, r, world)
@@ -60,11 +72,7 @@ def allgather_calls(results, n_calls, max_tokens, device, group=None):
         tok[j, 0], tok[j, 1] = c, len(t)
         tok[j, 2:2 + len(t)] = torch.tensor(t, dtype=torch.int32)
         ent[j, 0], ent[j, 1] = emax, emean
-    tok_all = torch.empty((world * per, 2 + max_tokens), dtype=torch.int32, device=device)
-    ent_all = torch.empty((world * per, 2), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(tok_all, tok, group=group)
-    dist.all_gather_into_tensor(ent_all, ent, group=group)
-    tok_all, ent_all = tok_all.cpu(), ent_all.cpu()
+    tok_all, ent_all = _all_gather_cat(tok, group).cpu(), _all_gather_cat(ent, group).cpu()
     out = {}
     for j in range(tok_all.shape[0]):
         c = int(tok_all[j, 0])

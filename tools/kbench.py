@@ -26,9 +26,9 @@ def main():
     which = set(sys.argv[1:]) or {"gemm", "gemv", "attn"}
     dev = torch.device("cuda:0")
     D, F, V = 4096, 11008, 32000
-    for geo in ((0,) if "gemm" in which else ()):
-        hip.lib().rv_set_gemm_geometry(geo)
-        print(f"--- stream-K geometry: {geo} waves per workgroup")
+    for geo in ((0, 1) if "gemm" in which else ()):
+        hip.lib().rv_set_gemm_tile_variant(geo)
+        print(f"--- tile variant {geo}")
         for M in (975, 1197):
             for name, N, K, act, od in (("qkv", 3 * D, D, 0, torch.float32), ("o", D, D, 0, torch.float32),
                                         ("gateup", 2 * F, D, 2, torch.bfloat16), ("down", D, F, 0, torch.float32)):
