@@ -283,3 +283,95 @@ def test_stage1_driver_runs():
     answers, info = stage1.run_query(m, tok, feat, None, feats("s1.qc", (768,)).cuda(), "a man", (10.0, 20.0), 600.0, batch=2,
                                      num_frames=24)
     assert len(answers) == 5 and set(info) == {"iou", "scores"} and len(info["iou"]) == len(info["scores"])
+
+
+def test_stage2_ragged_levels_and_33_window_plan():
+    """batch not divisible by the zoom (the stage2_long_33 situation: 33 // 4 = 8 -> 32, 32 and 33 video rows per call):
+    calls are grouped by row count; batched and per-call recursion still agree."""
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = _model(shape, _args())
+    m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    W, batch = 9, 7
+    feat = feats("s2r.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
+    qf = feats("s2r.q", (5, 768), bf16=True).to(torch.bfloat16).cuda()
+    qc = feats("s2r.qc", (768,)).cuda()
+    plan = stage2.plan_groups(W, batch)
+    assert sorted({(e - s) * z for z, s, e in plan}) == [4, 6, 7]
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(2))
+    real = m.generate
+    m.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 4})
+    # (a sentence long enough that every call has > 16 rows after the shared prompt prefix: both modes then run the
+    #  same kernel variants and agree to fp32 rounding; with <= 16 rows the batched mode's prefill would take the
+    #  key-split attention variant and agree only to bf16 tolerance)
+    sent = "a man is walking his dog across the street near the old park in the rain"
+    a = stage2.run_query(m, tok, feat, qf, qc, sent, batch=batch, perms=perms, mode="reference")
+    b = stage2.run_query(m, tok, feat, qf, qc, sent, batch=batch, perms=perms, mode="batched", max_new_tokens=4)
+    assert a["answers"] == b["answers"] and np.allclose(a["max_entropy"], b["max_entropy"], rtol=1e-4)
+    assert np.allclose(a["score_cos"], b["score_cos"], rtol=1e-5, atol=1e-6)
+    assert [p[1] for p in stage2.plan_groups(33, 33)] == [0, 8, 16, 24, 25, 0, 16, 17, 0]
+
+
+def test_sparse_adapter_1024_frames():
+    """stage1_sparse configuration: one segment of 1024 frames through the text-conditioned ClipEncoder (1025-key self
+    attention) vs the oracle."""
+    from oracle import adapter
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    from helpers import clip_weights
+    eng = engine.Engine(synth.LlamaShape(layers=0), adapter_text=True, device="cuda:0")
+    eng.init_synthetic(seed=SEED, llm=False, clip=True, clip_prefix="mm_projector.")
+    w, w32 = clip_weights(text=True, bf16=True), clip_weights(text=True, bf16=False)
+    for k_ in w:
+        if w[k_].dim() == 1:
+            w[k_] = w32[k_]
+    x = feats("ce1024.x", (1, 1024, 768), bf16=True)
+    txt = feats("ce1024.txt", (1, 16, 768), bf16=True)
+    y = eng.clip_encoder(x, txt, torch.ones(1, 16), "cls")
+    ref = adapter.clip_encoder(x, w, txt, torch.ones(1, 16), True, "cls", False)[:, 0]
+    assert rel_err(y.cpu(), ref) < 2e-2
+
+
+@pytest.fixture(scope="module")
+def model_7b():
+    from revisionllm_amd.utils import synth
+    m = _model(synth.VICUNA_7B, _args(), seed=3)
+    return m
+
+
+def test_full_size_properties_7b(model_7b):
+    """Size-independent properties at BASELINE.json's full sizes (Vicuna-7B shapes, 100 windows x 256 frames):
+    determinism, batch independence of the adapter and of the LLM (a call's logits do not depend on its batch-mates),
+    and decode == prefill consistency (teacher forcing: the logits of step t from the KV cache equal a fresh prefill
+    of the extended prompt to bf16 tolerance)."""
+    from revisionllm_amd import ops
+    from revisionllm_amd.utils import synth
+    m = model_7b
+    eng = m.engine
+    dev = eng.device
+    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
+    qf = ops.init_hash_(torch.empty(1, 16, 768, dtype=torch.bfloat16, device=dev), "fs.q", 3, synth.SQRT3)
+    ones = torch.ones(1, 16)
+    cls = eng.clip_encoder(feat, qf, ones, "cls")
+    assert torch.isfinite(cls).all() and cls.shape == (100, 4096)
+    assert torch.equal(cls, eng.clip_encoder(feat, qf, ones, "cls"))                      # deterministic
+    sub = eng.clip_encoder(feat[37:41], qf, ones, "cls")                                  # batch independent: only the final
+    assert rel_err(sub.cpu(), cls[37:41].cpu()) < 1e-5                                    # projection switches kernel (M <= 16)
+    ids = T(synth.synthetic_prompt_ids(72, 40, 3))[None]
+    rows = torch.cat([cls, cls.flip(0)], 0)                                               # two different 100-token calls
+    kw = dict(rows_per_sample=100, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
+    both = m.generate(ids.repeat(2, 1), video_rows=rows, **kw)
+    one = m.generate(ids, video_rows=rows[100:], **kw)
+    lb, lo = torch.stack(both["logits"]), torch.stack(one["logits"])
+    assert torch.isfinite(lb).all()
+    assert torch.equal(both["sequences"][1], one["sequences"][0])
+    assert (lb[:, 1] - lo[:, 0]).abs().max() <= 2e-2 * lo.abs().max()                     # shared-prefix path vs plain prefill
+    plain = m.generate(ids.repeat(2, 1), video_rows=rows, share_prefix=False, **kw)
+    assert torch.equal(torch.stack(plain["logits"]), lb)                                  # prefix sharing is exact
+    # decode step 1 from the cache == prefill of prompt + first generated token
+    ext = torch.cat([ids, one["sequences"][:, -3:-2].cpu()], 1)
+    again = m.generate(ext, video_rows=rows[100:], rows_per_sample=100, do_sample=False, max_new_tokens=1,
+                       return_dict_in_generate=True, output_logits=True)
+    assert (again["logits"][0] - one["logits"][1]).abs().max() <= 3e-2 * one["logits"][1].abs().max()
