@@ -317,7 +317,7 @@ extern "C" size_t rv_kv_bytes(const rv_ctx* c, int32_t B, int32_t Smax) {
 namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
-    float *qkv32, *cs;
+    float *qkv32, *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
     void* sk;
     size_t sk_bytes;
     size_t bytes;
@@ -335,6 +335,7 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
+    w.ss = (float*)k.take((size_t)(D / 16) * 16 * 4);
     w.bytes = k.off;
     return w;
 }
@@ -366,12 +367,22 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // (cos, sin) table for positions [P0 ? 0 : pos0, pos0 + S)
     const int tab0 = P0 > 0 ? 0 : pos0;
     RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
+    // Decode steps (M <= 16) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
+    // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
+    const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
+    const int nb_d = gemv_blocks(RV_ACT_NONE, D);
+    GemvNorm consume;
+    consume.in_sumsq = w.ss;
+    consume.in_nblk = nb_d;
+    consume.inv_d = 1.0f / (float)D;
+    consume.eps = g.rms_eps;
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
-        RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, w.sk, w.sk_bytes, st));
+        if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, w.sk, w.sk_bytes, st,
+                            (fuse_norm && l > 0) ? &consume : nullptr));
         if (P0 > 0) {
             RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, P0, P0, 0, H, dh, Smax, B, st));
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
@@ -384,11 +395,22 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                    (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
         RV_TRY(k_attention(a, st));
-        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st));
-        RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st));
-        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st));
+        GemvNorm produce;
+        produce.xw_out = w.xn16;
+        produce.out_sumsq = w.ss;
+        produce.w_next = L.norm2;
+        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
+                            fuse_norm ? &produce : nullptr));
+        if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
+        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
+                            fuse_norm ? &consume : nullptr));
+        produce.w_next = l + 1 < g.layers ? c->layers[l + 1].norm1 : c->final_norm;
+        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st,
+                            fuse_norm ? &produce : nullptr));
     }
+    if (fuse_norm && g.layers > 0)  // S == 1: every row is a last position; xn16 already holds w_final * h, ss its squares
+        return rv_gemm_impl(w.xn16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st,
+                            &consume);
     // final norm + lm_head on the last position of every sequence only
     RV_TRY(k_rmsnorm(h + ((int64_t)P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
     return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st);

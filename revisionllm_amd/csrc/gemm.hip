@@ -337,13 +337,20 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
 template <int NT, int OUT_BF16, int ACT, int WP>
 __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
-                                                   int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K) {
+                                                   int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm) {
     __shared__ __attribute__((aligned(16))) float red[8 * NT * 256];
+    __shared__ float ssq[32][16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nkb = K >> 7;
+    if (nrm.in_sumsq) {  // consumer: gather the producer's partial sums of squares (fixed order -> deterministic)
+        const int bb = tid & 15, part = tid >> 4;
+        float a = 0.f;
+        for (int i = part; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[i * 16 + bb];
+        ssq[part][bb] = a;
+    }
 
     const int xr = fr < M ? fr : M - 1;
     const bf16_t* xp = X + (int64_t)xr * lda + kg * 8;
@@ -399,10 +406,18 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
         for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
     }
     const int b = fr;  // batch row
-    if (b >= M) return;
+    if (nrm.in_sumsq) {
+        float tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) tot += ssq[p][b];
+        const float rr = rsqrtf(tot * nrm.inv_d + nrm.eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s[t] *= rr;
+    }
+    if (b >= M && !nrm.out_sumsq) return;
     if (ACT == RV_ACT_SILU_MUL) {
         const int no = blockIdx.x * 16 + kg * 4;
-        if (n0 >= N) return;
+        if (n0 >= N || b >= M) return;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
@@ -413,10 +428,11 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
         }
     } else {
+        float sq = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = n0 + t * 16 + kg * 4;
-            if (n >= N) continue;
+            if (n >= N || b >= M) continue;
             f32x4 v = s[t];
             if (bias) v += *(const f32x4*)(bias + n);
             if (ACT == RV_ACT_RELU) {
@@ -430,6 +446,17 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             } else {
                 *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
             }
+            if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
+                const f32x4 wn = *(const f32x4*)(nrm.w_next + n);
+                *(u32x2*)((bf16_t*)nrm.xw_out + (int64_t)b * N + n) =
+                    u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
+                sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            }
+        }
+        if (nrm.out_sumsq) {
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (kg == 0) nrm.out_sumsq[blockIdx.x * 16 + b] = b < M ? sq : 0.f;
         }
     }
 }
@@ -451,16 +478,16 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 
 template <int OUT_BF16, int ACT, int WP>
 void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
-                 int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
+                 int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
     if constexpr (ACT == RV_ACT_SILU_MUL) {
         hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K);
+                           bias, res, ldr, C, ldc, M, N, K, nrm);
     } else if (N >= 16384) {
         hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K);
+                           bias, res, ldr, C, ldc, M, N, K, nrm);
     } else {
         hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K);
+                           bias, res, ldr, C, ldc, M, N, K, nrm);
     }
 }
 
@@ -468,7 +495,7 @@ void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st) {
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm) {
     RV_CHECK_ARG(A && W && C, "rv_gemm: null operand");
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -484,12 +511,14 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
+    RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion is only available in the M <= 16 kernel");
+    const GemvNorm nrm = norm ? *norm : GemvNorm{};
     if (!gemv && ws && ws_bytes >= gemm_sk_ws_bytes() && gemm_sk_supported(w_layout, M, N, K))
         return gemm_sk_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, st);
 #define RV_DISPATCH2(OB, AC, WP)                                                                            \
     do {                                                                                                     \
         if (gemv)                                                                                            \
-            launch_gemv<OB, AC, WP>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st); \
+            launch_gemv<OB, AC, WP>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st, nrm); \
         else                                                                                                 \
             launch_tile<OB, AC, WP>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st); \
     } while (0)
@@ -510,6 +539,8 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_LAUNCH("rv_gemm");
     return RV_OK;
 }
+
+int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
 extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = v == 1 ? 1 : 0; }
 

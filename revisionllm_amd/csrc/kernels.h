@@ -2,10 +2,25 @@
 #pragma once
 #include "common.h"
 
+// Optional RMSNorm fusion for the decode (M <= 16) kernel.  RMSNorm(h)[b,k] = w[k] * h[b,k] * r[b] with
+// r[b] = rsqrt(mean_k h[b,k]^2 + eps) and r factors out of the dot product: out[b,n] = r[b] * sum_k W[n,k] * (w[k] h[b,k]).
+// PRODUCER (a projection whose output is the residual stream h): besides h it writes xw = bf16(w_next * h) and, per
+// workgroup, the partial sum of squares of its 16 (or 32) output rows per batch row (no atomics: deterministic).
+// CONSUMER (the next projection): reads xw as its activation and scales its accumulators by r[b] rebuilt from the partials.
+struct GemvNorm {
+    const float* in_sumsq = nullptr;  // [in_nblk][16] partial sums of squares written by the producer
+    int in_nblk = 0;
+    float inv_d = 0.f, eps = 0.f;     // 1 / hidden, rms eps
+    void* xw_out = nullptr;           // bf16 [M, N] (row stride N): w_next[n] * h[b,n]
+    const float* w_next = nullptr;    // [N] norm weight of the consumer
+    float* out_sumsq = nullptr;       // [gridDim.x][16]
+};
+
 // ws: optional zero-initialised stream-K workspace (>= gemm_sk_ws_bytes()); NULL -> plain tiled kernel
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st);
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
+int gemv_blocks(int act, int64_t N);  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
 size_t gemm_sk_ws_bytes();
 bool gemm_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
 int gemm_sk_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
