@@ -71,7 +71,7 @@ def roofline_legs(model, n_calls, M):
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
     ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
-    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2,3>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
                                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops,
                                        grid_threads=((M + 127) // 128) * (2 * s.inter // 128) * 256)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the

@@ -83,8 +83,9 @@ size_t rv_gemm_ws_bytes(void);
 /* Tuning knob (process-wide): 0 = output-tiled GEMM only (default); stream-K workgroup geometry 4 = 128x128 tiles, two
  * 4-wave workgroups per CU; 8 = 128x256 tiles, one 8-wave workgroup per CU with a 3-stage LDS ring. */
 void rv_set_gemm_geometry(int32_t waves);
-/* Tuning knob (process-wide): output-tiled kernel pipeline for packed W, 1 (default) = 128x128x32 four-stage LDS ring
- * with counted vmcnt (three stages in flight), 0 = 128x128x64 double buffer.  Results are bit-identical. */
+/* Tuning knob (process-wide): output-tiled kernel pipeline for packed W.  2 (default) = 128x128x32 steps, 3-stage LDS
+ * ring (48 KiB: three workgroups per CU), counted vmcnt; 1 = 4-stage ring (two workgroups per CU); 0 = 128x128x64 double
+ * buffer.  Results are bit-identical. */
 void rv_set_gemm_tile_variant(int32_t variant);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 // (in-flight bytes per CU x 1/latency ~ 0.9 PF/s); this variant raises the bytes in flight by 1.5x.
 // A rows are 64 B here; chunk c of row r lives in LDS slot c ^ ((r >> 2) & 2), which makes every ds_read_b128 lane
 // group hit 16 distinct 16-byte slots.
-constexpr int P4_BK = 32, P4_STAGES = 4, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
+constexpr int P4_BK = 32, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
 
 __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int N,
                                               int K, int m0, int n0, int k0, char* slot, int wave, int lane) {
@@ -218,11 +218,13 @@ __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int6
     }
 }
 
-template <int OUT_BF16, int ACT>
+// ST = ring depth: 4 (64 KiB, two workgroups per CU) or 3 (48 KiB, THREE workgroups per CU = three waves per SIMD, so
+// that one wave's MFMA burst can overlap two other waves' wait / LDS phases).
+template <int OUT_BF16, int ACT, int ST>
 __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                     const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                     int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) char smem[P4_STAGES * P4_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[ST * P4_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tm, tn;
@@ -252,18 +254,19 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
     const int nks = K / P4_BK;
     p4_stage_load(A, lda, W, M, N, K, m0, n0, 0, smem, wave, lane);
     if (nks > 1) p4_stage_load(A, lda, W, M, N, K, m0, n0, P4_BK, smem + P4_STAGE, wave, lane);
-    if (nks > 2) p4_stage_load(A, lda, W, M, N, K, m0, n0, 2 * P4_BK, smem + 2 * P4_STAGE, wave, lane);
+    if (ST == 4 && nks > 2) p4_stage_load(A, lda, W, M, N, K, m0, n0, 2 * P4_BK, smem + 2 * P4_STAGE, wave, lane);
     int slot = 0;
     for (int i = 0; i < nks; ++i) {
-        // stage i must have landed; up to two later stages (4 loads per lane each) stay in flight across the barrier
+        // stage i must have landed; up to ST-2 later stages (4 loads per lane each) stay in flight across the barrier
         const int later = nks - 1 - i;
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ST == 4 && later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (i + 3 < nks) {
-            const int s3 = (slot + 3) & 3;   // the slot read in step i-1: every wave is past it after this barrier
-            p4_stage_load(A, lda, W, M, N, K, m0, n0, (i + 3) * P4_BK, smem + s3 * P4_STAGE, wave, lane);
+        if (i + ST - 1 < nks) {
+            int s3 = slot + ST - 1;   // the slot read in step i-1: every wave is past it after this barrier
+            s3 = s3 >= ST ? s3 - ST : s3;
+            p4_stage_load(A, lda, W, M, N, K, m0, n0, (i + ST - 1) * P4_BK, smem + s3 * P4_STAGE, wave, lane);
         }
         const char* a_s = smem + slot * P4_STAGE;
         const char* w_s = a_s + P4_A_BYTES;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        slot = (slot + 1) & 3;
+        slot = slot + 1 == ST ? 0 : slot + 1;
     }
 
 #pragma unroll
@@ -461,14 +464,19 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     }
 }
 
-int g_tile_variant = 1;  // 1 (default) = 128x128x32 4-stage counted-vmcnt ring (packed W only); 0 = 128x128x64 2-stage
+int g_tile_variant = 2;  // packed W: 2 (default) = 128x128x32 3-stage ring, 3 workgroups/CU; 1 = 4-stage, 2 workgroups/CU; 0 = 128x128x64 2-stage
 
 template <int OUT_BF16, int ACT, int WP>
 void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
     if (WP && g_tile_variant == 1) {
-        hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
+        hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
+                           ldc, M, N, K, tiles_m, tiles_n);
+        return;
+    }
+    if (WP && g_tile_variant == 2) {
+        hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n);
         return;
     }
@@ -542,7 +550,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 
 int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
-extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = v == 1 ? 1 : 0; }
+extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 2) ? v : 1; }
 
 extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_sk_ws_bytes(); }
 

@@ -71,9 +71,10 @@ def test_gemm(dev, M, N, K, out):
     if wpk is not None:
         yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False)
         assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
-        hip.lib().rv_set_gemm_tile_variant(1)                        # 4-stage counted-vmcnt pipeline: same sums, same order
-        assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False), y)
-        hip.lib().rv_set_gemm_tile_variant(0)
+        for variant in (0, 1):                                       # other pipeline depths: same sums, same order
+            hip.lib().rv_set_gemm_tile_variant(variant)
+            assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False), y)
+        hip.lib().rv_set_gemm_tile_variant(2)
         for geo in (4, 8):                                           # opt-in persistent stream-K kernels
             hip.lib().rv_set_gemm_geometry(geo)
             ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True)
