@@ -321,6 +321,128 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Register-double-buffered variant of gemm_tile_p4 (4-stage ring, two workgroups per CU): the MFMA operand fragments of
+// step i+1 are read from LDS BEFORE the MFMAs of step i are issued, so the ds_read latency (and the lgkmcnt wait) hides
+// under the wave's own 16 MFMAs instead of sitting between the barrier and the first MFMA.  Because a stage is fully in
+// registers one step early, its LDS slot is free one barrier earlier and the ring prefetches one stage deeper.
+#define P5_READ(WF, AF, SLOT)                                                                      \
+    do {                                                                                           \
+        const char* a_s_ = smem + (SLOT) * P4_STAGE;                                               \
+        const char* w_s_ = a_s_ + P4_A_BYTES;                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+            WF[q] = *(const bf16x8*)(w_s_ + (wc * 4 + q) * 1024 + lane * 16);                      \
+            const int row_ = wr * 64 + q * 16 + fr;                                                \
+            AF[q] = *(const bf16x8*)(a_s_ + row_ * (P4_BK * 2) + ((kg ^ ((row_ >> 2) & 2)) << 4)); \
+        }                                                                                          \
+    } while (0)
+#define P5_MMA(WF, AF)                                                                             \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ni], AF[mi], acc[ni][mi], 0, 0, 0)
+
+template <int OUT_BF16, int ACT>
+__global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int ST = 4;
+    __shared__ __attribute__((aligned(16))) char smem[ST * P4_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        const int tiles_n8 = tiles_n & ~7;
+        if (b < tiles_n8 * tiles_m) {
+            const int xcd = b & 7, idx = b >> 3;
+            tn = (idx / tiles_m) * 8 + xcd;
+            tm = idx % tiles_m;
+        } else {
+            const int r = b - tiles_n8 * tiles_m;
+            tm = r % tiles_m;
+            tn = tiles_n8 + r / tiles_m;
+        }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nks = K / P4_BK;   // even (K % 64 == 0)
+    // prologue: stages 0..3 in flight, stage 0 into registers
+    for (int s = 0; s < ST && s < nks; ++s) p4_stage_load(A, lda, W, M, N, K, m0, n0, s * P4_BK, smem + s * P4_STAGE, wave, lane);
+    {
+        const int later = nks - 1 < ST - 1 ? nks - 1 : ST - 1;
+        if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    bf16x8 wfA[4], afA[4], wfB[4], afB[4];
+    P5_READ(wfA, afA, 0);
+    // step i: [wait stage i+1] [barrier: also every wave has finished READING stage i] [refill slot of stage i with
+    // stage i+ST] [read stage i+1 -> other register set] [MFMA stage i]
+#define P5_STEP(I, WCUR, ACUR, WNXT, ANXT)                                                          \
+    do {                                                                                            \
+        const int i_ = (I);                                                                         \
+        if (i_ + 1 < nks) {                                                                         \
+            const int later_ = nks - 2 - i_ < ST - 2 ? nks - 2 - i_ : ST - 2; /* stages i+2.. in flight */ \
+            if (later_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
+            else if (later_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of stage i are done */ \
+            __builtin_amdgcn_s_barrier();                                                           \
+            if (i_ + ST < nks) p4_stage_load(A, lda, W, M, N, K, m0, n0, (i_ + ST) * P4_BK, smem + (i_ & 3) * P4_STAGE, wave, lane); \
+            P5_READ(WNXT, ANXT, (i_ + 1) & 3);                                                      \
+        }                                                                                           \
+        P5_MMA(WCUR, ACUR);                                                                         \
+    } while (0)
+    for (int i = 0; i < nks; i += 2) {
+        P5_STEP(i, wfA, afA, wfB, afB);
+        P5_STEP(i + 1, wfB, afB, wfA, afA);
+    }
+#undef P5_STEP
+
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + mi * 16 + fr;
+        if (m >= M) continue;
+        if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int n = n0 + wc * 64 + ni * 16;
+                if (n >= N) continue;
+                const int no = (n >> 1) + kg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+                if (n >= N) continue;
+                f32x4 v = acc[ni][mi];
+                if (bias) v += *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight-streaming kernel for M <= 16 rows (decode).  Block = 8 waves = NT 16-row weight tiles; wave w takes
 // k-blocks (128 wide) w, w+8, ... two at a time, so 8*NT independent 1-KiB weight loads are in flight per wave
 // before the first MFMA.  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and x[r][k] for
@@ -475,6 +597,11 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
                            ldc, M, N, K, tiles_m, tiles_n);
         return;
     }
+    if (WP && g_tile_variant == 3) {
+        hipLaunchKernelGGL((gemm_tile_p5<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
+                           ldc, M, N, K, tiles_m, tiles_n);
+        return;
+    }
     if (WP && g_tile_variant == 2) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n);
@@ -550,7 +677,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 
 int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
-extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 2) ? v : 1; }
+extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 3) ? v : 2; }
 
 extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_sk_ws_bytes(); }
 

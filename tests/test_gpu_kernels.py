@@ -71,7 +71,7 @@ def test_gemm(dev, M, N, K, out):
     if wpk is not None:
         yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False)
         assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
-        for variant in (0, 1):                                       # other pipeline depths: same sums, same order
+        for variant in (0, 1, 3):                                    # other pipelines: same sums, same order
             hip.lib().rv_set_gemm_tile_variant(variant)
             assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False), y)
         hip.lib().rv_set_gemm_tile_variant(2)

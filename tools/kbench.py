@@ -26,7 +26,7 @@ def main():
     which = set(sys.argv[1:]) or {"gemm", "gemv", "attn"}
     dev = torch.device("cuda:0")
     D, F, V = 4096, 11008, 32000
-    for geo in ((1, 2) if "gemm" in which else ()):
+    for geo in ((2, 3) if "gemm" in which else ()):
         hip.lib().rv_set_gemm_tile_variant(geo)
         print(f"--- tile variant {geo}")
         for M in (975, 1197):
