@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--frames", type=int, default=256)
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
+    p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
@@ -216,7 +217,15 @@ def main():
                 "reading a newspaper and then both of them leave the room together")
     stages = parallel.HipStages(model, tok)
 
+    if args.queries > 1:   # extra measurement: Q queries of one movie share every decode weight pass
+        qs = [(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
+               ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), sentence)
+              for i in range(args.queries)]
+        perms_q = [stage2.make_perms(plan, gen) for _ in range(args.queries)]
+
     def step():
+        if args.queries > 1:
+            return parallel.run_queries_sharded(stages, tok, feats, W, qs, batch=100, perms=perms_q, max_new_tokens=args.decode_steps)[0]
         return parallel.run_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms,
                                           max_new_tokens=args.decode_steps)
 
@@ -253,11 +262,11 @@ def main():
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         out = {
             "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
-            "value": W * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": W * args.queries * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
-                       "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
+                       "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
                        "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
                        "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
                        "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},

@@ -157,19 +157,27 @@ def build_call_rows(cls, plan, perms):
 
 
 def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
-    """Run the LLM for the given call indices.  Calls with the same number of video rows have equal prompt lengths and
-    run as one batched generate.  -> {call: (new_token_ids list, max_entropy, mean_entropy)} with the statistics taken
-    over the steps a batch-1 generate would have produced."""
-    ids1, _ = _prompt_ids(query, tokenizer, 1)
+    """Run the LLM for the given call indices.  ``query`` is one prompt for all calls or a {call: prompt} mapping (several
+    queries of one movie batched together).  Calls whose prompts have the same length (same number of video rows and of
+    text tokens) run as one batched generate.  -> {call: (new_token_ids list, max_entropy, mean_entropy)} with the
+    statistics taken over the steps a batch-1 generate would have produced."""
     eos = model.generation_config.eos_token_id
-    by_rows = {}
+    ids_of = {}
+
+    def prompt_ids(c):
+        q = query if isinstance(query, str) else query[c]
+        if q not in ids_of:
+            ids_of[q] = _prompt_ids(q, tokenizer, 1)[0]
+        return ids_of[q]
+
+    groups = {}
     for c in calls:
-        by_rows.setdefault(rows[c].shape[0], []).append(c)
+        groups.setdefault((rows[c].shape[0], prompt_ids(c).shape[1]), []).append(c)
     res = {}
-    for n_rows, cs in by_rows.items():
+    for (n_rows, _), cs in groups.items():
         for c0 in range(0, len(cs), max_calls_per_generate):
             sel = cs[c0:c0 + max_calls_per_generate]
-            ids = ids1.repeat(len(sel), 1)
+            ids = torch.cat([prompt_ids(c) for c in sel], 0)
             u = None if uniforms is None else uniforms[:, sel]
             out = model.generate(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows, do_sample=True,
                                  temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens, output_scores=False,

@@ -98,6 +98,44 @@ class HipStages:
         return stage2.generate_calls(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens)
 
 
+def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
+                        max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Several queries of ONE movie in one pass: ``queries`` = [(query_feats, query_cls, sentence), ...] over the same
+    windows.  The adapter runs per (window, query); all calls of all queries are dealt over the ranks and batched in the
+    LLM (a decode step streams the weights once for up to 16 calls, so two queries cost barely more than one).
+    ``perms``: one list of permutations per query.  Returns one record per query, identical to running them one by one."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(W, rank, world)
+    assert features_local.shape[0] == hi - lo, f"rank {rank} must hold windows [{lo},{hi})"
+    zooms = tuple(zooms)
+    plan = stage2.plan_groups(W, batch, zooms)
+    nc = len(plan)
+    if grounding_windows is None:
+        grounding_windows = list(range(W))
+    rows, prompts, cos_all = [], {}, []
+    for qi, (qf, qc, sentence) in enumerate(queries):
+        cls_local, cos_local = stages.encode(features_local, qf), stages.cosine(features_local, qc)
+        if world > 1:
+            cls_local = allgather_rows(cls_local, W, group)
+            cos_local = allgather_rows(cos_local[:, None], W, group)[:, 0]
+        cos_all.append(cos_local.cpu())
+        pq = [torch.as_tensor(p).long() for p in perms[qi]]
+        rows.extend(stage2.build_call_rows(cls_local, plan, pq))
+        for c in range(nc):
+            prompts[qi * nc + c] = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
+    mine = deal(nc * len(queries), rank, world)
+    res = stages.generate(prompts, rows, mine, uniforms, max_new_tokens)
+    if world > 1:
+        res = allgather_calls(res, nc * len(queries), max_new_tokens, features_local.device, group)
+    out = []
+    for qi in range(len(queries)):
+        pq = [torch.as_tensor(p).long() for p in perms[qi]]
+        out.append(stage2.assemble(plan, pq, {c: res[qi * nc + c] for c in range(nc)}, cos_all[qi], tokenizer, zooms,
+                                   grounding_windows, single))
+    return out
+
+
 def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
                       perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
     """Stage-2 recursion over ``W`` windows with the windows block-partitioned over the ranks of ``group``.

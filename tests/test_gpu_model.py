@@ -375,3 +375,27 @@ def test_full_size_properties_7b(model_7b):
     again = m.generate(ext, video_rows=rows[100:], rows_per_sample=100, do_sample=False, max_new_tokens=1,
                        return_dict_in_generate=True, output_logits=True)
     assert (again["logits"][0] - one["logits"][1]).abs().max() <= 3e-2 * one["logits"][1].abs().max()
+
+
+def test_multi_query_batching_on_device():
+    """Two queries of one movie batched through one set of LLM passes give the records of two separate runs."""
+    from revisionllm_amd import parallel
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = _model(shape, _args())
+    m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    W, batch = 13, 8
+    feat = feats("mq.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
+    qs = [(feats(f"mq.q{i}", (5, 768), bf16=True).to(torch.bfloat16).cuda(), feats(f"mq.qc{i}", (768,)).cuda(),
+           "a man is walking his dog across the street near the old park" + (" today" if i else " again")) for i in range(2)]
+    plan = stage2.plan_groups(W, batch)
+    perms = [stage2.make_perms(plan, torch.Generator().manual_seed(i)) for i in range(2)]
+    st = parallel.HipStages(m, tok)
+    both = parallel.run_queries_sharded(st, tok, feat, W, qs, batch=batch, perms=perms, max_new_tokens=4)
+    for i in range(2):
+        one = parallel.run_query_sharded(st, tok, feat, W, *qs[i], batch=batch, perms=perms[i], max_new_tokens=4)
+        assert both[i]["answers"] == one["answers"]
+        assert np.allclose(both[i]["max_entropy"], one["max_entropy"], rtol=1e-4)
+        assert np.allclose(both[i]["score_cos"], one["score_cos"], rtol=1e-5, atol=1e-6)

@@ -56,6 +56,21 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_multi_query_batching_matches_single_queries():
+    """run_queries_sharded (several queries of one movie in one pass) == each query run on its own."""
+    feats, qf, qc, perms = _inputs()
+    qf2, qc2 = qf * 0.5 + 1.0, qc.flip(0)
+    plan = stage2.plan_groups(W, BATCH)
+    perms2 = stage2.make_perms(plan, torch.Generator().manual_seed(9))
+    tok = synth.FakeTokenizer()
+    both = parallel.run_queries_sharded(StubStages(), tok, feats, W, [(qf, qc, "a man"), (qf2, qc2, "a dog runs")], batch=BATCH,
+                                        perms=[perms, perms2], max_new_tokens=8)
+    one = parallel.run_query_sharded(StubStages(), tok, feats, W, qf, qc, "a man", batch=BATCH, perms=perms, max_new_tokens=8)
+    two = parallel.run_query_sharded(StubStages(), tok, feats, W, qf2, qc2, "a dog runs", batch=BATCH, perms=perms2, max_new_tokens=8)
+    for got, want in ((both[0], one), (both[1], two)):
+        assert got["answers"] == want["answers"] and got["max_entropy"] == want["max_entropy"] and got["score_cos"] == want["score_cos"]
+
+
 def test_shard_bounds_and_deal():
     for n in (0, 1, 7, 100, 101):
         for world in (1, 2, 3, 8):
