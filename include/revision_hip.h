@@ -57,7 +57,8 @@ int rv_ctx_create(const rv_config* cfg, rv_ctx** out);
 void rv_ctx_destroy(rv_ctx* ctx);
 /* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout").  Every bf16 MATRIX
  * except llm.embed is fragment-packed (rv_gemm w_layout 1); vectors are plain f32:
- *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows); llm.L{i}.wo [D,D];
+ *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows; inside every head the q and k rows are
+ *   pair-interleaved: row 2j = dim j, row 2j+1 = dim j+64, so RoPE partners meet in one lane); llm.L{i}.wo [D,D];
  *   llm.L{i}.wgu [2F,D] bf16, gate/up interleaved in 16-row blocks; llm.L{i}.wdown [D,F];
  *   llm.L{i}.norm1 / norm2 [D] f32; llm.norm [D] f32; llm.lm_head [V,D] bf16;
  *   adp.cls_token / adp.cls_pos [768] f32; adp.{t2v,enc}.{l}.{w_in[2304,768],w_out,w1,w2} bf16,

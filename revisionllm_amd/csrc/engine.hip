@@ -317,7 +317,7 @@ extern "C" size_t rv_kv_bytes(const rv_ctx* c, int32_t B, int32_t Smax) {
 namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
-    float *qkv32, *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
+    float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
     void* sk;
     size_t sk_bytes;
     size_t bytes;
@@ -329,7 +329,6 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.sk_bytes = gemm_sk_ws_bytes();
     w.sk = k.take(w.sk_bytes);
     w.xn16 = (bf16_t*)k.take((size_t)M * D * 2);
-    w.qkv32 = (float*)k.take((size_t)M * 3 * D * 4);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.a16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
@@ -381,17 +380,20 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wqkv, D, 1, nullptr, nullptr, 0, w.qkv32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, D, w.sk, w.sk_bytes, st,
-                            (fuse_norm && l > 0) ? &consume : nullptr));
+        // fused q/k/v projection: RoPE-rotated Q -> q16, rotated K and V^T -> this layer's cache (no f32 qkv round trip)
+        QkvRope qr;
+        qr.cs = w.cs;
+        qr.q16 = w.q16;
+        qr.kc = kc;
+        qr.vtc = vtc;
+        qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
+        RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, st));
         if (P0 > 0) {
-            RV_TRY(k_rope_kv(w.qkv32, w.cs, w.q16, kc, vtc, P0, P0, 0, H, dh, Smax, B, st));
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                         (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
             RV_TRY(k_attention(ap, st));
         }
         const int64_t r0 = P0;  // first row of the per-sequence part
-        RV_TRY(k_rope_kv(w.qkv32 + r0 * 3 * D, w.cs + (int64_t)(pos0 - tab0) * dh, w.q16 + r0 * D, kc, vtc, (int64_t)B * S, S, pos0, H,
-                         dh, Smax, 0, st));
         AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                    (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
         RV_TRY(k_attention(a, st));

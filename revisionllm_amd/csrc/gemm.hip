@@ -195,6 +195,36 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 // (in-flight bytes per CU x 1/latency ~ 0.9 PF/s); this variant raises the bytes in flight by 1.5x.
 // A rows are 64 B here; chunk c of row r lives in LDS slot c ^ ((r >> 2) & 2), which makes every ds_read_b128 lane
 // group hit 16 distinct 16-byte slots.
+// Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
+__device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
+    const int D = q.H * 128;
+    const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
+    int b, pos;
+    bool prefix = false;
+    if (m < q.P0) { b = 0; pos = m; prefix = true; }
+    else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
+    if (sec < 2) {
+        const f32x4 t = *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
+        const float a0 = v[0] * t[0] - v[1] * t[1], b0 = v[1] * t[0] + v[0] * t[1];
+        const float a1 = v[2] * t[2] - v[3] * t[3], b1 = v[3] * t[2] + v[2] * t[3];
+        const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+        if (sec == 0) {
+            *(u32x2*)((bf16_t*)q.q16 + (int64_t)m * D + hd) = o;
+        } else {
+            const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+            for (int bb = b0_; bb < b1_; ++bb)
+                *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
+        }
+    } else {
+        const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+        for (int bb = b0_; bb < b1_; ++bb) {
+            bf16_t* dst = (bf16_t*)q.vtc + (((int64_t)bb * q.H + head) * 128 + p) * q.Smax + pos;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * q.Smax] = f32_to_bf16(v[r]);
+        }
+    }
+}
+
 constexpr int P4_BK = 32, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
 
 __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int N,
@@ -220,10 +250,10 @@ __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int6
 
 // ST = ring depth: 4 (64 KiB, two workgroups per CU) or 3 (48 KiB, THREE workgroups per CU = three waves per SIMD, so
 // that one wave's MFMA burst can overlap two other waves' wait / LDS phases).
-template <int OUT_BF16, int ACT, int ST>
+template <int OUT_BF16, int ACT, int ST, int ROPE = 0>
 __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                     const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
-                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, QkvRope qr) {
     __shared__ __attribute__((aligned(16))) char smem[ST * P4_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,6 +315,19 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
         slot = slot + 1 == ST ? 0 : slot + 1;
     }
 
+    if constexpr (ROPE) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wr * 64 + mi * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+                if (n < N) qkv_rope_store(qr, m, n, acc[ni][mi]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wr * 64 + mi * 16 + fr;
@@ -459,10 +502,11 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
     for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + kb * 128 + j * 32);
 }
 
-template <int NT, int OUT_BF16, int ACT, int WP>
+template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0>
 __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
-                                                   int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm) {
+                                                   int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm,
+                                                   QkvRope qr) {
     __shared__ __attribute__((aligned(16))) float red[8 * NT * 256];
     __shared__ float ssq[32][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -539,6 +583,16 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
         for (int t = 0; t < NT; ++t) s[t] *= rr;
     }
+    if constexpr (ROPE) {
+        if (b < M) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + kg * 4;
+                if (n < N) qkv_rope_store(qr, b, n, s[t]);
+            }
+        }
+        return;
+    }
     if (b >= M && !nrm.out_sumsq) return;
     if (ACT == RV_ACT_SILU_MUL) {
         const int no = blockIdx.x * 16 + kg * 4;
@@ -594,7 +648,7 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
     if (WP && g_tile_variant == 1) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
-                           ldc, M, N, K, tiles_m, tiles_n);
+                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
         return;
     }
     if (WP && g_tile_variant == 3) {
@@ -604,7 +658,7 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
     }
     if (WP && g_tile_variant == 2) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
-                           ldc, M, N, K, tiles_m, tiles_n);
+                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
         return;
     }
     hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT, WP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
@@ -616,13 +670,13 @@ void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
     if constexpr (ACT == RV_ACT_SILU_MUL) {
         hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm);
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else if (N >= 16384) {
         hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm);
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else {
         hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm);
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     }
 }
 
@@ -672,6 +726,26 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 #undef RV_DISPATCH2
 #undef RV_DISPATCH
     RV_CHECK_LAUNCH("rv_gemm");
+    return RV_OK;
+}
+
+int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
+                  hipStream_t st) {
+    RV_CHECK_ARG(A && Wp && r.cs && r.q16 && r.kc && r.vtc, "gemm_qkv_rope: null argument");
+    RV_CHECK_ARG(D % 128 == 0 && D == (int64_t)r.H * 128 && M == (int64_t)r.P0 + (int64_t)r.B * r.S, "gemm_qkv_rope: bad geometry");
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* w = (const bf16_t*)Wp;
+    const int N = (int)(3 * D), K = (int)D;
+    if (M <= 16) {
+        hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                           nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
+    } else {
+        RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
+        const int tiles_m = (int)cdiv(M, BM), tiles_n = N / BN;
+        hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a, lda, w, nullptr, nullptr,
+                           (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, tiles_m, tiles_n, r);
+    }
+    RV_CHECK_LAUNCH("gemm_qkv_rope");
     return RV_OK;
 }
 

@@ -16,6 +16,22 @@ struct GemvNorm {
     float* out_sumsq = nullptr;       // [gridDim.x][16]
 };
 
+// Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
+// (bf16 [M,D]), RoPE-rotated K into the cache and V into the transposed cache - instead of an f32 [M,3D] buffer that two
+// more kernels re-read.  The q/k rows of wqkv are PAIR-INTERLEAVED per head at pack time (row 2j = dim j, row 2j+1 =
+// dim j+64), so the rotate_half partners (j, j+64) sit in one lane's 4 consecutive outputs; Q and K are stored in that
+// permuted order (the q.k dot product is invariant under a common permutation), V is not permuted.
+// Rows: [P0 shared-prefix rows (pos = row; K/V broadcast to all B caches)] then B sequences x S rows (pos0 + s).
+struct QkvRope {
+    const float* cs = nullptr;  // (cos, sin) table [pos - cs_pos0][dh/2]
+    void* q16 = nullptr;        // bf16 [M, D]
+    void* kc = nullptr;         // bf16 [B, H, Smax, dh]   (this layer)
+    void* vtc = nullptr;        // bf16 [B, H, dh, Smax]
+    int B = 0, S = 0, P0 = 0, pos0 = 0, cs_pos0 = 0, H = 0, Smax = 0;
+};
+int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
+                  hipStream_t st);
+
 // ws: optional zero-initialised stream-K workspace (>= gemm_sk_ws_bytes()); NULL -> plain tiled kernel
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
@@ -35,8 +51,6 @@ int k_build_x(const void* src16, const float* src32, const float* cls, const flo
 int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st);
-int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
-              int Smax, int nb_bcast, hipStream_t st);
 int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st);
 
 struct AttnArgs {

@@ -1,5 +1,5 @@
 // Row-wise / elementwise kernels of the grounding path (all HBM-bound, 16-byte vector accesses):
-// LayerNorm, RMSNorm, sine position table, adapter row assembly, V transposes, RoPE + KV-cache append,
+// LayerNorm, RMSNorm, sine position table, adapter row assembly, V transposes, RoPE table,
 // embedding gather + video-row splice.
 #include "common.h"
 #include "kernels.h"
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     }
 }
 
-// ---- RoPE (rotate_half) + KV-cache append.  qkv f32 [M,3D]; row m = b*S + s at position pos0 + s. ----
+// ---- RoPE (cos, sin) table; the rotation itself and the KV-cache append live in the fused QKV epilogue (gemm.hip) ----
 // cs: (cos, sin) table [S][dh/2] for positions pos0..pos0+S-1, built once per forward (shared by all layers).
 __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int dh, float theta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,80 +185,6 @@ __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int 
     const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)dh);
     const float ang = (float)(pos0 + s) * inv;
     cs[i] = make_float2(cosf(ang), sinf(ang));
-}
-
-// q -> q16 bf16 [M,D] rotated; k -> kc [B,H,Smax,dh] rotated.  One thread = 4 consecutive pair indices j (float4
-// loads of both halves, 8-byte bf16 stores).  V is handled by v_cache_kernel below.
-__global__ __launch_bounds__(256) void rope_qk_kernel(const float* __restrict__ qkv, const float2* __restrict__ cs,
-                                                      bf16_t* __restrict__ q16, bf16_t* __restrict__ kc,
-                                                      bf16_t* __restrict__ vtc_decode, int S, int pos0, int H, int dh, int Smax,
-                                                      int nb_bcast) {
-    // nb_bcast > 0: the rows are a prefix shared by nb_bcast sequences - K is written into every one of their caches
-    const int64_t m = blockIdx.x;
-    const int b = (int)(m / S), s = (int)(m % S);
-    const int pos = pos0 + s;
-    const int D = H * dh, half = dh / 2, q4 = half / 4;
-    const float* row = qkv + m * 3 * (int64_t)D;
-    const float2* csr = cs + (int64_t)s * half;
-    for (int i = threadIdx.x; i < 2 * H * q4; i += 256) {
-        const int which = i / (H * q4);          // 0 = q, 1 = k
-        const int r = i % (H * q4);
-        const int h = r / q4, j = (r % q4) * 4;
-        const float* src = row + which * D + h * dh + j;
-        const f32x4 x1 = *(const f32x4*)src, x2 = *(const f32x4*)(src + half);
-        float o1[4], o2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float2 t = csr[j + e];
-            o1[e] = x1[e] * t.x - x2[e] * t.y;
-            o2[e] = x2[e] * t.x + x1[e] * t.y;
-        }
-        const u32x2 lo = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
-        const u32x2 hi = u32x2{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
-        if (which == 0) {
-            bf16_t* dst = q16 + m * D + h * dh + j;
-            *(u32x2*)dst = lo;
-            *(u32x2*)(dst + half) = hi;
-        } else {
-            const int b0 = nb_bcast > 0 ? 0 : b, b1 = nb_bcast > 0 ? nb_bcast : b + 1;
-            for (int bb = b0; bb < b1; ++bb) {
-                bf16_t* dst = kc + (((int64_t)bb * H + h) * Smax + pos) * dh + j;
-                *(u32x2*)dst = lo;
-                *(u32x2*)(dst + half) = hi;
-            }
-        }
-    }
-    if (vtc_decode) {  // decode step (S == 1): append V^T here too instead of launching the tiled transpose
-        for (int i = threadIdx.x; i < D; i += 256) {
-            const int h = i / dh, d = i % dh;
-            vtc_decode[(((int64_t)b * H + h) * dh + d) * Smax + pos] = f32_to_bf16(row[2 * D + i]);
-        }
-    }
-}
-
-// V rows of qkv f32 [M,3D] -> vtc [B,H,dh,Smax] bf16 (transposed cache).  Block = (64 positions, head, batch):
-// coalesced reads of 64 x dh floats through LDS, then 128-byte row writes along the position axis.
-template <int DH>
-__global__ __launch_bounds__(256) void v_cache_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ vtc, int S, int pos0,
-                                                      int H, int Smax, int bcast) {
-    __shared__ bf16_t tile[64][DH + 2];
-    const int s0 = blockIdx.x * 64, h = blockIdx.y;
-    const int bd = blockIdx.z, b = bcast ? 0 : bd;   // destination cache / source sequence
-    const int D = H * DH;
-    for (int i = threadIdx.x; i < 64 * (DH / 4); i += 256) {
-        const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (s0 + r < S) v = *(const f32x4*)(qkv + ((int64_t)b * S + s0 + r) * 3 * D + 2 * D + h * DH + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tile[r][c + e] = f32_to_bf16(v[e]);
-    }
-    __syncthreads();
-    bf16_t* o = vtc + (((int64_t)bd * H + h) * DH) * Smax + pos0 + s0;
-    const int n = min(64, S - s0);
-    for (int i = threadIdx.x; i < DH * 64; i += 256) {
-        const int d = i / 64, l = i % 64;
-        if (l < n) o[(int64_t)d * Smax + l] = tile[l][d];
-    }
 }
 
 // ---- embedding gather + video-row splice -> f32 residual stream ----
@@ -364,22 +290,6 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st) {
     hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)cdiv((int64_t)S * (dh / 2), 256)), dim3(256), 0, st, (float2*)cs, S, pos0, dh, theta);
     RV_CHECK_LAUNCH("rope_table");
-    return RV_OK;
-}
-
-int k_rope_kv(const float* qkv, const float* cs, void* q16, void* kc, void* vtc, int64_t M, int S, int pos0, int H, int dh,
-              int Smax, int nb_bcast, hipStream_t st) {
-    RV_CHECK_ARG(dh == 128, "rope_kv: head dim must be 128");
-    RV_CHECK_ARG(nb_bcast == 0 || M == S, "rope_kv: a broadcast prefix is a single sequence");
-    const bool fuse_v = S == 1 && nb_bcast == 0;
-    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, (const float2*)cs, (bf16_t*)q16, (bf16_t*)kc,
-                       fuse_v ? (bf16_t*)vtc : nullptr, S, pos0, H, dh, Smax, nb_bcast);
-    RV_CHECK_LAUNCH("rope_qk");
-    if (fuse_v) return RV_OK;
-    const int B = nb_bcast > 0 ? nb_bcast : (int)(M / S);
-    hipLaunchKernelGGL(v_cache_kernel<128>, dim3((unsigned)cdiv(S, 64), (unsigned)H, (unsigned)B), dim3(256), 0, st, qkv,
-                       (bf16_t*)vtc, S, pos0, H, Smax, nb_bcast > 0 ? 1 : 0);
-    RV_CHECK_LAUNCH("v_cache");
     return RV_OK;
 }
 

@@ -73,6 +73,7 @@ class Engine:
         for i in range(s.layers):
             p = f"model.layers.{i}."
             q, k, v = (_dev_bf16(get(p + f"self_attn.{n}_proj.weight"), dev) for n in "qkv")
+            q, k = pair_interleave_heads(q, s.heads), pair_interleave_heads(k, s.heads)
             self.bind(f"llm.L{i}.wqkv", ops.pack_fragments(torch.cat([q, k, v], dim=0).contiguous()))
             del q, k, v
             self.bind(f"llm.L{i}.wo", _dev_packed(get(p + "self_attn.o_proj.weight"), dev))
@@ -211,6 +212,14 @@ class Engine:
         hip.check(self.lib.rv_llm_prefill_shared(self._ctx, hip.ptr(h), B, P0, S, hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws),
                                                  ws.numel(), hip.stream()), "rv_llm_prefill_shared")
         return logits
+
+
+def pair_interleave_heads(w, heads):
+    """Permute the rows of a q / k projection inside every head: new row 2j = dim j, new row 2j+1 = dim j + dh/2, so the
+    rotate_half partners are adjacent (the fused QKV epilogue rotates them in one lane; q.k is permutation invariant)."""
+    rows, D = w.shape
+    dh = rows // heads
+    return w.view(heads, 2, dh // 2, D).transpose(1, 2).reshape(rows, D).contiguous()
 
 
 def pack_gate_up(gate, up):
