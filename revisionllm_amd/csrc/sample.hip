@@ -217,6 +217,10 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
             out_hp[b] = h_raw;
             out_nkeep[b] = 0;
         }
+        if (tid < KCAP && out_idx && out_val) {
+            out_idx[b * KCAP + tid] = -1;
+            out_val[b * KCAP + tid] = -INFINITY;
+        }
         return;
     }
     if (tid == 0) {

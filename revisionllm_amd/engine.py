@@ -184,10 +184,20 @@ class Engine:
         hip.check(self.lib.rv_splice_embed(self._ctx, hip.ptr(rm), hip.ptr(vr), hip.ptr(h), B * S, hip.stream()), "rv_splice_embed")
         return h
 
-    def new_kv(self, B, Smax):
+    def new_kv(self, B, Smax, reuse=True):
+        """KV cache for B rows x Smax positions (rounded up to 32).  Caches are pooled per (B, Smax): a recycled cache holds
+        stale but finite bf16 values, which is all the kernels need beyond the current length (P = 0 there)."""
         Smax = (Smax + 31) // 32 * 32
-        nbytes = self.lib.rv_kv_bytes(self._ctx, B, Smax)
-        return torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device), Smax
+        key = ("kv", B, Smax)
+        t = self._ws.get(key) if reuse else None
+        if t is None:
+            nbytes = self.lib.rv_kv_bytes(self._ctx, B, Smax)
+            t = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device)
+            if reuse:
+                for k_ in [k_ for k_ in self._ws if isinstance(k_, tuple) and k_[0] == "kv"][:-3]:
+                    del self._ws[k_]   # keep the pool small
+                self._ws[key] = t
+        return t, Smax
 
     def llm_forward(self, h, pos0, kv, Smax, logits=None):
         """h f32 [B,S,D] (clobbered) -> logits f32 [B,V] of the last position; appends K/V at pos0..pos0+S-1."""

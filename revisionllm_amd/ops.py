@@ -100,14 +100,15 @@ def attention(q, k, v, causal=False, key_pad=None, q_pos0=0, scale=None):
 
 
 def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0):
-    """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B])."""
+    """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B]).
+    (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""
     B, V = logits.shape
     dev = logits.device
     o = dict(tokens=torch.empty(B, dtype=torch.int32, device=dev), entropy_proc=torch.empty(B, dtype=torch.float32, device=dev),
              entropy_raw=torch.empty(B, dtype=torch.float32, device=dev),
-             topk_idx=torch.full((B, hip.TOPK_CAP), -1, dtype=torch.int32, device=dev),
-             topk_val=torch.full((B, hip.TOPK_CAP), float("-inf"), dtype=torch.float32, device=dev),
-             n_keep=torch.zeros(B, dtype=torch.int32, device=dev))
+             topk_idx=torch.empty((B, hip.TOPK_CAP), dtype=torch.int32, device=dev),
+             topk_val=torch.empty((B, hip.TOPK_CAP), dtype=torch.float32, device=dev),
+             n_keep=torch.empty(B, dtype=torch.int32, device=dev))
     hip.check(hip.lib().rv_sample(hip.ptr(_c(logits)), B, V, hip.ptr(uniforms), int(do_sample), float(temperature), int(top_k),
                                   float(top_p if top_p is not None else 1.0), hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
                                   hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]),
