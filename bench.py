@@ -89,6 +89,16 @@ def roofline_legs(model, n_calls, M):
     nbytes = 2.0 * s.hidden * 2 * s.inter
     legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
                                       peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
+    # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
+    #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised
+    if "proj.w" not in eng._keep:
+        eng.init_synthetic(seed=0, llm=False, clip=False, linear=True)
+    xf = torch.randn(100 * 256, 768, device=dev).to(torch.bfloat16)
+    ms = event_time_ms(lambda: eng.project_dense(xf, torch.bfloat16), 20)
+    nbytes = xf.numel() * 2 + 100 * 256 * s.hidden * 2
+    legs["dense_projector_scan"] = dict(kernel="gemm_tile_p4<1,0,3>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
+                                        unit="GB/s", algorithmic=nbytes, grid_threads=200 * 32 * 256,
+                                        tflops=2.0 * 100 * 256 * 768 * s.hidden / ms / 1e9)
     return legs
 
 
@@ -258,7 +268,8 @@ def main():
         P0 = model._common_text_prefix(row_map) if n_calls_rank > 1 else 0
         M_prefill = P0 + n_calls_rank * (S - P0)
         legs = roofline_legs(model, n_calls_rank, M_prefill)
-        dom = max(legs.values(), key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (args.decode_steps - 1)))
+        dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
+                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (args.decode_steps - 1)))
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         out = {
             "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",

@@ -148,7 +148,8 @@ def finalize(model):
     sd = model._host_sd
     eng = model._ensure_engine()
     eng.load_llm(lambda n: sd[n])
-    proj = {k[len("model.mm_projector."):]: v for k, v in sd.items() if k.startswith("model.mm_projector.")}
+    root = "model.cross_attn." if getattr(model.get_model(), "cross_attn_variant", False) else "model.mm_projector."
+    proj = {k[len(root):]: v for k, v in sd.items() if k.startswith(root)}
     if proj:
         if model.get_model().clip_adapter:
             eng.load_clip_adapter(lambda n: proj[n])

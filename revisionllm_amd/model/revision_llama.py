@@ -67,9 +67,15 @@ class _Inner:
         a = model_args
         assert not getattr(a, "clip_adapter", False) or not getattr(a, "cross_attn", False), \
             "both clip_adapter and cross_attn cannot be true"
-        if getattr(a, "cross_attn", False):
-            raise NotImplementedError("the separate cross_attn module (chapters variant, vtimellm_arch.py:52-71) is not built yet")
-        self.clip_adapter = bool(getattr(a, "clip_adapter", False))
+        self.cross_attn_variant = bool(getattr(a, "cross_attn", False))
+        if self.cross_attn_variant and getattr(a, "pretrain_clip_adapter", None) is None and state_dict is None:
+            raise NotImplementedError("cross_attn=True without pretrain_clip_adapter builds the 4096-d ClipEncoder with a text "
+                                      "projector (transformer.py:65-67,86) - not built")
+        # chapters variant (scripts/chapters/*.sh: --cross_attn True --pretrain_clip_adapter ...): mm_projector is a Linear
+        # whose output is computed and then DISCARDED (vtimellm_arch.py:125,132-133); the separate ``cross_attn`` module is a
+        # 768-d ClipEncoder applied to the RAW features.  That is exactly the clip_adapter data path with the weights
+        # living under ``cross_attn.`` instead of ``mm_projector.``.
+        self.clip_adapter = bool(getattr(a, "clip_adapter", False)) or self.cross_attn_variant
         self.clip_adapter_text = bool(getattr(a, "clip_adapter_text", False))
         self.clip_adapter_feature = getattr(a, "clip_adapter_feature", "cls")
         if not isinstance(self.clip_adapter_feature, str):  # e2e2.py:72 declares it type=bool
@@ -89,6 +95,8 @@ class _Inner:
             else:
                 eng.load_linear_projector(lambda n: state_dict[n])
         self.mm_projector = _Projector(self)
+        if self.cross_attn_variant:
+            self.cross_attn = self.mm_projector
 
 
 class ReVisionLlamaForCausalLM:

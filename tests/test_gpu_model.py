@@ -399,3 +399,27 @@ def test_multi_query_batching_on_device():
         assert both[i]["answers"] == one["answers"]
         assert np.allclose(both[i]["max_entropy"], one["max_entropy"], rtol=1e-4)
         assert np.allclose(both[i]["score_cos"], one["score_cos"], rtol=1e-5, atol=1e-6)
+
+
+def test_chapters_cross_attn_variant(tmp_path):
+    """scripts/chapters: --cross_attn True --pretrain_clip_adapter <file>: the separate cross_attn ClipEncoder on the raw
+    features (vtimellm_arch.py:52-71,127-144) is the clip_adapter data path with weights from the pretrain file."""
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    clip = synth.build_numpy(synth.clip_encoder_spec(hidden=shape.hidden), SEED, prefix="model.mm_projector.")
+    path = tmp_path / "clip_adapter.bin"
+    torch.save({k: T(v) for k, v in clip.items()}, path)
+    ref = _model(shape, _args())
+    m = ReVisionLlamaForCausalLM(shape, device="cuda:0")
+    m.get_model().initialize_vision_modules(_args(clip_adapter=False, cross_attn=True, pretrain_clip_adapter=str(path)))
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=False)
+    m.generation_config.eos_token_id = None
+    assert m.get_model().cross_attn is m.get_model().mm_projector
+    ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None]
+    feat = feats("ch.feat", (1, 6, 16, 768), bf16=True)
+    q = (feats("ch.q", (1, 4, 768), bf16=True), torch.ones(1, 4))
+    kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
+    assert torch.equal(torch.stack(m.generate(ids, **kw)["logits"]), torch.stack(ref.generate(ids, **kw)["logits"]))
+    with pytest.raises(NotImplementedError):
+        ReVisionLlamaForCausalLM(shape, device="cuda:0").get_model().initialize_vision_modules(_args(clip_adapter=False, cross_attn=True))
