@@ -238,6 +238,12 @@ def run_query(model, tokenizer, features, query_feats, query_cls, sentence, batc
     if grounding_windows is None:
         grounding_windows = list(range(W))
     zooms = tuple(zooms)
+    if W == 0:   # video shorter than one window stride: nothing to score (the reference loops zero times)
+        return dict(answers=[], starts=[], indexes=[], hierarchy_zooms=[], max_entropy=[], mean_entropy=[], score_cos=[],
+                    grounding_windows=grounding_windows, plan=[])
+    if W < batch:
+        raise ValueError(f"{W} windows < batch {batch}: the reference's back-shift (e2e2.py:342-343) would index windows < 0; "
+                         "call with batch <= number of windows")
     plan = plan_groups(W, batch, zooms)
     perms = [torch.as_tensor(p).long() for p in (perms if perms is not None else make_perms(plan))]
     query = "<video>\n" + QUERY_TEMPLATE.format(sentence)

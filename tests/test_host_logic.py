@@ -139,3 +139,27 @@ def test_product_has_no_cpu_fallback():
     code = "import sys; import revisionllm_amd, revisionllm_amd.parallel, revisionllm_amd.eval.stage2, revisionllm_amd.inference; " \
            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_stage2_empty_and_too_short_inputs():
+    rec = stage2.run_query(None, None, torch.zeros(0, 250, 768), torch.zeros(4, 768), torch.zeros(768), "x", batch=100)
+    assert rec["answers"] == [] and rec["plan"] == []
+    with pytest.raises(ValueError, match="windows < batch"):
+        stage2.run_query(None, None, torch.zeros(5, 250, 768), torch.zeros(4, 768), torch.zeros(768), "x", batch=100)
+    assert stage2.plan_groups(0, 100) == []
+    info = stage2.log_record(dict(answers=["In video 3.", "nothing"], starts=[0, 0], indexes=[[1, 0, 2, 3], [0, 1]], hierarchy_zooms=[1, 2],
+                                  grounding_windows=list(range(10)), score_cos=[0.5], mean_entropy=[1.0, 2.0], max_entropy=[1.0, 2.0]),
+                             [2, 3], batch=4)
+    assert info["frames"] == {0: (2, 4)} and info["iou"] == [1] and set(info) >= {"gt", "score_cos", "hierarchy_zooms"}
+
+
+def test_mm_utils_helpers(tmp_path):
+    tok = synth.FakeTokenizer()
+    crit = mm_utils.KeywordsStoppingCriteria(["."], tok, torch.zeros(1, 3, dtype=torch.long))
+    assert crit(torch.tensor([[5, 6, 7, 19]])) and not crit(torch.tensor([[5, 6, 7, 8]]))
+    assert mm_utils.get_model_name_from_path("/a/b/checkpoint-100/") == "b_checkpoint-100"
+    assert mm_utils.get_model_name_from_path("/a/vicuna-7b") == "vicuna-7b"
+    log = tmp_path / "p.txt"
+    stage2.write_log(str(log), "v", "grounding", "q1", ["In video 3."], info={"iou": [1]})
+    import json
+    assert json.loads(open(log).read()) == {"video_id": "v", "task": "grounding", "query_id": "q1", "answer": ["In video 3."], "info": {"iou": [1]}}
