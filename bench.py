@@ -72,7 +72,7 @@ def roofline_legs(model, n_calls, M):
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
     ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
-    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2,3>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2,3,0>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
                                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops,
                                        grid_threads=((M + 127) // 128) * (2 * s.inter // 128) * 256)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
@@ -87,7 +87,7 @@ def roofline_legs(model, n_calls, M):
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
-    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
+    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
                                       peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
     #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised
@@ -96,7 +96,7 @@ def roofline_legs(model, n_calls, M):
     xf = torch.randn(100 * 256, 768, device=dev).to(torch.bfloat16)
     ms = event_time_ms(lambda: eng.project_dense(xf, torch.bfloat16), 20)
     nbytes = xf.numel() * 2 + 100 * 256 * s.hidden * 2
-    legs["dense_projector_scan"] = dict(kernel="gemm_tile_p4<1,0,3>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
+    legs["dense_projector_scan"] = dict(kernel="gemm_tile_p4<1,0,3,0>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", algorithmic=nbytes, grid_threads=200 * 32 * 256,
                                         tflops=2.0 * 100 * 256 * 768 * s.hidden / ms / 1e9)
     return legs
