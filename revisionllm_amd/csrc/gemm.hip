@@ -328,6 +328,50 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
         }
         return;
     }
+    if constexpr (OUT_BF16 != 0) {
+        // bf16 outputs: transpose the wave's 64-row sub-tile through LDS so that every store instruction writes whole
+        // 128-byte (64-byte for the gated epilogue) row segments instead of 16 rows x 32 B - the short-K adapter GEMMs
+        // and the dense "feature scan" projector are epilogue-bound otherwise.
+        if (!res && (N & 127) == 0 && (ldc & 7) == 0) {
+            constexpr int COLS = ACT == RV_ACT_SILU_MUL ? 32 : 64;   // output columns per wave
+            constexpr int RS = COLS * 2 + 16;                         // padded LDS row stride (bytes)
+            constexpr int LPR = COLS / 8, RPI = 64 / LPR;             // lanes per row, rows per store instruction
+            __syncthreads();                                          // every wave is done reading the ring
+            char* my = smem + wave * (64 * RS);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = mi * 16 + fr;
+                if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni += 2) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                        *(u32x2*)(my + row * RS + ((ni >> 1) * 16 + kg * 4) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        f32x4 v = acc[ni][mi];
+                        if (bias) v += *(const f32x4*)(bias + n0 + wc * 64 + ni * 16 + kg * 4);
+                        if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    }
+                }
+            }
+            const int ncol0 = ACT == RV_ACT_SILU_MUL ? ((n0 + wc * 64) >> 1) : n0 + wc * 64;
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + lane / LPR, chunk = lane % LPR;
+                const int m = m0 + wr * 64 + row;
+                if (m < M) *(u32x4*)((bf16_t*)Cv + (int64_t)m * ldc + ncol0 + chunk * 8) = *(const u32x4*)(my + row * RS + chunk * 16);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wr * 64 + mi * 16 + fr;

@@ -162,7 +162,7 @@ class Engine:
         if self.adapter_text:
             txt = _dev_bf16(txt, self.device)
             Nq, Lq = txt.shape[0], txt.shape[1]
-            m = (txt_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+            m = ops.h2d((txt_mask != 0).to(torch.uint8), self.device).contiguous()
         else:
             txt, m, Nq, Lq = None, None, 0, 0
         feat = hip.RV_FEAT_CLS if feature == "cls" else hip.RV_FEAT_ALL
@@ -179,7 +179,7 @@ class Engine:
         """row_map i32 [B,S] (>=0 token id, <0 video row -(v+1)); video_rows f32 [R,D] -> h f32 [B,S,D]."""
         B, S = row_map.shape
         h = torch.empty(B, S, self.shape.hidden, dtype=torch.float32, device=self.device)
-        rm = row_map.to(device=self.device, dtype=torch.int32).contiguous()
+        rm = ops.h2d(row_map, self.device, torch.int32).contiguous()
         vr = _dev_f32(video_rows, self.device) if video_rows is not None else None
         hip.check(self.lib.rv_splice_embed(self._ctx, hip.ptr(rm), hip.ptr(vr), hip.ptr(h), B * S, hip.stream()), "rv_splice_embed")
         return h

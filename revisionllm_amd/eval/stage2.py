@@ -147,13 +147,18 @@ def window_cosine(features, query_cls, k=3):
     return ops.topk_cosine(features, query_cls, min(features.shape[1], k))
 
 
-def build_call_rows(cls, plan, perms):
-    """Video rows of every call: cls[start:end][perm].repeat_interleave(zoom)  (e2e2.py:345-352 applied to CLS rows)."""
-    rows = []
-    for (z, start, end), idx in zip(plan, perms):
-        r = cls[start:end][idx.to(cls.device)]
-        rows.append(r.repeat_interleave(z, 0) if z > 1 else r)
-    return rows
+def call_row_index(plan, perms, device):
+    """Window index of every video row of every call, concatenated: start + perm, each repeated ``zoom`` times
+    (e2e2.py:345-352 applied to CLS rows) -> (int64 device tensor, per-call row counts).  Needs only the plan, so it is
+    uploaded before the adapter is launched and the host never waits on the device between the stages."""
+    idx = [(start + p.long()).repeat_interleave(z) if z > 1 else start + p.long() for (z, start, end), p in zip(plan, perms)]
+    return ops.h2d(torch.cat(idx), device), [int(i.numel()) for i in idx]
+
+
+def build_call_rows(cls, plan, perms, index=None):
+    """Video rows of every call: cls[start:end][perm].repeat_interleave(zoom), as views of ONE gather."""
+    idx, counts = index if index is not None else call_row_index(plan, perms, cls.device)
+    return list(cls.index_select(0, idx).split(counts))
 
 
 def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
@@ -249,11 +254,12 @@ def run_query(model, tokenizer, features, query_feats, query_cls, sentence, batc
     query = "<video>\n" + QUERY_TEMPLATE.format(sentence)
 
     if mode == "batched":
+        index = call_row_index(plan, perms, features.device)
         cls = encode_windows(model, features, query_feats)
-        cos = window_cosine(features, query_cls).cpu()
-        rows = build_call_rows(cls, plan, perms)
+        cos = window_cosine(features, query_cls)
+        rows = build_call_rows(cls, plan, perms, index)
         res = generate_calls(model, tokenizer, query, rows, list(range(len(plan))), uniforms, max_new_tokens, max_calls_per_generate)
-        return assemble(plan, perms, res, cos, tokenizer, zooms, grounding_windows, single)
+        return assemble(plan, perms, res, cos.cpu(), tokenizer, zooms, grounding_windows, single)
     if mode != "reference":
         raise ValueError(f"mode must be 'reference' or 'batched', got {mode!r}")
 

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librevision_hip.so")
+# REVISION_HIP_LIB: load another build of the same ABI (A/B kernel measurements); default is the in-tree library.
+LIB_PATH = os.environ.get("REVISION_HIP_LIB") or os.path.join(_HERE, "librevision_hip.so")
 
 RV_F32, RV_BF16, RV_I32, RV_I64, RV_U8 = 0, 1, 2, 3, 4
 RV_ACT_NONE, RV_ACT_RELU, RV_ACT_SILU_MUL = 0, 1, 2

@@ -232,6 +232,12 @@ class ReVisionLlamaForCausalLM:
                 video_rows, rows_per_sample = None, 0
             else:
                 video_rows, rows_per_sample = self.encode_images(images, query_feats)
+        # host inputs go up once, before the loop, through pinned non-blocking copies: a pageable upload inside the loop
+        # would make the host wait for the whole queue at every step and the launch queue would run dry behind it
+        if uniforms is not None:
+            uniforms = ops.h2d(uniforms, dev, torch.float32)
+        if forced_tokens is not None:
+            forced_tokens = ops.h2d(forced_tokens, dev, torch.long)
         row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
         B, S = row_map.shape
         cap = min(max_new_tokens, 64)
@@ -248,14 +254,14 @@ class ReVisionLlamaForCausalLM:
             h = eng.splice_embed(row_map, video_rows)
             logits = eng.llm_forward(h, 0, kv, Smax)
 
-        seqs = input_ids.to(dev).long()
+        seqs = ops.h2d(input_ids, dev, torch.long)
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
         raw_steps, score_steps, ent_p, ent_r, new_tokens = [], [], [], [], []
         pos = S
         for step in range(max_new_tokens):
             if do_sample:
                 if uniforms is not None:
-                    u = uniforms[step].to(dev).float().contiguous()
+                    u = uniforms[step].contiguous()
                 elif self.uniform_fn is not None:
                     u = self.uniform_fn(step, B).to(dev).float().contiguous()
                 else:
@@ -263,7 +269,7 @@ class ReVisionLlamaForCausalLM:
                 o = ops.sample(logits, u, True, temperature, top_k, top_p)
             else:
                 o = ops.sample(logits, None, False)
-            nxt = o["tokens"].long() if forced_tokens is None else forced_tokens[step].to(dev).long()
+            nxt = o["tokens"].long() if forced_tokens is None else forced_tokens[step]
             ent_p.append(o["entropy_proc"])
             ent_r.append(o["entropy_raw"])
             if output_logits or (output_scores and (not do_sample or self.scores_mode == "raw")):
@@ -278,7 +284,7 @@ class ReVisionLlamaForCausalLM:
             new_tokens.append(nxt)
             if eos is not None:
                 unfinished = unfinished * (nxt != eos).long()
-            if step == max_new_tokens - 1 or int(unfinished.max()) == 0:
+            if step == max_new_tokens - 1 or (eos is not None and int(unfinished.max()) == 0):   # the only host sync
                 break
             if pos + 1 > Smax:
                 kv, Smax = self._grow_kv(kv, B, Smax, min(S + max_new_tokens, Smax * 2))

@@ -99,6 +99,18 @@ def attention(q, k, v, causal=False, key_pad=None, q_pos0=0, scale=None):
     return out
 
 
+def h2d(t, device, dtype=None):
+    """Host -> device without stalling the host: a pageable ``.to(device)`` blocks until everything queued before it has
+    run (the launch queue then runs dry after every upload); a pinned, non-blocking copy just joins the stream."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    if t.device.type == "cpu" and torch.device(device).type == "cuda":
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous().pin_memory().to(device, non_blocking=True)
+    return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
+
+
 def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0):
     """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B]).
     (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""

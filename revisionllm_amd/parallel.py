@@ -114,14 +114,15 @@ def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100
     if grounding_windows is None:
         grounding_windows = list(range(W))
     rows, prompts, cos_all = [], {}, []
+    index = [stage2.call_row_index(plan, [torch.as_tensor(p).long() for p in perms[qi]], features_local.device)
+             for qi in range(len(queries))]
     for qi, (qf, qc, sentence) in enumerate(queries):
         cls_local, cos_local = stages.encode(features_local, qf), stages.cosine(features_local, qc)
         if world > 1:
             cls_local = allgather_rows(cls_local, W, group)
             cos_local = allgather_rows(cos_local[:, None], W, group)[:, 0]
-        cos_all.append(cos_local.cpu())
-        pq = [torch.as_tensor(p).long() for p in perms[qi]]
-        rows.extend(stage2.build_call_rows(cls_local, plan, pq))
+        cos_all.append(cos_local)
+        rows.extend(stage2.build_call_rows(cls_local, plan, None, index[qi]))
         for c in range(nc):
             prompts[qi * nc + c] = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
     mine = deal(nc * len(queries), rank, world)
@@ -131,7 +132,7 @@ def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100
     out = []
     for qi in range(len(queries)):
         pq = [torch.as_tensor(p).long() for p in perms[qi]]
-        out.append(stage2.assemble(plan, pq, {c: res[qi * nc + c] for c in range(nc)}, cos_all[qi], tokenizer, zooms,
+        out.append(stage2.assemble(plan, pq, {c: res[qi * nc + c] for c in range(nc)}, cos_all[qi].cpu(), tokenizer, zooms,
                                    grounding_windows, single))
     return out
 
@@ -157,6 +158,7 @@ def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_c
         grounding_windows = list(range(W))
     query = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
 
+    index = stage2.call_row_index(plan, perms, features_local.device)   # host inputs first: no host wait between stages
     cls_local = stages.encode(features_local, query_feats)
     cos_local = stages.cosine(features_local, query_cls)
     if world > 1:
@@ -164,7 +166,7 @@ def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_c
         cos = allgather_rows(cos_local[:, None], W, group)[:, 0]
     else:
         cls, cos = cls_local, cos_local
-    rows = stage2.build_call_rows(cls, plan, perms)
+    rows = stage2.build_call_rows(cls, plan, perms, index)
     mine = deal(len(plan), rank, world)
     res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
     if world > 1:

@@ -39,7 +39,7 @@ def main():
                 us = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True))
                 us0 = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True, stream_k=False))
                 print(f"gemm {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s   (tiled: {us0:7.1f} us)")
-        for name, M, N, K, act in (("adp.qk", 25700, 1536, 768, 0), ("adp.v", 25700, 768, 768, 0), ("adp.ffn1", 25700, 2048, 768, 1),
+        for name, M, N, K, act in (("dense.proj", 25600, 4096, 768, 0), ("adp.qk", 25700, 1536, 768, 0), ("adp.v", 25700, 768, 768, 0), ("adp.ffn1", 25700, 2048, 768, 1),
                                    ("adp.ffn2", 25700, 768, 2048, 0)):
             x = torch.randn(M, K, device=dev).to(torch.bfloat16)
             w = ops.pack_fragments((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16))
