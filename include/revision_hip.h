@@ -78,15 +78,15 @@ int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, floa
  * bias f32 or NULL, residual f32 (ldr) or NULL (may alias C), out dtype RV_BF16 or RV_F32 (ldc).
  * RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and the output has N/2 columns.  K % 64 == 0.
  * M <= 16 takes the weight-streaming (decode) kernel.  ws / ws_bytes: optional workspace of rv_gemm_ws_bytes() bytes
- * enabling the persistent stream-K kernel (packed W, N % 256 == 0); its first 4 KiB (hand-off flags) must be zero
- * before the first use and are left zero by every call.  NULL -> plain output-tiled kernel. */
+ * enabling the persistent stream-K form of the 256x256 ping-pong kernel (packed W, N % 256 == 0, M <= 1024); its first
+ * 8 KiB (hand-off flags) must be zero before the first use.  NULL -> output-tiled kernels only.  With stream-K the
+ * k-summation is split across workgroups in a fixed order: results are deterministic but differ in the last bits from
+ * the output-tiled kernels. */
 size_t rv_gemm_ws_bytes(void);
-/* Tuning knob (process-wide): 0 = output-tiled GEMM only (default); stream-K workgroup geometry 4 = 128x128 tiles, two
- * 4-wave workgroups per CU; 8 = 128x256 tiles, one 8-wave workgroup per CU with a 3-stage LDS ring. */
-void rv_set_gemm_geometry(int32_t waves);
-/* Tuning knob (process-wide): output-tiled kernel pipeline for packed W.  2 (default) = 128x128x32 steps, 3-stage LDS
- * ring (48 KiB: three workgroups per CU), counted vmcnt; 1 = 4-stage ring (two workgroups per CU); 0 = 128x128x64 double
- * buffer.  Results are bit-identical. */
+/* Tuning / measurement knob (process-wide) for packed W.  2 (default) = 128x128x32 3-stage LDS ring kernel plus the
+ * 256x256x64 ping-pong kernel where it pays (stream-K for few-row deep-K problems when ws is given, output-tiled for
+ * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
+ * 3 = register-double-buffered ring; 4 / 5 = ping-pong output-tiled / stream-K wherever supported. */
 void rv_set_gemm_tile_variant(int32_t variant);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,

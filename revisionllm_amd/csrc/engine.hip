@@ -161,7 +161,7 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
     w.Lpad = ((T + 1 + 31) / 32) * 32;
     w.Lqpad = ((Lq + 31) / 32) * 32;
     Carver k(ws, cap);
-    w.sk_bytes = gemm_sk_ws_bytes();
+    w.sk_bytes = gemm_pp_ws_bytes();
     w.sk = k.take(w.sk_bytes);
     w.pm = (float*)k.take((size_t)(T + 1) * d * 4);
     w.x32 = (float*)k.take((size_t)R1 * d * 4);
@@ -326,7 +326,7 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     const int64_t M = (int64_t)B * S, D = c->cfg.hidden, F = c->cfg.inter;
     Carver k(ws, cap);
     LlmWs w;
-    w.sk_bytes = gemm_sk_ws_bytes();
+    w.sk_bytes = gemm_pp_ws_bytes();
     w.sk = k.take(w.sk_bytes);
     w.xn16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
@@ -387,7 +387,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.kc = kc;
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
-        RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, st));
+        RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, w.sk, w.sk_bytes, st));
         if (P0 > 0) {
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                         (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};

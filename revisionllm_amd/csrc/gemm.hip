@@ -195,36 +195,6 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 // (in-flight bytes per CU x 1/latency ~ 0.9 PF/s); this variant raises the bytes in flight by 1.5x.
 // A rows are 64 B here; chunk c of row r lives in LDS slot c ^ ((r >> 2) & 2), which makes every ds_read_b128 lane
 // group hit 16 distinct 16-byte slots.
-// Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
-__device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
-    const int D = q.H * 128;
-    const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
-    int b, pos;
-    bool prefix = false;
-    if (m < q.P0) { b = 0; pos = m; prefix = true; }
-    else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
-    if (sec < 2) {
-        const f32x4 t = *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
-        const float a0 = v[0] * t[0] - v[1] * t[1], b0 = v[1] * t[0] + v[0] * t[1];
-        const float a1 = v[2] * t[2] - v[3] * t[3], b1 = v[3] * t[2] + v[2] * t[3];
-        const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
-        if (sec == 0) {
-            *(u32x2*)((bf16_t*)q.q16 + (int64_t)m * D + hd) = o;
-        } else {
-            const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
-            for (int bb = b0_; bb < b1_; ++bb)
-                *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
-        }
-    } else {
-        const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
-        for (int bb = b0_; bb < b1_; ++bb) {
-            bf16_t* dst = (bf16_t*)q.vtc + (((int64_t)bb * q.H + head) * 128 + p) * q.Smax + pos;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(int64_t)r * q.Smax] = f32_to_bf16(v[r]);
-        }
-    }
-}
-
 constexpr int P4_BK = 32, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
 
 __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int N,
@@ -684,7 +654,10 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     }
 }
 
-int g_tile_variant = 2;  // packed W: 2 (default) = 128x128x32 3-stage ring, 3 workgroups/CU; 1 = 4-stage, 2 workgroups/CU; 0 = 128x128x64 2-stage
+// packed W: 2 (default) = 128x128x32 3-stage ring (3 workgroups/CU) + the 256x256 ping-pong kernel where it pays;
+// 6 = ring only; 1 = 4-stage ring (2 workgroups/CU); 0 = 128x128x64 2-stage; 3 = register-double-buffered ring;
+// 4 = ping-pong output-tiled wherever supported; 5 = ping-pong stream-K wherever supported (A/B measurement knobs)
+int g_tile_variant = 2;
 
 template <int OUT_BF16, int ACT, int WP>
 void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
@@ -700,7 +673,7 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
                            ldc, M, N, K, tiles_m, tiles_n);
         return;
     }
-    if (WP && g_tile_variant == 2) {
+    if (WP && (g_tile_variant == 2 || g_tile_variant >= 4)) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
         return;
@@ -746,8 +719,15 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
     RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion is only available in the M <= 16 kernel");
     const GemvNorm nrm = norm ? *norm : GemvNorm{};
-    if (!gemv && ws && ws_bytes >= gemm_sk_ws_bytes() && gemm_sk_supported(w_layout, M, N, K))
-        return gemm_sk_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, st);
+    if (!gemv && gemm_pp_supported(w_layout, M, N, K)) {
+        // 256x256 ping-pong kernel (gemm_pp.hip): persistent stream-K for few-row, deep-K problems (the o / down projections
+        // of the prefill), output-tiled when the tile count fills the CUs; everything else stays on the 128x128 ring kernel
+        void* sk_ws = (ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(w_layout, M, N, K)) ? ws : nullptr;
+        const int v = g_tile_variant;
+        if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_profitable(M, N, K)) || gemm_pp_dp_profitable(M, N, K))))
+            return gemm_pp_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K,
+                                  (v == 5 || (v == 2 && sk_ws && gemm_pp_sk_profitable(M, N, K))) ? sk_ws : nullptr, st);
+    }
 #define RV_DISPATCH2(OB, AC, WP)                                                                            \
     do {                                                                                                     \
         if (gemv)                                                                                            \
@@ -774,7 +754,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st) {
     RV_CHECK_ARG(A && Wp && r.cs && r.q16 && r.kc && r.vtc, "gemm_qkv_rope: null argument");
     RV_CHECK_ARG(D % 128 == 0 && D == (int64_t)r.H * 128 && M == (int64_t)r.P0 + (int64_t)r.B * r.S, "gemm_qkv_rope: bad geometry");
     const bf16_t* a = (const bf16_t*)A;
@@ -785,6 +765,9 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
                            nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
     } else {
         RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
+        const bool sk = ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(1, M, N, K);
+        if (sk && (g_tile_variant == 5 || (g_tile_variant == 2 && gemm_pp_sk_profitable(M, N, K))))
+            return gemm_pp_qkv_rope(A, lda, Wp, M, N, K, r, ws, st);
         const int tiles_m = (int)cdiv(M, BM), tiles_n = N / BN;
         hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a, lda, w, nullptr, nullptr,
                            (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, tiles_m, tiles_n, r);
@@ -795,9 +778,9 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 
 int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
-extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 3) ? v : 2; }
+extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 6) ? v : 2; }
 
-extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_sk_ws_bytes(); }
+extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_pp_ws_bytes(); }
 
 extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                        const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,

@@ -1,0 +1,590 @@
+// Ping-pong GEMM for the prefill / adapter regime: C[M,N] = A[M,K] . W[N,K]^T, fragment-packed W, 256 x 256 x 64 tiles.
+//
+// Why a second tiled kernel: the 128 x 128 ring kernel (gemm.hip) moves (128 + 128) x 2 B of operands per 128 x 128 MACs
+// and k, which at the MFMA rate is exactly the 64 B/clk a CU's vector-memory path delivers, so it tops out near 0.9
+// PFLOP/s whatever the schedule.  A 256 x 256 tile halves the bytes per MAC; what it costs is occupancy (128 KiB of LDS,
+// one workgroup per CU, two waves per SIMD), so the overlap has to be built by hand:
+//
+//   * 8 waves = 2 (M) x 4 (N); every wave owns 128 x 64 outputs = 8 x 4 MFMA fragments (128 accumulator registers).
+//     Waves w and w + 4 share a SIMD.  The two M-groups run the same phase sequence ONE BARRIER APART: while group 0
+//     issues its LDS reads and LDS-DMA loads (the "memory part" of a phase), group 1 runs its 16-MFMA burst (the "compute
+//     part"), and vice versa, so each SIMD always has one wave in its MFMA burst.
+//   * a k-tile (64) is four phases, one per 64 x 32 quadrant of the wave's outputs: (m0,n0) (m0,n1) (m1,n1) (m1,n0); the
+//     register sub-tiles are loaded once per phase (12 / 4 / 8 / 0 ds_read_b128) and the n0 fragments stay resident.
+//   * two LDS stages of four 16 KiB UNITS, ordered by first use: U0 = A rows of the m0 quadrants (both groups),
+//     U1 = W columns of the n0 quadrants (all four wave columns), U2 = W n1, U3 = A m1.  Phase p of tile t issues unit
+//     U_p of tile t+1 (2 LDS-DMA pieces of 1 KiB per wave) into the other stage, whose unit U_p was last read a whole
+//     tile earlier.  Loads therefore stay in flight across every barrier: the only waits are COUNTED (vmcnt(4): the two
+//     youngest units may still be in flight), placed before the barrier that precedes the first read of the unit.
+//   * A is staged in full 128-byte rows (8 rows per 1 KiB piece) with the 16-byte chunks XOR-swizzled by (row & 7) through
+//     the per-lane SOURCE address (LDS-DMA destinations are lane-linear); W pieces are MFMA fragments already.  Both are
+//     read back with conflict-free ds_read_b128.
+//
+// Hazards (slots = barrier-to-barrier intervals; group 0 runs memory part of phase k in slot 2k, group 1 in slot 2k+1):
+//   RAW  a unit is read in slot >= 2k only after every wave waited for its own pieces of it before the barrier ending
+//        slot 2k-1;
+//   WAR  a unit of stage s is overwritten from slot 8(t+1)+2p on; its last read (tile t, phase <= 2 by either group) was
+//        issued by slot 8t+5 and retired (lgkmcnt(0)) before the barrier ending slot 8t+6.
+#include <atomic>
+
+#include "kernels.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+constexpr int PBM = 256, PBN = 256, PBK = 64;
+constexpr int UNIT = 128 * 128;      // bytes: 128 rows (or W columns) x 64 k x bf16
+constexpr int STAGE = 4 * UNIT;      // U0 = A m0 | U1 = W n0 | U2 = W n1 | U3 = A m1
+constexpr int PP_LDS = 2 * STAGE;    // 128 KiB
+
+struct PpSrc {
+    const char* A;        // uniform bases; the per-lane parts are 32-bit byte offsets (operands are < 4 GiB), which keeps the
+    const char* W;        // load addresses in SGPR-base + VGPR-offset form and 8 VGPRs out of the main loop
+    unsigned a0[2];       // this wave's two pieces of A unit U0 (rows of the m0 quadrants), k = 0
+    unsigned a1[2];       // ... of A unit U3 (m1 quadrants, 64 rows further down)
+    unsigned w0[2];       // ... of W unit U1 (n0 quadrants), one per k32 half
+    unsigned w1[2];       // ... of W unit U2 (n1 quadrants)
+};
+
+__device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M,
+                                           int K, int m0, int n0, int wave, int lane) {
+    s.A = (const char*)A;
+    s.W = (const char*)Wp;
+    // A unit: local row lr in [0,128): group = lr >> 6, tile row = group * 128 + mq * 64 + (lr & 63); piece = 8 rows of 128 B;
+    // lane -> row (lane >> 3); LDS slot (lane & 7) of that row holds global chunk slot ^ (row & 7).
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave * 2 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        const int trow = (lr >> 6) * 128 + (lr & 63);
+        int g0 = m0 + trow, g1 = m0 + trow + 64;
+        g0 = g0 < M ? g0 : M - 1;
+        g1 = g1 < M ? g1 : M - 1;
+        s.a0[i] = (unsigned)(((int64_t)g0 * lda + chunk * 8) * 2);
+        s.a1[i] = (unsigned)(((int64_t)g1 * lda + chunk * 8) * 2);
+    }
+    // W unit (nq): piece pc = (wcol * 2 + j) * 2 + ks; this wave issues pc = 2 * wave + ks: wcol = wave >> 1, j = wave & 1
+    const int kfr = K >> 5;
+    const int nb0 = (n0 >> 4) + (wave >> 1) * 4 + (wave & 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        s.w0[ks] = (unsigned)(((((int64_t)nb0 * kfr + ks) * 64 + lane) * 8) * 2);
+        s.w1[ks] = (unsigned)(((((int64_t)(nb0 + 2) * kfr + ks) * 64 + lane) * 8) * 2);
+    }
+}
+
+// Issue unit U (0..3) of the k-tile at element offset k0 into `stage`.  Every wave issues 2 pieces of 1 KiB.
+template <int U>
+__device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* stage, int wave) {
+    char* dst = stage + U * UNIT + wave * 2048;
+    const char* ab = s.A + (int64_t)k0 * 2;
+    const char* wb = s.W + (int64_t)k0 * 32;       // k32 block kb sits at kb * 1024 bytes = k0 * 32
+    if constexpr (U == 0) {
+        glds16(ab + s.a0[0], dst);
+        glds16(ab + s.a0[1], dst + 1024);
+    } else if constexpr (U == 3) {
+        glds16(ab + s.a1[0], dst);
+        glds16(ab + s.a1[1], dst + 1024);
+    } else if constexpr (U == 1) {
+        glds16(wb + s.w0[0], dst);
+        glds16(wb + s.w0[1], dst + 1024);
+    } else {
+        glds16(wb + s.w1[0], dst);
+        glds16(wb + s.w1[1], dst + 1024);
+    }
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// acc += A[tile rows, k-tiles kt0 .. kt0+nks) . W[tile cols, same k]^T.  On entry no LDS access and no load of this
+// workgroup is outstanding; the same holds on return (every wave has passed the same number of barriers).
+__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, kg = lane >> 4;
+    // A fragment (f, ks) of unit U0 / U3: row lr = wr * 64 + f * 16 + fr at lr * 128 + (((ks * 4 + kg) ^ (lr & 7)) << 4)
+    const int a_rd = (wr * 64 + fr) * 128;
+    const int a_c0 = ((kg ^ (fr & 7)) << 4), a_c1 = (((4 + kg) ^ (fr & 7)) << 4);
+    // W fragment (j, ks) of unit U1 / U2: piece (wc * 2 + j) * 2 + ks
+    const int w_rd = wc * 4096 + lane * 16;
+
+    issue_unit<0>(src, kt0 * PBK, smem, wave);
+    issue_unit<1>(src, kt0 * PBK, smem, wave);
+    issue_unit<2>(src, kt0 * PBK, smem, wave);
+    issue_unit<3>(src, kt0 * PBK, smem, wave);
+    wait_vm<4>();                                // U0, U1 landed
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
+
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    for (int t = 0; t < nks; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
+        const bool more = t + 1 < nks;
+        const int k1 = (kt0 + t + 1) * PBK;
+
+#define PP_MFMA(B, NI, MI0)                                                                                         \
+    do {                                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+            _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                                 \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+    } while (0)
+#define PP_READ_A(UOFF)                                                                                             \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                 \
+        af[f][0] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c0);                                         \
+        af[f][1] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c1);                                         \
+    }
+#define PP_READ_W(B, UOFF)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                   \
+        B[j][ks] = *(const bf16x8*)(cur + (UOFF) + w_rd + j * 2048 + ks * 1024);
+        // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
+        // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
+#define PP_SYNC_M(WAITN)                                   \
+    if (wr == 1) { WAITN; }                                \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_SYNC_C(WAITN)                                   \
+    if (wr == 0) { WAITN; }                                \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+        // ---- phase 0: quadrant (m0, n0) ----
+        PP_READ_W(b0, UNIT)
+        PP_READ_A(0)
+        if (more) issue_unit<0>(src, k1, nxt, wave);
+        PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<2>())      // U2 of this tile must have landed
+        PP_MFMA(b0, 0, 0);
+        PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<2>())
+        // ---- phase 1: quadrant (m0, n1) ----
+        PP_READ_W(b1, 2 * UNIT)
+        if (more) issue_unit<1>(src, k1, nxt, wave);
+        PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<0>())      // U3 of this tile
+        PP_MFMA(b1, 2, 0);
+        PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<0>())
+        // ---- phase 2: quadrant (m1, n1) ----
+        PP_READ_A(3 * UNIT)
+        if (more) issue_unit<2>(src, k1, nxt, wave);
+        PP_SYNC_M((void)0)
+        PP_MFMA(b1, 2, 4);
+        PP_SYNC_C((void)0)
+        // ---- phase 3: quadrant (m1, n0) ----
+        if (more) issue_unit<3>(src, k1, nxt, wave);
+        PP_SYNC_M(if (more) wait_vm<4>())                          // U0, U1 of the next tile
+        PP_MFMA(b0, 0, 4);
+        PP_SYNC_C(if (more) wait_vm<4>())
+    }
+#undef PP_MFMA
+#undef PP_READ_A
+#undef PP_READ_W
+#undef PP_SYNC_M
+#undef PP_SYNC_C
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+}
+
+// Epilogue: lane owns row m = .. + fr, columns n = .. + kg * 4 .. + 3 of every 16 x 16 fragment.
+template <int OUT_BF16, int ACT, int ROPE>
+__device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[4][8], const float* __restrict__ bias, const float* res, int64_t ldr,
+                                            void* Cv, int64_t ldc, int M, int m0, int n0, int wave, int lane, const QkvRope& qr) {
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wr * 128 + mi * 16 + fr;
+        if (m >= M) continue;
+        if constexpr (ROPE) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) qkv_rope_store(qr, m, n0 + wc * 64 + ni * 16 + kg * 4, acc[ni][mi]);
+        } else if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int n = n0 + wc * 64 + ni * 16;
+                const int no = (n >> 1) + kg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+                f32x4 v = acc[ni][mi];
+                if (bias) v += *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+            }
+        }
+    }
+}
+
+// ---- output-tiled launch: one workgroup per 256 x 256 tile ------------------------------------------------------------
+template <int OUT_BF16, int ACT>
+__global__ __launch_bounds__(512) void gemm_pp(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+                                               const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                               int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    {   // XCD-aware tile map: the m-tiles of one W column panel run on one XCD (private L2) at about the same time
+        const int b = blockIdx.x;
+        const int tiles_n8 = tiles_n & ~7;
+        if (b < tiles_n8 * tiles_m) {
+            const int xcd = b & 7, idx = b >> 3;
+            tn = (idx / tiles_m) * 8 + xcd;
+            tm = idx % tiles_m;
+        } else {
+            const int r = b - tiles_n8 * tiles_m;
+            tm = r % tiles_m;
+            tn = tiles_n8 + r / tiles_m;
+        }
+    }
+    const int m0 = tm * PBM, n0 = tn * PBN;
+    PpSrc src;
+    pp_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+    f32x4 acc[4][8];   // [ni = nq * 2 + j][mi = mq * 4 + f]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pp_mainloop(acc, src, 0, K / PBK, smem, wave, lane);
+    pp_epilogue<OUT_BF16, ACT, 0>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, QkvRope{});
+}
+
+// ---- persistent stream-K launch for few-row problems (tiles_m <= 4, i.e. the LLM prefill) ------------------------------
+// One workgroup per CU.  The m-tiles of one W column panel form a TEAM of TS = 1 / 2 / 4 workgroups on ONE XCD (block b
+// lands on XCD b % 8) that walk the same (panel, k) range together, so a W piece is fetched from HBM once and the other
+// team members hit the XCD's L2 - the coincidence the output-tiled launch gets for free.  The (panel, k-tile) space is cut
+// into equal contiguous ranges, one per team (stream-K): every CU runs the same number of k-tiles whatever N is.
+//
+// A panel whose k-range is shared by c teams is finished by ALL of them together, after their own ranges: every
+// participant publishes its fp32 partial tile (register order, 256 KiB, coalesced 16-byte stores) and a flag, and then
+// reduces and stores 1/c of the tile: it sums the c partials of its share in ascending-k order (fixed order: results are
+// deterministic for a given shape) and runs the epilogue on it.  With the accumulators dead by then, each wave has its
+// whole share (32 x 16 B per lane) in flight at once, so a hand-off costs about one memory round trip instead of c - 1
+// serial 256 KiB reads by a single finisher.
+// Vector L1s and the per-XCD L2s are not coherent, so partials and flags move with sc1 (agent-coherent, write-through /
+// L2-missing) stores and loads - NOT with release / acquire fences, whose buffer_wbl2 / buffer_inv sweep the whole L2 of
+// the XCD once per hand-off and stall its other 31 workgroups (measured: +150 us on the gate/up projection).  A flag holds
+// the launch EPOCH (a host-side counter), so nothing has to be cleaned up and a reader never writes.
+constexpr int PARTIAL_F4 = 8 * 32 * 64;   // f32x4 per partial tile; two slots per workgroup (first / last segment)
+constexpr int PP_HDR = 8192;              // bytes: 2 flags per workgroup (<= 2046) + status word
+// 16-byte agent-coherent (sc1) accesses to the partial-tile slots through a raw buffer descriptor (compiler-tracked vmcnt;
+// an offset beyond the descriptor's range reads as zero, which is how absent participants are masked)
+typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PP_SC1 = 16;   // cache-policy bit 4 = sc1 on gfx940+
+constexpr unsigned PP_OOB = 0x7fffff00u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_slot_rsrc(f32x4* partial, int id) {
+    return __builtin_amdgcn_make_buffer_rsrc(partial + (int64_t)id * PARTIAL_F4, 0, PARTIAL_F4 * 16, 0x00020000);
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), r, (int)byte_off, 0, PP_SC1);
+}
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, PP_SC1));
+}
+
+// Epilogue of one reduction unit = the fragment pair (ni = 2 nip, 2 nip + 1) x mi of wave w's sub-tile.
+template <int OUT_BF16, int ACT, int ROPE>
+__device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int mi, int nip, const float* __restrict__ bias,
+                                                 const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int m0, int n0, int lane,
+                                                 const QkvRope& qr) {
+    const int fr = lane & 15, kg = lane >> 4;
+    const int m = m0 + (w >> 2) * 128 + mi * 16 + fr;
+    if (m >= M) return;
+    const int nf = n0 + (w & 3) * 64 + nip * 32;   // first column of fragment ni = 2 nip
+    if constexpr (ROPE) {
+        qkv_rope_store(qr, m, nf + kg * 4, v0);
+        qkv_rope_store(qr, m, nf + 16 + kg * 4, v1);
+    } else if (ACT == RV_ACT_SILU_MUL) {
+        const int no = (nf >> 1) + kg * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu(v0[r]) * v1[r];
+        if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int n = nf + e * 16 + kg * 4;
+            f32x4 v = e ? v1 : v0;
+            if (bias) v += *(const f32x4*)(bias + n);
+            if (ACT == RV_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+            if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+        }
+    }
+}
+
+// Reduce + store this workgroup's share of a shared panel: units x = j, j + c, ... of the 128 (wave, mi, ni-pair) units,
+// dealt to the 8 waves.  C participants are read per pass (ids[base .. base + C), absent ones masked); C = c for c <= 4.
+template <int C, int OUT_BF16, int ACT, int ROPE>
+__device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, int c, int j, int wave, int lane,
+                                                const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv, int64_t ldc,
+                                                int M, int m0, int n0, const QkvRope& qr) {
+    constexpr int UPW = C <= 4 ? (128 + 8 * C - 1) / (8 * C) : 1;   // units per wave and pass
+    const int per_pass = 8 * UPW;
+    for (int q0 = 0; j + q0 * c < 128; q0 += per_pass) {
+        f32x4 s[UPW][2];
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) s[u][0] = s[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < c; base += C) {
+            f32x4 v[UPW][C][2];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const bool have = base + i < c;
+                const __amdgpu_buffer_rsrc_t r = pp_slot_rsrc(partial, __builtin_amdgcn_readfirstlane(ids[have ? base + i : 0]));
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    const int x = j + (q0 + wave + 8 * u) * c;
+                    const unsigned off = (have && x < 128) ? (unsigned)((((x >> 4) * 32 + (x & 1) * 16 + ((x >> 1) & 7)) * 64 + lane) * 16) : PP_OOB;
+                    v[u][i][0] = ld_sc1(r, off);
+                    v[u][i][1] = ld_sc1(r, off == PP_OOB ? PP_OOB : off + 8 * 1024);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UPW; ++u)
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    s[u][0] += v[u][i][0];
+                    s[u][1] += v[u][i][1];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int x = j + (q0 + wave + 8 * u) * c;
+            if (x < 128) pp_epilogue_unit<OUT_BF16, ACT, ROPE>(s[u][0], s[u][1], x >> 4, (x >> 1) & 7, x & 1, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr);
+        }
+    }
+}
+
+template <int OUT_BF16, int ACT, int ROPE>
+__global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+                                                  const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                                  int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int total_units,
+                                                  f32x4* partial, int* flags, int* status, int epoch, QkvRope qr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int teams_per_x = (gridDim.x >> 3) / TS;
+    const int team = xcd * teams_per_x + slot / TS, tm = slot % TS;
+    const int T = 8 * teams_per_x;
+    if (tm >= tiles_m || slot >= teams_per_x * TS) return;
+    const int m0_wg = tm * PBM;
+    auto ub = [&](int t) { return (int)((int64_t)t * total_units / T); };   // first unit of team t's range
+    const int u_begin = ub(team), u_end = ub(team + 1);
+    int shared_panel[2] = {-1, -1};   // panels this workgroup published a partial of: slot 0 = entered mid-panel, 1 = head
+
+    for (int u = u_begin; u < u_end;) {
+        const int panel = u / nk, ks0 = u - panel * nk;
+        const int nks = min(nk - ks0, u_end - u);
+        const int n0 = panel * PBN;
+        // m0 is the same for every segment: launder it so that the row-dependent address math of the epilogue is not hoisted
+        // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
+        int m0 = m0_wg;
+        asm volatile("" : "+s"(m0));
+        PpSrc src;
+        pp_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pp_mainloop(acc, src, ks0, nks, smem, wave, lane);
+        u += nks;
+
+        if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
+            pp_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
+            continue;
+        }
+        // shared panel: publish the partial accumulators (write-through sc1 stores), then the flag
+        const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tm) * 2 + ps;
+        shared_panel[ps] = panel;
+        const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
+        const unsigned off = (wave * 32 * 64 + lane) * 16;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) st_sc1(pr, off + (ni * 8 + mi) * 1024, acc[ni][mi]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + id, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- finish the shared panels: every participant reduces and stores its 1/c share --------------------------------
+    int* ids = (int*)smem;   // participants' slot ids, ascending k
+    for (int ps = 0; ps < 2; ++ps) {
+        const int panel = shared_panel[ps];
+        if (panel < 0) continue;
+        const int lo = panel * nk, hi = lo + nk;
+        int t0 = team, t1 = team;
+        while (t0 > 0 && ub(t0) > lo) --t0;
+        while (t1 + 1 < T && ub(t1 + 1) < hi) ++t1;
+        __syncthreads();   // ids is reused
+        int c = 0, j = 0;
+        for (int t = t0; t <= t1; ++t) {
+            if (ub(t) == ub(t + 1)) continue;   // empty range: took no part
+            if (t == team) j = c;
+            if (tid == 0) ids[c] = (t * TS + tm) * 2 + (ub(t) <= lo ? 1 : 0);
+            ++c;
+        }
+        if (tid == 0) {
+            for (int i = 0; i < c; ++i) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(flags + ids[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 24)) {
+                        *status = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int m0 = m0_wg, n0 = panel * PBN;
+        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
+        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
+        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
+        else pp_reduce_share<8, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
+    }
+}
+
+int pp_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <typename Kern>
+int reserve_lds(Kern k, bool& done) {
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) {
+            rv_set_error("gemm_pp: cannot reserve %d bytes of LDS", PP_LDS);
+            return RV_ERR_HIP;
+        }
+        done = true;
+    }
+    return RV_OK;
+}
+
+template <int OUT_BF16, int ACT>
+int launch(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+           int M, int N, int K, hipStream_t st) {
+    static bool attr_set = false;
+    if (int rc = reserve_lds(gemm_pp<OUT_BF16, ACT>, attr_set)) return rc;
+    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / PBN;
+    hipLaunchKernelGGL((gemm_pp<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
+                       tiles_m, tiles_n);
+    return RV_OK;
+}
+
+std::atomic<int> g_epoch{0};
+
+template <int OUT_BF16, int ACT, int ROPE>
+int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+              int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr) {
+    static bool attr_set = false;
+    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE>, attr_set)) return rc;
+    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / PBN, nk = K / PBK;
+    const int TS = tiles_m <= 1 ? 1 : tiles_m == 2 ? 2 : 4;
+    const int G = pp_num_cus() & ~31;   // whole teams on every XCD
+    int epoch = ++g_epoch;
+    if (epoch <= 0) { g_epoch = 1; epoch = 1; }   // 0 = the zero-initialised workspace
+    int* flags = (int*)ws;
+    int* status = flags + PP_HDR / 4 - 1;
+    f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
+    hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
+                       tiles_m, TS, nk, tiles_n * nk, partial, flags, status, epoch, qr);
+    return RV_OK;
+}
+
+}  // namespace
+
+size_t gemm_pp_ws_bytes() { return PP_HDR + (size_t)2 * pp_num_cus() * PARTIAL_F4 * sizeof(f32x4); }
+
+bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
+    return w_layout == 1 && M > 16 && N % PBN == 0 && K % PBK == 0;
+}
+
+// stream-K form: few-row problems only (teams of <= 4 m-tiles); needs the zero-initialised workspace
+bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
+    const int cus = pp_num_cus();
+    return gemm_pp_supported(w_layout, M, N, K) && M <= 4 * PBM && cus >= 32 && cus <= 1023 && (N / PBN) * (K / PBK) < (1ll << 30);
+}
+
+// Stream-K pays when a panel is cut at least 4 ways (every workgroup then owns ONE piece of one panel: one 256 KiB
+// publish and one shared reduction per launch) and every team still has a few k-tiles of work.  Measured on MI355X at
+// M = 1005: down projection 128 -> 92 us, o projection 57 -> 52 us; the wide projections (1.3 / 0.75 panels per team) move
+// 2 pieces per workgroup through HBM and end up level with the ring kernel, so they stay there.
+bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K) {
+    const int tiles_m = (int)cdiv(M, PBM), TS = tiles_m <= 1 ? 1 : tiles_m == 2 ? 2 : 4;
+    const int64_t T = (pp_num_cus() & ~31) / TS, panels = N / PBN, nk = K / PBK;
+    return panels * 4 <= T && panels * nk >= 8 * T;
+}
+
+// Output-tiled ping-pong pays for long K (the prologue / epilogue of a 256x256 tile is ~3 us) when the tiles fill the
+// CUs: 1.2 vs 0.86 PFLOP/s at 4096^3; short-K adapter GEMMs (K = 768) and ragged tile counts stay on the ring kernel.
+bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = cdiv(M, PBM) * (N / PBN), cus = pp_num_cus();
+    const int64_t rounds = cdiv(tiles, cus);
+    return K >= 2048 && tiles >= cus && tiles * 100 >= rounds * cus * 85;
+}
+
+int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
+                   int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st) {
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* w = (const bf16_t*)Wp;
+    const int ob = out_dtype == RV_BF16;
+    const bool sk = ws && gemm_pp_sk_supported(1, M, N, K);
+    int rc;
+#define PP(OB, AC)                                                                                                       \
+    rc = sk ? launch_sk<OB, AC, 0>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})         \
+            : launch<OB, AC>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)
+    if (ob && act == RV_ACT_NONE) PP(1, RV_ACT_NONE);
+    else if (ob && act == RV_ACT_RELU) PP(1, RV_ACT_RELU);
+    else if (ob && act == RV_ACT_SILU_MUL) PP(1, RV_ACT_SILU_MUL);
+    else if (!ob && act == RV_ACT_NONE) PP(0, RV_ACT_NONE);
+    else if (!ob && act == RV_ACT_RELU) PP(0, RV_ACT_RELU);
+    else PP(0, RV_ACT_SILU_MUL);
+#undef PP
+    if (rc) return rc;
+    RV_CHECK_LAUNCH("gemm_pp");
+    return RV_OK;
+}
+
+// fused QKV projection (RoPE + KV-cache append epilogue) on the stream-K kernel
+int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
+                     hipStream_t st) {
+    int rc = launch_sk<0, RV_ACT_NONE, 1>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
+                                          (int)K, ws, st, r);
+    if (rc) return rc;
+    RV_CHECK_LAUNCH("gemm_pp_qkv_rope");
+    return RV_OK;
+}

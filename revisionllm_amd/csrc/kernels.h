@@ -29,18 +29,54 @@ struct QkvRope {
     void* vtc = nullptr;        // bf16 [B, H, dh, Smax]
     int B = 0, S = 0, P0 = 0, pos0 = 0, cs_pos0 = 0, H = 0, Smax = 0;
 };
-int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  hipStream_t st);
+// Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
+static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
+    const int D = q.H * 128;
+    const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
+    int b, pos;
+    bool prefix = false;
+    if (m < q.P0) { b = 0; pos = m; prefix = true; }
+    else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
+    if (sec < 2) {
+        const f32x4 t = *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
+        const float a0 = v[0] * t[0] - v[1] * t[1], b0 = v[1] * t[0] + v[0] * t[1];
+        const float a1 = v[2] * t[2] - v[3] * t[3], b1 = v[3] * t[2] + v[2] * t[3];
+        const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+        if (sec == 0) {
+            *(u32x2*)((bf16_t*)q.q16 + (int64_t)m * D + hd) = o;
+        } else {
+            const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+            for (int bb = b0_; bb < b1_; ++bb)
+                *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
+        }
+    } else {
+        const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+        for (int bb = b0_; bb < b1_; ++bb) {
+            bf16_t* dst = (bf16_t*)q.vtc + (((int64_t)bb * q.H + head) * 128 + p) * q.Smax + pos;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * q.Smax] = f32_to_bf16(v[r]);
+        }
+    }
+}
 
-// ws: optional zero-initialised stream-K workspace (>= gemm_sk_ws_bytes()); NULL -> plain tiled kernel
+int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
+                  void* ws, size_t ws_bytes, hipStream_t st);
+
+// ws: optional zero-initialised stream-K workspace (>= gemm_pp_ws_bytes()); NULL -> output-tiled kernels only
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
 int gemv_blocks(int act, int64_t N);  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
-size_t gemm_sk_ws_bytes();
-bool gemm_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
-int gemm_sk_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
+// 256x256x64 ping-pong kernel (gemm_pp.hip): output-tiled, or persistent stream-K when ws != NULL and M <= 1024
+bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K);
+bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
+bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K);   // split-K deep enough to pay for the partial-tile hand-off
+bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K);   // long K and a tile count that fills the CUs
+size_t gemm_pp_ws_bytes();
+int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st);
+int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
+                     hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
                 int64_t period, int64_t rows, int d, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);

@@ -71,16 +71,16 @@ def test_gemm(dev, M, N, K, out):
     if wpk is not None:
         yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False)
         assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
-        for variant in (0, 1, 3):                                    # other pipelines: same sums, same order
+        for variant in (0, 1, 3, 4, 6):                              # other pipelines (4 = 256x256 ping-pong): same sums, same order
             hip.lib().rv_set_gemm_tile_variant(variant)
             assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False), y)
-        hip.lib().rv_set_gemm_tile_variant(2)
-        for geo in (4, 8):                                           # opt-in persistent stream-K kernels
-            hip.lib().rv_set_gemm_geometry(geo)
-            ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True)
+        for variant in (5, 2):                                       # persistent stream-K ping-pong: forced / where the policy picks it
+            hip.lib().rv_set_gemm_tile_variant(variant)
+            ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True)
             assert rel_err(ys.float().cpu(), ref0) < tol
-            assert torch.equal(ys, ops.gemm(ad, wpk, out_dtype=od, w_packed=True))   # deterministic split-k summation
-        hip.lib().rv_set_gemm_geometry(0)
+            for _ in range(3):                                       # fixed split-k summation order: deterministic (and a race screen)
+                assert torch.equal(ys, ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True))
+        hip.lib().rv_set_gemm_tile_variant(2)
     y = ops.gemm(ad, wd, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU)
     ref = torch.relu(ref0 + bias.double()) + res.double()
     assert rel_err(y.float().cpu(), ref) < tol
@@ -90,9 +90,17 @@ def test_gemm(dev, M, N, K, out):
         r3 = ref0.view(M, N // 32, 2, 16)
         ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
         assert rel_err(y.float().cpu(), ref) < tol
-        hip.lib().rv_set_gemm_geometry(8)
-        assert rel_err(ops.gemm(ad, wpk, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True).float().cpu(), ref) < tol
-        hip.lib().rv_set_gemm_geometry(0)
+        for variant in (4, 5):
+            hip.lib().rv_set_gemm_tile_variant(variant)
+            ys = ops.gemm(ad, wpk, bias=None, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=True)
+            assert rel_err(ys.float().cpu(), ref) < tol
+        hip.lib().rv_set_gemm_tile_variant(2)
+        if wpk is not None:                                          # bias + relu + residual epilogue of the ping-pong kernels
+            for variant in (4, 5):
+                hip.lib().rv_set_gemm_tile_variant(variant)
+                ys = ops.gemm(ad, wpk, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU, w_packed=True, stream_k=True)
+                assert rel_err(ys.float().cpu(), torch.relu(ref0 + bias.double()) + res.double()) < tol
+            hip.lib().rv_set_gemm_tile_variant(2)
 
 
 def test_gemm_strided_rows_and_inplace_residual(dev):
