@@ -269,8 +269,8 @@ __global__ __launch_bounds__(512) void gemm_pp(const bf16_t* __restrict__ A, int
     pp_epilogue<OUT_BF16, ACT, 0>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, QkvRope{});
 }
 
-// ---- persistent stream-K launch for few-row problems (tiles_m <= 4, i.e. the LLM prefill) ------------------------------
-// One workgroup per CU.  The m-tiles of one W column panel form a TEAM of TS = 1 / 2 / 4 workgroups on ONE XCD (block b
+// ---- persistent stream-K launch for few-row problems (up to 32 m-tiles, i.e. the LLM prefill) -------------------------
+// One workgroup per CU.  The m-tiles of one W column panel form a TEAM of TS = tiles_m workgroups on ONE XCD (block b
 // lands on XCD b % 8) that walk the same (panel, k) range together, so a W piece is fetched from HBM once and the other
 // team members hit the XCD's L2 - the coincidence the output-tiled launch gets for free.  The (panel, k-tile) space is cut
 // into equal contiguous ranges, one per team (stream-K): every CU runs the same number of k-tiles whatever N is.
@@ -383,8 +383,8 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
 template <int OUT_BF16, int ACT, int ROPE>
 __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
                                                   const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
-                                                  int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int total_units,
-                                                  f32x4* partial, int* flags, int* status, int epoch, QkvRope qr) {
+                                                  int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
+                                                  int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,11 +396,27 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
     const int m0_wg = tm * PBM;
     auto ub = [&](int t) { return (int)((int64_t)t * total_units / T); };   // first unit of team t's range
     const int u_begin = ub(team), u_end = ub(team + 1);
-    int shared_panel[2] = {-1, -1};   // panels this workgroup published a partial of: slot 0 = entered mid-panel, 1 = head
+    int shared_panel[2] = {-1, -1};   // stream-K panels this workgroup published a partial of: slot 0 = entered mid-panel, 1 = head
 
-    for (int u = u_begin; u < u_end;) {
-        const int panel = u / nk, ks0 = u - panel * nk;
-        const int nks = min(nk - ks0, u_end - u);
+    // Work list: first this team's range of the stream-K unit space (the last `panels % T` panels, cut evenly: always
+    // partial pieces), then its whole panels (panel r * T + team) - the pieces are published long before they are needed.
+    const int whole_rounds = dp_panels / T;
+    for (int u = u_begin, r = 0;;) {
+        int panel, ks0, nks, sk_panel = -1;
+        if (u < u_end) {
+            sk_panel = u / nk;
+            ks0 = u - sk_panel * nk;
+            nks = min(nk - ks0, u_end - u);
+            panel = dp_panels + sk_panel;
+            u += nks;
+        } else if (r < whole_rounds) {
+            panel = r * T + team;
+            ks0 = 0;
+            nks = nk;
+            ++r;
+        } else {
+            break;
+        }
         const int n0 = panel * PBN;
         // m0 is the same for every segment: launder it so that the row-dependent address math of the epilogue is not hoisted
         // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
@@ -414,7 +430,6 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         pp_mainloop(acc, src, ks0, nks, smem, wave, lane);
-        u += nks;
 
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
             pp_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         }
         // shared panel: publish the partial accumulators (write-through sc1 stores), then the flag
         const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tm) * 2 + ps;
-        shared_panel[ps] = panel;
+        shared_panel[ps] = sk_panel;
         const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
         const unsigned off = (wave * 32 * 64 + lane) * 16;
 #pragma unroll
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
             }
         }
         __syncthreads();
-        const int m0 = m0_wg, n0 = panel * PBN;
+        const int m0 = m0_wg, n0 = (dp_panels + panel) * PBN;
         if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
         else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
         else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
@@ -513,15 +528,16 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     static bool attr_set = false;
     if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / PBN, nk = K / PBK;
-    const int TS = tiles_m <= 1 ? 1 : tiles_m == 2 ? 2 : 4;
-    const int G = pp_num_cus() & ~31;   // whole teams on every XCD
+    const int TS = tiles_m;             // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle
+    const int G = pp_num_cus() & ~7;
+    const int T = 8 * ((G >> 3) / TS), dp_panels = tiles_n / T * T;
     int epoch = ++g_epoch;
     if (epoch <= 0) { g_epoch = 1; epoch = 1; }   // 0 = the zero-initialised workspace
     int* flags = (int*)ws;
     int* status = flags + PP_HDR / 4 - 1;
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
     hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
-                       tiles_m, TS, nk, tiles_n * nk, partial, flags, status, epoch, qr);
+                       tiles_m, TS, nk, dp_panels, (tiles_n - dp_panels) * nk, partial, flags, status, epoch, qr);
     return RV_OK;
 }
 
@@ -536,17 +552,21 @@ bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
 // stream-K form: few-row problems only (teams of <= 4 m-tiles); needs the zero-initialised workspace
 bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
     const int cus = pp_num_cus();
-    return gemm_pp_supported(w_layout, M, N, K) && M <= 4 * PBM && cus >= 32 && cus <= 1023 && (N / PBN) * (K / PBK) < (1ll << 30);
+    return gemm_pp_supported(w_layout, M, N, K) && cdiv(M, PBM) <= (cus >> 3) && cus >= 8 && cus <= 1023 && (N / PBN) * (K / PBK) < (1ll << 30);
 }
 
 // Stream-K pays when a panel is cut at least 4 ways (every workgroup then owns ONE piece of one panel: one 256 KiB
 // publish and one shared reduction per launch) and every team still has a few k-tiles of work.  Measured on MI355X at
 // M = 1005: down projection 128 -> 92 us, o projection 57 -> 52 us; the wide projections (1.3 / 0.75 panels per team) move
-// 2 pieces per workgroup through HBM and end up level with the ring kernel, so they stay there.
+// 2 pieces per workgroup through HBM and end up level with the ring kernel, so they stay there.  With at least one whole
+// panel per team (gate/up: 86 panels on 64 teams) only the remainder panels are split: whole panels + a stream-K tail.
 bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K) {
-    const int tiles_m = (int)cdiv(M, PBM), TS = tiles_m <= 1 ? 1 : tiles_m == 2 ? 2 : 4;
-    const int64_t T = (pp_num_cus() & ~31) / TS, panels = N / PBN, nk = K / PBK;
-    return panels * 4 <= T && panels * nk >= 8 * T;
+    const int tiles_m = (int)cdiv(M, PBM), per_x = pp_num_cus() >> 3;
+    const int64_t T = 8 * (per_x / tiles_m), panels = N / PBN, nk = K / PBK, sk_panels = panels % T;
+    if (K < 2048 || (per_x % tiles_m) * 10 > per_x) return false;   // short K, or > 10 % of the CUs left without a team
+    if (panels < T) return panels * 4 <= T && panels * nk >= 8 * T;   // pure split-k: >= 4 pieces per panel, >= 8 k-tiles each
+    // whole panels + a stream-K tail of sk_panels: one piece (sometimes two) per workgroup
+    return sk_panels == 0 || (sk_panels * 8 >= T && sk_panels * nk >= 8 * T);
 }
 
 // Output-tiled ping-pong pays for long K (the prologue / epilogue of a 256x256 tile is ~3 us) when the tiles fill the

@@ -32,7 +32,7 @@ bad = 0
 for (M, N, K, act, odt, res) in [(256, 256, 64, 0, torch.float32, False), (256, 256, 128, 0, torch.float32, False),
                                  (256, 512, 256, 0, torch.float32, False), (1005, 4096, 4096, 0, torch.float32, True), (171, 4096, 4096, 0, torch.float32, True), (400, 12288, 4096, 0, torch.float32, False), (700, 4096, 11008, 0, torch.float32, True),
                                  (1005, 22016, 4096, 2, torch.bfloat16, False), (300, 768, 2048, 1, torch.bfloat16, False),
-                                 (1005, 12288, 4096, 0, torch.float32, False), (1197, 4096, 11008, 0, torch.float32, True),
+                                 (1005, 12288, 4096, 0, torch.float32, False), (1197, 4096, 11008, 0, torch.float32, True), (2010, 22016, 4096, 2, torch.bfloat16, False), (2010, 4096, 11008, 0, torch.float32, True), (2010, 12288, 4096, 0, torch.float32, False), (700, 22016, 4096, 2, torch.bfloat16, False),
                                  (25700, 1536, 768, 0, torch.bfloat16, False)]:
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
