@@ -724,9 +724,9 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
         // of the prefill), output-tiled when the tile count fills the CUs; everything else stays on the 128x128 ring kernel
         void* sk_ws = (ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(w_layout, M, N, K)) ? ws : nullptr;
         const int v = g_tile_variant;
-        if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_profitable(M, N, K)) || gemm_pp_dp_profitable(M, N, K))))
+        if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0) || gemm_pp_dp_profitable(M, N, K))))
             return gemm_pp_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K,
-                                  (v == 5 || (v == 2 && sk_ws && gemm_pp_sk_profitable(M, N, K))) ? sk_ws : nullptr, st);
+                                  (v == 5 || (v == 2 && sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0)) ? sk_ws : nullptr, st);
     }
 #define RV_DISPATCH2(OB, AC, WP)                                                                            \
     do {                                                                                                     \
@@ -766,7 +766,7 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
     } else {
         RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
         const bool sk = ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(1, M, N, K);
-        if (sk && (g_tile_variant == 5 || (g_tile_variant == 2 && gemm_pp_sk_profitable(M, N, K))))
+        if (sk && (g_tile_variant == 5 || (g_tile_variant == 2 && gemm_pp_sk_plan(M, N, K, false) != 0)))
             return gemm_pp_qkv_rope(A, lda, Wp, M, N, K, r, ws, st);
         const int tiles_m = (int)cdiv(M, BM), tiles_n = N / BN;
         hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a, lda, w, nullptr, nullptr,

@@ -50,6 +50,8 @@ struct PpSrc {
     unsigned w1[2];       // ... of W unit U2 (n1 quadrants)
 };
 
+// NF = MFMA fragments per wave along N: 4 -> 256-column panels, 3 -> 192-column panels (n1 quadrant = one fragment)
+template <int NF>
 __device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M,
                                            int K, int m0, int n0, int wave, int lane) {
     s.A = (const char*)A;
@@ -67,18 +69,24 @@ __device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ 
         s.a0[i] = (unsigned)(((int64_t)g0 * lda + chunk * 8) * 2);
         s.a1[i] = (unsigned)(((int64_t)g1 * lda + chunk * 8) * 2);
     }
-    // W unit (nq): piece pc = (wcol * 2 + j) * 2 + ks; this wave issues pc = 2 * wave + ks: wcol = wave >> 1, j = wave & 1
+    // W unit n0: piece pc = (wcol * 2 + j) * 2 + ks; this wave issues pc = 2 * wave + ks: wcol = wave >> 1, j = wave & 1.
+    // W unit n1, NF = 4: the same two fragments further on; NF = 3: one fragment per wave column -> piece wcol * 2 + ks,
+    // one piece per wave: wcol = wave >> 1, ks = wave & 1 (kept in w1[0]).
     const int kfr = K >> 5;
-    const int nb0 = (n0 >> 4) + (wave >> 1) * 4 + (wave & 1);
+    const int nb0 = (n0 >> 4) + (wave >> 1) * NF + (wave & 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         s.w0[ks] = (unsigned)(((((int64_t)nb0 * kfr + ks) * 64 + lane) * 8) * 2);
         s.w1[ks] = (unsigned)(((((int64_t)(nb0 + 2) * kfr + ks) * 64 + lane) * 8) * 2);
     }
+    if constexpr (NF == 3) {
+        const int nb1 = (n0 >> 4) + (wave >> 1) * NF + 2;
+        s.w1[0] = (unsigned)(((((int64_t)nb1 * kfr + (wave & 1)) * 64 + lane) * 8) * 2);
+    }
 }
 
 // Issue unit U (0..3) of the k-tile at element offset k0 into `stage`.  Every wave issues 2 pieces of 1 KiB.
-template <int U>
+template <int U, int NF>
 __device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* stage, int wave) {
     char* dst = stage + U * UNIT + wave * 2048;
     const char* ab = s.A + (int64_t)k0 * 2;
@@ -92,22 +100,28 @@ __device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* stage, 
     } else if constexpr (U == 1) {
         glds16(wb + s.w0[0], dst);
         glds16(wb + s.w0[1], dst + 1024);
-    } else {
+    } else if constexpr (NF == 4) {
         glds16(wb + s.w1[0], dst);
         glds16(wb + s.w1[1], dst + 1024);
+    } else {
+        glds16(wb + s.w1[0], stage + U * UNIT + wave * 1024);   // NF = 3: one piece per wave
     }
 }
 
 template <int N_>
 __device__ __forceinline__ void wait_vm() {
     if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // acc += A[tile rows, k-tiles kt0 .. kt0+nks) . W[tile cols, same k]^T.  On entry no LDS access and no load of this
 // workgroup is outstanding; the same holds on return (every wave has passed the same number of barriers).
-__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
+template <int NF>
+__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
+    constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant
+    constexpr int VM_N1 = 2 + NJ1;   // loads of units U2 + U3 per wave = what may stay in flight when U0, U1 are needed
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kg = lane >> 4;
     // A fragment (f, ks) of unit U0 / U3: row lr = wr * 64 + f * 16 + fr at lr * 128 + (((ks * 4 + kg) ^ (lr & 7)) << 4)
@@ -115,12 +129,13 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src
     const int a_c0 = ((kg ^ (fr & 7)) << 4), a_c1 = (((4 + kg) ^ (fr & 7)) << 4);
     // W fragment (j, ks) of unit U1 / U2: piece (wc * 2 + j) * 2 + ks
     const int w_rd = wc * 4096 + lane * 16;
+    const int w_rd1 = NF == 4 ? w_rd : wc * 2048 + lane * 16;   // unit U2: pieces (wc * NJ1 + j) * 2 + ks
 
-    issue_unit<0>(src, kt0 * PBK, smem, wave);
-    issue_unit<1>(src, kt0 * PBK, smem, wave);
-    issue_unit<2>(src, kt0 * PBK, smem, wave);
-    issue_unit<3>(src, kt0 * PBK, smem, wave);
-    wait_vm<4>();                                // U0, U1 landed
+    issue_unit<0, NF>(src, kt0 * PBK, smem, wave);
+    issue_unit<1, NF>(src, kt0 * PBK, smem, wave);
+    issue_unit<2, NF>(src, kt0 * PBK, smem, wave);
+    issue_unit<3, NF>(src, kt0 * PBK, smem, wave);
+    wait_vm<VM_N1>();                            // U0, U1 landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
 
@@ -131,10 +146,10 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src
         const bool more = t + 1 < nks;
         const int k1 = (kt0 + t + 1) * PBK;
 
-#define PP_MFMA(B, NI, MI0)                                                                                         \
+#define PP_MFMA(B, NI, MI0, NJ)                                                                                     \
     do {                                                                                                            \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < (NJ); ++j)            \
             _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                                 \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0);   \
         __builtin_amdgcn_s_setprio(0);                                                                              \
@@ -144,9 +159,9 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src
         af[f][0] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c0);                                         \
         af[f][1] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c1);                                         \
     }
-#define PP_READ_W(B, UOFF)                                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                   \
-        B[j][ks] = *(const bf16x8*)(cur + (UOFF) + w_rd + j * 2048 + ks * 1024);
+#define PP_READ_W(B, UOFF, RD, NJ)                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                \
+        B[j][ks] = *(const bf16x8*)(cur + (UOFF) + (RD) + j * 2048 + ks * 1024);
         // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
         // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
 #define PP_SYNC_M(WAITN)                                   \
@@ -161,29 +176,29 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src
     __builtin_amdgcn_sched_barrier(0);
 
         // ---- phase 0: quadrant (m0, n0) ----
-        PP_READ_W(b0, UNIT)
+        PP_READ_W(b0, UNIT, w_rd, 2)
         PP_READ_A(0)
-        if (more) issue_unit<0>(src, k1, nxt, wave);
+        if (more) issue_unit<0, NF>(src, k1, nxt, wave);
         PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<2>())      // U2 of this tile must have landed
-        PP_MFMA(b0, 0, 0);
+        PP_MFMA(b0, 0, 0, 2);
         PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<2>())
         // ---- phase 1: quadrant (m0, n1) ----
-        PP_READ_W(b1, 2 * UNIT)
-        if (more) issue_unit<1>(src, k1, nxt, wave);
+        PP_READ_W(b1, 2 * UNIT, w_rd1, NJ1)
+        if (more) issue_unit<1, NF>(src, k1, nxt, wave);
         PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<0>())      // U3 of this tile
-        PP_MFMA(b1, 2, 0);
+        PP_MFMA(b1, 2, 0, NJ1);
         PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<0>())
         // ---- phase 2: quadrant (m1, n1) ----
         PP_READ_A(3 * UNIT)
-        if (more) issue_unit<2>(src, k1, nxt, wave);
+        if (more) issue_unit<2, NF>(src, k1, nxt, wave);
         PP_SYNC_M((void)0)
-        PP_MFMA(b1, 2, 4);
+        PP_MFMA(b1, 2, 4, NJ1);
         PP_SYNC_C((void)0)
         // ---- phase 3: quadrant (m1, n0) ----
-        if (more) issue_unit<3>(src, k1, nxt, wave);
-        PP_SYNC_M(if (more) wait_vm<4>())                          // U0, U1 of the next tile
-        PP_MFMA(b0, 0, 4);
-        PP_SYNC_C(if (more) wait_vm<4>())
+        if (more) issue_unit<3, NF>(src, k1, nxt, wave);
+        PP_SYNC_M(if (more) wait_vm<VM_N1>())                      // U0, U1 of the next tile
+        PP_MFMA(b0, 0, 4, 2);
+        PP_SYNC_C(if (more) wait_vm<VM_N1>())
     }
 #undef PP_MFMA
 #undef PP_READ_A
@@ -194,9 +209,11 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[4][8], const PpSrc& src
 }
 
 // Epilogue: lane owns row m = .. + fr, columns n = .. + kg * 4 .. + 3 of every 16 x 16 fragment.
-template <int OUT_BF16, int ACT, int ROPE>
-__device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[4][8], const float* __restrict__ bias, const float* res, int64_t ldr,
+template <int OUT_BF16, int ACT, int ROPE, int NF>
+__device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const float* __restrict__ bias, const float* res, int64_t ldr,
                                             void* Cv, int64_t ldc, int M, int m0, int n0, int wave, int lane, const QkvRope& qr) {
+    static_assert(NF == 4 || ACT != RV_ACT_SILU_MUL, "the gated epilogue pairs fragments: 256-column panels only");
+    constexpr int WN = NF * 16;   // columns per wave
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -205,11 +222,11 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[4][8], const floa
         if (m >= M) continue;
         if constexpr (ROPE) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) qkv_rope_store(qr, m, n0 + wc * 64 + ni * 16 + kg * 4, acc[ni][mi]);
+            for (int ni = 0; ni < NF; ++ni) qkv_rope_store(qr, m, n0 + wc * WN + ni * 16 + kg * 4, acc[ni][mi]);
         } else if (ACT == RV_ACT_SILU_MUL) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ni += 2) {
-                const int n = n0 + wc * 64 + ni * 16;
+            for (int ni = 0; ni + 1 < NF; ni += 2) {
+                const int n = n0 + wc * WN + ni * 16;
                 const int no = (n >> 1) + kg * 4;
                 float v[4];
 #pragma unroll
@@ -219,8 +236,8 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[4][8], const floa
             }
         } else {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = n0 + wc * 64 + ni * 16 + kg * 4;
+            for (int ni = 0; ni < NF; ++ni) {
+                const int n = n0 + wc * WN + ni * 16 + kg * 4;
                 f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
                 if (ACT == RV_ACT_RELU) {
@@ -236,7 +253,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[4][8], const floa
 }
 
 // ---- output-tiled launch: one workgroup per 256 x 256 tile ------------------------------------------------------------
-template <int OUT_BF16, int ACT>
+template <int OUT_BF16, int ACT, int NF>
 __global__ __launch_bounds__(512) void gemm_pp(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
                                                const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
@@ -257,16 +274,16 @@ __global__ __launch_bounds__(512) void gemm_pp(const bf16_t* __restrict__ A, int
             tn = tiles_n8 + r / tiles_m;
         }
     }
-    const int m0 = tm * PBM, n0 = tn * PBN;
+    const int m0 = tm * PBM, n0 = tn * (NF * 64);
     PpSrc src;
-    pp_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
-    f32x4 acc[4][8];   // [ni = nq * 2 + j][mi = mq * 4 + f]
+    pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+    f32x4 acc[NF][8];   // [ni = nq * 2 + j][mi = mq * 4 + f]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pp_mainloop(acc, src, 0, K / PBK, smem, wave, lane);
-    pp_epilogue<OUT_BF16, ACT, 0>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, QkvRope{});
+    pp_mainloop<NF>(acc, src, 0, K / PBK, smem, wave, lane);
+    pp_epilogue<OUT_BF16, ACT, 0, NF>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, QkvRope{});
 }
 
 // ---- persistent stream-K launch for few-row problems (up to 32 m-tiles, i.e. the LLM prefill) -------------------------
@@ -380,7 +397,7 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
     }
 }
 
-template <int OUT_BF16, int ACT, int ROPE>
+template <int OUT_BF16, int ACT, int ROPE, int NF>
 __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
                                                   const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                   int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
@@ -417,37 +434,40 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         } else {
             break;
         }
-        const int n0 = panel * PBN;
+        const int n0 = panel * (NF * 64);
         // m0 is the same for every segment: launder it so that the row-dependent address math of the epilogue is not hoisted
         // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
         int m0 = m0_wg;
         asm volatile("" : "+s"(m0));
         PpSrc src;
-        pp_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
-        f32x4 acc[4][8];
+        pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+        f32x4 acc[NF][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pp_mainloop(acc, src, ks0, nks, smem, wave, lane);
+        pp_mainloop<NF>(acc, src, ks0, nks, smem, wave, lane);
 
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
-            pp_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
+            pp_epilogue<OUT_BF16, ACT, ROPE, NF>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
             continue;
         }
-        // shared panel: publish the partial accumulators (write-through sc1 stores), then the flag
-        const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tm) * 2 + ps;
-        shared_panel[ps] = sk_panel;
-        const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
-        const unsigned off = (wave * 32 * 64 + lane) * 16;
+        if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
+            // shared panel: publish the partial accumulators (write-through sc1 stores), then the flag
+            const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tm) * 2 + ps;
+            shared_panel[ps] = sk_panel;
+            const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
+            const unsigned off = (wave * 32 * 64 + lane) * 16;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) st_sc1(pr, off + (ni * 8 + mi) * 1024, acc[ni][mi]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + id, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int mi = 0; mi < 8; ++mi) st_sc1(pr, off + (ni * 8 + mi) * 1024, acc[ni][mi]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + id, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if constexpr (NF != 4) return;
 
     // ---- finish the shared panels: every participant reduces and stores its 1/c share --------------------------------
     int* ids = (int*)smem;   // participants' slot ids, ascending k
@@ -509,34 +529,44 @@ int reserve_lds(Kern k, bool& done) {
     return RV_OK;
 }
 
-template <int OUT_BF16, int ACT>
+template <int OUT_BF16, int ACT, int NF>
 int launch(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
            int M, int N, int K, hipStream_t st) {
     static bool attr_set = false;
-    if (int rc = reserve_lds(gemm_pp<OUT_BF16, ACT>, attr_set)) return rc;
-    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / PBN;
-    hipLaunchKernelGGL((gemm_pp<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
-                       tiles_m, tiles_n);
+    if (int rc = reserve_lds(gemm_pp<OUT_BF16, ACT, NF>, attr_set)) return rc;
+    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64);
+    hipLaunchKernelGGL((gemm_pp<OUT_BF16, ACT, NF>), dim3(tiles_m * tiles_n), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N,
+                       K, tiles_m, tiles_n);
     return RV_OK;
 }
 
 std::atomic<int> g_epoch{0};
 
-template <int OUT_BF16, int ACT, int ROPE>
+// teams on the chip for a problem of M rows (team = the m-tiles of one panel, all on one XCD)
+int pp_teams(int64_t M) {
+    const int tiles_m = (int)cdiv(M, PBM), per_x = pp_num_cus() >> 3;
+    return tiles_m <= per_x ? 8 * (per_x / tiles_m) : 0;
+}
+
+template <int OUT_BF16, int ACT, int ROPE, int NF>
 int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
               int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr) {
     static bool attr_set = false;
-    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE>, attr_set)) return rc;
-    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / PBN, nk = K / PBK;
+    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF>, attr_set)) return rc;
+    const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64), nk = K / PBK;
     const int TS = tiles_m;             // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle
     const int G = pp_num_cus() & ~7;
-    const int T = 8 * ((G >> 3) / TS), dp_panels = tiles_n / T * T;
+    const int T = pp_teams(M), dp_panels = tiles_n / T * T;
+    if (NF != 4 && dp_panels != tiles_n) {
+        rv_set_error("gemm_pp: 192-column panels need a panel count that is a multiple of the %d teams", T);
+        return RV_ERR_ARG;
+    }
     int epoch = ++g_epoch;
     if (epoch <= 0) { g_epoch = 1; epoch = 1; }   // 0 = the zero-initialised workspace
     int* flags = (int*)ws;
     int* status = flags + PP_HDR / 4 - 1;
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
-    hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
+    hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
                        tiles_m, TS, nk, dp_panels, (tiles_n - dp_panels) * nk, partial, flags, status, epoch, qr);
     return RV_OK;
 }
@@ -549,25 +579,31 @@ bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
     return w_layout == 1 && M > 16 && N % PBN == 0 && K % PBK == 0;
 }
 
-// stream-K form: few-row problems only (teams of <= 4 m-tiles); needs the zero-initialised workspace
+// stream-K form: few-row problems only (a team of tiles_m workgroups must fit on one XCD); needs the zero-initialised workspace
 bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
     const int cus = pp_num_cus();
-    return gemm_pp_supported(w_layout, M, N, K) && cdiv(M, PBM) <= (cus >> 3) && cus >= 8 && cus <= 1023 && (N / PBN) * (K / PBK) < (1ll << 30);
+    return gemm_pp_supported(w_layout, M, N, K) && pp_teams(M) > 0 && cus <= 1023 && (N / PBN) * (K / PBK) < (1ll << 30);
 }
 
+// Persistent-launch plan for a few-row problem: 0 = not worth it, 4 = 256-column panels (whole panels + stream-K tail),
+// 3 = 192-column panels when they deal out EXACTLY (panel count a multiple of the teams: no hand-off and no idle CU - the
+// fused QKV projection at M ~ 1000: 64 panels of 192 on 64 teams, 130 -> ~100 us against the ring kernel).
 // Stream-K pays when a panel is cut at least 4 ways (every workgroup then owns ONE piece of one panel: one 256 KiB
 // publish and one shared reduction per launch) and every team still has a few k-tiles of work.  Measured on MI355X at
-// M = 1005: down projection 128 -> 92 us, o projection 57 -> 52 us; the wide projections (1.3 / 0.75 panels per team) move
-// 2 pieces per workgroup through HBM and end up level with the ring kernel, so they stay there.  With at least one whole
-// panel per team (gate/up: 86 panels on 64 teams) only the remainder panels are split: whole panels + a stream-K tail.
-bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K) {
+// M = 1005: down projection 128 -> 92 us, o projection 57 -> 52 us, gate/up (64 whole panels + 22 split ones on 64 teams)
+// 200 -> 180 us; a problem with 0.75 panels per team moves 2 pieces per workgroup through HBM and ends up level with the
+// ring kernel, so it stays there.
+int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated) {
     const int tiles_m = (int)cdiv(M, PBM), per_x = pp_num_cus() >> 3;
-    const int64_t T = 8 * (per_x / tiles_m), panels = N / PBN, nk = K / PBK, sk_panels = panels % T;
-    if (K < 2048 || (per_x % tiles_m) * 10 > per_x) return false;   // short K, or > 10 % of the CUs left without a team
-    if (panels < T) return panels * 4 <= T && panels * nk >= 8 * T;   // pure split-k: >= 4 pieces per panel, >= 8 k-tiles each
-    // whole panels + a stream-K tail of sk_panels: one piece (sometimes two) per workgroup
-    return sk_panels == 0 || (sk_panels * 8 >= T && sk_panels * nk >= 8 * T);
+    const int64_t T = pp_teams(M), nk = K / PBK;
+    if (T == 0 || K < 2048 || (per_x % tiles_m) * 10 > per_x) return 0;   // short K, or > 10 % of the CUs left without a team
+    if (!gated && N % 192 == 0 && (N / 192) % T == 0) return 3;
+    const int64_t panels = N / PBN, sk_panels = panels % T;
+    if (sk_panels == 0) return 4;
+    if (panels < T) return (panels * 4 <= T && panels * nk >= 8 * T) ? 4 : 0;   // pure split-k: >= 4 pieces per panel, >= 8 k-tiles each
+    return (sk_panels * 8 >= T && sk_panels * nk >= 8 * T) ? 4 : 0;            // whole panels + tail: one piece (sometimes two) per workgroup
 }
+bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K) { return gemm_pp_sk_plan(M, N, K, true) != 0; }
 
 // Output-tiled ping-pong pays for long K (the prologue / epilogue of a 256x256 tile is ~3 us) when the tiles fill the
 // CUs: 1.2 vs 0.86 PFLOP/s at 4096^3; short-K adapter GEMMs (K = 768) and ragged tile counts stay on the ring kernel.
@@ -583,27 +619,37 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
     const bf16_t* w = (const bf16_t*)Wp;
     const int ob = out_dtype == RV_BF16;
     const bool sk = ws && gemm_pp_sk_supported(1, M, N, K);
+    const bool nf3 = sk && act != RV_ACT_SILU_MUL && gemm_pp_sk_plan(M, N, K, false) == 3;
     int rc;
 #define PP(OB, AC)                                                                                                       \
-    rc = sk ? launch_sk<OB, AC, 0>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})         \
-            : launch<OB, AC>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)
-    if (ob && act == RV_ACT_NONE) PP(1, RV_ACT_NONE);
+    rc = sk ? launch_sk<OB, AC, 0, 4>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})      \
+            : launch<OB, AC, 4>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)
+#define PP3(OB, AC) rc = launch_sk<OB, AC, 0, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})
+    if (nf3 && ob && act == RV_ACT_NONE) PP3(1, RV_ACT_NONE);
+    else if (nf3 && ob) PP3(1, RV_ACT_RELU);
+    else if (nf3 && act == RV_ACT_NONE) PP3(0, RV_ACT_NONE);
+    else if (nf3) PP3(0, RV_ACT_RELU);
+    else if (ob && act == RV_ACT_NONE) PP(1, RV_ACT_NONE);
     else if (ob && act == RV_ACT_RELU) PP(1, RV_ACT_RELU);
     else if (ob && act == RV_ACT_SILU_MUL) PP(1, RV_ACT_SILU_MUL);
     else if (!ob && act == RV_ACT_NONE) PP(0, RV_ACT_NONE);
     else if (!ob && act == RV_ACT_RELU) PP(0, RV_ACT_RELU);
     else PP(0, RV_ACT_SILU_MUL);
 #undef PP
+#undef PP3
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_pp");
     return RV_OK;
 }
 
-// fused QKV projection (RoPE + KV-cache append epilogue) on the stream-K kernel
+// fused QKV projection (RoPE + KV-cache append epilogue) on the persistent kernel
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st) {
-    int rc = launch_sk<0, RV_ACT_NONE, 1>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
-                                          (int)K, ws, st, r);
+    int rc = gemm_pp_sk_plan(M, N, K, false) == 3
+                 ? launch_sk<0, RV_ACT_NONE, 1, 3>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
+                                                   (int)K, ws, st, r)
+                 : launch_sk<0, RV_ACT_NONE, 1, 4>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
+                                                   (int)K, ws, st, r);
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_pp_qkv_rope");
     return RV_OK;

@@ -70,7 +70,8 @@ int gemv_blocks(int act, int64_t N);  // workgroups the decode kernel launches f
 // 256x256x64 ping-pong kernel (gemm_pp.hip): output-tiled, or persistent stream-K when ws != NULL and M <= 1024
 bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K);
 bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
-bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K);   // split-K deep enough to pay for the partial-tile hand-off
+int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated);   // 0 = no, 4 / 3 = persistent launch with 256- / 192-column panels
+bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K);
 bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K);   // long K and a tile count that fills the CUs
 size_t gemm_pp_ws_bytes();
 int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,

@@ -375,6 +375,42 @@ def test_full_size_properties_7b(model_7b):
     again = m.generate(ext, video_rows=rows[100:], rows_per_sample=100, do_sample=False, max_new_tokens=1,
                        return_dict_in_generate=True, output_logits=True)
     assert (again["logits"][0] - one["logits"][1]).abs().max() <= 3e-2 * one["logits"][1].abs().max()
+    # the recursion's 7-call batch (M ~ 1000 rows): persistent ping-pong GEMMs (stream-K o / down / gate-up, 192-column
+    # fused QKV + RoPE + cache append) against the 128x128 ring kernel - prefill logits and a decode step off that cache
+    from revisionllm_amd import hip
+    rows7 = torch.cat([cls[torch.randperm(100, generator=torch.Generator().manual_seed(i))] for i in range(7)], 0)
+    kw7 = dict(rows_per_sample=100, do_sample=False, max_new_tokens=2, return_dict_in_generate=True, output_logits=True)
+    hip.lib().rv_set_gemm_tile_variant(6)
+    ring = torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"])
+    hip.lib().rv_set_gemm_tile_variant(2)
+    auto = torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"])
+    # (a different f32 summation order flips bf16 roundings; through 32 random layers that grows to ~2 % of the largest logit)
+    assert torch.isfinite(auto).all() and (auto - ring).abs().max() <= 4e-2 * ring.abs().max()
+    assert torch.equal(auto, torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"]))   # deterministic
+
+
+def test_persistent_qkv_rope_epilogue_is_bit_exact():
+    """One 7B-shaped layer, the recursion's 7-call shared-prefix prefill (1005 rows): the persistent ping-pong QKV projection
+    (192-column panels, fused RoPE + KV-cache append) sums whole panels in the ring kernel's order, so the layer's K and
+    V^T caches must be BIT-identical to the ring kernel's; the logits (stream-K o / down / gate-up) agree to f32 rounding."""
+    from revisionllm_amd import engine, hip
+    from revisionllm_amd.utils import synth
+    eng = engine.Engine(synth.LlamaShape(hidden=4096, inter=11008, layers=1, heads=32, vocab=32000), device="cuda:0")
+    eng.init_synthetic(seed=1)
+    B, S, P0 = 7, 171, 32
+    h0 = feats("pp.h0", (P0 + B * (S - P0), 4096)).to("cuda:0") * 0.02
+    out = {}
+    try:
+        for v in (6, 2):
+            hip.lib().rv_set_gemm_tile_variant(v)
+            kv, Smax = eng.new_kv(B, S + 8, reuse=False)
+            logits = eng.llm_prefill_shared(h0.clone(), B, P0, kv, Smax)
+            per = B * 32 * Smax * 128
+            out[v] = (kv[:per].view(B, 32, Smax, 128)[:, :, :S].clone(), kv[per:2 * per].view(B, 32, 128, Smax)[..., :S].clone(), logits)
+    finally:
+        hip.lib().rv_set_gemm_tile_variant(2)
+    assert torch.equal(out[6][0], out[2][0]) and torch.equal(out[6][1], out[2][1])
+    assert (out[6][2] - out[2][2]).abs().max() <= 5e-3 * out[6][2].abs().max()
 
 
 def test_multi_query_batching_on_device():
