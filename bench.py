@@ -72,9 +72,10 @@ def roofline_legs(model, n_calls, M):
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
     ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
-    legs["prefill_gateup_gemm"] = dict(kernel="gemm_tile_p4<1,2,3,0>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
-                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops,
-                                       grid_threads=((M + 127) // 128) * (2 * s.inter // 128) * 256)
+    # M <= 8192 rows: the persistent 256x256x64 ping-pong kernel (one 512-thread workgroup per CU), whole panels + stream-K tail
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_pp_sk<1,2,0,4>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops, grid_threads=(cus & ~7) * 512)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
     #     256 MB infinity cache cannot serve the weights
     xs = torch.randn(n_calls, s.hidden, device=dev).to(torch.bfloat16)

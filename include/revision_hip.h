@@ -33,7 +33,7 @@ extern "C" {
 
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
 typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
-typedef enum { RV_ACT_NONE = 0, RV_ACT_RELU = 1, RV_ACT_SILU_MUL = 2 } rv_act;
+typedef enum { RV_ACT_NONE = 0, RV_ACT_RELU = 1, RV_ACT_SILU_MUL = 2, RV_ACT_QUICK_GELU = 3 } rv_act;
 typedef enum { RV_W_ROWMAJOR = 0, RV_W_PACKED = 1 } rv_wlayout;
 /* ClipEncoder output selection, revisionllm/model/adapter/transformer.py:134-145 */
 typedef enum { RV_FEAT_CLS = 0, RV_FEAT_ALL = 2 } rv_feature;

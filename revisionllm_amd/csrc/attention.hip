@@ -1,5 +1,5 @@
-// softmax(Q K^T * scale + mask) V with MFMA 16x16x32, head dims 96 (adapter, nn.MultiheadAttention) and
-// 128 (Llama).  One wave = 16 query rows of one (batch, head); keys are walked 32 at a time with an
+// softmax(Q K^T * scale + mask) V with MFMA 16x16x32, head dims 96 (adapter, nn.MultiheadAttention), 128 (Llama)
+// and 64 (CLIP towers).  One wave = 16 query rows of one (batch, head); keys are walked 32 at a time with an
 // online softmax.  Both products use swapped operands so that every per-query quantity is lane-local:
 //   S^T[key][q] = K . Q^T     lane (q = lane & 15, g = lane >> 4) holds keys {g*4+r} and {16+g*4+r}
 //   O^T[d][q]   = V^T . P^T   the same 8 scores ARE the lane's B fragment (the sum over keys is
@@ -161,7 +161,11 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     const bool split = a.Lq <= 16;
     dim3 grid((unsigned)cdiv(a.Lq, split ? 16 : 64), (unsigned)a.H, (unsigned)a.B);
-    if (a.dh == 96 && !split)
+    if (a.dh == 64 && !split)
+        hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a);
+    else if (a.dh == 64)
+        hipLaunchKernelGGL((attn_kernel<64, true>), grid, dim3(256), 0, st, a);
+    else if (a.dh == 96 && !split)
         hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a);
     else if (a.dh == 96)
         hipLaunchKernelGGL((attn_kernel<96, true>), grid, dim3(256), 0, st, a);
@@ -170,7 +174,7 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     else if (a.dh == 128)
         hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, st, a);
     else {
-        rv_set_error("attention: head dim %d unsupported (96, 128)", a.dh);
+        rv_set_error("attention: head dim %d unsupported (64, 96, 128)", a.dh);
         return RV_ERR_ARG;
     }
     RV_CHECK_LAUNCH("attention");

@@ -57,5 +57,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// element-wise epilogue activations of the GEMMs: ReLU (adapter FFN), QuickGELU x * sigmoid(1.702 x) (CLIP MLP)
+template <int ACT>
+__device__ __forceinline__ float rv_act_apply(float x) {
+    if constexpr (ACT == RV_ACT_RELU) return fmaxf(x, 0.f);
+    else if constexpr (ACT == RV_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    else return x;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

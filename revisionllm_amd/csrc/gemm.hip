@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
                 if (n >= N) continue;
                 f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
-                if (ACT == RV_ACT_RELU) {
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
                 if (OUT_BF16) {
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
                     for (int ni = 0; ni < 4; ++ni) {
                         f32x4 v = acc[ni][mi];
                         if (bias) v += *(const f32x4*)(bias + n0 + wc * 64 + ni * 16 + kg * 4);
-                        if (ACT == RV_ACT_RELU) {
+                        if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                         }
                         *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                     }
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
                 if (n >= N) continue;
                 f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
-                if (ACT == RV_ACT_RELU) {
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
                 if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
                 if (n >= N) continue;
                 f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
-                if (ACT == RV_ACT_RELU) {
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
                 if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -628,9 +628,9 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             if (n >= N || b >= M) continue;
             f32x4 v = s[t];
             if (bias) v += *(const f32x4*)(bias + n);
-            if (ACT == RV_ACT_RELU) {
+            if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
             if (res) v += *(const f32x4*)(res + (int64_t)b * ldr + n);
             if (OUT_BF16) {
@@ -710,7 +710,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_ARG(w_layout == 0 || w_layout == 1, "rv_gemm: w_layout must be 0 (row-major) or 1 (fragment-packed)");
     RV_CHECK_ARG(w_layout == 1 ? (N % 16 == 0) : (ldw % 8 == 0), "rv_gemm: packed W needs N%%16==0; row-major W needs ldw%%8==0");
     RV_CHECK_ARG(out_dtype == RV_BF16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
-    RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_SILU_MUL, "rv_gemm: bad activation %d", act);
+    RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_QUICK_GELU, "rv_gemm: bad activation %d", act);
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || (N % 32 == 0 && !bias && !residual),
                  "rv_gemm: SILU_MUL needs N%%32==0 and no bias/residual");
     RV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "rv_gemm: dims exceed int32");
@@ -744,8 +744,10 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     if (ob && act == RV_ACT_NONE) RV_DISPATCH(1, RV_ACT_NONE);
     else if (ob && act == RV_ACT_RELU) RV_DISPATCH(1, RV_ACT_RELU);
     else if (ob && act == RV_ACT_SILU_MUL) RV_DISPATCH(1, RV_ACT_SILU_MUL);
+    else if (ob && act == RV_ACT_QUICK_GELU) RV_DISPATCH(1, RV_ACT_QUICK_GELU);
     else if (!ob && act == RV_ACT_NONE) RV_DISPATCH(0, RV_ACT_NONE);
     else if (!ob && act == RV_ACT_RELU) RV_DISPATCH(0, RV_ACT_RELU);
+    else if (!ob && act == RV_ACT_QUICK_GELU) RV_DISPATCH(0, RV_ACT_QUICK_GELU);
     else RV_DISPATCH(0, RV_ACT_SILU_MUL);
 #undef RV_DISPATCH2
 #undef RV_DISPATCH

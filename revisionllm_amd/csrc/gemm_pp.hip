@@ -240,9 +240,9 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const flo
                 const int n = n0 + wc * WN + ni * 16 + kg * 4;
                 f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
-                if (ACT == RV_ACT_RELU) {
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
                 if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -344,9 +344,9 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
             const int n = nf + e * 16 + kg * 4;
             f32x4 v = e ? v1 : v0;
             if (bias) v += *(const f32x4*)(bias + n);
-            if (ACT == RV_ACT_RELU) {
+            if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
             if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
             if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -626,14 +626,18 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
             : launch<OB, AC, 4>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)
 #define PP3(OB, AC) rc = launch_sk<OB, AC, 0, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})
     if (nf3 && ob && act == RV_ACT_NONE) PP3(1, RV_ACT_NONE);
-    else if (nf3 && ob) PP3(1, RV_ACT_RELU);
+    else if (nf3 && ob && act == RV_ACT_RELU) PP3(1, RV_ACT_RELU);
+    else if (nf3 && ob) PP3(1, RV_ACT_QUICK_GELU);
     else if (nf3 && act == RV_ACT_NONE) PP3(0, RV_ACT_NONE);
-    else if (nf3) PP3(0, RV_ACT_RELU);
+    else if (nf3 && act == RV_ACT_RELU) PP3(0, RV_ACT_RELU);
+    else if (nf3) PP3(0, RV_ACT_QUICK_GELU);
     else if (ob && act == RV_ACT_NONE) PP(1, RV_ACT_NONE);
     else if (ob && act == RV_ACT_RELU) PP(1, RV_ACT_RELU);
     else if (ob && act == RV_ACT_SILU_MUL) PP(1, RV_ACT_SILU_MUL);
+    else if (ob && act == RV_ACT_QUICK_GELU) PP(1, RV_ACT_QUICK_GELU);
     else if (!ob && act == RV_ACT_NONE) PP(0, RV_ACT_NONE);
     else if (!ob && act == RV_ACT_RELU) PP(0, RV_ACT_RELU);
+    else if (!ob && act == RV_ACT_QUICK_GELU) PP(0, RV_ACT_QUICK_GELU);
     else PP(0, RV_ACT_SILU_MUL);
 #undef PP
 #undef PP3

@@ -218,12 +218,14 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
         hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
     else if (d == 4096)
         hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+    else if (d == 1024)
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
     else if (d == 256)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
     else if (d == 512)
         hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
     else {
-        rv_set_error("layernorm: unsupported width %d (256, 512, 768, 4096)", d);
+        rv_set_error("layernorm: unsupported width %d (256, 512, 768, 1024, 4096)", d);
         return RV_ERR_ARG;
     }
     RV_CHECK_LAUNCH("layernorm");

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REVISION_HIP_LIB") or os.path.join(_HERE, "librevision_hip.so")
 
 RV_F32, RV_BF16, RV_I32, RV_I64, RV_U8 = 0, 1, 2, 3, 4
-RV_ACT_NONE, RV_ACT_RELU, RV_ACT_SILU_MUL = 0, 1, 2
+RV_ACT_NONE, RV_ACT_RELU, RV_ACT_SILU_MUL, RV_ACT_QUICK_GELU = 0, 1, 2, 3
 RV_FEAT_CLS, RV_FEAT_ALL = 0, 2
 TOPK_CAP = 64
 

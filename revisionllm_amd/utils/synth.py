@@ -88,6 +88,40 @@ def clip_encoder_spec(d=768, ff=2048, hidden=4096, n_layers=2, text=True):
     return spec
 
 
+def clip_towers_spec(embed_dim=768, image_res=224, patch=14, v_width=1024, v_layers=24, ctx=77, vocab=49408, t_width=768,
+                      t_layers=12):
+    """State dict of the CLIP model the feature extractors load (clip/model.py:245-296; defaults = ViT-L/14).
+    Matrices uniform with the std of the reference's own initialiser (model.py:298-321), vectors small and non-trivial."""
+    def block(p, w, n):
+        attn_a, proj_a, fc_a = SQRT3 * w ** -0.5, SQRT3 * w ** -0.5 * (2 * n) ** -0.5, SQRT3 * (2 * w) ** -0.5
+        return [(p + "attn.in_proj_weight", (3 * w, w), attn_a, 0.0), (p + "attn.in_proj_bias", (3 * w,), 0.05, 0.0),
+                (p + "attn.out_proj.weight", (w, w), proj_a, 0.0), (p + "attn.out_proj.bias", (w,), 0.05, 0.0),
+                (p + "ln_1.weight", (w,), 0.1, 1.0), (p + "ln_1.bias", (w,), 0.05, 0.0),
+                (p + "mlp.c_fc.weight", (4 * w, w), fc_a, 0.0), (p + "mlp.c_fc.bias", (4 * w,), 0.05, 0.0),
+                (p + "mlp.c_proj.weight", (w, 4 * w), proj_a, 0.0), (p + "mlp.c_proj.bias", (w,), 0.05, 0.0),
+                (p + "ln_2.weight", (w,), 0.1, 1.0), (p + "ln_2.bias", (w,), 0.05, 0.0)]
+    vs = SQRT3 * v_width ** -0.5
+    spec = [("visual.conv1.weight", (v_width, 3, patch, patch), SQRT3 * (3 * patch * patch) ** -0.5, 0.0),
+            ("visual.class_embedding", (v_width,), vs, 0.0),
+            ("visual.positional_embedding", ((image_res // patch) ** 2 + 1, v_width), vs, 0.0),
+            ("visual.ln_pre.weight", (v_width,), 0.1, 1.0), ("visual.ln_pre.bias", (v_width,), 0.05, 0.0)]
+    for l in range(v_layers):
+        spec += block(f"visual.transformer.resblocks.{l}.", v_width, v_layers)
+    spec += [("visual.ln_post.weight", (v_width,), 0.1, 1.0), ("visual.ln_post.bias", (v_width,), 0.05, 0.0),
+             ("visual.proj", (v_width, embed_dim), vs, 0.0),
+             ("token_embedding.weight", (vocab, t_width), SQRT3 * 0.02, 0.0), ("positional_embedding", (ctx, t_width), SQRT3 * 0.01, 0.0)]
+    for l in range(t_layers):
+        spec += block(f"transformer.resblocks.{l}.", t_width, t_layers)
+    spec += [("ln_final.weight", (t_width,), 0.1, 1.0), ("ln_final.bias", (t_width,), 0.05, 0.0),
+             ("text_projection", (t_width, embed_dim), SQRT3 * t_width ** -0.5, 0.0)]
+    return spec
+
+
+# a CLIP small enough for committed goldens: 2 + 2 layers, widths 256 (4 heads of 64), 28-pixel images in 14-pixel patches
+CLIP_TINY = dict(embed_dim=64, image_res=28, patch=14, v_width=256, v_layers=2, ctx=16, vocab=600, t_width=256, t_layers=2)
+CLIP_TINY_TEXT_HEADS = 4
+
+
 def linear_projector_spec(d=768, hidden=4096):
     return [("weight", (hidden, d), _xavier(hidden, d), 0.0), ("bias", (hidden,), 0.05, 0.0)]
 

@@ -360,6 +360,96 @@ def g10_metrics(M):
     print("wrote g10_metrics.json", {k: (len(v) if isinstance(v, dict) else v) for k, v in out.items()})
 
 
+def _load_file_module(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+CLIP_DIR = os.path.join(ref_import.REF_ROOT, "revisionllm", "data", "feature_extraction", "clip")
+
+
+def g11_clip_towers(M):
+    """f-4: the vendored CLIP model (clip/model.py) on a tiny configuration: image features, text last_hidden_state and
+    pooler_output.  model.py is loaded by path (the package __init__ pulls PIL / torchvision, absent here)."""
+    model = _load_file_module("ref_clip_model", os.path.join(CLIP_DIR, "model.py"))
+    c = synth.CLIP_TINY
+    net = model.CLIP(c["embed_dim"], c["image_res"], c["v_layers"], c["v_width"], c["patch"], c["ctx"], c["vocab"], c["t_width"],
+                     synth.CLIP_TINY_TEXT_HEADS, c["t_layers"]).float().eval()
+    w = synth.build_numpy(synth.clip_towers_spec(**c), SEED, prefix="clip.")
+    sd = net.state_dict()
+    for k in sd:
+        if k in ("logit_scale", "input_resolution", "context_length", "vocab_size"):
+            continue
+        sd[k].copy_(T(w["clip." + k]))
+    img = T(synth.features("g11.img", (3, 3, c["image_res"], c["image_res"]), SEED))
+    tok = torch.zeros(3, c["ctx"], dtype=torch.long)
+    rows = [[598, 5, 17, 301, 44, 599], [598, 9, 599], [598] + list(range(20, 33)) + [599]]
+    for i, r in enumerate(rows):
+        tok[i, :len(r)] = torch.tensor(r)
+    out = net.encode_text(tok)
+    save("g11_clip_towers", image_features=net.encode_image(img), tokens=tok, last_hidden_state=out["last_hidden_state"],
+         pooler_output=out["pooler_output"])
+
+
+TOKENIZER_TEXTS = ["A person opens the door and walks into the kitchen.", "He's running!!  It's 12:30pm -- cafe deja vu?",
+                   "weird  spacing\tand\nnewlines 1234567890", "don't, won't, I'll, they've; naive cooperation",
+                   "the man in the red jacket picks up a phone &amp; leaves", "x"]
+
+
+def g12_clip_tokenizer(M):
+    """f-4: token ids of the vendored SimpleTokenizer (clip/simple_tokenizer.py) with the real merge table, and with a small
+    synthetic merge table that is committed next to the ids (the real one is CLIP data and does not travel).
+    ftfy is absent from the image: stubbed as the identity (the texts are clean ASCII)."""
+    import gzip
+    import types
+    had = sys.modules.get("ftfy")
+    sys.modules["ftfy"] = types.SimpleNamespace(fix_text=lambda t: t)
+    try:
+        tokmod = _load_file_module("ref_clip_tok", os.path.join(CLIP_DIR, "simple_tokenizer.py"))
+    finally:
+        if had is None:
+            del sys.modules["ftfy"]
+    full = tokmod.SimpleTokenizer()
+    # synthetic merge table: a few hundred merges learnt greedily from the test sentences themselves
+    sym = tokmod.bytes_to_unicode()
+    import regex
+    pat = regex.compile(r"'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
+    words = []
+    for t in TOKENIZER_TEXTS * 3:
+        for tk in pat.findall(t.lower()):
+            s_ = [sym[b] for b in tk.encode("utf-8")]
+            s_[-1] += "</w>"
+            words.append(s_)
+    merges = []
+    for _ in range(120):
+        cnt = {}
+        for w_ in words:
+            for a, b in zip(w_, w_[1:]):
+                cnt[(a, b)] = cnt.get((a, b), 0) + 1
+        if not cnt:
+            break
+        best = sorted(cnt.items(), key=lambda kv: (-kv[1], kv[0]))[0][0]
+        merges.append(best)
+        for w_ in words:
+            i = 0
+            while i + 1 < len(w_):
+                if (w_[i], w_[i + 1]) == best:
+                    w_[i:i + 2] = [w_[i] + w_[i + 1]]
+                else:
+                    i += 1
+    path = os.path.join(HERE, "g12_bpe_merges.txt.gz")
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic test merges\n" + "\n".join(f"{a} {b}" for a, b in merges))
+    small = tokmod.SimpleTokenizer(bpe_path=path)
+    with open(os.path.join(HERE, "g12_clip_tokenizer.json"), "w") as f:
+        json.dump({"texts": TOKENIZER_TEXTS, "ids_full_vocab": [full.encode(t) for t in TOKENIZER_TEXTS],
+                   "ids_synthetic_merges": [small.encode(t) for t in TOKENIZER_TEXTS], "n_synthetic_merges": len(merges)}, f, indent=1)
+    print("wrote g12_clip_tokenizer.json", len(merges), "merges")
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -368,7 +458,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g9=g9_driver, g10=g10_metrics)
+                  g7=g7_scores, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
     for k, fn in groups.items():
         if only and k not in only:
             continue

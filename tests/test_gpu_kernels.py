@@ -103,6 +103,28 @@ def test_gemm(dev, M, N, K, out):
             hip.lib().rv_set_gemm_tile_variant(2)
 
 
+@pytest.mark.parametrize("M,N,K", [(9, 1024, 256), (771, 4096, 1024), (1000, 1024, 4096)])
+def test_gemm_quick_gelu_epilogue(dev, M, N, K):
+    """bias + QuickGELU (x * sigmoid(1.702 x), the CLIP MLP activation) fused into the GEMM epilogue: every kernel family."""
+    from revisionllm_amd import hip, ops
+    a = feats(f"qg.a.{M}.{K}", (M, K), bf16=True)
+    w = bf(feats(f"qg.w.{N}.{K}", (N, K), bf16=True) * (1.0 / math.sqrt(K))).float()
+    bias = feats(f"qg.b.{N}", (N,))
+    z = a.double() @ w.double().t() + bias.double()
+    ref = z * torch.sigmoid(1.702 * z)
+    ad, wd = bf(a).to(dev), bf(w).to(dev)
+    y = ops.gemm(ad, wd, bias=bias.to(dev), act=hip.RV_ACT_QUICK_GELU)
+    assert rel_err(y.float().cpu(), ref) < BF16_TOL
+    wpk = ops.pack_fragments(wd)
+    try:
+        for variant in (2, 4, 5, 6):
+            hip.lib().rv_set_gemm_tile_variant(variant)
+            yp = ops.gemm(ad, wpk, bias=bias.to(dev), act=hip.RV_ACT_QUICK_GELU, out_dtype=torch.float32, w_packed=True, stream_k=True)
+            assert rel_err(yp.cpu(), ref) < F32_TOL * 5
+    finally:
+        hip.lib().rv_set_gemm_tile_variant(2)
+
+
 def test_gemm_strided_rows_and_inplace_residual(dev):
     from revisionllm_amd import ops
     x = bf(feats("gemm.s", (20, 5, 768), bf16=True)).to(dev)
@@ -159,13 +181,14 @@ def _ref_attn(q, k, v, causal, pad, q_pos0, kv_div):
     return torch.einsum("bhqk,bkhd->bqhd", p, v.double()).reshape(B, Lq, H * dh)
 
 
-@pytest.mark.parametrize("case", ["self96", "cross96", "causal128", "decode128", "long96", "split96", "split128"])
+@pytest.mark.parametrize("case", ["self96", "cross96", "causal128", "decode128", "long96", "split96", "split128", "vit64", "text64"])
 def test_attention(dev, case):
     from revisionllm_amd import ops
     cfg = {"self96": (3, 3, 257, 257, 8, 96, False, False, 0), "cross96": (6, 2, 50, 13, 8, 96, False, True, 0),
            "causal128": (2, 2, 171, 171, 4, 128, True, False, 0), "decode128": (3, 3, 1, 173, 4, 128, True, False, 172),
            "long96": (1, 1, 1025, 1025, 8, 96, False, False, 0), "split96": (4, 2, 9, 77, 8, 96, False, True, 0),
-           "split128": (2, 2, 16, 300, 4, 128, True, False, 284)}[case]
+           "split128": (2, 2, 16, 300, 4, 128, True, False, 284), "vit64": (3, 3, 257, 257, 16, 64, False, False, 0),
+           "text64": (2, 2, 77, 77, 12, 64, True, False, 0)}[case]
     B, Bk, Lq, Lk, H, dh, causal, use_pad, q_pos0 = cfg
     q = feats(f"at.q.{case}", (B, Lq, H, dh), bf16=True)
     k = feats(f"at.k.{case}", (Bk, Lk, H, dh), bf16=True)

@@ -459,3 +459,54 @@ def test_chapters_cross_attn_variant(tmp_path):
     assert torch.equal(torch.stack(m.generate(ids, **kw)["logits"]), torch.stack(ref.generate(ids, **kw)["logits"]))
     with pytest.raises(NotImplementedError):
         ReVisionLlamaForCausalLM(shape, device="cuda:0").get_model().initialize_vision_modules(_args(clip_adapter=False, cross_attn=True))
+
+
+# ---- f-4: CLIP feature extraction on the HIP kernels ------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_clip_towers_vs_reference_golden_and_oracle():
+    """Tiny CLIP (2 + 2 layers, width 256, 64-wide heads): image features, text last_hidden_state and pooler_output against the
+    golden produced by the reference's vendored model (g11) and against the fp32 oracle on fresh inputs."""
+    from oracle import clip_vit
+    from revisionllm_amd.data.clip_model import ClipTowers
+    from revisionllm_amd.utils import synth
+    c = synth.CLIP_TINY
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_clip_towers.npz"))
+    m = ClipTowers(**c, t_heads=synth.CLIP_TINY_TEXT_HEADS).init_synthetic(seed=SEED)
+    img = T(synth.features("g11.img", (3, 3, c["image_res"], c["image_res"]), SEED))
+    assert rel_err(m.encode_image(img).cpu(), T(g["image_features"])) < 2e-2
+    out = m.encode_text(T(g["tokens"]))
+    assert rel_err(out["last_hidden_state"].cpu(), T(g["last_hidden_state"])) < 2e-2
+    assert rel_err(out["pooler_output"].cpu(), T(g["pooler_output"])) < 2e-2
+    # fresh inputs, 17 frames (ragged batch) vs the oracle on bf16-rounded weights
+    w = {k[len("clip."):]: T(v) for k, v in synth.build_numpy(synth.clip_towers_spec(**c), SEED, prefix="clip.").items()}
+    img2 = feats("clip.img2", (17, 3, c["image_res"], c["image_res"]))
+    assert rel_err(m.encode_image(img2).cpu(), clip_vit.encode_image(img2, w)) < 2e-2
+
+
+@pytest.mark.gpu
+def test_clip_extractor_vit_l14_shapes():
+    """ViT-L/14 geometry (224-pixel frames -> 257 tokens of width 1024, 16 heads of 64; 77-token text, width 768) with TWO
+    layers per tower against the oracle, through the extractor mirror: preprocessing, batching, per-query slicing."""
+    from oracle import clip_vit
+    from revisionllm_amd.data.clip_extractor import ClipFeatureExtractor, preprocess
+    from revisionllm_amd.data.clip_model import ClipTowers
+    from revisionllm_amd.utils import synth
+    cfg = dict(embed_dim=768, image_res=224, patch=14, v_width=1024, v_layers=2, ctx=77, vocab=49408, t_width=768, t_layers=2)
+    m = ClipTowers(**cfg).init_synthetic(seed=SEED)
+    ex = ClipFeatureExtractor(m)
+    w = {k[len("clip."):]: T(v) for k, v in synth.build_numpy(synth.clip_towers_spec(**cfg), SEED, prefix="clip.").items()}
+    frames = (feats("clip.frames", (5, 3, 224, 224)) * 40 + 128).clamp(0, 255).round()
+    vf = ex.encode_video(frames, bsz=2)                                  # 3 batches: 2 + 2 + 1
+    assert vf.shape == (5, 768)
+    assert rel_err(vf.cpu(), clip_vit.encode_image(preprocess(frames), w)) < 2e-2
+    tok = torch.zeros(3, 77, dtype=torch.long)
+    for i, n in enumerate((5, 12, 77)):
+        tok[i, :n] = torch.cat([torch.tensor([49406]), torch.randint(1, 49000, (n - 2,), generator=torch.Generator().manual_seed(i)),
+                                torch.tensor([49407])])
+    tf, eot = ex.encode_text(None, tokens=tok)
+    hid, pool = clip_vit.encode_text(tok, w, 12)
+    assert [t.shape[0] for t in tf] == [3, 10, 75] and eot[0].shape == (768,)
+    for j, n in enumerate((5, 12, 77)):
+        assert rel_err(tf[j].cpu(), hid[j, 1:n - 1]) < 2e-2
+        assert rel_err(eot[j].cpu(), pool[j]) < 2e-2

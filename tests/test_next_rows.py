@@ -94,3 +94,49 @@ def test_stage1_windows_and_iou(golden):
     s1 = golden.json("g9_driver")["stage1"]
     frames, ious, keep = stage1.iou(s1["outputs"], tuple(s1["gt"]), 250, 2000, [.5, .6, .7, .8, .9, 1.0, 1.1])
     assert {str(k): list(v) for k, v in frames.items()} == s1["frames"] and ious == s1["ious"] and keep == s1["keep"]
+
+
+# ---- f-4: CLIP feature extraction (oracle + tokenizer pinned to the vendored reference model) ---------------------
+
+def _clip_tiny_weights():
+    from revisionllm_amd.utils import synth
+    from helpers import SEED
+    w = synth.build_numpy(synth.clip_towers_spec(**synth.CLIP_TINY), SEED, prefix="clip.")
+    return {k[len("clip."):]: torch.from_numpy(v) for k, v in w.items()}
+
+
+def test_clip_towers_oracle_matches_reference_golden():
+    """g11: encode_image / encode_text of the reference's vendored CLIP (clip/model.py) on the tiny configuration."""
+    import numpy as np
+    from oracle import clip_vit
+    from revisionllm_amd.utils import synth
+    from helpers import SEED
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_clip_towers.npz"))
+    w = _clip_tiny_weights()
+    c = synth.CLIP_TINY
+    img = torch.from_numpy(synth.features("g11.img", (3, 3, c["image_res"], c["image_res"]), SEED))
+    assert np.abs(clip_vit.encode_image(img, w).numpy() - g["image_features"]).max() < 2e-5
+    hid, pool = clip_vit.encode_text(torch.from_numpy(g["tokens"]), w, synth.CLIP_TINY_TEXT_HEADS)
+    assert np.abs(hid.numpy() - g["last_hidden_state"]).max() < 2e-5
+    assert np.abs(pool.numpy() - g["pooler_output"]).max() < 2e-5
+
+
+def test_clip_tokenizer_matches_reference_golden():
+    """g12: ids of the vendored SimpleTokenizer - with the committed synthetic merge table everywhere, and with CLIP's own
+    table where it is on disk (the build container; it is CLIP data and does not travel)."""
+    import json
+    from revisionllm_amd.data.clip_tokenizer import ClipTokenizer
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    g = json.load(open(os.path.join(gd, "g12_clip_tokenizer.json")))
+    tok = ClipTokenizer(os.path.join(gd, "g12_bpe_merges.txt.gz"))
+    assert [tok.encode(t) for t in g["texts"]] == g["ids_synthetic_merges"]
+    batch = tok.tokenize(g["texts"][:2], context_length=77)
+    assert batch.shape == (2, 77) and batch[0, 0] == tok.sot and int(batch[0].argmax()) == len(g["ids_synthetic_merges"][0]) + 1
+    with pytest.raises(RuntimeError):
+        tok.tokenize(["a b c d e f g h i j"], context_length=4)
+    full = os.environ.get("CLIP_BPE_PATH") or "/root/reference/revisionllm/data/feature_extraction/clip/bpe_simple_vocab_16e6.txt.gz"
+    if os.path.exists(full):
+        tf = ClipTokenizer(full)
+        assert [tf.encode(t) for t in g["texts"]] == g["ids_full_vocab"]
+        assert tf.sot == 49406 and tf.eot == 49407
+        assert tf.decode(tf.encode("a person opens the door")).strip() == "a person opens the door"
