@@ -516,7 +516,7 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
     for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + kb * 128 + j * 32);
 }
 
-template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0>
+template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2>
 __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
                                                    int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm,
@@ -555,26 +555,27 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int kb = wave;
-    for (; kb + 8 < nkb; kb += 16) {
-        bf16x8 wf0[NT][4], wf1[NT][4], xf0[4], xf1[4];
-        gemv_load<NT, WP>(wp, xp, kb, wf0, xf0);
-        gemv_load<NT, WP>(wp, xp, kb + 8, wf1, xf1);
+    // Rolling DEPTH-deep pipeline over this wave's k-blocks (wave, wave + 8, ...): a block is re-loaded as soon as its
+    // registers are consumed, so DEPTH - 1 .. DEPTH 128-k blocks per wave stay in flight until the very end (a batch loop
+    // drains to zero between batches, and with all workgroups of a short launch in lock-step the HBM queue empties with it).
+    // DEPTH = 2 everywhere: 4 was measured slower on the N = 4096 projections (down 16.8 -> 18.2 us) and level elsewhere.
+    {
+        bf16x8 wf[DEPTH][NT][4], xf[DEPTH][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int d = 0; d < DEPTH; ++d)
+            if (kb + 8 * d < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * d, wf[d], xf[d]);
+        for (; kb < nkb; kb += 8 * DEPTH) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[t][j], xf0[j], acc[t], 0, 0, 0);
+            for (int d = 0; d < DEPTH; ++d) {
+                if (kb + 8 * d < nkb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[t][j], xf1[j], acc[t], 0, 0, 0);
-    }
-    if (kb < nkb) {
-        bf16x8 wf0[NT][4], xf0[4];
-        gemv_load<NT, WP>(wp, xp, kb, wf0, xf0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[t][j], xf0[j], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][t][j], xf[d][j], acc[t], 0, 0, 0);
+                    if (kb + 8 * (d + DEPTH) < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * (d + DEPTH), wf[d], xf[d]);
+                }
+            }
+        }
     }
 
 #pragma unroll
