@@ -528,13 +528,14 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     const int fr = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nkb = K >> 7;
-    if (nrm.in_sumsq) {  // consumer: gather the producer's partial sums of squares (fixed order -> deterministic)
-        const int bb = tid & 15, part = tid >> 4;
-        float a = 0.f;
-        for (int i = part; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[i * 16 + bb];
-        ssq[part][bb] = a;
+    // consumer of a fused RMSNorm: the producer's partial sums of squares are fetched now (their L2 latency hides under the
+    // weight stream) and added up after it
+    float ssq_pre[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = (tid >> 4) + 32 * j;
+        ssq_pre[j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[i * 16 + (tid & 15)] : 0.f;
     }
-
     const int xr = fr < M ? fr : M - 1;
     const bf16_t* xp = X + (int64_t)xr * lda + kg * 8;
     const bf16_t* wp[NT];
@@ -578,6 +579,13 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
         }
     }
 
+    if (nrm.in_sumsq) {  // consumer: add up the producer's partial sums of squares (fixed order -> deterministic)
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += ssq_pre[j];
+        for (int i = (tid >> 4) + 256; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[i * 16 + (tid & 15)];
+        ssq[tid >> 4][tid & 15] = a;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
     __syncthreads();
