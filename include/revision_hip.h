@@ -88,6 +88,10 @@ size_t rv_gemm_ws_bytes(void);
  * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
  * 3 = register-double-buffered ring; 4 / 5 = ping-pong output-tiled / stream-K wherever supported. */
 void rv_set_gemm_tile_variant(int32_t variant);
+/* Measurement knob (process-wide): 1 = the KV-cached decode step runs attention + o projection as one launch (the o weights
+ * stream while the attention chain runs); 0 (default) = two launches (level on MI355X: the in-kernel hand-off costs what the
+ * saved launch gains).  Same results to f32 rounding of the softmax merge. */
+void rv_set_decode_fusion(int32_t on);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);

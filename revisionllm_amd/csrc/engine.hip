@@ -345,6 +345,13 @@ extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
     return carve_llm(c, nullptr, 0, 1, B * S).bytes;
 }
 
+// Measurement knob: 1 = the decode step runs attention + o projection as ONE launch (decode_fused.hip).  Measured on MI355X
+// (B = 7, 171 cached positions): 2.98 ms per step fused vs 2.96 ms with two launches - the saved launch and the overlapped
+// weight stream are paid back by the in-kernel hand-off (sc1 store -> flag -> poll -> sc1 loads: three memory round trips),
+// so it is OFF by default and kept tested.
+int g_fuse_decode_attn = 0;
+extern "C" void rv_set_decode_fusion(int32_t on) { g_fuse_decode_attn = on != 0; }
+
 namespace {
 // Rows of h: [P0 shared-prefix rows (positions 0..P0-1)] then B sequences of S rows (positions pos0..pos0+S-1, with
 // pos0 == P0 when P0 > 0).  P0 == 0 is the plain prefill / decode step.
@@ -369,6 +376,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // Decode steps (M <= 16) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
     const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
+    const bool fuse_attn = fuse_norm && g_fuse_decode_attn && attn_oproj_decode_supported(B, H, dh, D) && w.sk_bytes >= 8192;
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
     GemvNorm consume;
     consume.in_sumsq = w.ss;
@@ -393,16 +401,22 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                         (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
             RV_TRY(k_attention(ap, st));
         }
-        const int64_t r0 = P0;  // first row of the per-sequence part
-        AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                   (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
-        RV_TRY(k_attention(a, st));
         GemvNorm produce;
         produce.xw_out = w.xn16;
         produce.out_sumsq = w.ss;
         produce.w_next = L.norm2;
-        RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
-                            fuse_norm ? &produce : nullptr));
+        if (fuse_attn) {
+            // decode: attention + o projection in one launch, the o weights streaming while the attention chain runs
+            int* sync = (int*)w.sk + 1024;   // spare words [1024, 1536) of the (zero-initialised) hand-off header; status word at 2047
+            RV_TRY(attn_oproj_decode_launch(w.q16, kc, vtc, w.a16, L.wo, h, produce, sync, (int*)w.sk + 2047, B, H, pos0 + 1, Smax, D, scale, st));
+        } else {
+            const int64_t r0 = P0;  // first row of the per-sequence part
+            AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                       (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
+            RV_TRY(k_attention(a, st));
+            RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
+                                fuse_norm ? &produce : nullptr));
+        }
         if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
         RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
                             fuse_norm ? &consume : nullptr));

@@ -78,6 +78,11 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st);
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st);
+// decode step: attention + o projection (+ residual, fused-RMSNorm producer) in one launch (decode_fused.hip).
+// sync: one int per workgroup (<= #CUs), zero-initialised once; status: 1 int (set non-zero if a bounded wait gave up)
+bool attn_oproj_decode_supported(int B, int H, int dh, int64_t D);
+int attn_oproj_decode_launch(const void* q16, const void* kc, const void* vtc, void* a16, const void* wo, float* h, const GemvNorm& nrm,
+                             int* sync, int* status, int B, int H, int Lk, int Smax, int64_t D, float scale, hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
                 int64_t period, int64_t rows, int d, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);

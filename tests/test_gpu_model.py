@@ -389,6 +389,35 @@ def test_full_size_properties_7b(model_7b):
     assert torch.equal(auto, torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"]))   # deterministic
 
 
+def test_decode_attention_oproj_fusion_matches_separate_launches(model_7b):
+    """KV-cached decode steps of the 7-call batch with attention + o projection fused into one launch (opt-in knob) against the
+    two-launch path: same K/V caches, logits equal to f32 rounding of the softmax merge (8- vs 4-way key split), greedy tokens
+    equal; and the fused path is deterministic."""
+    from revisionllm_amd import hip, ops
+    from revisionllm_amd.utils import synth
+    m = model_7b
+    dev = m.engine.device
+    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
+    qf = ops.init_hash_(torch.empty(1, 16, 768, dtype=torch.bfloat16, device=dev), "fs.q", 3, synth.SQRT3)
+    cls = m.engine.clip_encoder(feat, qf, torch.ones(1, 16), "cls")
+    ids = T(synth.synthetic_prompt_ids(72, 40, 3))[None]
+    rows7 = torch.cat([cls[torch.randperm(100, generator=torch.Generator().manual_seed(i))] for i in range(7)], 0)
+    kw = dict(rows_per_sample=100, do_sample=False, max_new_tokens=5, return_dict_in_generate=True, output_logits=True)
+    out = {}
+    try:
+        for on in (0, 1):
+            hip.lib().rv_set_decode_fusion(on)
+            out[on] = m.generate(ids.repeat(7, 1), video_rows=rows7, **kw)
+        again = m.generate(ids.repeat(7, 1), video_rows=rows7, **kw)
+    finally:
+        hip.lib().rv_set_decode_fusion(0)
+    a, b = torch.stack(out[0]["logits"]), torch.stack(out[1]["logits"])
+    assert torch.equal(a[0], b[0])                                        # prefill: untouched
+    assert (a - b).abs().max() <= 2e-2 * a.abs().max()
+    assert torch.equal(out[0]["sequences"], out[1]["sequences"])
+    assert torch.equal(b, torch.stack(again["logits"]))
+
+
 def test_persistent_qkv_rope_epilogue_is_bit_exact():
     """One 7B-shaped layer, the recursion's 7-call shared-prefix prefill (1005 rows): the persistent ping-pong QKV projection
     (192-column panels, fused RoPE + KV-cache append) sums whole panels in the ring kernel's order, so the layer's K and
