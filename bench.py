@@ -88,7 +88,7 @@ def roofline_legs(model, n_calls, M):
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
-    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
+    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0,2>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
                                       peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
     #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised

@@ -159,7 +159,7 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
-    const bool split = a.Lq <= 16;
+    const bool split = a.Lq <= 16 && !a.no_split;
     dim3 grid((unsigned)cdiv(a.Lq, split ? 16 : 64), (unsigned)a.H, (unsigned)a.B);
     if (a.dh == 64 && !split)
         hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a);

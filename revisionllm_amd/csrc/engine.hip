@@ -284,6 +284,31 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
 
     for (size_t l = 0; l < c->enc.size(); ++l) {
         const AdapterLayer& L = c->enc[l];
+        if (feature == RV_FEAT_CLS && l + 1 == c->enc.size() && N > 16 && T >= 3) {
+            // Last layer, CLS feature: only row 0 of every sequence is read afterwards, so only K and V are computed for all
+            // rows; the query, the attention row, out-proj, LN1, FFN and LN2 run on the N CLS rows alone (78 % of the layer's
+            // GEMM work gone).  Same kernels and summation orders as the full-length launches (N > 16 keeps the GEMMs on the
+            // tiled kernel, the attention keeps the non-split variant), so the CLS rows are bit-identical to the full layer's.
+            const int64_t sx = (int64_t)(T + 1) * d;   // row stride between the CLS rows of consecutive sequences
+            bf16_t* kk16 = w.qk16;                      // K  [R1, d]
+            bf16_t* qc16 = w.h16;                       // Q of the CLS rows [N, d] (h16 is free until the FFN)
+            float* y0 = w.y32;                          // [N, d] attention + residual
+            float* y1 = w.y32 + (int64_t)N * d;         // [N, d] LN1 output (FFN residual)
+            float* y2 = w.y32 + (int64_t)2 * N * d;     // [N, d] FFN + residual
+            RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, kk16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.xp16, sx, L.w_in, d, 1, L.b_in, nullptr, 0, qc16, d, RV_BF16, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));
+            AttnArgs a{qc16, d, d, kk16, d, (int64_t)(T + 1) * d, dh, w.vt16, (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, d,
+                       nullptr, N, H, dh, 1, T + 1, 0, 0, 1, scale, 1};
+            RV_TRY(k_attention(a, st));
+            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, sx, y0, d, RV_F32, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, y1, d, y2, d, RV_F32, RV_ACT_NONE, N, d, ff, w.sk, w.sk_bytes, st));
+            RV_TRY(k_layernorm(y2, L.ln2_w, L.ln2_b, nullptr, w.x16, nullptr, nullptr, 0, N, (int)d, st));
+            return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D, d, w.sk, w.sk_bytes, st);
+        }
         RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_BF16, RV_ACT_NONE, R1, 2 * d, d, w.sk, w.sk_bytes, st));
         RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));

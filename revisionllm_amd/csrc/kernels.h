@@ -103,5 +103,6 @@ struct AttnArgs {
     const uint8_t* key_pad;  // [B / kv_div, Lk], 1 = ignore
     int B, H, dh, Lq, Lk, causal, q_pos0, kv_div;
     float scale;
+    int no_split = 0;  // 1: never use the key-split (Lq <= 16) variant - keeps a row's arithmetic identical to a full-length launch
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
