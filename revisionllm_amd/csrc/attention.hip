@@ -15,13 +15,12 @@ namespace {
 // w, w+4, ...; their (m, l, O) partials are merged through LDS.  A decode step is pure latency (one wave would
 // walk all keys serially), so this cuts it ~4x.
 template <int DH, bool SPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int b) {
     constexpr int NC = DH / 32, ND = DH / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = SPLIT ? blockIdx.x * 16 : blockIdx.x * 64 + wave * 16;
+    const int q0 = SPLIT ? bx * 16 : bx * 64 + wave * 16;
     if (q0 >= a.Lq) return;
     const int kb_ = b / a.kv_div;
 
@@ -151,7 +150,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
 }
 
+template <int DH, bool SPLIT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    attn_body<DH, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
+// themselves, the per-call rows attend to prefix + own keys): blockIdx.z < a.B -> problem a, else problem b.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b) {
+    if ((int)blockIdx.z < a.B) attn_body<DH, false>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    else attn_body<DH, false>(b, blockIdx.x, blockIdx.y, blockIdx.z - a.B);
+}
+
 }  // namespace
+
+static int attn_check(const AttnArgs& a) {
+    RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");
+    RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
+    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
+                 "attention: stride alignment");
+    RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
+    return RV_OK;
+}
+
+int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st) {
+    if (int rc = attn_check(a)) return rc;
+    if (int rc = attn_check(b)) return rc;
+    RV_CHECK_ARG(a.dh == 128 && b.dh == 128 && a.H == b.H && a.Lq > 16 && b.Lq > 16, "attention pair: 128-wide heads, same head count, prefill lengths only");
+    const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
+    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3((unsigned)tiles, (unsigned)a.H, (unsigned)(a.B + b.B)), dim3(256), 0, st, a, b);
+    RV_CHECK_LAUNCH("attention pair");
+    return RV_OK;
+}
 
 int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");

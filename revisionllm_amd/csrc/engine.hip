@@ -421,10 +421,19 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
         RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, w.sk, w.sk_bytes, st));
+        bool prefix_done = false;
         if (P0 > 0) {
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                         (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
-            RV_TRY(k_attention(ap, st));
+            if (P0 > 16 && S > 16 && dh == 128) {   // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch)
+                AttnArgs am{w.q16 + (int64_t)P0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
+                            (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
+                            S, pos0 + S, 1, pos0, 1, scale};
+                RV_TRY(k_attention_pair(ap, am, st));
+                prefix_done = true;
+            } else {
+                RV_TRY(k_attention(ap, st));
+            }
         }
         GemvNorm produce;
         produce.xw_out = w.xn16;
@@ -438,7 +447,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             const int64_t r0 = P0;  // first row of the per-sequence part
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                        (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
-            RV_TRY(k_attention(a, st));
+            if (!prefix_done) RV_TRY(k_attention(a, st));
             RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
                                 fuse_norm ? &produce : nullptr));
         }

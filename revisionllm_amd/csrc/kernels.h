@@ -106,3 +106,4 @@ struct AttnArgs {
     int no_split = 0;  // 1: never use the key-split (Lq <= 16) variant - keeps a row's arithmetic identical to a full-length launch
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
+int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st);   // two prefill problems (dh 128) in one launch

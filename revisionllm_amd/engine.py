@@ -145,6 +145,18 @@ class Engine:
             self._ws[key] = t
         return t
 
+    def check_handoff_status(self):
+        """Raise if a bounded in-kernel wait of the stream-K GEMMs / fused decode kernel ever gave up (a workgroup that never
+        arrived would otherwise show up as silently wrong numbers).  The status word sits at int 2047 of the hand-off header
+        at the start of every workspace; reading it synchronises, so call it where the host waits for results anyway."""
+        for key in ("llm", "clip"):
+            ws = self._ws.get(key)
+            if ws is not None and ws.numel() >= 8192:
+                st = int(ws[8188:8192].view(torch.int32).item())
+                if st != 0:
+                    ws[8188:8192].zero_()
+                    raise hip.HipLibraryError(f"workspace '{key}': an in-kernel hand-off wait timed out (status {st}); results of the last calls are invalid")
+
     # ---- adapter ---------------------------------------------------------------------------------
     def project_dense(self, x, out_dtype=torch.float32):
         """nn.Linear(768, D) on [..., 768] bf16 -> [..., D]."""

@@ -189,6 +189,7 @@ def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_
                                  return_dict_in_generate=True, uniforms=u)
             new = out["sequences"][:, ids.shape[1]:].cpu()
             ent = out["entropy"].cpu()
+            model.engine.check_handoff_status()   # (the host is synchronised here anyway)
             for j, (c, g) in enumerate(zip(sel, _steps_until_eos(new, eos))):
                 e = ent[j, :g]
                 res[c] = (new[j, :g].tolist(), float(e.max()), float(e.mean()))
