@@ -161,12 +161,12 @@ def build_call_rows(cls, plan, perms, index=None):
     return list(cls.index_select(0, idx).split(counts))
 
 
-def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
-    """Run the LLM for the given call indices.  ``query`` is one prompt for all calls or a {call: prompt} mapping (several
-    queries of one movie batched together).  Calls whose prompts have the same length (same number of video rows and of
-    text tokens) run as one batched generate.  -> {call: (new_token_ids list, max_entropy, mean_entropy)} with the
-    statistics taken over the steps a batch-1 generate would have produced."""
-    eos = model.generation_config.eos_token_id
+def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None):
+    """Enqueue the LLM work for the given call indices WITHOUT waiting for it (when no EOS id is configured ``generate`` never
+    synchronises).  ``query`` is one prompt for all calls or a {call: prompt} mapping (several queries of one movie batched
+    together).  Calls whose prompts have the same length (same number of video rows and of text tokens) run as one batched
+    generate.  -> (calls in row order, new tokens int32 [n, width], step entropies f32 [n, width], produced steps int32 [n]),
+    device tensors; ``width`` defaults to the longest generate."""
     ids_of = {}
 
     def prompt_ids(c):
@@ -178,7 +178,7 @@ def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_
     groups = {}
     for c in calls:
         groups.setdefault((rows[c].shape[0], prompt_ids(c).shape[1]), []).append(c)
-    res = {}
+    order, toks, ents = [], [], []
     for (n_rows, _), cs in groups.items():
         for c0 in range(0, len(cs), max_calls_per_generate):
             sel = cs[c0:c0 + max_calls_per_generate]
@@ -187,13 +187,48 @@ def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_
             out = model.generate(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows, do_sample=True,
                                  temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens, output_scores=False,
                                  return_dict_in_generate=True, uniforms=u)
-            new = out["sequences"][:, ids.shape[1]:].cpu()
-            ent = out["entropy"].cpu()
-            model.engine.check_handoff_status()   # (the host is synchronised here anyway)
-            for j, (c, g) in enumerate(zip(sel, _steps_until_eos(new, eos))):
-                e = ent[j, :g]
-                res[c] = (new[j, :g].tolist(), float(e.max()), float(e.mean()))
+            order.extend(sel)
+            toks.append(out["sequences"][:, ids.shape[1]:])
+            ents.append(out["entropy"])
+    dev = model.engine.device
+    if not order:
+        w0 = width or 0
+        return [], torch.zeros(0, w0, dtype=torch.int32, device=dev), torch.zeros(0, w0, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+    width = width or max(t.shape[1] for t in toks)
+    tok = torch.zeros(len(order), width, dtype=torch.int32, device=dev)
+    ent = torch.zeros(len(order), width, dtype=torch.float32, device=dev)
+    nst = torch.empty(len(order), dtype=torch.int32, device=dev)
+    r = 0
+    for t, e in zip(toks, ents):
+        n, g = t.shape
+        if g > width:
+            raise ValueError(f"a call generated {g} tokens > wire capacity {width}")
+        tok[r:r + n, :g] = t
+        ent[r:r + n, :g] = e
+        nst[r:r + n] = g
+        r += n
+    return order, tok, ent, nst
+
+
+def finish_calls(order, tok, ent, nst, eos):
+    """Host side of ``launch_calls`` (CPU tensors): -> {call: (new_token_ids list, max_entropy, mean_entropy)} with the
+    statistics taken over the steps a batch-1 generate would have produced (up to and including EOS)."""
+    res = {}
+    for j, c in enumerate(order):
+        n = int(nst[j])
+        row = tok[j, :n]
+        g = _steps_until_eos(row[None], eos)[0]
+        e = ent[j, :g]
+        res[c] = (row[:g].tolist(), float(e.max()), float(e.mean()))
     return res
+
+
+def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
+    """Run the LLM for the given call indices and wait for the results: ``finish_calls(launch_calls(...))``."""
+    order, tok, ent, nst = launch_calls(model, tokenizer, query, rows, calls, uniforms, max_new_tokens, max_calls_per_generate)
+    tok, ent, nst = tok.cpu(), ent.cpu(), nst.cpu()
+    model.engine.check_handoff_status()   # (the host is synchronised here anyway)
+    return finish_calls(order, tok, ent, nst, model.generation_config.eos_token_id)
 
 
 def assemble(plan, perms, call_results, cos, tokenizer, zooms, grounding_windows, single=True):

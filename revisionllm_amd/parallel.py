@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .eval import stage2
+from .ops import h2d as ops_h2d
 
 
 def shard_bounds(n, rank, world):
@@ -97,6 +98,17 @@ class HipStages:
     def generate(self, query, rows, calls, uniforms, max_new_tokens):
         return stage2.generate_calls(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens)
 
+    def generate_async(self, query, rows, calls, uniforms, max_new_tokens, width):
+        """Enqueue only: -> (calls in row order, tokens int32 [n, width], entropies f32 [n, width], produced steps int32 [n])."""
+        return stage2.launch_calls(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens, width=width)
+
+    @property
+    def eos(self):
+        return self.model.generation_config.eos_token_id
+
+    def check(self):
+        self.model.engine.check_handoff_status()
+
 
 def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
                         max_new_tokens=64, grounding_windows=None, group=None, single=True):
@@ -137,14 +149,16 @@ def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100
     return out
 
 
-def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
-                      perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
-    """Stage-2 recursion over ``W`` windows with the windows block-partitioned over the ranks of ``group``.
+class PendingQuery:
+    """A launched, not yet collected recursion (``launch_query_sharded``)."""
 
-    ``features_local`` [hi-lo, T, 768] are this rank's windows (``shard_bounds(W, rank, world)``).  ``perms`` and
-    ``uniforms`` must be identical on all ranks (derive them from a shared seed).  Returns the same record as
-    ``stage2.run_query`` on every rank.
-    """
+
+def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
+                         perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """First half of ``run_query_sharded``: enqueue the whole recursion (adapter, both exchanges, LLM calls, device -> pinned
+    host copies of the proposals) and return without waiting for the device, so a driver can launch the next query before it
+    collects this one (the host-side assembly then overlaps device work).  Stages without ``generate_async`` (CPU stand-ins)
+    and an EOS-terminated generate (which synchronises per step) simply do their waiting here."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(W, rank, world)
@@ -168,7 +182,58 @@ def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_c
         cls, cos = cls_local, cos_local
     rows = stage2.build_call_rows(cls, plan, perms, index)
     mine = deal(len(plan), rank, world)
-    res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
-    if world > 1:
-        res = allgather_calls(res, len(plan), max_new_tokens, cls.device, group)   # exchange 2: proposals
-    return stage2.assemble(plan, perms, res, cos.cpu(), tokenizer, zooms, grounding_windows, single)
+    p = PendingQuery()
+    p.args = (plan, perms, tokenizer, zooms, grounding_windows, single)
+    p.stages = stages
+    if hasattr(stages, "generate_async") and cls.is_cuda:
+        width = min(max_new_tokens, 128)
+        order, tok, ent, nst = stages.generate_async(query, rows, mine, uniforms, max_new_tokens, width)
+        per = -(-len(plan) // world)
+        # wire: int32 [per, 2 + width] = (call id or -1, produced steps, tokens...) and f32 [per, width] step entropies
+        tw = torch.full((per, 2 + width), -1, dtype=torch.int32, device=cls.device)
+        ew = torch.zeros((per, width), dtype=torch.float32, device=cls.device)
+        n = len(order)
+        if n:
+            tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), cls.device)
+            tw[:n, 1] = nst
+            tw[:n, 2:] = tok
+            ew[:n] = ent
+        if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
+            tw, ew = _all_gather_cat(tw, group), _all_gather_cat(ew, group)
+        p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
+        for h, t in zip(p.host, (tw, ew, cos)):
+            h.copy_(t, non_blocking=True)
+        p.event = torch.cuda.Event()
+        p.event.record()
+    else:
+        res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
+        if world > 1:
+            res = allgather_calls(res, len(plan), max_new_tokens, cls.device, group)   # exchange 2: proposals
+        p.res, p.cos = res, cos.cpu()
+    return p
+
+
+def collect_query(p):
+    """Second half: wait for the launched recursion and assemble its record (identical on every rank)."""
+    plan, perms, tokenizer, zooms, grounding_windows, single = p.args
+    if hasattr(p, "event"):
+        p.event.synchronize()
+        tw, ew, cos = p.host
+        rows_ = [j for j in range(tw.shape[0]) if int(tw[j, 0]) >= 0]
+        res = stage2.finish_calls([int(tw[j, 0]) for j in rows_], tw[rows_][:, 2:], ew[rows_], tw[rows_][:, 1], p.stages.eos)
+        p.stages.check()
+    else:
+        res, cos = p.res, p.cos
+    return stage2.assemble(plan, perms, res, cos, tokenizer, zooms, grounding_windows, single)
+
+
+def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
+                      perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Stage-2 recursion over ``W`` windows with the windows block-partitioned over the ranks of ``group``.
+
+    ``features_local`` [hi-lo, T, 768] are this rank's windows (``shard_bounds(W, rank, world)``).  ``perms`` and
+    ``uniforms`` must be identical on all ranks (derive them from a shared seed).  Returns the same record as
+    ``stage2.run_query`` on every rank.  = ``collect_query(launch_query_sharded(...))``.
+    """
+    return collect_query(launch_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch, zooms,
+                                              perms, uniforms, max_new_tokens, grounding_windows, group, single))
