@@ -185,7 +185,7 @@ def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, quer
     p = PendingQuery()
     p.args = (plan, perms, tokenizer, zooms, grounding_windows, single)
     p.stages = stages
-    if hasattr(stages, "generate_async") and cls.is_cuda:
+    if hasattr(stages, "generate_async"):
         width = min(max_new_tokens, 128)
         order, tok, ent, nst = stages.generate_async(query, rows, mine, uniforms, max_new_tokens, width)
         per = -(-len(plan) // world)
@@ -195,16 +195,20 @@ def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, quer
         n = len(order)
         if n:
             tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), cls.device)
+            nst, tok, ent = nst.to(cls.device), tok.to(cls.device), ent.to(cls.device)
             tw[:n, 1] = nst
             tw[:n, 2:] = tok
             ew[:n] = ent
         if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
             tw, ew = _all_gather_cat(tw, group), _all_gather_cat(ew, group)
-        p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
-        for h, t in zip(p.host, (tw, ew, cos)):
-            h.copy_(t, non_blocking=True)
-        p.event = torch.cuda.Event()
-        p.event.record()
+        if cls.is_cuda:
+            p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
+            for h, t in zip(p.host, (tw, ew, cos)):
+                h.copy_(t, non_blocking=True)
+            p.event = torch.cuda.Event()
+            p.event.record()
+        else:                                               # CPU stand-in stages (tests): nothing to wait for
+            p.host, p.event = (tw, ew, cos), None
     else:
         res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
         if world > 1:
@@ -217,7 +221,8 @@ def collect_query(p):
     """Second half: wait for the launched recursion and assemble its record (identical on every rank)."""
     plan, perms, tokenizer, zooms, grounding_windows, single = p.args
     if hasattr(p, "event"):
-        p.event.synchronize()
+        if p.event is not None:
+            p.event.synchronize()
         tw, ew, cos = p.host
         rows_ = [j for j in range(tw.shape[0]) if int(tw[j, 0]) >= 0]
         res = stage2.finish_calls([int(tw[j, 0]) for j in rows_], tw[rows_][:, 2:], ew[rows_], tw[rows_][:, 1], p.stages.eos)

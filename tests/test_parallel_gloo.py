@@ -35,6 +35,29 @@ class StubStages:
         return out
 
 
+class AsyncStubStages(StubStages):
+    """The same stand-ins through the launch / collect wire format (device-side proposal exchange of HipStages)."""
+    eos = None
+
+    def generate_async(self, query, rows, calls, uniforms, max_new_tokens, width):
+        res = self.generate(query, rows, calls, uniforms, max_new_tokens)
+        order = list(calls)
+        tok = torch.zeros(len(order), width, dtype=torch.int32)
+        ent = torch.zeros(len(order), width)
+        nst = torch.zeros(len(order), dtype=torch.int32)
+        for j, c in enumerate(order):
+            t, emax, emean = res[c]
+            tok[j, :len(t)] = torch.tensor(t, dtype=torch.int32)
+            nst[j] = len(t)
+            # step entropies whose max / mean are the stub's numbers: [emax, 2*emean - emax, emean, emean, ...]
+            ent[j, :len(t)] = emean
+            ent[j, 0], ent[j, 1] = emax, 2 * emean - emax
+        return order, tok, ent, nst
+
+    def check(self):
+        pass
+
+
 def _inputs():
     feats = torch.from_numpy(synth.features("par.feat", (W, T, 768), 5))
     qf = torch.from_numpy(synth.features("par.q", (4, 768), 5))
@@ -51,6 +74,16 @@ def _worker(rank, world, port, q):
     lo, hi = parallel.shard_bounds(W, rank, world)
     rec = parallel.run_query_sharded(StubStages(), synth.FakeTokenizer(), feats[lo:hi], W, qf, qc, "a man", batch=BATCH,
                                      perms=perms, max_new_tokens=8)
+    # the launch / collect wire (proposals exchanged as tensors), two queries in flight
+    pa = parallel.launch_query_sharded(AsyncStubStages(), synth.FakeTokenizer(), feats[lo:hi], W, qf, qc, "a man", batch=BATCH,
+                                       perms=perms, max_new_tokens=8)
+    pb = parallel.launch_query_sharded(AsyncStubStages(), synth.FakeTokenizer(), feats[lo:hi], W, qf * 0.5, qc, "a man", batch=BATCH,
+                                       perms=perms, max_new_tokens=8)
+    ra, rb = parallel.collect_query(pa), parallel.collect_query(pb)
+    assert ra["answers"] == rec["answers"] and ra["score_cos"] == rec["score_cos"] and ra["starts"] == rec["starts"]
+    assert all(abs(x - y) < 1e-6 for x, y in zip(ra["max_entropy"], rec["max_entropy"]))
+    assert all(abs(x - y) < 1e-6 for x, y in zip(ra["mean_entropy"], rec["mean_entropy"]))
+    assert rb["starts"] == rec["starts"]
     q.put((rank, rec["answers"], rec["max_entropy"], rec["mean_entropy"], rec["score_cos"], rec["starts"]))
     dist.barrier()
     dist.destroy_process_group()
