@@ -536,6 +536,22 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
         const int i = (tid >> 4) + 32 * j;
         ssq_pre[j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[i * 16 + (tid & 15)] : 0.f;
     }
+    f32x4 rope_pre = f32x4{0.f, 0.f, 0.f, 0.f};   // (cos, sin) of this lane's output group, fetched under the weight stream too
+    if constexpr (ROPE) {
+        static_assert(NT == 1, "the fused RoPE epilogue is instantiated for one 16-row tile per workgroup");
+        if (wave == 0 && fr < M && n0 + kg * 4 < N) rope_pre = qkv_rope_coeffs(qr, fr, n0 + kg * 4);
+    }
+    // epilogue operands of the one-tile kernels (bias, residual, next norm weight): independent of the weight stream, so
+    // they are fetched under it instead of as a dependent chain in the tail of every workgroup
+    f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f}, res_pre = bias_pre, wn_pre = bias_pre;
+    if constexpr (NT == 1 && ACT != RV_ACT_SILU_MUL && ROPE == 0) {
+        const int n = n0 + kg * 4;
+        if (wave == 0 && fr < M && n < N) {
+            if (bias) bias_pre = *(const f32x4*)(bias + n);
+            if (res) res_pre = *(const f32x4*)(res + (int64_t)fr * ldr + n);
+            if (nrm.out_sumsq) wn_pre = *(const f32x4*)(nrm.w_next + n);
+        }
+    }
     const int xr = fr < M ? fr : M - 1;
     const bf16_t* xp = X + (int64_t)xr * lda + kg * 8;
     const bf16_t* wp[NT];
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int n = n0 + t * 16 + kg * 4;
-                if (n < N) qkv_rope_store(qr, b, n, s[t]);
+                if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre);
             }
         }
         return;
@@ -636,12 +652,12 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             const int n = n0 + t * 16 + kg * 4;
             if (n >= N || b >= M) continue;
             f32x4 v = s[t];
-            if (bias) v += *(const f32x4*)(bias + n);
+            if (bias) v += NT == 1 ? bias_pre : *(const f32x4*)(bias + n);
             if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
-            if (res) v += *(const f32x4*)(res + (int64_t)b * ldr + n);
+            if (res) v += NT == 1 ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
             if (OUT_BF16) {
                 u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + n) = p;
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
                 *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
             }
             if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
-                const f32x4 wn = *(const f32x4*)(nrm.w_next + n);
+                const f32x4 wn = NT == 1 ? wn_pre : *(const f32x4*)(nrm.w_next + n);
                 *(u32x2*)((bf16_t*)nrm.xw_out + (int64_t)b * N + n) =
                     u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
                 sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];

@@ -30,7 +30,18 @@ struct QkvRope {
     int B = 0, S = 0, P0 = 0, pos0 = 0, cs_pos0 = 0, H = 0, Smax = 0;
 };
 // Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
-static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
+// qkv_rope_coeffs fetches the (cos, sin) pairs the group needs (zeros for V columns); the decode kernel calls it BEFORE its
+// weight stream so that the table's memory latency is not paid in the tail of every workgroup.
+static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m, int n) {
+    const int D = q.H * 128;
+    const int sec = n / D, p = (n - sec * D) & 127;
+    int pos;
+    if (m < q.P0) pos = m;
+    else { const int r = m - q.P0; const int b = r / q.S; pos = q.pos0 + (r - b * q.S); }
+    if (sec >= 2) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
+}
+static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) {
     const int D = q.H * 128;
     const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
     int b, pos;
@@ -38,7 +49,6 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
     if (m < q.P0) { b = 0; pos = m; prefix = true; }
     else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
     if (sec < 2) {
-        const f32x4 t = *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
         const float a0 = v[0] * t[0] - v[1] * t[1], b0 = v[1] * t[0] + v[0] * t[1];
         const float a1 = v[2] * t[2] - v[3] * t[3], b1 = v[3] * t[2] + v[2] * t[3];
         const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
@@ -57,6 +67,9 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
             for (int r = 0; r < 4; ++r) dst[(int64_t)r * q.Smax] = f32_to_bf16(v[r]);
         }
     }
+}
+static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
+    qkv_rope_store(q, m, n, v, qkv_rope_coeffs(q, m, n));
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
