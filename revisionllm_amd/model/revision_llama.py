@@ -255,21 +255,21 @@ class ReVisionLlamaForCausalLM:
             logits = eng.llm_forward(h, 0, kv, Smax)
 
         seqs = ops.h2d(input_ids, dev, torch.long)
-        unfinished = torch.ones(B, dtype=torch.long, device=dev)
+        unfinished = torch.ones(B, dtype=torch.int32, device=dev)
         raw_steps, score_steps, ent_p, ent_r, new_tokens = [], [], [], [], []
         pos = S
+        if do_sample and uniforms is None and self.uniform_fn is None:
+            uniforms = torch.rand(max_new_tokens, B, device=dev)        # one launch instead of one per step
         for step in range(max_new_tokens):
             if do_sample:
                 if uniforms is not None:
                     u = uniforms[step].contiguous()
-                elif self.uniform_fn is not None:
-                    u = self.uniform_fn(step, B).to(dev).float().contiguous()
                 else:
-                    u = torch.rand(B, device=dev)
+                    u = self.uniform_fn(step, B).to(dev).float().contiguous()
                 o = ops.sample(logits, u, True, temperature, top_k, top_p)
             else:
                 o = ops.sample(logits, None, False)
-            nxt = o["tokens"].long() if forced_tokens is None else forced_tokens[step]
+            nxt = o["tokens"] if forced_tokens is None else forced_tokens[step].int()     # int32 [B]
             ent_p.append(o["entropy_proc"])
             ent_r.append(o["entropy_raw"])
             if output_logits or (output_scores and (not do_sample or self.scores_mode == "raw")):
@@ -280,19 +280,19 @@ class ReVisionLlamaForCausalLM:
                 keep = torch.arange(hip.TOPK_CAP, device=dev)[None] < o["n_keep"][:, None]
                 idx = torch.where(keep, o["topk_idx"], torch.full_like(o["topk_idx"], V)).long()
                 score_steps.append(sc.scatter(1, idx, o["topk_val"])[:, :V].contiguous())
-            nxt = nxt * unfinished + pad * (1 - unfinished)
+            if eos is not None:   # rows that already emitted EOS keep producing the pad id (HF _sample bookkeeping)
+                nxt = nxt * unfinished + pad * (1 - unfinished)
+                unfinished = unfinished * (nxt != eos).int()
             new_tokens.append(nxt)
-            if eos is not None:
-                unfinished = unfinished * (nxt != eos).long()
             if step == max_new_tokens - 1 or (eos is not None and int(unfinished.max()) == 0):   # the only host sync
                 break
             if pos + 1 > Smax:
                 kv, Smax = self._grow_kv(kv, B, Smax, min(S + max_new_tokens, Smax * 2))
-            h1 = eng.splice_embed(nxt.int()[:, None], None)
+            h1 = eng.splice_embed(nxt[:, None], None)
             logits = eng.llm_forward(h1, pos, kv, Smax)
             pos += 1
 
-        seqs = torch.cat([seqs, torch.stack(new_tokens, dim=1)], dim=1)
+        seqs = torch.cat([seqs, torch.stack(new_tokens, dim=1).long()], dim=1)
         if not return_dict_in_generate:
             return seqs
         out = GenerateOutput(sequences=seqs, entropy=torch.stack(ent_p, 1), entropy_raw=torch.stack(ent_r, 1))
