@@ -38,6 +38,9 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
+    p.add_argument("--streams", type=int, default=2,
+                   help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
+                        "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
@@ -246,8 +249,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
+    counter = {"i": 0}
+
     def launch():
-        return parallel.launch_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms, max_new_tokens=args.decode_steps)
+        if streams is None:
+            return parallel.launch_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms, max_new_tokens=args.decode_steps)
+        k = counter["i"] % len(streams)
+        counter["i"] += 1
+        model.engine.slot = k
+        with torch.cuda.stream(streams[k]):
+            return parallel.launch_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms, max_new_tokens=args.decode_steps)
 
     def run(n):
         """n steps.  A step's device work is enqueued before the previous step's record is collected, so the host-side
@@ -257,14 +269,14 @@ def main():
             for _ in range(n):
                 rec = step()
             return rec
-        rec, pending = None, None
+        rec, pending = None, []
+        depth = max(1, args.streams)
         for _ in range(n):
-            nxt = launch()
-            if pending is not None:
-                rec = parallel.collect_query(pending)
-            pending = nxt
-        if pending is not None:
-            rec = parallel.collect_query(pending)
+            pending.append(launch())
+            if len(pending) > depth:
+                rec = parallel.collect_query(pending.pop(0))
+        while pending:
+            rec = parallel.collect_query(pending.pop(0))
         return rec
 
     rec = run(args.warmup)
@@ -300,6 +312,7 @@ def main():
                        "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
                        "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
                        "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
+                       "recursions_in_flight": 1 if args.queries > 1 else max(1, args.streams),
                        "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,

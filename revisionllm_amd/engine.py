@@ -44,6 +44,7 @@ class Engine:
         hip.check(self.lib.rv_ctx_create(C.byref(cfg), C.byref(self._ctx)), "rv_ctx_create")
         self._keep = {}      # name -> tensor (keeps device memory alive while bound)
         self._ws = {}        # workspace cache
+        self.slot = 0        # workspace / KV-pool namespace: one per in-flight call stream (weights are shared, read-only)
         self.has_llm = self.has_clip = self.has_linear = False
 
     def __del__(self):
@@ -139,6 +140,7 @@ class Engine:
 
     # ---- workspaces ------------------------------------------------------------------------------
     def _workspace(self, key, nbytes):
+        key = (self.slot, key)
         t = self._ws.get(key)
         if t is None or t.numel() < nbytes:
             t = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)  # zero: stream-K flags
@@ -149,9 +151,8 @@ class Engine:
         """Raise if a bounded in-kernel wait of the stream-K GEMMs / fused decode kernel ever gave up (a workgroup that never
         arrived would otherwise show up as silently wrong numbers).  The status word sits at int 2047 of the hand-off header
         at the start of every workspace; reading it synchronises, so call it where the host waits for results anyway."""
-        for key in ("llm", "clip"):
-            ws = self._ws.get(key)
-            if ws is not None and ws.numel() >= 8192:
+        for key, ws in list(self._ws.items()):
+            if isinstance(key, tuple) and key[0] != "kv" and key[1] in ("llm", "clip") and ws.numel() >= 8192:
                 st = int(ws[8188:8192].view(torch.int32).item())
                 if st != 0:
                     ws[8188:8192].zero_()
@@ -200,16 +201,32 @@ class Engine:
         """KV cache for B rows x Smax positions (rounded up to 32).  Caches are pooled per (B, Smax): a recycled cache holds
         stale but finite bf16 values, which is all the kernels need beyond the current length (P = 0 there)."""
         Smax = (Smax + 31) // 32 * 32
-        key = ("kv", B, Smax)
+        key = ("kv", self.slot, B, Smax)
         t = self._ws.get(key) if reuse else None
         if t is None:
             nbytes = self.lib.rv_kv_bytes(self._ctx, B, Smax)
             t = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device)
             if reuse:
-                for k_ in [k_ for k_ in self._ws if isinstance(k_, tuple) and k_[0] == "kv"][:-3]:
+                for k_ in [k_ for k_ in self._ws if isinstance(k_, tuple) and k_[0] == "kv" and k_[1] == self.slot][:-3]:
                     del self._ws[k_]   # keep the pool small
                 self._ws[key] = t
         return t, Smax
+
+    # The prefill GEMMs are PERSISTENT kernels: one workgroup per CU, and a workgroup waits in-kernel for the partial tiles of
+    # its panel's other workgroups, so all of a launch's workgroups must become resident.  Two such launches running at once
+    # (calls in flight on different streams) could each hold half the CUs and wait for the other half forever, so prefills are
+    # ordered across streams with an event (device-side wait only; decode steps and the adapter overlap freely).
+    _persist_event = {}
+
+    def _persist_begin(self):
+        ev = Engine._persist_event.get(self.device.index)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def _persist_end(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        Engine._persist_event[self.device.index] = ev
 
     def llm_forward(self, h, pos0, kv, Smax, logits=None):
         """h f32 [B,S,D] (clobbered) -> logits f32 [B,V] of the last position; appends K/V at pos0..pos0+S-1."""
@@ -219,8 +236,12 @@ class Engine:
             logits = torch.empty(B, self.shape.vocab, dtype=torch.float32, device=self.device)
         nbytes = self.lib.rv_llm_ws_bytes(self._ctx, B, S)
         ws = self._workspace("llm", nbytes)
+        if B * S > 16:
+            self._persist_begin()
         hip.check(self.lib.rv_llm_forward(self._ctx, hip.ptr(h), B, S, pos0, hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws),
                                           ws.numel(), hip.stream()), "rv_llm_forward")
+        if B * S > 16:
+            self._persist_end()
         return logits
 
 
@@ -231,8 +252,10 @@ class Engine:
         if logits is None:
             logits = torch.empty(B, self.shape.vocab, dtype=torch.float32, device=self.device)
         ws = self._workspace("llm", self.lib.rv_llm_prefill_shared_ws_bytes(self._ctx, B, P0, S))
+        self._persist_begin()
         hip.check(self.lib.rv_llm_prefill_shared(self._ctx, hip.ptr(h), B, P0, S, hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws),
                                                  ws.numel(), hip.stream()), "rv_llm_prefill_shared")
+        self._persist_end()
         return logits
 
 

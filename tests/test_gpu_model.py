@@ -418,6 +418,44 @@ def test_decode_attention_oproj_fusion_matches_separate_launches(model_7b):
     assert torch.equal(b, torch.stack(again["logits"]))
 
 
+def test_recursions_in_flight_on_two_streams_match_sequential(model_7b):
+    """Three stage-2 recursions launched back to back on alternating HIP streams (workspace slot per stream, weights shared,
+    prefills ordered by an event because their GEMMs are persistent kernels) give exactly the records of running them one
+    at a time on the default stream."""
+    from revisionllm_amd import ops, parallel
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    m = model_7b
+    dev = m.engine.device
+    tok = synth.FakeTokenizer()
+    st = parallel.HipStages(m, tok)
+    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
+    qcs = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "fs.qc", 3, synth.SQRT3)
+    qfs = [ops.init_hash_(torch.empty(12 + i, 768, dtype=torch.bfloat16, device=dev), f"fs.q{i}", 3, synth.SQRT3) for i in range(3)]
+    plan = stage2.plan_groups(100, 100)
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(5))
+    uni = torch.rand(6, len(plan), generator=torch.Generator().manual_seed(6))
+    eos = m.generation_config.eos_token_id
+    m.generation_config.eos_token_id = None            # a configured EOS id makes generate synchronise per step
+    kw = dict(batch=100, perms=perms, uniforms=uni, max_new_tokens=6)
+    try:
+        seq = [parallel.run_query_sharded(st, tok, feat, 100, qfs[i], qcs, f"query {i}", **kw) for i in range(3)]
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        torch.cuda.synchronize()
+        pend = []
+        for i in range(3):
+            m.engine.slot = i % 2
+            with torch.cuda.stream(streams[i % 2]):
+                pend.append(parallel.launch_query_sharded(st, tok, feat, 100, qfs[i], qcs, f"query {i}", **kw))
+        par = [parallel.collect_query(p) for p in pend]
+    finally:
+        m.engine.slot = 0
+        m.generation_config.eos_token_id = eos
+    for a, b in zip(seq, par):
+        assert a["answers"] == b["answers"] and a["max_entropy"] == b["max_entropy"] and a["mean_entropy"] == b["mean_entropy"]
+        assert a["score_cos"] == b["score_cos"]
+
+
 def test_persistent_qkv_rope_epilogue_is_bit_exact():
     """One 7B-shaped layer, the recursion's 7-call shared-prefix prefill (1005 rows): the persistent ping-pong QKV projection
     (192-column panels, fused RoPE + KV-cache append) sums whole panels in the ring kernel's order, so the layer's K and
