@@ -23,5 +23,7 @@ Modules (each function cites the reference file:line it follows):
   sampling   logits processors (temperature / top-k / top-p), token selection, the generate loop
   scores     get_entropy_statistics, _topk_pooling + cosine
   recursion  window cutting, hierarchy groups, answer -> window index mapping, hit test, stage-1 IoU
-  metrics    stage-1 / stage-2 log merge and R@k / mIoU
+  clip_vit   CLIP towers of the feature extractors (ViT image encoder, causal text transformer),
+             pinned by golden g11 from the reference's vendored clip/model.py
+(the metric merge of f-1 is pinned directly by golden g10; there is no oracle module for it)
 """

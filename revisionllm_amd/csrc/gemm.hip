@@ -1,13 +1,15 @@
 // nn.Linear on gfx950: C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, bf16 operands, fp32 accumulate.
 //
-// Two kernels behind rv_gemm():
-//   gemm_tile   M > 16: 128x128x64 tiles, 4 waves (2x2, 64x64 each, 4x4 MFMA 16x16x32 fragments),
-//               operands staged HBM -> LDS with 16-byte global_load_lds (LDS-DMA, no VGPR round trip),
-//               double-buffered; the LDS image is XOR-swizzled through the per-lane SOURCE address
+// Kernels behind rv_gemm() (dispatch in rv_gemm_impl at the end of this file):
+//   gemm_pp / gemm_pp_sk (gemm_pp.hip)  M > 16, long K, few rows: 256x256x64 ping-pong tiles, persistent stream-K - the
+//               prefill projections.
+//   gemm_tile_p4 (+ gemm_tile, gemm_tile_p5)  every other M > 16 problem: 128x128 tiles, 4 waves (2x2, 64x64 each, 4x4 MFMA
+//               16x16x32 fragments), operands staged HBM -> LDS with 16-byte global_load_lds (LDS-DMA, no VGPR round trip)
+//               into a 3-stage ring with counted vmcnt; the LDS image is XOR-swizzled through the per-lane SOURCE address
 //               (LDS-DMA destinations are lane-linear) so ds_read_b128 fragment reads are conflict-free.
 //   gemv_stream M <= 16 (KV-cached decode): weight-streaming; W fragments go HBM -> VGPR directly
-//               (each weight byte is used once, an LDS round trip is pure overhead), 8 waves split K,
-//               cross-wave reduction in LDS.  HBM-bound: algorithmic bytes = N*K*2.
+//               (each weight byte is used once, an LDS round trip is pure overhead), 8 waves split K with a rolling
+//               two-deep k-block pipeline, cross-wave reduction in LDS.  HBM-bound: algorithmic bytes = N*K*2.
 // Weight layout.  W may be row-major [N,K] (w_layout 0) or FRAGMENT-PACKED (w_layout 1, what the engine binds):
 //   Wp[(((n>>4) * (K/32) + (k>>5)) * 64 + lane) * 8 + (k&7)],  lane = (n&15) + 16*((k>>3)&3)
 // i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block in exactly the lane order the
