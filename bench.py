@@ -31,7 +31,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--windows", type=int, default=100, help="windows (segments) per GPU")
     p.add_argument("--frames", type=int, default=256)
