@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--streams", type=int, default=2,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
+    p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
@@ -205,7 +206,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
-    from revisionllm_amd import ops, parallel
+    from revisionllm_amd import hip, ops, parallel
     from revisionllm_amd.eval import stage2
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
@@ -249,6 +250,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    hip.lib().rv_set_gemm_cus(args.gemm_cus)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
 

@@ -88,6 +88,10 @@ size_t rv_gemm_ws_bytes(void);
  * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
  * 3 = register-double-buffered ring; 4 / 5 = ping-pong output-tiled / stream-K wherever supported. */
 void rv_set_gemm_tile_variant(int32_t variant);
+/* Process-wide: number of CUs (multiple of 8; 0 = all) the persistent prefill GEMMs occupy.  Their 128 KiB-LDS workgroups own a
+ * CU each, so a smaller grid leaves whole CUs to the launches of another stream (two recursions in flight: the other one's
+ * HBM-bound decode GEMVs keep streaming on the free CUs while this one's prefill runs on the rest). */
+void rv_set_gemm_cus(int32_t n);
 /* Measurement knob (process-wide): 1 = the KV-cached decode step runs attention + o projection as one launch (the o weights
  * stream while the attention chain runs); 0 (default) = two launches (level on MI355X: the in-kernel hand-off costs what the
  * saved launch gains).  Same results to f32 rounding of the softmax merge. */

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
     }
 }
 
-int pp_num_cus() {
+int g_pp_cus = 0;   // 0 = every CU of the device; otherwise the persistent GEMMs use this many (a multiple of 8)
+int pp_device_cus() {
     static int n = 0;
     if (n == 0) {
         int dev = 0;
@@ -515,6 +516,10 @@ int pp_num_cus() {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     }
     return n;
+}
+int pp_num_cus() {
+    const int n = pp_device_cus();
+    return (g_pp_cus > 0 && g_pp_cus <= n) ? g_pp_cus : n;
 }
 
 template <typename Kern>
@@ -573,7 +578,12 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
 
 }  // namespace
 
-size_t gemm_pp_ws_bytes() { return PP_HDR + (size_t)2 * pp_num_cus() * PARTIAL_F4 * sizeof(f32x4); }
+// The persistent prefill GEMMs may be told to leave CUs free (rv_set_gemm_cus): a 128 KiB-LDS workgroup owns its CU, so with a
+// grid of 192 on a 256-CU device 8 CUs per XCD stay available to whatever another stream launches (the HBM-bound decode
+// GEMVs of a second recursion in flight cannot share a CU with these workgroups: both fill the register file).
+extern "C" void rv_set_gemm_cus(int32_t n) { g_pp_cus = n > 0 ? (n & ~7) : 0; }
+
+size_t gemm_pp_ws_bytes() { return PP_HDR + (size_t)2 * pp_device_cus() * PARTIAL_F4 * sizeof(f32x4); }
 
 bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
     return w_layout == 1 && M > 16 && N % PBN == 0 && K % PBK == 0;
