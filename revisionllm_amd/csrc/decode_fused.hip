@@ -19,7 +19,6 @@
 namespace {
 
 std::atomic<int> g_decode_epoch{0};
-typedef unsigned int df_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SC1 = 16;   // cache-policy bit 4 = sc1 on gfx940+
 constexpr int DH = 128, NC = DH / 32, ND = DH / 16;
 constexpr int MAXKB = 4;  // 128-k blocks per wave held in registers: D <= 8 waves x 4 x 128 = 4096
@@ -258,7 +257,7 @@ int attn_oproj_decode_launch(const void* q16, const void* kc, const void* vtc, v
     RV_CHECK_ARG(q16 && kc && vtc && a16 && wo && h && sync && status, "attn_oproj_decode: null argument");
     RV_CHECK_ARG(attn_oproj_decode_supported(B, H, DH, D) && Lk >= 1 && Lk <= Smax && Smax % 32 == 0, "attn_oproj_decode: bad geometry");
     int cus = 0, dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const int tiles = (int)(D >> 4), units = B * H;
     const int grid = tiles > (units < cus ? units : cus) ? tiles : (units < cus ? units : cus);   // all resident: <= one per CU

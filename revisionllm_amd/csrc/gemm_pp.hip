@@ -512,7 +512,7 @@ int pp_device_cus() {
     static int n = 0;
     if (n == 0) {
         int dev = 0;
-        hipGetDevice(&dev);
+        (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     }
     return n;
