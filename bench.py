@@ -238,48 +238,42 @@ def main():
               for i in range(args.queries)]
         perms_q = [stage2.make_perms(plan, gen) for _ in range(args.queries)]
 
-    def step():
-        if args.queries > 1:
-            return parallel.run_queries_sharded(stages, tok, feats, W, qs, batch=100, perms=perms_q, max_new_tokens=args.decode_steps)[0]
-        return parallel.run_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms,
-                                          max_new_tokens=args.decode_steps)
+    if args.queries <= 1:
+        qs, perms_q = [(qf, qc, sentence)], [perms]
+    hip.lib().rv_set_gemm_cus(args.gemm_cus)
+    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
+    counter = {"i": 0}
+
+    def launch():
+        kw = dict(batch=100, perms=perms_q, max_new_tokens=args.decode_steps)
+        if streams is None:
+            return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
+        k = counter["i"] % len(streams)
+        counter["i"] += 1
+        model.engine.slot = k
+        with torch.cuda.stream(streams[k]):
+            return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
+
+    def run(n):
+        """n steps.  A step's device work is enqueued before the previous steps' records are collected (``--streams`` steps in
+        flight, each on its own HIP stream), so one step's HBM-bound decode launches fill the gaps of the other's MFMA-bound
+        adapter / prefill and the host-side exchange / assembly overlaps device work; every step's work and record are
+        produced inside the timed region."""
+        rec, pending = None, []
+        depth = max(1, args.streams)
+        for _ in range(n):
+            pending.append(launch())
+            if len(pending) > depth:
+                rec = parallel.collect_queries(pending.pop(0))[0]
+        while pending:
+            rec = parallel.collect_queries(pending.pop(0))[0]
+        return rec
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
-
-    hip.lib().rv_set_gemm_cus(args.gemm_cus)
-    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
-    counter = {"i": 0}
-
-    def launch():
-        if streams is None:
-            return parallel.launch_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms, max_new_tokens=args.decode_steps)
-        k = counter["i"] % len(streams)
-        counter["i"] += 1
-        model.engine.slot = k
-        with torch.cuda.stream(streams[k]):
-            return parallel.launch_query_sharded(stages, tok, feats, W, qf, qc, sentence, batch=100, perms=perms, max_new_tokens=args.decode_steps)
-
-    def run(n):
-        """n steps.  A step's device work is enqueued before the previous step's record is collected, so the host-side
-        exchange / assembly of step i overlaps the device work of step i+1 (every step's work and record are still produced
-        inside the timed region; the multi-query mode keeps the plain loop)."""
-        if args.queries > 1:
-            for _ in range(n):
-                rec = step()
-            return rec
-        rec, pending = None, []
-        depth = max(1, args.streams)
-        for _ in range(n):
-            pending.append(launch())
-            if len(pending) > depth:
-                rec = parallel.collect_query(pending.pop(0))
-        while pending:
-            rec = parallel.collect_query(pending.pop(0))
-        return rec
 
     rec = run(args.warmup)
     sync()
@@ -314,7 +308,7 @@ def main():
                        "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
                        "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
                        "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
-                       "recursions_in_flight": 1 if args.queries > 1 else max(1, args.streams),
+                       "steps_in_flight": max(1, args.streams),
                        "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,

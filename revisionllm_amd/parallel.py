@@ -110,98 +110,66 @@ class HipStages:
         self.model.engine.check_handoff_status()
 
 
-def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
-                        max_new_tokens=64, grounding_windows=None, group=None, single=True):
-    """Several queries of ONE movie in one pass: ``queries`` = [(query_feats, query_cls, sentence), ...] over the same
-    windows.  The adapter runs per (window, query); all calls of all queries are dealt over the ranks and batched in the
-    LLM (a decode step streams the weights once for up to 16 calls, so two queries cost barely more than one).
-    ``perms``: one list of permutations per query.  Returns one record per query, identical to running them one by one."""
+class PendingQuery:
+    """A launched, not yet collected pass of one or more recursions (``launch_queries_sharded``)."""
+
+
+def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
+                           max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Enqueue several recursions as ONE pass and return without waiting for the device.
+
+    ``queries`` = [(query_feats, query_cls, sentence), ...]; every recursion runs over the windows ``features_local`` (this
+    rank's block of ``W``; pass a list of per-query feature tensors for recursions over different videos of the same window
+    count).  The adapter runs per (window, query); all calls of all recursions are dealt over the ranks and batched in the LLM:
+    a decode step streams the weights once for up to 16 calls, so two recursions (14 calls) cost barely more than one.
+    ``perms``: one list of permutations per query; ``uniforms`` [G, calls * queries].  Both exchanges, the LLM calls and the
+    device -> pinned-host copies of the proposals are enqueued here, so a driver can launch the next pass before it collects
+    this one.  Stages without ``generate_async`` (CPU stand-ins) and an EOS-terminated generate (which synchronises per step)
+    do their waiting here.  Records (``collect_queries``) are identical to running the recursions one by one."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(W, rank, world)
-    assert features_local.shape[0] == hi - lo, f"rank {rank} must hold windows [{lo},{hi})"
+    feats_of = features_local if isinstance(features_local, (list, tuple)) else [features_local] * len(queries)
+    assert len(feats_of) == len(queries) and all(f.shape[0] == hi - lo for f in feats_of), f"rank {rank} must hold windows [{lo},{hi})"
     zooms = tuple(zooms)
     plan = stage2.plan_groups(W, batch, zooms)
-    nc = len(plan)
+    nc, nq = len(plan), len(queries)
+    if perms is None:
+        raise ValueError("perms must be given (identical on all ranks); use stage2.make_perms with a seeded generator")
+    perms = [[torch.as_tensor(p).long() for p in pq] for pq in perms]
     if grounding_windows is None:
         grounding_windows = list(range(W))
+    dev = feats_of[0].device
+    index = [stage2.call_row_index(plan, perms[qi], dev) for qi in range(nq)]   # host inputs first: no host wait between stages
     rows, prompts, cos_all = [], {}, []
-    index = [stage2.call_row_index(plan, [torch.as_tensor(p).long() for p in perms[qi]], features_local.device)
-             for qi in range(len(queries))]
     for qi, (qf, qc, sentence) in enumerate(queries):
-        cls_local, cos_local = stages.encode(features_local, qf), stages.cosine(features_local, qc)
+        cls_local, cos_local = stages.encode(feats_of[qi], qf), stages.cosine(feats_of[qi], qc)
         if world > 1:
-            cls_local = allgather_rows(cls_local, W, group)
+            cls_local = allgather_rows(cls_local, W, group)          # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
             cos_local = allgather_rows(cos_local[:, None], W, group)[:, 0]
         cos_all.append(cos_local)
         rows.extend(stage2.build_call_rows(cls_local, plan, None, index[qi]))
         for c in range(nc):
             prompts[qi * nc + c] = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
-    mine = deal(nc * len(queries), rank, world)
-    res = stages.generate(prompts, rows, mine, uniforms, max_new_tokens)
-    if world > 1:
-        res = allgather_calls(res, nc * len(queries), max_new_tokens, features_local.device, group)
-    out = []
-    for qi in range(len(queries)):
-        pq = [torch.as_tensor(p).long() for p in perms[qi]]
-        out.append(stage2.assemble(plan, pq, {c: res[qi * nc + c] for c in range(nc)}, cos_all[qi].cpu(), tokenizer, zooms,
-                                   grounding_windows, single))
-    return out
-
-
-class PendingQuery:
-    """A launched, not yet collected recursion (``launch_query_sharded``)."""
-
-
-def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
-                         perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
-    """First half of ``run_query_sharded``: enqueue the whole recursion (adapter, both exchanges, LLM calls, device -> pinned
-    host copies of the proposals) and return without waiting for the device, so a driver can launch the next query before it
-    collects this one (the host-side assembly then overlaps device work).  Stages without ``generate_async`` (CPU stand-ins)
-    and an EOS-terminated generate (which synchronises per step) simply do their waiting here."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    lo, hi = shard_bounds(W, rank, world)
-    assert features_local.shape[0] == hi - lo, f"rank {rank} must hold windows [{lo},{hi})"
-    zooms = tuple(zooms)
-    plan = stage2.plan_groups(W, batch, zooms)
-    if perms is None:
-        raise ValueError("perms must be given (identical on all ranks); use stage2.make_perms with a seeded generator")
-    perms = [torch.as_tensor(p).long() for p in perms]
-    if grounding_windows is None:
-        grounding_windows = list(range(W))
-    query = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
-
-    index = stage2.call_row_index(plan, perms, features_local.device)   # host inputs first: no host wait between stages
-    cls_local = stages.encode(features_local, query_feats)
-    cos_local = stages.cosine(features_local, query_cls)
-    if world > 1:
-        cls = allgather_rows(cls_local, W, group)          # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
-        cos = allgather_rows(cos_local[:, None], W, group)[:, 0]
-    else:
-        cls, cos = cls_local, cos_local
-    rows = stage2.build_call_rows(cls, plan, perms, index)
-    mine = deal(len(plan), rank, world)
+    mine = deal(nc * nq, rank, world)
     p = PendingQuery()
-    p.args = (plan, perms, tokenizer, zooms, grounding_windows, single)
+    p.args = (plan, perms, tokenizer, zooms, grounding_windows, single, nq)
     p.stages = stages
+    cos = torch.stack(cos_all, 0)
     if hasattr(stages, "generate_async"):
         width = min(max_new_tokens, 128)
-        order, tok, ent, nst = stages.generate_async(query, rows, mine, uniforms, max_new_tokens, width)
-        per = -(-len(plan) // world)
+        order, tok, ent, nst = stages.generate_async(prompts, rows, mine, uniforms, max_new_tokens, width)
+        per = -(-(nc * nq) // world)
         # wire: int32 [per, 2 + width] = (call id or -1, produced steps, tokens...) and f32 [per, width] step entropies
-        tw = torch.full((per, 2 + width), -1, dtype=torch.int32, device=cls.device)
-        ew = torch.zeros((per, width), dtype=torch.float32, device=cls.device)
+        tw = torch.full((per, 2 + width), -1, dtype=torch.int32, device=dev)
+        ew = torch.zeros((per, width), dtype=torch.float32, device=dev)
         n = len(order)
         if n:
-            tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), cls.device)
-            nst, tok, ent = nst.to(cls.device), tok.to(cls.device), ent.to(cls.device)
-            tw[:n, 1] = nst
-            tw[:n, 2:] = tok
-            ew[:n] = ent
+            tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), dev)
+            tw[:n, 1], tw[:n, 2:], ew[:n] = nst.to(dev), tok.to(dev), ent.to(dev)
         if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
             tw, ew = _all_gather_cat(tw, group), _all_gather_cat(ew, group)
-        if cls.is_cuda:
+        if dev.type == "cuda":
             p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
             for h, t in zip(p.host, (tw, ew, cos)):
                 h.copy_(t, non_blocking=True)
@@ -210,16 +178,17 @@ def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, quer
         else:                                               # CPU stand-in stages (tests): nothing to wait for
             p.host, p.event = (tw, ew, cos), None
     else:
-        res = stages.generate(query, rows, mine, uniforms, max_new_tokens)
+        res = stages.generate(prompts, rows, mine, uniforms, max_new_tokens)
         if world > 1:
-            res = allgather_calls(res, len(plan), max_new_tokens, cls.device, group)   # exchange 2: proposals
+            res = allgather_calls(res, nc * nq, max_new_tokens, dev, group)   # exchange 2: proposals
         p.res, p.cos = res, cos.cpu()
     return p
 
 
-def collect_query(p):
-    """Second half: wait for the launched recursion and assemble its record (identical on every rank)."""
-    plan, perms, tokenizer, zooms, grounding_windows, single = p.args
+def collect_queries(p):
+    """Second half: wait for the launched pass and assemble one record per recursion (identical on every rank)."""
+    plan, perms, tokenizer, zooms, grounding_windows, single, nq = p.args
+    nc = len(plan)
     if hasattr(p, "event"):
         if p.event is not None:
             p.event.synchronize()
@@ -229,7 +198,28 @@ def collect_query(p):
         p.stages.check()
     else:
         res, cos = p.res, p.cos
-    return stage2.assemble(plan, perms, res, cos, tokenizer, zooms, grounding_windows, single)
+    return [stage2.assemble(plan, perms[qi], {c: res[qi * nc + c] for c in range(nc)}, cos[qi], tokenizer, zooms, grounding_windows, single)
+            for qi in range(nq)]
+
+
+def run_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
+                        max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Several recursions in one pass (see ``launch_queries_sharded``) -> one record per query."""
+    return collect_queries(launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch, zooms, perms, uniforms,
+                                                  max_new_tokens, grounding_windows, group, single))
+
+
+def launch_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
+                         perms=None, uniforms=None, max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """One recursion: ``launch_queries_sharded`` with a single query."""
+    if perms is None:
+        raise ValueError("perms must be given (identical on all ranks); use stage2.make_perms with a seeded generator")
+    return launch_queries_sharded(stages, tokenizer, features_local, W, [(query_feats, query_cls, sentence)], batch, zooms, [perms],
+                                  uniforms, max_new_tokens, grounding_windows, group, single)
+
+
+def collect_query(p):
+    return collect_queries(p)[0]
 
 
 def run_query_sharded(stages, tokenizer, features_local, W, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1),
