@@ -26,6 +26,7 @@
 //   WAR  a unit of stage s is overwritten from slot 8(t+1)+2p on; its last read (tile t, phase <= 2 by either group) was
 //        issued by slot 8t+5 and retired (lgkmcnt(0)) before the barrier ending slot 8t+6.
 #include <atomic>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -140,10 +141,12 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
 
     bf16x8 af[4][2], b0[2][2], b1[2][2];
-    for (int t = 0; t < nks; ++t) {
+    // one k-tile; `more` (another tile follows: its units are issued here) is a compile-time constant so that the steady-state
+    // loop carries no per-phase branches on it - the last tile is peeled
+    auto tile = [&](auto more_c, int t) {
+        constexpr bool more = decltype(more_c)::value;
         char* cur = smem + (t & 1) * STAGE;
         char* nxt = smem + ((t + 1) & 1) * STAGE;
-        const bool more = t + 1 < nks;
         const int k1 = (kt0 + t + 1) * PBK;
 
 #define PP_MFMA(B, NI, MI0, NJ)                                                                                     \
@@ -199,7 +202,9 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         PP_SYNC_M(if (more) wait_vm<VM_N1>())                      // U0, U1 of the next tile
         PP_MFMA(b0, 0, 4, 2);
         PP_SYNC_C(if (more) wait_vm<VM_N1>())
-    }
+    };
+    for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, t);
+    tile(std::false_type{}, nks - 1);
 #undef PP_MFMA
 #undef PP_READ_A
 #undef PP_READ_W
