@@ -143,8 +143,9 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     bf16x8 af[4][2], b0[2][2], b1[2][2];
     // one k-tile; `more` (another tile follows: its units are issued here) is a compile-time constant so that the steady-state
     // loop carries no per-phase branches on it - the last tile is peeled
-    auto tile = [&](auto more_c, int t) {
+    auto tile = [&](auto more_c, auto group_c, int t) {
         constexpr bool more = decltype(more_c)::value;
+        constexpr int grp = decltype(group_c)::value;   // this wave's M-group, a compile-time constant inside the loop
         char* cur = smem + (t & 1) * STAGE;
         char* nxt = smem + ((t + 1) & 1) * STAGE;
         const int k1 = (kt0 + t + 1) * PBK;
@@ -168,12 +169,12 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
         // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
 #define PP_SYNC_M(WAITN)                                   \
-    if (wr == 1) { WAITN; }                                \
+    if constexpr (grp == 1) { WAITN; }                     \
     __builtin_amdgcn_sched_barrier(0);                     \
     __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
 #define PP_SYNC_C(WAITN)                                   \
-    if (wr == 0) { WAITN; }                                \
+    if constexpr (grp == 0) { WAITN; }                     \
     __builtin_amdgcn_sched_barrier(0);                     \
     __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
@@ -203,8 +204,13 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         PP_MFMA(b0, 0, 4, 2);
         PP_SYNC_C(if (more) wait_vm<VM_N1>())
     };
-    for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, t);
-    tile(std::false_type{}, nks - 1);
+    if (wr == 0) {   // the two groups run separate copies of the loop: no wave-uniform branches on the group inside it
+        for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, std::integral_constant<int, 0>{}, t);
+        tile(std::false_type{}, std::integral_constant<int, 0>{}, nks - 1);
+    } else {
+        for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, std::integral_constant<int, 1>{}, t);
+        tile(std::false_type{}, std::integral_constant<int, 1>{}, nks - 1);
+    }
 #undef PP_MFMA
 #undef PP_READ_A
 #undef PP_READ_W
