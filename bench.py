@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--streams", type=int, default=2,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
+    p.add_argument("--fp8-decode", action="store_true",
+                   help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,7 +217,7 @@ def main():
     model.get_model().initialize_vision_modules(SimpleNamespace(
         clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
         adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
-    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True)
+    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode)
     model.generation_config.eos_token_id = None     # forced decode length
     tok = synth.FakeTokenizer()
 
@@ -303,7 +305,7 @@ def main():
             "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
             "value": W * args.queries * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16 (decode weights fp8 e4m3: extra measurement)" if args.fp8_decode else "bf16", "data": "synthetic",
             "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
                        "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
                        "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",

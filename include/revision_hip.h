@@ -83,6 +83,11 @@ int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, floa
  * k-summation is split across workgroups in a fixed order: results are deterministic but differ in the last bits from
  * the output-tiled kernels. */
 size_t rv_gemm_ws_bytes(void);
+/* Decode projection (M <= 16 rows) with FP8 weights: W8 = e4m3fn (OCP) bytes in the fp8 fragment-packed layout
+ * (revisionllm_amd.ops.pack_fragments_fp8), w_scale f32 [N] per-output-row dequantisation scales; everything else as rv_gemm
+ * (act: NONE or SILU_MUL).  Opt-in "fp8 LLM path" (BASELINE.json configs[4]): not what the parity / headline numbers use. */
+int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const float* w_scale, const float* bias, const float* residual,
+                int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
 /* Tuning / measurement knob (process-wide) for packed W.  2 (default) = 128x128x32 3-stage LDS ring kernel plus the
  * 256x256x64 ping-pong kernel where it pays (stream-K for few-row deep-K problems when ws is given, output-tiled for
  * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
@@ -96,6 +101,9 @@ void rv_set_gemm_cus(int32_t n);
  * stream while the attention chain runs); 0 (default) = two launches (level on MI355X: the in-kernel hand-off costs what the
  * saved launch gains).  Same results to f32 rounding of the softmax merge. */
 void rv_set_decode_fusion(int32_t on);
+/* 1 (default): KV-cached decode steps stream the FP8 weight copies when all of them are bound ("<name>.f8" / "<name>.s8" next
+ * to every LLM projection and lm_head, see Engine.load_llm(fp8_decode=True)); 0: always decode on the bf16 weights. */
+void rv_set_fp8_decode(int32_t on);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);

@@ -137,3 +137,26 @@ def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=N
         h = h[:, -1:]
     h = rmsnorm(h, w["model.norm.weight"], cfg.eps)
     return F.linear(h, w["lm_head.weight"])
+
+
+def fp8_rows(w):
+    """Per-row symmetric FP8 (e4m3fn, OCP) fake quantisation: w -> q * scale with scale = max|row| / 448 (float64 divisions,
+    one rounding to f32 for the scale), q rounded to e4m3fn.  Mirrors the build's opt-in FP8 decode weights (there is no
+    reference counterpart: BASELINE.json configs[4] names an fp8 LLM path, the reference runs bf16 / fp16)."""
+    wd = w.double()
+    amax = wd.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).float()
+    q = (wd / scale.double()[:, None]).float().to(torch.float8_e4m3fn)
+    return q.float() * scale[:, None]
+
+
+def fp8_decode_weights(w, cfg: LlamaCfg):
+    """Copy of the weight dict whose projections and lm_head are FP8-fake-quantised (embeddings and norms untouched)."""
+    out = dict(w)
+    names = ["lm_head.weight"]
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}."
+        names += [p + f"self_attn.{n}_proj.weight" for n in "qkvo"] + [p + f"mlp.{n}_proj.weight" for n in ("gate", "up", "down")]
+    for n in names:
+        out[n] = fp8_rows(w[n])
+    return out

@@ -58,12 +58,14 @@ def select_token(scores, uniform=None):
 
 def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_kw, do_sample=False,
              temperature=1.0, top_k=0, top_p=1.0, max_new_tokens=8, eos_token_id=2, pad_token_id=0,
-             uniforms=None, forced_tokens=None, n_layers=None):
+             uniforms=None, forced_tokens=None, n_layers=None, w_llm_decode=None):
     """The generate loop as driven by inference.py:45-59.
 
     Returns dict(sequences [B,P+G], logits list of G [B,V] raw, scores list of G [B,V] processed).
     ``forced_tokens`` [G,B] teacher-forces the continuation (used to compare per-step logits on
     random-init models where free-running tokens would diverge on near-ties).
+    ``w_llm_decode``: weights used by the KV-cached decode steps instead of ``w_llm`` (the build's opt-in FP8 decode path:
+    ``oracle.llama.fp8_decode_weights``); the prefill always uses ``w_llm``.
     """
     feats = _adapter.encode_images(images, w_adapter, query_feats, **adapter_kw)
     embeds, mask, pos, _ = _splice.splice(input_ids, list(feats), w_llm["model.embed_tokens.weight"])
@@ -88,5 +90,5 @@ def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_k
             break
         mask, p1 = _splice.decode_step_inputs(mask, cache.seq_len())
         e1 = w_llm["model.embed_tokens.weight"][nxt][:, None]
-        logits = _llama.forward(e1, w_llm, cfg, mask, p1, cache, n_layers=n_layers)[:, -1]
+        logits = _llama.forward(e1, w_llm if w_llm_decode is None else w_llm_decode, cfg, mask, p1, cache, n_layers=n_layers)[:, -1]
     return {"sequences": seqs, "logits": raw, "scores": proc}

@@ -21,6 +21,9 @@ struct AdapterLayer {
 struct LlmLayer {
     const bf16_t *wqkv, *wo, *wgu, *wdown;
     const float *norm1, *norm2;
+    // optional FP8 copies for the decode kernels ("<name>.f8" e4m3fn bytes, "<name>.s8" per-row scales); all or none
+    const uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *wgu8 = nullptr, *wdown8 = nullptr;
+    const float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sdown = nullptr;
 };
 
 struct rv_ctx {
@@ -34,6 +37,9 @@ struct rv_ctx {
     std::vector<LlmLayer> layers;
     const bf16_t *embed = nullptr, *lm_head = nullptr;
     const float* final_norm = nullptr;
+    const uint8_t* lm_head8 = nullptr;   // FP8 decode copies bound for every projection -> fp8_decode
+    const float* slm_head = nullptr;
+    bool fp8_decode = false;
 };
 
 namespace {
@@ -121,6 +127,24 @@ int resolve_llm(rv_ctx* c) {
         FIND(p + "norm1", RV_F32, D, L.norm1);
         FIND(p + "norm2", RV_F32, D, L.norm2);
         c->layers.push_back(L);
+    }
+    // FP8 decode path: used when the copies of ALL projections are bound
+    c->fp8_decode = c->w.count("llm.lm_head.f8") != 0;
+    if (c->fp8_decode) {
+        FIND("llm.lm_head.f8", RV_U8, V * D, c->lm_head8);
+        FIND("llm.lm_head.s8", RV_F32, V, c->slm_head);
+        for (int l = 0; l < g.layers; ++l) {
+            const std::string p = "llm.L" + std::to_string(l) + ".";
+            LlmLayer& L = c->layers[l];
+            FIND(p + "wqkv.f8", RV_U8, 3 * D * D, L.wqkv8);
+            FIND(p + "wqkv.s8", RV_F32, 3 * D, L.sqkv);
+            FIND(p + "wo.f8", RV_U8, D * D, L.wo8);
+            FIND(p + "wo.s8", RV_F32, D, L.so);
+            FIND(p + "wgu.f8", RV_U8, 2 * F * D, L.wgu8);
+            FIND(p + "wgu.s8", RV_F32, 2 * F, L.sgu);
+            FIND(p + "wdown.f8", RV_U8, D * F, L.wdown8);
+            FIND(p + "wdown.s8", RV_F32, D, L.sdown);
+        }
     }
     c->resolved_llm = true;
     return RV_OK;
@@ -375,6 +399,8 @@ extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
 // weight stream are paid back by the in-kernel hand-off (sc1 store -> flag -> poll -> sc1 loads: three memory round trips),
 // so it is OFF by default and kept tested.
 int g_fuse_decode_attn = 0;
+int g_use_fp8_decode = 1;   // measurement knob: 0 = ignore bound FP8 copies (decode on the bf16 weights)
+extern "C" void rv_set_fp8_decode(int32_t on) { g_use_fp8_decode = on != 0; }
 extern "C" void rv_set_decode_fusion(int32_t on) { g_fuse_decode_attn = on != 0; }
 
 namespace {
@@ -401,7 +427,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // Decode steps (M <= 16) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
     const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
-    const bool fuse_attn = fuse_norm && g_fuse_decode_attn && attn_oproj_decode_supported(B, H, dh, D) && w.sk_bytes >= 8192;
+    const bool f8 = fuse_norm && c->fp8_decode && g_use_fp8_decode;   // FP8 weight copies: KV-cached decode steps only
+    const bool fuse_attn = !f8 && fuse_norm && g_fuse_decode_attn && attn_oproj_decode_supported(B, H, dh, D) && w.sk_bytes >= 8192;
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
     GemvNorm consume;
     consume.in_sumsq = w.ss;
@@ -420,7 +447,13 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.kc = kc;
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
-        RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, w.sk, w.sk_bytes, st));
+        if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
+            GemvNorm cq = (fuse_norm && l > 0) ? consume : GemvNorm{};
+            cq.w_scale = L.sqkv;
+            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv8, M, D, qr, &cq, nullptr, 0, st, 2));
+        } else {
+            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, w.sk, w.sk_bytes, st));
+        }
         bool prefix_done = false;
         if (P0 > 0) {
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
@@ -448,15 +481,34 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                        (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
             if (!prefix_done) RV_TRY(k_attention(a, st));
-            RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
-                                fuse_norm ? &produce : nullptr));
+            if (f8) {
+                GemvNorm po = produce;
+                po.w_scale = L.so;
+                RV_TRY(rv_gemm_impl(w.a16, D, L.wo8, D, 2, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, nullptr, 0, st, &po));
+            } else {
+                RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
+                                    fuse_norm ? &produce : nullptr));
+            }
         }
         if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
-        RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
-                            fuse_norm ? &consume : nullptr));
         produce.w_next = l + 1 < g.layers ? c->layers[l + 1].norm1 : c->final_norm;
-        RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st,
-                            fuse_norm ? &produce : nullptr));
+        if (f8) {
+            GemvNorm cg = consume, pd = produce;
+            cg.w_scale = L.sgu;
+            pd.w_scale = L.sdown;
+            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu8, D, 2, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, 0, st, &cg));
+            RV_TRY(rv_gemm_impl(w.act16, F, L.wdown8, F, 2, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, nullptr, 0, st, &pd));
+        } else {
+            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
+                                fuse_norm ? &consume : nullptr));
+            RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st,
+                                fuse_norm ? &produce : nullptr));
+        }
+    }
+    if (f8 && g.layers > 0) {
+        GemvNorm cl = consume;
+        cl.w_scale = c->slm_head;
+        return rv_gemm_impl(w.xn16, D, c->lm_head8, D, 2, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, nullptr, 0, st, &cl);
     }
     if (fuse_norm && g.layers > 0)  // S == 1: every row is a last position; xn16 already holds w_final * h, ss its squares
         return rv_gemm_impl(w.xn16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st,

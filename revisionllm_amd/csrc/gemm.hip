@@ -507,15 +507,46 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
 // before the first MFMA.  Lane (r = lane & 15, kg = lane >> 4) holds W[n0 + r][k] and x[r][k] for
 // k = kb*128 + j*32 + kg*8 .. +8, j = 0..3 - the native 16x16x32 operand layout, no cross-lane movement.
 // Every weight byte is read exactly once (non-temporal: it will not be re-used before the next step).
+// WP: 0 row-major bf16, 1 fragment-packed bf16, 2 fragment-packed FP8 (e4m3fn, OCP) with a per-row scale: element (n, k) at
+//   ((( (n>>4) * (K/64) + (k>>6) ) * 64 + (n&15) + 16*((k>>3)&3)) * 16 + ((k>>5)&1) * 8 + (k&7)) bytes
+// i.e. a lane's 16-byte load holds its MFMA operand of TWO consecutive 32-k blocks; the bytes are widened to bf16 in
+// registers (exact: e4m3 has 3 mantissa bits) right before the MFMA - the decode step is HBM-bound, the weights move as
+// half the bytes and the arithmetic stays bf16 x bf16 -> f32.
+template <int WP> struct GemvW { typedef bf16x8 frag[4]; };
+template <> struct GemvW<2> { typedef u32x4 frag[2]; };
+
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    union { bf16x8 v; unsigned u[4]; } r;   // f32 -> bf16 by truncation (the value came from 8 bits)
+    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
+    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
+    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
+    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
+    return r.v;
+}
+
 template <int NT, int WP>
-__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* xp, int kb, bf16x8 (&wf)[NT][4], bf16x8 (&xf)[4]) {
+__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* xp, int kb, typename GemvW<WP>::frag (&wf)[NT], bf16x8 (&xf)[4]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        if constexpr (WP == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + (WP ? (kb * 4 + j) * 512 : kb * 128 + j * 32)));
+            for (int h = 0; h < 2; ++h) wf[t][h] = __builtin_nontemporal_load((const u32x4*)((const char*)wp[t] + (kb * 2 + h) * 1024));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + (WP ? (kb * 4 + j) * 512 : kb * 128 + j * 32)));
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + kb * 128 + j * 32);
+}
+template <int WP>
+__device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, int j) {
+    if constexpr (WP == 2) return fp8x8_to_bf16x8(w[j >> 1][(j & 1) * 2], w[j >> 1][(j & 1) * 2 + 1]);
+    else return w[j];
 }
 
 template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2>
@@ -559,7 +590,11 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     const bf16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (WP) {
+        if (WP == 2) {   // fp8: one 16-row n-block = K/64 chunks of 1 KiB
+            int nt = (n0 >> 4) + t;
+            nt = nt < (N >> 4) ? nt : (N >> 4) - 1;
+            wp[t] = (const bf16_t*)((const char*)W + ((int64_t)nt * (K >> 6) * 64 + lane) * 16);
+        } else if (WP) {
             int nt = (n0 >> 4) + t;
             nt = nt < (N >> 4) ? nt : (N >> 4) - 1;
             wp[t] = W + (int64_t)nt * (K >> 5) * 512 + lane * 8;
@@ -579,7 +614,8 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     // drains to zero between batches, and with all workgroups of a short launch in lock-step the HBM queue empties with it).
     // DEPTH = 2 everywhere: 4 was measured slower on the N = 4096 projections (down 16.8 -> 18.2 us) and level elsewhere.
     {
-        bf16x8 wf[DEPTH][NT][4], xf[DEPTH][4];
+        typename GemvW<WP>::frag wf[DEPTH][NT];
+        bf16x8 xf[DEPTH][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (kb + 8 * d < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * d, wf[d], xf[d]);
@@ -590,7 +626,7 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][t][j], xf[d][j], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemv_frag<WP>(wf[d][t], j), xf[d][j], acc[t], 0, 0, 0);
                     if (kb + 8 * (d + DEPTH) < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * (d + DEPTH), wf[d], xf[d]);
                 }
             }
@@ -616,6 +652,13 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
         for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
     }
     const int b = fr;  // batch row
+    if constexpr (WP == 2) {   // fp8 weights: per-output-row scale (the lane owns rows n0 + t * 16 + kg * 4 .. + 3)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 16 + kg * 4;
+            if (n < N) s[t] *= *(const f32x4*)(nrm.w_scale + n);
+        }
+    }
     if (nrm.in_sumsq) {
         float tot = 0.f;
 #pragma unroll
@@ -734,8 +777,8 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
                  (long long)K);
     RV_CHECK_ARG(K % 64 == 0, "rv_gemm: K=%lld must be a multiple of 64", (long long)K);
     RV_CHECK_ARG(N % 4 == 0 && lda % 8 == 0 && ldc % 4 == 0, "rv_gemm: alignment (N%%4, lda%%8, ldc%%4)");
-    RV_CHECK_ARG(w_layout == 0 || w_layout == 1, "rv_gemm: w_layout must be 0 (row-major) or 1 (fragment-packed)");
-    RV_CHECK_ARG(w_layout == 1 ? (N % 16 == 0) : (ldw % 8 == 0), "rv_gemm: packed W needs N%%16==0; row-major W needs ldw%%8==0");
+    RV_CHECK_ARG(w_layout >= 0 && w_layout <= 2, "rv_gemm: w_layout must be 0 (row-major), 1 (fragment-packed) or 2 (fp8 fragment-packed)");
+    RV_CHECK_ARG(w_layout != 0 ? (N % 16 == 0) : (ldw % 8 == 0), "rv_gemm: packed W needs N%%16==0; row-major W needs ldw%%8==0");
     RV_CHECK_ARG(out_dtype == RV_BF16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
     RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_QUICK_GELU, "rv_gemm: bad activation %d", act);
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || (N % 32 == 0 && !bias && !residual),
@@ -744,8 +787,19 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
-    RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion is only available in the M <= 16 kernel");
+    RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion / fp8 weights are only available in the M <= 16 kernel");
     const GemvNorm nrm = norm ? *norm : GemvNorm{};
+    if (w_layout == 2) {   // fp8 weights: the weight-streaming kernel only (decode), scales ride in the norm descriptor
+        RV_CHECK_ARG(gemv && nrm.w_scale, "rv_gemm: fp8 weights need M <= 16, K %% 128 == 0 and per-row scales");
+        const int ob8 = out_dtype == RV_BF16;
+#define RV_GEMV8(OB, AC) launch_gemv<OB, AC, 2>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st, nrm)
+        if (act == RV_ACT_SILU_MUL) { if (ob8) RV_GEMV8(1, RV_ACT_SILU_MUL); else RV_GEMV8(0, RV_ACT_SILU_MUL); }
+        else if (act == RV_ACT_NONE) { if (ob8) RV_GEMV8(1, RV_ACT_NONE); else RV_GEMV8(0, RV_ACT_NONE); }
+        else { rv_set_error("rv_gemm: fp8 weights support no activation or SILU_MUL"); return RV_ERR_ARG; }
+#undef RV_GEMV8
+        RV_CHECK_LAUNCH("rv_gemm (fp8 weights)");
+        return RV_OK;
+    }
     if (!gemv && gemm_pp_supported(w_layout, M, N, K)) {
         // 256x256 ping-pong kernel (gemm_pp.hip): persistent stream-K for few-row, deep-K problems (the o / down projections
         // of the prefill), output-tiled when the tile count fills the CUs; everything else stays on the 128x128 ring kernel
@@ -783,16 +837,21 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  void* ws, size_t ws_bytes, hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout) {
     RV_CHECK_ARG(A && Wp && r.cs && r.q16 && r.kc && r.vtc, "gemm_qkv_rope: null argument");
     RV_CHECK_ARG(D % 128 == 0 && D == (int64_t)r.H * 128 && M == (int64_t)r.P0 + (int64_t)r.B * r.S, "gemm_qkv_rope: bad geometry");
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)Wp;
     const int N = (int)(3 * D), K = (int)D;
-    if (M <= 16) {
+    if (M <= 16 && w_layout == 2) {
+        RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");
+        hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                           nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
+    } else if (M <= 16) {
         hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                            nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
     } else {
+        RV_CHECK_ARG(w_layout == 1, "gemm_qkv_rope: the prefill path takes bf16 fragment-packed weights");
         RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
         const bool sk = ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(1, M, N, K);
         if (sk && (g_tile_variant == 5 || (g_tile_variant == 2 && gemm_pp_sk_plan(M, N, K, false) != 0)))
@@ -816,4 +875,14 @@ extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, i
                        int64_t K, void* ws, size_t ws_bytes, void* stream) {
     return rv_gemm_impl(A, lda, W, ldw, w_layout, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, ws_bytes,
                         as_stream(stream));
+}
+
+// Decode projection with FP8 (e4m3fn) fragment-packed weights and per-output-row scales (opt-in "fp8 LLM path": half the
+// weight bytes per decode step; activations, accumulation and every epilogue stay bf16 / f32).  M <= 16, K % 128 == 0.
+extern "C" int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const float* w_scale, const float* bias, const float* residual,
+                           int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream) {
+    RV_CHECK_ARG(w_scale, "rv_gemv_fp8: null scales");
+    GemvNorm nrm;
+    nrm.w_scale = w_scale;
+    return rv_gemm_impl(A, lda, W8, K, 2, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, nullptr, 0, as_stream(stream), &nrm);
 }

@@ -14,6 +14,7 @@ struct GemvNorm {
     void* xw_out = nullptr;           // bf16 [M, N] (row stride N): w_next[n] * h[b,n]
     const float* w_next = nullptr;    // [N] norm weight of the consumer
     float* out_sumsq = nullptr;       // [gridDim.x][16]
+    const float* w_scale = nullptr;   // fp8 weights (w_layout 2): per-output-row dequantisation scale [N]
 };
 
 // Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
@@ -73,7 +74,7 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  void* ws, size_t ws_bytes, hipStream_t st);
+                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout = 1);
 
 // ws: optional zero-initialised stream-K workspace (>= gemm_pp_ws_bytes()); NULL -> output-tiled kernels only
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,

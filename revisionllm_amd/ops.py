@@ -58,6 +58,44 @@ def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_AC
     return out
 
 
+FP8_MAX = 448.0   # largest finite e4m3fn value
+
+
+def quantize_rows_fp8(w):
+    """Per-row symmetric FP8 (e4m3fn, OCP) quantisation of a [N,K] matrix: -> (q float8_e4m3fn [N,K], scale f32 [N]) with
+    w ~ q * scale[:, None], scale = max|row| / 448 (1 for an all-zero row)."""
+    w = w.double()            # float64 divisions are correctly rounded on host and device alike: the same bits everywhere
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax)).float()
+    q = (w / scale.double()[:, None]).float().to(torch.float8_e4m3fn)
+    return q, scale.contiguous()
+
+
+def pack_fragments_fp8(w):
+    """[N,K] (any float dtype; N % 16 == 0, K % 64 == 0) -> (uint8 [N*K] in the FP8 fragment-packed layout of the decode
+    kernel, f32 [N] row scales).  Byte of element (n, k): (((n>>4)*(K/64) + (k>>6))*64 + (n&15) + 16*((k>>3)&3))*16 +
+    ((k>>5)&1)*8 + (k&7): a lane's 16-byte load carries its MFMA operand of two consecutive 32-k blocks."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 64 == 0
+    q, scale = quantize_rows_fp8(w)
+    b = q.view(torch.uint8).view(N // 16, 16, K // 64, 2, 4, 8)           # (nb, r, kc, half, kq, e)
+    packed = b.permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)            # (nb, kc, kq, r, half, e): lane = kq * 16 + r
+    return packed, scale
+
+
+def gemv_fp8(a, w8, scale, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None):
+    """Decode projection (M <= 16) with FP8 fragment-packed weights: act(a @ (q * scale).T + bias) + residual."""
+    M, K = a.shape
+    N = scale.numel()
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
+    hip.check(hip.lib().rv_gemv_fp8(hip.ptr(a), a.stride(0), hip.ptr(w8), hip.ptr(scale), hip.ptr(bias), hip.ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0), hip.dtype_code(out),
+                                    act, M, N, K, hip.stream()), "rv_gemv_fp8")
+    return out
+
+
 def layernorm(x, w, b, pos=None, period=0, want=("f32", "bf16")):
     rows, d = x.shape
     y32 = torch.empty_like(x) if "f32" in want else None

@@ -125,6 +125,31 @@ def test_gemm_quick_gelu_epilogue(dev, M, N, K):
         hip.lib().rv_set_gemm_tile_variant(2)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(7, 4096, 4096, 0), (1, 12288, 4096, 0), (16, 4096, 11008, 0), (7, 22016, 4096, 2), (3, 512, 1408 // 128 * 128, 0)])
+def test_gemv_fp8_weights(dev, M, N, K, act):
+    """Decode projection with FP8 (e4m3fn) fragment-packed weights + per-row scales against the same quantised weights in
+    float64: the only differences are bf16 inputs (exact) and f32 accumulation."""
+    from revisionllm_amd import hip, ops
+    a = bf(feats(f"f8.a.{M}.{K}", (M, K), bf16=True))
+    w = feats(f"f8.w.{N}.{K}", (N, K)) * (1.0 / math.sqrt(K))
+    q, scale = ops.quantize_rows_fp8(w)
+    wdq = q.float().double() * scale.double()[:, None]
+    ref = a.double() @ wdq.t()
+    w8, sc = ops.pack_fragments_fp8(w.to(dev))
+    assert torch.equal(sc.cpu(), scale)
+    if act == hip.RV_ACT_SILU_MUL:
+        r3 = ref.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
+        y = ops.gemv_fp8(a.to(dev), w8, sc, act=act, out_dtype=torch.float32)
+        assert rel_err(y.cpu(), ref) < F32_TOL * 5
+    else:
+        res = feats(f"f8.r.{M}.{N}", (M, N))
+        y = ops.gemv_fp8(a.to(dev), w8, sc, residual=res.to(dev), out_dtype=torch.float32)
+        assert rel_err(y.cpu(), ref + res.double()) < F32_TOL * 5
+        yb = ops.gemv_fp8(a.to(dev), w8, sc, out_dtype=torch.bfloat16)
+        assert rel_err(yb.float().cpu(), ref) < BF16_TOL
+
+
 def test_gemm_strided_rows_and_inplace_residual(dev):
     from revisionllm_amd import ops
     x = bf(feats("gemm.s", (20, 5, 768), bf16=True)).to(dev)

@@ -84,6 +84,43 @@ def test_generate_vs_reference_golden_and_oracle(golden, tag):
     assert rel_err(out["entropy_raw"].t().cpu(), _entropy(want)) < 2e-3
 
 
+def test_fp8_decode_weights_vs_oracle_with_the_same_quantisation():
+    """Opt-in FP8 decode path: KV-cached decode steps stream e4m3fn copies of every projection (per-row scales); the oracle
+    runs its decode steps on the same fake-quantised weights, so the comparison is as tight as the bf16 path's.  Prefill is
+    untouched (same first-step logits as the bf16 engine), and the knob switches the copies off again."""
+    from oracle import llama, sampling
+    from revisionllm_amd import hip
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    args = _args()
+    m = ReVisionLlamaForCausalLM(shape, device="cuda:0")
+    m.get_model().initialize_vision_modules(args)
+    m.engine.init_synthetic(seed=SEED, fp8_decode=True)
+    m.generation_config.eos_token_id = None
+    ids = T(synth.synthetic_prompt_ids(40, 20, 1, vocab=shape.vocab))[None]
+    feat = feats("f8.feat", (1, 12, 32, 768))
+    q = (feats("f8.q", (1, 6, 768)), torch.ones(1, 6))
+    forced = torch.randint(3, shape.vocab, (5, 1), generator=torch.Generator().manual_seed(2))
+    kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=5, return_dict_in_generate=True, output_logits=True,
+              forced_tokens=forced)
+    got = torch.stack(m.generate(ids, **kw)["logits"]).cpu()
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    w, wa = _oracle_weights(shape, True)
+    fb, qb = feat.to(torch.bfloat16).float(), (q[0].to(torch.bfloat16).float(), q[1])
+    ok = dict(adapter_kw=dict(clip_adapter=True, hierarchy=True), max_new_tokens=5, eos_token_id=-1, forced_tokens=forced)
+    want8 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, w_llm_decode=llama.fp8_decode_weights(w, cfg), **ok)["logits"])
+    want16 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, **ok)["logits"])
+    assert rel_err(got, want8) < 3e-2
+    assert rel_err(got[1:], want8[1:]) < rel_err(got[1:], want16[1:])          # it really is the quantised weights that ran
+    try:
+        hip.lib().rv_set_fp8_decode(0)
+        off = torch.stack(m.generate(ids, **kw)["logits"]).cpu()
+    finally:
+        hip.lib().rv_set_fp8_decode(1)
+    assert torch.equal(off[0], got[0]) and rel_err(off, want16) < 3e-2
+
+
 def _entropy(logits):
     p = torch.softmax(logits.float(), -1)
     return -(p * torch.log(p + 1e-10)).sum(-1)

@@ -60,7 +60,14 @@ def main():
                     ops.gemm(x, ws[st["i"] % len(ws)], out=out, act=act, w_packed=True)
                     st["i"] += 1
                 us = timeit(f, iters=40, warm=4)
-                print(f"gemv {name:7s} M={M:2d} N={N} K={K}: {us:7.1f} us  {2.0*N*K/us/1e3:7.0f} GB/s")
+                w8s = [ops.pack_fragments_fp8((torch.randn(N, K, device=dev) * 0.02)) for _ in range(max(2, int(6e8 // (N * K))))]
+
+                def f8():
+                    w8, sc = w8s[st["i"] % len(w8s)]
+                    ops.gemv_fp8(x, w8, sc, out=out, act=act)
+                    st["i"] += 1
+                us8 = timeit(f8, iters=40, warm=4)
+                print(f"gemv {name:7s} M={M:2d} N={N} K={K}: {us:7.1f} us  {2.0*N*K/us/1e3:7.0f} GB/s | fp8 weights {us8:7.1f} us {1.0*N*K/us8/1e3:7.0f} GB/s")
     if "attn" in which:
         for B, Lq, Lk, H, dh, causal, q0 in ((7, 151, 151, 32, 128, True, 0), (7, 1, 158, 32, 128, True, 157), (100, 257, 257, 8, 96, False, 0)):
             q = torch.randn(B, Lq, H, dh, device=dev).to(torch.bfloat16)
