@@ -228,6 +228,7 @@ def main():
     qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "bench.qcls", args.seed, synth.SQRT3)
     plan = stage2.plan_groups(W, 100)
     gen = torch.Generator().manual_seed(args.seed)
+    torch.manual_seed(args.seed)                    # the device-side sampling draws (torch.rand in generate)
     perms = stage2.make_perms(plan, gen)
     # 20 words: with the v1 template the prompt is P = 72 ids, i.e. prefill length S = 171 per call
     sentence = ("a person opens the door and walks into the kitchen while another person is sitting at the table "
@@ -317,7 +318,7 @@ def main():
                          "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"],
                          "other": {k: {"achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
                                        "avg_launch_ms": v["ms"]} for k, v in legs.items()}},
-            "answers_sample": rec["answers"][:2],
+            "answers_sample": rec["answers"][:2] if not os.environ.get("REVISION_BENCH_ALL_ANSWERS") else rec["answers"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, len(plan), int(P))

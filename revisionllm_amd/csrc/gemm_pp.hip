@@ -11,20 +11,17 @@
 //     part"), and vice versa, so each SIMD always has one wave in its MFMA burst.
 //   * a k-tile (64) is four phases, one per 64 x 32 quadrant of the wave's outputs: (m0,n0) (m0,n1) (m1,n1) (m1,n0); the
 //     register sub-tiles are loaded once per phase (12 / 4 / 8 / 0 ds_read_b128) and the n0 fragments stay resident.
-//   * two LDS stages of four 16 KiB UNITS, ordered by first use: U0 = A rows of the m0 quadrants (both groups),
-//     U1 = W columns of the n0 quadrants (all four wave columns), U2 = W n1, U3 = A m1.  Phase p of tile t issues unit
-//     U_p of tile t+1 (2 LDS-DMA pieces of 1 KiB per wave) into the other stage, whose unit U_p was last read a whole
-//     tile earlier.  Loads therefore stay in flight across every barrier: the only waits are COUNTED (vmcnt(4): the two
-//     youngest units may still be in flight), placed before the barrier that precedes the first read of the unit.
+//   * the operands live in LDS as 16 KiB UNITS ordered by first use: U0 = A rows of the m0 quadrants (both groups),
+//     U1 = W columns of the n0 quadrants (all four wave columns), U2 = W n1, U3 = A m1; two A stages and THREE W stages
+//     (all 160 KiB).  Every phase issues one unit (2 LDS-DMA pieces of 1 KiB per wave): the A units of tile t+1, the W
+//     units of tile t+2 (the weights come cold from HBM and get twice the latency budget).  Loads stay in flight across
+//     every barrier: the only waits are COUNTED vmcnt, placed before the barrier that precedes the first read of a unit
+//     (schedule and hazard table at pp_mainloop).
 //   * A is staged in full 128-byte rows (8 rows per 1 KiB piece) with the 16-byte chunks XOR-swizzled by (row & 7) through
 //     the per-lane SOURCE address (LDS-DMA destinations are lane-linear); W pieces are MFMA fragments already.  Both are
 //     read back with conflict-free ds_read_b128.
-//
-// Hazards (slots = barrier-to-barrier intervals; group 0 runs memory part of phase k in slot 2k, group 1 in slot 2k+1):
-//   RAW  a unit is read in slot >= 2k only after every wave waited for its own pieces of it before the barrier ending
-//        slot 2k-1;
-//   WAR  a unit of stage s is overwritten from slot 8(t+1)+2p on; its last read (tile t, phase <= 2 by either group) was
-//        issued by slot 8t+5 and retired (lgkmcnt(0)) before the barrier ending slot 8t+6.
+//   * slots = barrier-to-barrier intervals; group 0 runs the memory part of phase k in slot 2k, group 1 in slot 2k+1.  RAW: a
+//     unit is read in slot >= 2k only after every wave waited for its own pieces of it before the barrier ending slot 2k-1.
 #include <atomic>
 #include <type_traits>
 
@@ -39,8 +36,7 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int UNIT = 128 * 128;      // bytes: 128 rows (or W columns) x 64 k x bf16
-constexpr int STAGE = 4 * UNIT;      // U0 = A m0 | U1 = W n0 | U2 = W n1 | U3 = A m1
-constexpr int PP_LDS = 2 * STAGE;    // 128 KiB
+constexpr int PP_LDS = 10 * UNIT;    // 160 KiB: two A stages (U0 = A m0 | U3 = A m1) + three W stages (U1 = W n0 | U2 = W n1)
 
 struct PpSrc {
     const char* A;        // uniform bases; the per-lane parts are 32-bit byte offsets (operands are < 4 GiB), which keeps the
@@ -86,10 +82,11 @@ __device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ 
     }
 }
 
-// Issue unit U (0..3) of the k-tile at element offset k0 into `stage`.  Every wave issues 2 pieces of 1 KiB.
+// Issue unit U (0..3) of the k-tile at element offset k0 into LDS at `dst0` (the unit's base).  Every wave issues 2 pieces of
+// 1 KiB (1 piece for the one-fragment n1 unit of NF = 3).
 template <int U, int NF>
-__device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* stage, int wave) {
-    char* dst = stage + U * UNIT + wave * 2048;
+__device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* dst0, int wave) {
+    char* dst = dst0 + wave * 2048;
     const char* ab = s.A + (int64_t)k0 * 2;
     const char* wb = s.W + (int64_t)k0 * 32;       // k32 block kb sits at kb * 1024 bytes = k0 * 32
     if constexpr (U == 0) {
@@ -105,24 +102,41 @@ __device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* stage, 
         glds16(wb + s.w1[0], dst);
         glds16(wb + s.w1[1], dst + 1024);
     } else {
-        glds16(wb + s.w1[0], stage + U * UNIT + wave * 1024);   // NF = 3: one piece per wave
+        glds16(wb + s.w1[0], dst0 + wave * 1024);   // NF = 3: one piece per wave
     }
 }
 
 template <int N_>
 __device__ __forceinline__ void wait_vm() {
-    if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(N_ >= 0 && N_ <= 8, "extend the table");
+    if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N_ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // acc += A[tile rows, k-tiles kt0 .. kt0+nks) . W[tile cols, same k]^T.  On entry no LDS access and no load of this
 // workgroup is outstanding; the same holds on return (every wave has passed the same number of barriers).
+//
+// LDS: two A stages (U0 = A m0 | U3 = A m1, 32 KiB each) and THREE W stages (U1 = W n0 | U2 = W n1, 32 KiB each) = all 160 KiB.
+// The activation panel is L2 / MALL resident (re-read by every team of the XCD) and stays one tile ahead; the weights come from
+// HBM exactly once and are issued TWO tiles ahead, which doubles the latency they may take (6 phases instead of 3: in the
+// recursion, where W is cold, the old distance showed as +20 % on the QKV projection against a MALL-warm benchmark loop).
+// Issue order inside tile c:  ph0 A-U0(c+1) | ph1 A-U3(c+1) | ph2 W-U1(c+2) | ph3 W-U2(c+2)  - the A units first, so that
+// waiting for them never forces the younger, slower W loads to land early (a wave's loads retire in order).  Waits (counted,
+// before the barrier that precedes the first read, as before):
+//   end of ph1: U3(c) landed          -> may stay in flight: U1, U2 (c+1), U0, U3 (c+1)        = 6 + n1 loads (0 if last tile)
+//   end of ph3: U0(c+1) landed (and with it the older U1, U2 (c+1))  -> U3(c+1) [+ U1, U2 (c+2)] = 2 [+ 2 + n1 loads]
+// WAR: a W stage is rewritten >= 1 tile after its last read, A unit U0 one tile, U3 four slots after its last read retired.
+constexpr int PP_A_STAGE = 2 * UNIT, PP_W_BASE = 2 * PP_A_STAGE, PP_W_STAGE = 2 * UNIT;
 template <int NF>
 __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
-    constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant
-    constexpr int VM_N1 = 2 + NJ1;   // loads of units U2 + U3 per wave = what may stay in flight when U0, U1 are needed
+    constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant = loads per wave of unit U2
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kg = lane >> 4;
     // A fragment (f, ks) of unit U0 / U3: row lr = wr * 64 + f * 16 + fr at lr * 128 + (((ks * 4 + kg) ^ (lr & 7)) << 4)
@@ -132,23 +146,32 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     const int w_rd = wc * 4096 + lane * 16;
     const int w_rd1 = NF == 4 ? w_rd : wc * 2048 + lane * 16;   // unit U2: pieces (wc * NJ1 + j) * 2 + ks
 
+    // prologue: all of tile 0, then the W units of tile 1
     issue_unit<0, NF>(src, kt0 * PBK, smem, wave);
-    issue_unit<1, NF>(src, kt0 * PBK, smem, wave);
-    issue_unit<2, NF>(src, kt0 * PBK, smem, wave);
-    issue_unit<3, NF>(src, kt0 * PBK, smem, wave);
-    wait_vm<VM_N1>();                            // U0, U1 landed
+    issue_unit<3, NF>(src, kt0 * PBK, smem + UNIT, wave);
+    issue_unit<1, NF>(src, kt0 * PBK, smem + PP_W_BASE, wave);
+    issue_unit<2, NF>(src, kt0 * PBK, smem + PP_W_BASE + UNIT, wave);
+    if (nks > 1) {
+        issue_unit<1, NF>(src, (kt0 + 1) * PBK, smem + PP_W_BASE + PP_W_STAGE, wave);
+        issue_unit<2, NF>(src, (kt0 + 1) * PBK, smem + PP_W_BASE + PP_W_STAGE + UNIT, wave);
+        wait_vm<2 + NJ1>();                      // tile 0 landed
+    } else {
+        wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
 
     bf16x8 af[4][2], b0[2][2], b1[2][2];
-    // one k-tile; `more` (another tile follows: its units are issued here) is a compile-time constant so that the steady-state
-    // loop carries no per-phase branches on it - the last tile is peeled
-    auto tile = [&](auto more_c, auto group_c, int t) {
-        constexpr bool more = decltype(more_c)::value;
-        constexpr int grp = decltype(group_c)::value;   // this wave's M-group, a compile-time constant inside the loop
-        char* cur = smem + (t & 1) * STAGE;
-        char* nxt = smem + ((t + 1) & 1) * STAGE;
-        const int k1 = (kt0 + t + 1) * PBK;
+    // One k-tile.  m1 / m2 (tile c+1 / c+2 exists: their units are issued here) and the wave's M-group are compile-time
+    // constants: the steady-state loop carries no branches - the last two tiles are peeled, the two groups run separate copies.
+    auto tile = [&](auto m1_c, auto m2_c, auto group_c, int c, int ws) {   // ws = c % 3
+        constexpr bool m1 = decltype(m1_c)::value, m2 = decltype(m2_c)::value;
+        constexpr int grp = decltype(group_c)::value;
+        char* acur = smem + (c & 1) * PP_A_STAGE;
+        char* anxt = smem + ((c + 1) & 1) * PP_A_STAGE;
+        char* wcur = smem + PP_W_BASE + ws * PP_W_STAGE;
+        char* wnn = smem + PP_W_BASE + (ws == 0 ? 2 : ws - 1) * PP_W_STAGE;   // (c + 2) % 3
+        const int k1 = (kt0 + c + 1) * PBK, k2 = k1 + PBK;
 
 #define PP_MFMA(B, NI, MI0, NJ)                                                                                     \
     do {                                                                                                            \
@@ -158,14 +181,14 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0);   \
         __builtin_amdgcn_s_setprio(0);                                                                              \
     } while (0)
-#define PP_READ_A(UOFF)                                                                                             \
+#define PP_READ_A(BASE)                                                                                             \
     _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                 \
-        af[f][0] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c0);                                         \
-        af[f][1] = *(const bf16x8*)(cur + (UOFF) + a_rd + f * 2048 + a_c1);                                         \
+        af[f][0] = *(const bf16x8*)((BASE) + a_rd + f * 2048 + a_c0);                                               \
+        af[f][1] = *(const bf16x8*)((BASE) + a_rd + f * 2048 + a_c1);                                               \
     }
-#define PP_READ_W(B, UOFF, RD, NJ)                                                                                  \
+#define PP_READ_W(B, BASE, RD, NJ)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                \
-        B[j][ks] = *(const bf16x8*)(cur + (UOFF) + (RD) + j * 2048 + ks * 1024);
+        B[j][ks] = *(const bf16x8*)((BASE) + (RD) + j * 2048 + ks * 1024);
         // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
         // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
 #define PP_SYNC_M(WAITN)                                   \
@@ -180,37 +203,45 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     __builtin_amdgcn_sched_barrier(0);
 
         // ---- phase 0: quadrant (m0, n0) ----
-        PP_READ_W(b0, UNIT, w_rd, 2)
-        PP_READ_A(0)
-        if (more) issue_unit<0, NF>(src, k1, nxt, wave);
-        PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<2>())      // U2 of this tile must have landed
+        PP_READ_W(b0, wcur, w_rd, 2)
+        PP_READ_A(acur)
+        if constexpr (m1) issue_unit<0, NF>(src, k1, anxt, wave);
+        PP_SYNC_M((void)0)
         PP_MFMA(b0, 0, 0, 2);
-        PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<2>())
+        PP_SYNC_C((void)0)
         // ---- phase 1: quadrant (m0, n1) ----
-        PP_READ_W(b1, 2 * UNIT, w_rd1, NJ1)
-        if (more) issue_unit<1, NF>(src, k1, nxt, wave);
-        PP_SYNC_M(if (more) wait_vm<4>(); else wait_vm<0>())      // U3 of this tile
+        PP_READ_W(b1, wcur + UNIT, w_rd1, NJ1)
+        if constexpr (m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
+        PP_SYNC_M(wait_vm<m1 ? 6 + NJ1 : 0>())                    // U3 of this tile
         PP_MFMA(b1, 2, 0, NJ1);
-        PP_SYNC_C(if (more) wait_vm<4>(); else wait_vm<0>())
+        PP_SYNC_C(wait_vm<m1 ? 6 + NJ1 : 0>())
         // ---- phase 2: quadrant (m1, n1) ----
-        PP_READ_A(3 * UNIT)
-        if (more) issue_unit<2, NF>(src, k1, nxt, wave);
+        PP_READ_A(acur + UNIT)
+        if constexpr (m2) issue_unit<1, NF>(src, k2, wnn, wave);
         PP_SYNC_M((void)0)
         PP_MFMA(b1, 2, 4, NJ1);
         PP_SYNC_C((void)0)
         // ---- phase 3: quadrant (m1, n0) ----
-        if (more) issue_unit<3, NF>(src, k1, nxt, wave);
-        PP_SYNC_M(if (more) wait_vm<VM_N1>())                      // U0, U1 of the next tile
+        if constexpr (m2) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
+        PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 4 + NJ1 : 2>())  // U0 (and the older U1, U2) of the next tile
         PP_MFMA(b0, 0, 4, 2);
-        PP_SYNC_C(if (more) wait_vm<VM_N1>())
+        PP_SYNC_C(if constexpr (m1) wait_vm<m2 ? 4 + NJ1 : 2>())
     };
-    if (wr == 0) {   // the two groups run separate copies of the loop: no wave-uniform branches on the group inside it
-        for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, std::integral_constant<int, 0>{}, t);
-        tile(std::false_type{}, std::integral_constant<int, 0>{}, nks - 1);
-    } else {
-        for (int t = 0; t + 1 < nks; ++t) tile(std::true_type{}, std::integral_constant<int, 1>{}, t);
-        tile(std::false_type{}, std::integral_constant<int, 1>{}, nks - 1);
-    }
+    auto run = [&](auto group_c) {
+        int c = 0, ws = 0;
+        for (; c + 2 < nks; ++c) {
+            tile(std::true_type{}, std::true_type{}, group_c, c, ws);
+            ws = ws == 2 ? 0 : ws + 1;
+        }
+        if (c + 1 < nks) {
+            tile(std::true_type{}, std::false_type{}, group_c, c, ws);
+            ws = ws == 2 ? 0 : ws + 1;
+            ++c;
+        }
+        tile(std::false_type{}, std::false_type{}, group_c, c, ws);
+    };
+    if (wr == 0) run(std::integral_constant<int, 0>{});   // the two groups run separate copies of the loop
+    else run(std::integral_constant<int, 1>{});
 #undef PP_MFMA
 #undef PP_READ_A
 #undef PP_READ_W
