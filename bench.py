@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the extra legs (two queries per step, FP8 decode weights) timed AFTER the headline")
     p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
     p.add_argument("--cpu-segments", type=int, default=16, help="segments encoded by the CPU baseline sample")
     return p.parse_args()
@@ -217,7 +218,11 @@ def main():
     model.get_model().initialize_vision_modules(SimpleNamespace(
         clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
         adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
-    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode)
+    # extra legs (single GPU, after the headline's timed region): the same loop with two queries of the movie per step and /
+    # or the FP8 decode-weight copies.  The copies are resident from the start and switched off for the headline.
+    extras = world == 1 and not args.no_extras and not args.fp8_decode and args.queries == 1
+    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras)
+    hip.lib().rv_set_fp8_decode(1 if args.fp8_decode else 0)
     model.generation_config.eos_token_id = None     # forced decode length
     tok = synth.FakeTokenizer()
 
@@ -235,25 +240,27 @@ def main():
                 "reading a newspaper and then both of them leave the room together")
     stages = parallel.HipStages(model, tok)
 
-    if args.queries > 1:   # extra measurement: Q queries of one movie share every decode weight pass
-        qs = [(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
-               ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), sentence)
-              for i in range(args.queries)]
-        perms_q = [stage2.make_perms(plan, gen) for _ in range(args.queries)]
+    def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
+        return ([(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
+                  ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), sentence)
+                 for i in range(n)], [stage2.make_perms(plan, gen) for _ in range(n)])
 
-    if args.queries <= 1:
-        qs, perms_q = [(qf, qc, sentence)], [perms]
+    work = {"qs": [(qf, qc, sentence)], "perms": [perms]}
+    if args.queries > 1:
+        work["qs"], work["perms"] = query_set(args.queries)
     hip.lib().rv_set_gemm_cus(args.gemm_cus)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
 
     def launch():
-        kw = dict(batch=100, perms=perms_q, max_new_tokens=args.decode_steps)
+        kw = dict(batch=100, perms=work["perms"], max_new_tokens=args.decode_steps)
+        qs = work["qs"]
         if streams is None:
             return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
         k = counter["i"] % len(streams)
         counter["i"] += 1
         model.engine.slot = k
+        streams[k].wait_stream(torch.cuda.current_stream(dev))     # inputs written on the caller's stream
         with torch.cuda.stream(streams[k]):
             return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
 
@@ -278,6 +285,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    sync()       # weights / inputs were written on the default stream; the step streams do not wait for it implicitly
     rec = run(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -288,6 +296,28 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if any(e != e for e in rec["max_entropy"]) or not all(rec["answers"]):
+        raise RuntimeError(f"bench: the last record is not finite / empty: {rec['answers']} {rec['max_entropy']}")
+    extra = {}
+    if extras:
+        def leg(name, nq, fp8):
+            if nq > 1 and len(work["qs"]) != nq:
+                work["qs"], work["perms"] = query_set(nq)
+            hip.lib().rv_set_fp8_decode(int(fp8))
+            run(args.warmup)
+            sync()
+            t = time.perf_counter()
+            run(args.steps)
+            sync()
+            t = time.perf_counter() - t
+            extra[name] = {"value": W * nq * args.steps / t, "unit": "segment-query pairs/s" if nq > 1 else "segments/s",
+                           "ms_per_step": t / args.steps * 1e3, "queries_per_step": nq,
+                           "decode_weights": "fp8 e4m3fn, per-row scale (prefill bf16)" if fp8 else "bf16"}
+        leg("fp8_decode_weights", 1, True)
+        leg("two_queries_per_step", 2, False)
+        leg("two_queries_per_step_fp8_decode_weights", 2, True)
+        hip.lib().rv_set_fp8_decode(0)
 
     if rank == 0:
         ids1, _ = __import__("revisionllm_amd.inference", fromlist=["_prompt_ids"])._prompt_ids(
@@ -320,6 +350,8 @@ def main():
                                        "avg_launch_ms": v["ms"]} for k, v in legs.items()}},
             "answers_sample": rec["answers"][:2] if not os.environ.get("REVISION_BENCH_ALL_ANSWERS") else rec["answers"],
         }
+        if extra:
+            out["extra_measurements"] = extra       # NOT the headline: a different batch per step / reduced-precision decode weights
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, len(plan), int(P))
         print(json.dumps(out), flush=True)

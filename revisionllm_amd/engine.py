@@ -65,6 +65,12 @@ class Engine:
     def weight(self, name):
         return self._keep[name]
 
+    def _loaded(self):
+        """Weights are written by kernels on the loader's stream; calls may later run on other (non-blocking) HIP streams
+        that do not wait for it implicitly, so loading ends with a device synchronise (not on the hot path)."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def _bind_matrix(self, name, w, fp8):
         """Bind a row-major bf16 matrix fragment-packed; with ``fp8`` also its FP8 (e4m3fn, per-row scale) copy for the
         decode kernels (``<name>.f8`` uint8, ``<name>.s8`` f32 [rows])."""
@@ -98,6 +104,7 @@ class Engine:
             self.bind(f"llm.L{i}.norm1", _dev_f32(get(p + "input_layernorm.weight"), dev))
             self.bind(f"llm.L{i}.norm2", _dev_f32(get(p + "post_attention_layernorm.weight"), dev))
         self.has_llm = True
+        self._loaded()
 
     def load_clip_adapter(self, get):
         """``get(name)`` with ClipEncoder state-dict names (transformer.py:60-92), e.g. 'encoder.layers.0.linear1.weight'."""
@@ -122,11 +129,13 @@ class Engine:
                     self.bind(o + f"ln{n}_w", _dev_f32(get(r + f"norm{n}.weight"), dev))
                     self.bind(o + f"ln{n}_b", _dev_f32(get(r + f"norm{n}.bias"), dev))
         self.has_clip = True
+        self._loaded()
 
     def load_linear_projector(self, get):
         self.bind("proj.w", _dev_packed(get("weight"), self.device))
         self.bind("proj.b", _dev_f32(get("bias"), self.device))
         self.has_linear = True
+        self._loaded()
 
     # ---- synthetic weights generated on the device (bench / smoke / tests) -----------------------
     def _synth_get(self, spec, seed, prefix):
