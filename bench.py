@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
+    p.add_argument("--gemm-variant", type=int, default=2, help="rv_set_gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the extra legs (two queries per step, FP8 decode weights) timed AFTER the headline")
@@ -249,6 +250,7 @@ def main():
     if args.queries > 1:
         work["qs"], work["perms"] = query_set(args.queries)
     hip.lib().rv_set_gemm_cus(args.gemm_cus)
+    hip.lib().rv_set_gemm_tile_variant(args.gemm_variant)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
 

@@ -169,6 +169,9 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  * (vtimellm_llama.py:312-338; funs_get_feature_X.py:131-132).  logits f32 [B,V].
  * out_topk_idx i32 / out_topk_val f32 [B,top_k_cap]: kept candidates in descending order (processed
  * scores), n_keep i32 [B].  top_k <= 64. */
+/* Measurement / test knob (process-wide): 1 (default) = top-k selection through the compacted-candidate fast path when the
+ * row qualifies (V >= 1024, no tie across the k-th place); 0 = always the general 16-round selection.  Identical outputs. */
+void rv_set_sample_variant(int32_t v);
 int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
               int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
               int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream);

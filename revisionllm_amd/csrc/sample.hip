@@ -10,6 +10,7 @@ namespace {
 constexpr int TPB = 1024;   // threads per row
 constexpr int ITEMS = 32;   // V <= 32768
 constexpr int KCAP = 64;
+int g_sample_variant = 1;   // host copy of the knob (rv_set_sample_variant): passed to the kernel as an argument
 
 struct ArgMax {
     float v;
@@ -48,6 +49,59 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return t;
 }
 
+// K-th largest of the block's keys, ONE key per thread, 4 bits per round and one barrier per round: five ballots give lane
+// c < 16 of every wave the number of its wave's matching keys whose digit is c; the 16 x 16 wave histograms meet in LDS
+// (double-buffered by round parity), every wave adds them up and suffix-scans them redundantly, so the choice of the digit
+// is wave-uniform without a second barrier.  -> the want-th largest key; need_out = how many of the keys EQUAL to it are
+// among the `want` largest (exact form).  Requires want <= number of threads.
+template <bool BOUND_ONLY>
+__device__ __forceinline__ unsigned select_kth_per_thread(unsigned k, int want, int (*whist)[16][TPB / 64], int& need_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned prefix = 0u;
+    int need = want;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        const int shift = 28 - 4 * r;
+        const unsigned himask = r == 0 ? 0u : (0xffffffffu << (shift + 4));
+        const bool m = (k & himask) == prefix;
+        const unsigned d = (k >> shift) & 15u;
+        unsigned long long sel = __ballot(m);
+        const unsigned long long b0 = __ballot((d & 1u) != 0u), b1 = __ballot((d & 2u) != 0u), b2 = __ballot((d & 4u) != 0u),
+                                 b3 = __ballot((d & 8u) != 0u);
+        sel &= (lane & 1) ? b0 : ~b0;
+        sel &= (lane & 2) ? b1 : ~b1;
+        sel &= (lane & 4) ? b2 : ~b2;
+        sel &= (lane & 8) ? b3 : ~b3;
+        if (lane < 16) whist[r & 1][lane][wave] = __popcll(sel);
+        __syncthreads();
+        int ge = 0;
+        if (lane < 16) {
+            const int4* hp = reinterpret_cast<const int4*>(&whist[r & 1][lane][0]);   // this digit's count in the 16 waves
+#pragma unroll
+            for (int q = 0; q < TPB / 256; ++q) {
+                const int4 t = hp[q];
+                ge += (t.x + t.y) + (t.z + t.w);
+            }
+        }
+        // suffix sums over lanes 0..15 (one DPP row): ge[c] = matching keys with digit >= c
+        ge += __builtin_amdgcn_update_dpp(0, ge, 0x101, 0xf, 0xf, true);   // row_shl:1 (lane i reads lane i + 1, 0 past the row)
+        ge += __builtin_amdgcn_update_dpp(0, ge, 0x102, 0xf, 0xf, true);
+        ge += __builtin_amdgcn_update_dpp(0, ge, 0x104, 0xf, 0xf, true);
+        ge += __builtin_amdgcn_update_dpp(0, ge, 0x108, 0xf, 0xf, true);
+        const unsigned ok = (unsigned)(__ballot(lane < 16 && ge >= need) & 0xffffull);   // bit 0 is always set
+        const int dsel = 31 - __clz((int)ok);
+        const int above = __builtin_amdgcn_readlane(ge, dsel < 15 ? dsel + 1 : 0);
+        const int spare = __builtin_amdgcn_readlane(ge, dsel) - need;   // keys with this digit or a larger one beyond the wanted
+        need -= dsel < 15 ? above : 0;
+        prefix |= (unsigned)dsel << shift;
+        // BOUND_ONLY: the caller only needs a lower bound of the want-th largest key with few keys above it - the prefix with
+        // zero low bits is one as soon as at most 4 keys more than wanted are >= it
+        if (BOUND_ONLY && spare <= 4) break;
+    }
+    need_out = need;
+    return prefix;
+}
+
 // entropy of softmax(x) with the reference's formula H = -sum p*log(p + 1e-10); -inf entries give p = 0
 __device__ float block_entropy(const float* x, int V, float* sh) {
     float mx = -INFINITY;
@@ -69,24 +123,58 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
                                                      int do_sample, float temperature, int top_k, float top_p,
                                                      int32_t* __restrict__ out_tok, float* __restrict__ out_hp,
                                                      float* __restrict__ out_hr, int32_t* __restrict__ out_idx,
-                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nkeep) {
+                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nkeep, int variant) {
     __shared__ float sh[16];
     __shared__ float topv[KCAP];
     __shared__ int topi[KCAP];
     __shared__ float e[KCAP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (int64_t)b * V;
+#ifdef RV_SAMPLE_PROBE
+    long long tp[12];
+    for (int q = 0; q < 12; ++q) tp[q] = 0;
+    tp[0] = wall_clock64();
+#endif
 
-    const float h_raw = block_entropy(x, V, sh);
-    if (tid == 0) out_hr[b] = h_raw;
-
+    // the row is read ONCE into registers (32 independent loads per thread); the raw entropy uses the same per-thread
+    // element order and block reductions as block_entropy(), so it is bit-identical to rv_entropy_stats on the same row
     float v[ITEMS];
-    const float inv_t = do_sample ? 1.0f / temperature : 1.0f;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int i = tid + j * TPB;
-        v[j] = i < V ? x[i] * inv_t : -INFINITY;
+        v[j] = i < V ? x[i] : -INFINITY;
     }
+    float h_raw;
+    {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) mx = fmaxf(mx, v[j]);
+        mx = block_max(mx, sh);
+        float ex[ITEMS];
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            ex[j] = expf(v[j] - mx);   // exp(-inf) = 0 for the padding
+            z += ex[j];
+        }
+        z = block_sum(z, sh);
+        const float iz = 1.0f / z;
+        float hsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const float p = ex[j] * iz;
+            if (tid + j * TPB < V) hsum += p * logf(p + 1e-10f);
+        }
+        h_raw = -block_sum(hsum, sh);
+    }
+    if (tid == 0) out_hr[b] = h_raw;
+#ifdef RV_SAMPLE_PROBE
+    tp[1] = wall_clock64();
+#endif
+
+    const float inv_t = do_sample ? 1.0f / temperature : 1.0f;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) v[j] = tid + j * TPB < V ? v[j] * inv_t : -INFINITY;
     const int K = do_sample ? top_k : 1;
     // ---- top-K selection: radix select on order-preserving integer keys (2 bits per round, pure register counting +
     // one block reduction per round), then the <= K survivors are rank-sorted by (score desc, index asc).
@@ -101,116 +189,198 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
         if (tid + j * TPB >= V) key[j] = 0u;   // below every real score (-inf maps to 0x007fffff)
     }
-    unsigned prefix = 0u;   // bits of the K-th largest key decided so far
-    int need = K;           // how many of the keys matching the prefix are still wanted
-    for (int shift = 30; shift >= 0; shift -= 2) {
-        const unsigned himask = shift == 30 ? 0u : (0xffffffffu << (shift + 2));
-        int c1 = 0, c2 = 0, c3 = 0;   // keys (matching the prefix) whose next 2 bits are >= 1, >= 2, >= 3
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const bool m = (key[j] & himask) == prefix;
-            const unsigned d = (key[j] >> shift) & 3u;
-            c1 += (m && d >= 1u);
-            c2 += (m && d >= 2u);
-            c3 += (m && d >= 3u);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            c1 += __shfl_xor(c1, o, 64);
-            c2 += __shfl_xor(c2, o, 64);
-            c3 += __shfl_xor(c3, o, 64);
-        }
-        __syncthreads();
-        if (lane == 0) {
-            cnt_sh[wave][1] = c1;
-            cnt_sh[wave][2] = c2;
-            cnt_sh[wave][3] = c3;
-        }
-        __syncthreads();
-        int t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-        for (int w = 0; w < TPB / 64; ++w) {
-            t1 += cnt_sh[w][1];
-            t2 += cnt_sh[w][2];
-            t3 += cnt_sh[w][3];
-        }
-        // digit of the need-th largest key among the matching ones
-        unsigned dsel;
-        if (t3 >= need) dsel = 3u;
-        else if (t2 >= need) { dsel = 2u; need -= t3; }
-        else if (t1 >= need) { dsel = 1u; need -= t2; }
-        else { dsel = 0u; need -= t1; }
-        prefix |= dsel << shift;
-    }
-    // prefix = K-th largest key; `need` of the keys equal to it are wanted (the ones with the smallest indices)
+    // Fast path (the decode shape: every thread owns a real score, K <= 64): the K-th largest of the 1024 per-thread
+    // maxima is a lower bound L of the K-th largest score, and the scores >= L are few (K plus the runners-up that share a
+    // thread with a larger one); they are compacted into LDS and the exact K-th largest is selected among them with one key
+    // per thread.  Both selections cost 8 one-barrier rounds; the 16 register-counting rounds over all 32 keys per thread
+    // below are the general path (short rows, > 1024 candidates, or a tie straddling the K-th place).
+    __shared__ __attribute__((aligned(16))) int whist[2][16][TPB / 64];
+    __shared__ unsigned cand_key[TPB];
+    __shared__ int cand_idx[TPB];
+    __shared__ int n_cand;
+    bool fast = variant != 0 && V >= TPB && K <= KCAP;
     if (tid == 0) {
         n_list = 0;
         n_eq_taken = 0;
+        n_cand = 0;
     }
-    __syncthreads();
-    int n_eq_local = 0;
+    if (fast) {
+        unsigned tmax = 0u;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) n_eq_local += (key[j] == prefix);
-    const int n_eq_total = (int)(block_sum((float)n_eq_local, sh) + 0.5f);   // <= 32768: exact in fp32
-    const bool take_all_eq = n_eq_total == need;   // the usual case: no tie straddles the K-th place
+        for (int j = 0; j < ITEMS; ++j) tmax = key[j] > tmax ? key[j] : tmax;
+        int unused;
+        const unsigned L = select_kth_per_thread<true>(tmax, K, whist, unused);
+#ifdef RV_SAMPLE_PROBE
+        tp[5] = wall_clock64();
+#endif
+        int c_local = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (key[j] > prefix || (take_all_eq && key[j] == prefix)) {
-            const int p = atomicAdd(&n_list, 1);
-            if (p < KCAP) {
-                list_key[p] = key[j];
-                list_idx[p] = tid + j * TPB;
+        for (int j = 0; j < ITEMS; ++j) c_local += (key[j] >= L);
+        const int C = (int)(block_sum((float)c_local, sh) + 0.5f);   // <= 32768: exact in fp32
+#ifdef RV_SAMPLE_PROBE
+        tp[6] = wall_clock64();
+#endif
+        if (C > TPB) {
+            fast = false;
+        } else {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (key[j] >= L) {
+                    const int p = atomicAdd(&n_cand, 1);
+                    cand_key[p] = key[j];
+                    cand_idx[p] = tid + j * TPB;
+                }
             }
+            __syncthreads();
+#ifdef RV_SAMPLE_PROBE
+            tp[7] = wall_clock64();
+#endif
+            if (C <= 64) {
+                // the usual case: the candidates fit one wave - the rank sort below orders all of them by (score desc, index
+                // asc) and keeps the first K, which also settles ties across the K-th place
+                if (tid < C) {
+                    list_key[tid] = cand_key[tid];
+                    list_idx[tid] = cand_idx[tid];
+                }
+                if (tid == 0) n_list = C;
+            } else {
+                const unsigned ck = tid < C ? cand_key[tid] : 0u;
+                int need;
+                const unsigned kth = select_kth_per_thread<false>(ck, K, whist, need);
+                const int n_eq = (int)(block_sum(ck == kth ? 1.f : 0.f, sh) + 0.5f);
+                if (n_eq != need) {
+                    fast = false;   // a tie straddles the K-th place: the general path keeps the smallest indices
+                } else if (ck >= kth) {   // (padding keys are 0 < kth: every real key is >= 0x007fffff)
+                    const int p = atomicAdd(&n_list, 1);
+                    if (p < KCAP) {
+                        list_key[p] = ck;
+                        list_idx[p] = cand_idx[tid];
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if (!take_all_eq) {
-        // ties at the K-th value: keep the `need` smallest indices.  Walk the index space in ascending order: item j of
-        // every thread covers indices [j*TPB, (j+1)*TPB) in (wave, lane) order.
-        for (int j = 0; j < ITEMS; ++j) {
-            const bool eq = key[j] == prefix;
-            const unsigned long long bal = __ballot(eq);
-            if (lane == 0) cnt_sh[wave][0] = __popcll(bal);
+#ifdef RV_SAMPLE_PROBE
+    tp[2] = wall_clock64();
+#endif
+    if (!fast) {
+        unsigned prefix = 0u;   // bits of the K-th largest key decided so far
+        int need = K;           // how many of the keys matching the prefix are still wanted
+        for (int shift = 30; shift >= 0; shift -= 2) {
+            const unsigned himask = shift == 30 ? 0u : (0xffffffffu << (shift + 2));
+            int c1 = 0, c2 = 0, c3 = 0;   // keys (matching the prefix) whose next 2 bits are >= 1, >= 2, >= 3
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const bool m = (key[j] & himask) == prefix;
+                const unsigned d = (key[j] >> shift) & 3u;
+                c1 += (m && d >= 1u);
+                c2 += (m && d >= 2u);
+                c3 += (m && d >= 3u);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                c1 += __shfl_xor(c1, o, 64);
+                c2 += __shfl_xor(c2, o, 64);
+                c3 += __shfl_xor(c3, o, 64);
+            }
             __syncthreads();
-            int before = 0, total = 0;
+            if (lane == 0) {
+                cnt_sh[wave][1] = c1;
+                cnt_sh[wave][2] = c2;
+                cnt_sh[wave][3] = c3;
+            }
+            __syncthreads();
+            int t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
             for (int w = 0; w < TPB / 64; ++w) {
-                before += w < wave ? cnt_sh[w][0] : 0;
-                total += cnt_sh[w][0];
+                t1 += cnt_sh[w][1];
+                t2 += cnt_sh[w][2];
+                t3 += cnt_sh[w][3];
             }
-            const int taken = n_eq_taken;
-            if (eq) {
-                const int r = taken + before + __popcll(bal & ((1ull << lane) - 1ull));
-                if (r < need) {
-                    const int p = (K - need) + r;
+            // digit of the need-th largest key among the matching ones
+            unsigned dsel;
+            if (t3 >= need) dsel = 3u;
+            else if (t2 >= need) { dsel = 2u; need -= t3; }
+            else if (t1 >= need) { dsel = 1u; need -= t2; }
+            else { dsel = 0u; need -= t1; }
+            prefix |= dsel << shift;
+        }
+#ifdef RV_SAMPLE_PROBE
+        tp[2] = wall_clock64();
+#endif
+        // prefix = K-th largest key; `need` of the keys equal to it are wanted (the ones with the smallest indices)
+        __syncthreads();
+        int n_eq_local = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) n_eq_local += (key[j] == prefix);
+        const int n_eq_total = (int)(block_sum((float)n_eq_local, sh) + 0.5f);   // <= 32768: exact in fp32
+        const bool take_all_eq = n_eq_total == need;   // the usual case: no tie straddles the K-th place
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (key[j] > prefix || (take_all_eq && key[j] == prefix)) {
+                const int p = atomicAdd(&n_list, 1);
+                if (p < KCAP) {
                     list_key[p] = key[j];
                     list_idx[p] = tid + j * TPB;
                 }
             }
-            __syncthreads();
-            if (tid == 0) n_eq_taken = taken + total;
-            __syncthreads();
-            if (n_eq_taken >= need) break;
         }
+        __syncthreads();
+        if (!take_all_eq) {
+            // ties at the K-th value: keep the `need` smallest indices.  Walk the index space in ascending order: item j of
+            // every thread covers indices [j*TPB, (j+1)*TPB) in (wave, lane) order.
+            for (int j = 0; j < ITEMS; ++j) {
+                const bool eq = key[j] == prefix;
+                const unsigned long long bal = __ballot(eq);
+                if (lane == 0) cnt_sh[wave][0] = __popcll(bal);
+                __syncthreads();
+                int before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < TPB / 64; ++w) {
+                    before += w < wave ? cnt_sh[w][0] : 0;
+                    total += cnt_sh[w][0];
+                }
+                const int taken = n_eq_taken;
+                if (eq) {
+                    const int r = taken + before + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (r < need) {
+                        const int p = (K - need) + r;
+                        list_key[p] = key[j];
+                        list_idx[p] = tid + j * TPB;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) n_eq_taken = taken + total;
+                __syncthreads();
+                if (n_eq_taken >= need) break;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) n_list = K;   // (the tie walk places its entries without counting them)
         __syncthreads();
     }
     if (tid < 64) {
-        // rank sort of the K candidates: (key desc, index asc)
-        const unsigned kk = tid < K ? list_key[tid] : 0u;
-        const int ii = tid < K ? list_idx[tid] : 0x7fffffff;
+        // rank sort of the n >= K listed candidates by (key desc, index asc); the first K are the result
+        const int n = n_list < KCAP ? n_list : KCAP;
+        const unsigned kk = tid < n ? list_key[tid] : 0u;
+        const int ii = tid < n ? list_idx[tid] : 0x7fffffff;
         int rank = 0;
-        for (int q = 0; q < K; ++q) {
+        for (int q = 0; q < n; ++q) {
             const unsigned kq = list_key[q];
             const int iq = list_idx[q];
             rank += (kq > kk) || (kq == kk && iq < ii);
         }
-        if (tid < K) {
+        if (tid < n && rank < K) {
             const unsigned u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
             topv[rank] = __uint_as_float(u);
             topi[rank] = ii;
         }
     }
     __syncthreads();
+#ifdef RV_SAMPLE_PROBE
+    tp[3] = wall_clock64();
+#endif
     if (!do_sample) {
         if (tid == 0) {
             out_tok[b] = topi[0];
@@ -223,14 +393,16 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         }
         return;
     }
+    // The transcendental work (exp, divide, log) runs one candidate per lane; the SUMS stay sequential in thread 0, in the
+    // order HF's TopPLogitsWarper / multinomial accumulate (ascending index = descending probability).
+    __shared__ float pr[KCAP], lg[KCAP];
+    __shared__ float z2_sh;
+    __shared__ int keep_sh;
+    if (tid < K) e[tid] = expf(topv[tid] - topv[0]);
+    __syncthreads();
     if (tid == 0) {
-        // sequential, in the order HF's TopPLogitsWarper accumulates (ascending probability)
-        const float mx = topv[0];
         float z = 0.f;
-        for (int i = 0; i < K; ++i) {
-            e[i] = expf(topv[i] - mx);
-            z += e[i];
-        }
+        for (int i = 0; i < K; ++i) z += e[i];
         int keep = K;
         if (top_p < 1.0f) {
             float cum = 0.f;
@@ -245,12 +417,24 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         }
         float z2 = 0.f;
         for (int i = 0; i < keep; ++i) z2 += e[i];
+        z2_sh = z2;
+        keep_sh = keep;
+    }
+    __syncthreads();
+    const int keep = keep_sh;
+    if (tid < keep) {
+        const float p = e[tid] / z2_sh;
+        pr[tid] = p;
+        lg[tid] = logf(p + 1e-10f);
+    }
+    __syncthreads();
+    if (tid == 0) {
         float hp = 0.f, cum = 0.f;
         const float u = uniforms ? uniforms[b] : 0.f;
         int pos = 0;
         for (int i = 0; i < keep; ++i) {
-            const float p = e[i] / z2;
-            hp += p * logf(p + 1e-10f);
+            const float p = pr[i];
+            hp += p * lg[i];
             cum += p;
             if (cum <= u) pos = i + 1;
         }
@@ -258,9 +442,17 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         out_tok[b] = topi[pos];
         out_hp[b] = -hp;
         out_nkeep[b] = keep;
+#ifdef RV_SAMPLE_PROBE
+        tp[4] = wall_clock64();
+        for (int q = 1; q < 5; ++q) out_val[b * KCAP + 59 + q] = (float)(tp[q] - tp[q - 1]);
+        for (int q = 5; q < 9; ++q) out_val[b * KCAP + 50 + q] = (float)(tp[q] - tp[1]);
+#endif
     }
     if (tid < KCAP) {
         out_idx[b * KCAP + tid] = tid < K ? topi[tid] : -1;
+#ifdef RV_SAMPLE_PROBE
+        if (tid < 55)
+#endif
         out_val[b * KCAP + tid] = tid < K ? topv[tid] : -INFINITY;
     }
 }
@@ -365,10 +557,12 @@ extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float*
         RV_CHECK_ARG(out_topk_idx && out_topk_val, "rv_sample: candidate outputs required when sampling");
     }
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(TPB), 0, as_stream(stream), logits, V, uniforms, do_sample, temperature, top_k,
-                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep);
+                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep, g_sample_variant);
     RV_CHECK_LAUNCH("rv_sample");
     return RV_OK;
 }
+
+extern "C" void rv_set_sample_variant(int32_t v) { g_sample_variant = v; }
 
 extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream) {
     RV_CHECK_ARG(logits && out && B > 0 && G > 0 && V > 0, "rv_entropy_stats: bad arguments");

@@ -355,6 +355,28 @@ def test_sample_and_scores(dev):
     assert torch.isnan(st1[0, 3])
 
 
+def test_sample_fast_path_equals_general_path(dev):
+    """The compacted-candidate selection (default) and the general 16-round selection give identical outputs, bit for bit:
+    decode-like rows, rows with ties across the k-th place (the fast path hands over), a nearly flat row (> 1024 candidates)."""
+    from revisionllm_amd import hip, ops
+    logits = feats("smpf.logits", (7, 32000)) * 1.7
+    lt = (logits * 2).round() / 2
+    flat = logits * 1e-6
+    flat[3] = 0.25
+    u = torch.tensor([0.0, 0.2, 0.4, 0.6, 0.8, 0.95, 0.9999])
+    try:
+        for x in (logits, lt, flat):
+            for (temp, k, p) in ((0.05, 50, 1.0), (0.05, 50, 0.6), (1.0, 64, 0.9), (0.7, 7, 1.0), (1.0, 1, 1.0)):
+                outs = []
+                for variant in (0, 1):
+                    hip.lib().rv_set_sample_variant(variant)
+                    outs.append(ops.sample(x.to(dev), u.to(dev), True, temp, k, p))
+                for name in outs[0]:
+                    assert torch.equal(outs[0][name].cpu(), outs[1][name].cpu()), (name, temp, k, p)
+    finally:
+        hip.lib().rv_set_sample_variant(1)
+
+
 def test_topk_cosine(dev):
     from oracle import scores
     from revisionllm_amd import ops
