@@ -364,8 +364,10 @@ def test_sample_fast_path_equals_general_path(dev):
     flat = logits * 1e-6
     flat[3] = 0.25
     u = torch.tensor([0.0, 0.2, 0.4, 0.6, 0.8, 0.95, 0.9999])
+    small = [feats(f"smpf.v{v}", (7, v)) * 2.0 for v in (1024, 1500, 4099, 32768)]
+    small.append((small[1] * 4).round() / 4)          # short rows with ties
     try:
-        for x in (logits, lt, flat):
+        for x in [logits, lt, flat] + small:
             for (temp, k, p) in ((0.05, 50, 1.0), (0.05, 50, 0.6), (1.0, 64, 0.9), (0.7, 7, 1.0), (1.0, 1, 1.0)):
                 outs = []
                 for variant in (0, 1):
