@@ -43,6 +43,8 @@ def parse():
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
+    p.add_argument("--fp8-prefill", action="store_true",
+                   help="extra measurement (NOT the headline): prefill GEMMs run FP8 x FP8 (activations quantised per row on the fly)")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--gemm-variant", type=int, default=2, help="rv_set_gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--settle", type=int, default=16,
@@ -223,9 +225,10 @@ def main():
         adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
     # extra legs (single GPU, after the headline's timed region): the same loop with two queries of the movie per step and /
     # or the FP8 decode-weight copies.  The copies are resident from the start and switched off for the headline.
-    extras = world == 1 and not args.no_extras and not args.fp8_decode and args.queries == 1
-    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras)
+    extras = world == 1 and not args.no_extras and not args.fp8_decode and not args.fp8_prefill and args.queries == 1
+    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras)
     hip.lib().rv_set_fp8_decode(1 if args.fp8_decode else 0)
+    hip.lib().rv_set_fp8_prefill(1 if args.fp8_prefill else 0)
     model.generation_config.eos_token_id = None     # forced decode length
     tok = synth.FakeTokenizer()
 
@@ -312,11 +315,12 @@ def main():
         raise RuntimeError(f"bench: the last record is not finite / empty: {rec['answers']} {rec['max_entropy']}")
     extra = {}
     if extras:
-        def leg(name, nq, fp8):
+        def leg(name, nq, fp8, fp8p=False):
             if nq > 1 and len(work["qs"]) != nq:
                 work["qs"], work["perms"] = query_set(nq)
                 work["feats"] = video_set(nq)
             hip.lib().rv_set_fp8_decode(int(fp8))
+            hip.lib().rv_set_fp8_prefill(int(fp8p))
             run(args.warmup)
             sync()
             t = time.perf_counter()
@@ -326,11 +330,15 @@ def main():
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
                            "ms_per_step": t / args.steps * 1e3, "recursions_per_step": nq,
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
-                           "decode_weights": "fp8 e4m3fn, per-row scale (prefill bf16)" if fp8 else "bf16"}
+                           "decode_weights": "fp8 e4m3fn, per-row scale" if fp8 else "bf16",
+                           "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
         leg("fp8_decode_weights", 1, True)
+        leg("fp8_llm_path", 1, True, True)
         leg("two_videos_per_step", 2, False)
         leg("two_videos_per_step_fp8_decode_weights", 2, True)
+        leg("two_videos_per_step_fp8_llm_path", 2, True, True)
         hip.lib().rv_set_fp8_decode(0)
+        hip.lib().rv_set_fp8_prefill(0)
 
     if rank == 0:
         ids1, _ = __import__("revisionllm_amd.inference", fromlist=["_prompt_ids"])._prompt_ids(
@@ -349,7 +357,7 @@ def main():
             "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
             "value": W * args.queries * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (decode weights fp8 e4m3: extra measurement)" if args.fp8_decode else "bf16", "data": "synthetic",
+            "dtype": "bf16 (fp8 e4m3 LLM weights / prefill GEMMs: extra measurement)" if (args.fp8_decode or args.fp8_prefill) else "bf16", "data": "synthetic",
             "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
                        "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
                        "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",

@@ -88,6 +88,18 @@ size_t rv_gemm_ws_bytes(void);
  * (act: NONE or SILU_MUL).  Opt-in "fp8 LLM path" (BASELINE.json configs[4]): not what the parity / headline numbers use. */
 int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const float* w_scale, const float* bias, const float* residual,
                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
+/* Opt-in FP8 x FP8 prefill GEMM (the "fp8 MFMA LLM path" BASELINE.json configs[4] names; the reference has no counterpart, it
+ * runs bf16 / fp16 - never the parity target or the headline).  rv_quant_rows_fp8: bf16 activations x16 [rows, K] -> e4m3fn bytes
+ * q8 [rows, K] (row stride ldq bytes) + per-row scales max|row| / 448; q = RNE_e4m3(x / scale), IEEE f32 divisions.  rv_gemm_fp8: C = act((A8 . W8^T) * a_scale[m] * w_scale[n]) (+ residual); W8p = the [N, K] e4m3fn byte matrix
+ * taken as [N, K/2] 16-bit words in the bf16 fragment packing (ops.pack_fragments_fp8_prefill); v_mfma_scale_f32_16x16x128_f8f6f4
+ * on the persistent 256x256 ping-pong kernel; few-row deep-K shapes only (those with a stream-K plan), act NONE or SILU_MUL. */
+/* LlamaRMSNorm + rv_quant_rows_fp8 in one pass (d = 4096): quantises the bf16-rounded normalised row, i.e. the bytes and
+ * scales of rv_quant_rows_fp8(rv_rmsnorm(x)). */
+int rv_rmsnorm_quant_fp8(const float* x, const float* w, void* q8, float* scale, int64_t rows, int32_t d, float eps, void* stream);
+int rv_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int64_t K, void* stream);
+int rv_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
+                int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, size_t ws_bytes,
+                void* stream);
 /* Tuning / measurement knob (process-wide) for packed W.  2 (default) = 128x128x32 3-stage LDS ring kernel plus the
  * 256x256x64 ping-pong kernel where it pays (stream-K for few-row deep-K problems when ws is given, output-tiled for
  * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
@@ -104,6 +116,10 @@ void rv_set_decode_fusion(int32_t on);
 /* 1 (default): KV-cached decode steps stream the FP8 weight copies when all of them are bound ("<name>.f8" / "<name>.s8" next
  * to every LLM projection and lm_head, see Engine.load_llm(fp8_decode=True)); 0: always decode on the bf16 weights. */
 void rv_set_fp8_decode(int32_t on);
+/* 1 (default): prefill passes run their QKV / o / gate-up / down GEMMs as FP8 x FP8 (rv_gemm_fp8: activations quantised per row
+ * on the fly) when the "<name>.f8p" weight copies of every layer are bound (Engine.load_llm(fp8_prefill=True)) and the shape has
+ * a persistent plan; 0: always prefill on the bf16 weights.  Opt-in "fp8 MFMA LLM path", never the parity target. */
+void rv_set_fp8_prefill(int32_t on);
 int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);

@@ -79,12 +79,14 @@ class KVCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None):
-    """One Llama block: x + Wo(softmax(QK^T/sqrt(dh) + mask) V); then + W_down(silu(W_gate n) * W_up n)."""
+def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None, act_quant=None):
+    """One Llama block: x + Wo(softmax(QK^T/sqrt(dh) + mask) V); then + W_down(silu(W_gate n) * W_up n).
+    ``act_quant`` (build-defined, opt-in FP8 prefill mirror): applied to the input rows of the four projections."""
+    aq = act_quant if act_quant is not None else (lambda t: t)
     p = f"model.layers.{i}."
     B, S, D = h.shape
     H, dh = cfg.heads, cfg.head_dim
-    n = rmsnorm(h, w[p + "input_layernorm.weight"], cfg.eps)
+    n = aq(rmsnorm(h, w[p + "input_layernorm.weight"], cfg.eps))
     q = F.linear(n, w[p + "self_attn.q_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     k = F.linear(n, w[p + "self_attn.k_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     v = F.linear(n, w[p + "self_attn.v_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
@@ -96,11 +98,11 @@ def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = 
         s = s + attn_bias
     pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
     o = (pr @ v).transpose(1, 2).reshape(B, S, D)
-    h = h + F.linear(o, w[p + "self_attn.o_proj.weight"])
-    n = rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.eps)
+    h = h + F.linear(aq(o), w[p + "self_attn.o_proj.weight"])
+    n = aq(rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.eps))
     g = F.linear(n, w[p + "mlp.gate_proj.weight"])
     u = F.linear(n, w[p + "mlp.up_proj.weight"])
-    return h + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+    return h + F.linear(aq(F.silu(g) * u), w[p + "mlp.down_proj.weight"])
 
 
 def _bias_from_mask(attention_mask, q_len, past_len, dtype):
@@ -116,7 +118,7 @@ def _bias_from_mask(attention_mask, q_len, past_len, dtype):
 
 
 def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=None, cache: KVCache = None,
-            last_only=False, n_layers=None):
+            last_only=False, n_layers=None, act_quant=None):
     """``LlamaForCausalLM.forward(inputs_embeds=...)`` -> logits [B,S,V] (or [B,1,V] if last_only).
 
     attention_mask [B, past+S] (1 = real token); position_ids [B,S]; cache is updated in place.
@@ -132,7 +134,7 @@ def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=N
     bias = _bias_from_mask(attention_mask, S, past, inputs_embeds.dtype)
     h = inputs_embeds
     for i in range(cfg.layers if n_layers is None else n_layers):
-        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache)
+        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache, act_quant)
     if last_only:
         h = h[:, -1:]
     h = rmsnorm(h, w["model.norm.weight"], cfg.eps)
@@ -148,6 +150,16 @@ def fp8_rows(w):
     scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).float()
     q = (wd / scale.double()[:, None]).float().to(torch.float8_e4m3fn)
     return q.float() * scale[:, None]
+
+
+def fp8_act_rows(x):
+    """Mirror of the build's FP8 prefill activation quantiser (rv_quant_rows_fp8): the activation is rounded to bf16 (what the
+    bf16 path hands to its GEMM), then per row over the last dim: scale = max|row| / 448 (1 for a zero row), q =
+    RNE_e4m3(x / scale), IEEE f32 divisions; returns the dequantised q * scale."""
+    xb = x.to(torch.bfloat16).float()
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (xb / scale).to(torch.float8_e4m3fn).float() * scale
 
 
 def fp8_decode_weights(w, cfg: LlamaCfg):

@@ -24,6 +24,9 @@ struct LlmLayer {
     // optional FP8 copies for the decode kernels ("<name>.f8" e4m3fn bytes, "<name>.s8" per-row scales); all or none
     const uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *wgu8 = nullptr, *wdown8 = nullptr;
     const float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sdown = nullptr;
+    // optional FP8 copies for the prefill GEMMs ("<name>.f8p": the byte matrix in the bf16 fragment packing of its 16-bit
+    // words; same quantisation and ".s8" scales as the decode copies); all or none
+    const uint8_t *wqkv8p = nullptr, *wo8p = nullptr, *wgu8p = nullptr, *wdown8p = nullptr;
 };
 
 struct rv_ctx {
@@ -40,6 +43,7 @@ struct rv_ctx {
     const uint8_t* lm_head8 = nullptr;   // FP8 decode copies bound for every projection -> fp8_decode
     const float* slm_head = nullptr;
     bool fp8_decode = false;
+    bool fp8_prefill = false;   // ".f8p" copies bound for every layer projection
 };
 
 namespace {
@@ -143,6 +147,22 @@ int resolve_llm(rv_ctx* c) {
             FIND(p + "wgu.f8", RV_U8, 2 * F * D, L.wgu8);
             FIND(p + "wgu.s8", RV_F32, 2 * F, L.sgu);
             FIND(p + "wdown.f8", RV_U8, D * F, L.wdown8);
+            FIND(p + "wdown.s8", RV_F32, D, L.sdown);
+        }
+    }
+    // FP8 prefill path (FP8 x FP8 MFMA on the persistent GEMMs): used when the ".f8p" copies of every layer are bound
+    c->fp8_prefill = g.layers > 0 && c->w.count("llm.L0.wqkv.f8p") != 0;
+    if (c->fp8_prefill) {
+        for (int l = 0; l < g.layers; ++l) {
+            const std::string p = "llm.L" + std::to_string(l) + ".";
+            LlmLayer& L = c->layers[l];
+            FIND(p + "wqkv.f8p", RV_U8, 3 * D * D, L.wqkv8p);
+            FIND(p + "wqkv.s8", RV_F32, 3 * D, L.sqkv);
+            FIND(p + "wo.f8p", RV_U8, D * D, L.wo8p);
+            FIND(p + "wo.s8", RV_F32, D, L.so);
+            FIND(p + "wgu.f8p", RV_U8, 2 * F * D, L.wgu8p);
+            FIND(p + "wgu.s8", RV_F32, 2 * F, L.sgu);
+            FIND(p + "wdown.f8p", RV_U8, D * F, L.wdown8p);
             FIND(p + "wdown.s8", RV_F32, D, L.sdown);
         }
     }
@@ -367,6 +387,8 @@ namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
     float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
+    uint8_t* x8;     // FP8 prefill: the quantised GEMM operand [M, max(D, F)] ...
+    float* sa;       // ... and its row scales [M]
     void* sk;
     size_t sk_bytes;
     size_t bytes;
@@ -384,6 +406,8 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.ss = (float*)k.take((size_t)(D / 16) * 16 * 4);
+    w.x8 = (uint8_t*)k.take((size_t)M * (F > D ? F : D));
+    w.sa = (float*)k.take((size_t)M * 4);
     w.bytes = k.off;
     return w;
 }
@@ -400,7 +424,9 @@ extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
 // so it is OFF by default and kept tested.
 int g_fuse_decode_attn = 0;
 int g_use_fp8_decode = 1;   // measurement knob: 0 = ignore bound FP8 copies (decode on the bf16 weights)
+int g_use_fp8_prefill = 1;  // measurement knob: 0 = ignore bound ".f8p" copies (prefill on the bf16 weights)
 extern "C" void rv_set_fp8_decode(int32_t on) { g_use_fp8_decode = on != 0; }
+extern "C" void rv_set_fp8_prefill(int32_t on) { g_use_fp8_prefill = on != 0; }
 extern "C" void rv_set_decode_fusion(int32_t on) { g_fuse_decode_attn = on != 0; }
 
 namespace {
@@ -428,6 +454,16 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
     const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
     const bool f8 = fuse_norm && c->fp8_decode && g_use_fp8_decode;   // FP8 weight copies: KV-cached decode steps only
+    // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
+    // weights; the others (and lm_head) stay on the bf16 weights
+    const bool p8 = !fuse_norm && M > 16 && c->fp8_prefill && g_use_fp8_prefill && w.sk_bytes >= 8192;
+    const bool p8_qkv = p8 && gemm_pp_fp8_supported(M, 3 * D, D, false, true), p8_o = p8 && gemm_pp_fp8_supported(M, D, D, false, false);
+    const bool p8_gu = p8 && gemm_pp_fp8_supported(M, 2 * F, D, true, false), p8_down = p8 && gemm_pp_fp8_supported(M, D, F, false, false);
+    auto norm_quant = [&](const float* nw) -> int {   // RMSNorm(h) -> FP8 rows + scales (fused for d = 4096)
+        if (D == 4096) return k_rmsnorm_quant(h, D, nw, w.x8, w.sa, M, (int)D, g.rms_eps, st);
+        RV_TRY(k_rmsnorm(h, D, nw, w.xn16, M, (int)D, g.rms_eps, st));
+        return k_quant_rows_fp8(w.xn16, D, w.x8, D, w.sa, M, (int)D, st);
+    };
     const bool fuse_attn = !f8 && fuse_norm && g_fuse_decode_attn && attn_oproj_decode_supported(B, H, dh, D) && w.sk_bytes >= 8192;
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
     GemvNorm consume;
@@ -439,7 +475,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
-        if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
+        if (p8_qkv) RV_TRY(norm_quant(L.norm1));
+        else if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
         // fused q/k/v projection: RoPE-rotated Q -> q16, rotated K and V^T -> this layer's cache (no f32 qkv round trip)
         QkvRope qr;
         qr.cs = w.cs;
@@ -447,7 +484,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.kc = kc;
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
-        if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
+        if (p8_qkv) {
+            RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wqkv8p, L.sqkv, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, M, 3 * D, D, &qr, w.sk, st));
+        } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
             GemvNorm cq = (fuse_norm && l > 0) ? consume : GemvNorm{};
             cq.w_scale = L.sqkv;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv8, M, D, qr, &cq, nullptr, 0, st, 2));
@@ -481,7 +520,10 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                        (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
             if (!prefix_done) RV_TRY(k_attention(a, st));
-            if (f8) {
+            if (p8_o) {
+                RV_TRY(k_quant_rows_fp8(w.a16, D, w.x8, D, w.sa, M, (int)D, st));
+                RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wo8p, L.so, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, nullptr, w.sk, st));
+            } else if (f8) {
                 GemvNorm po = produce;
                 po.w_scale = L.so;
                 RV_TRY(rv_gemm_impl(w.a16, D, L.wo8, D, 2, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, nullptr, 0, st, &po));
@@ -490,9 +532,19 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                                     fuse_norm ? &produce : nullptr));
             }
         }
-        if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
+        if (p8_gu) RV_TRY(norm_quant(L.norm2));
+        else if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
         produce.w_next = l + 1 < g.layers ? c->layers[l + 1].norm1 : c->final_norm;
-        if (f8) {
+        if (p8_gu || p8_down) {
+            if (p8_gu) RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wgu8p, L.sgu, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, w.sk, st));
+            else RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
+            if (p8_down) {
+                RV_TRY(k_quant_rows_fp8(w.act16, F, w.x8, F, w.sa, M, (int)F, st));
+                RV_TRY(gemm_pp_fp8(w.x8, F, w.sa, L.wdown8p, L.sdown, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, nullptr, w.sk, st));
+            } else {
+                RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st, nullptr));
+            }
+        } else if (f8) {
             GemvNorm cg = consume, pd = produce;
             cg.w_scale = L.sgu;
             pd.w_scale = L.sdown;

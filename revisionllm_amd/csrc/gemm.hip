@@ -886,3 +886,20 @@ extern "C" int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const flo
     nrm.w_scale = w_scale;
     return rv_gemm_impl(A, lda, W8, K, 2, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, nullptr, 0, as_stream(stream), &nrm);
 }
+
+// Opt-in FP8 x FP8 prefill GEMM (test / tool entry of what rv_llm_forward uses when the ".f8p" weight copies are bound).
+extern "C" int rv_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int64_t K, void* stream) {
+    RV_CHECK_ARG(K <= 0x7fffffff, "rv_quant_rows_fp8: K too large");
+    return k_quant_rows_fp8(x16, ldx, q8, ldq, scale, rows, (int)K, as_stream(stream));
+}
+
+extern "C" int rv_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
+                           int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
+                           size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(A8 && a_scale && W8p && w_scale && C && ws, "rv_gemm_fp8: null argument");
+    RV_CHECK_ARG(ws_bytes >= gemm_pp_ws_bytes(), "rv_gemm_fp8: workspace %zu < rv_gemm_ws_bytes() = %zu", ws_bytes, gemm_pp_ws_bytes());
+    RV_CHECK_ARG(lda % 16 == 0 && gemm_pp_fp8_supported(M, N, K, act == RV_ACT_SILU_MUL, false),
+                 "rv_gemm_fp8: shape M=%lld N=%lld K=%lld has no persistent FP8 plan (few-row, deep-K problems only)", (long long)M, (long long)N,
+                 (long long)K);
+    return gemm_pp_fp8(A8, lda, a_scale, W8p, w_scale, residual, ldr, C, ldc, out_dtype, act, M, N, K, nullptr, ws, as_stream(stream));
+}

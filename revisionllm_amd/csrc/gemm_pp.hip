@@ -47,6 +47,18 @@ struct PpSrc {
     unsigned w1[2];       // ... of W unit U2 (n1 quadrants)
 };
 
+// FP8 operands: per-row scales of the quantised activations [M] and per-column scales of the quantised weights [N]; the f32
+// accumulator is multiplied by a[m] * w[n] before anything else in the epilogue.  Both null for bf16 operands.
+struct PpScale {
+    const float* a;
+    const float* w;
+};
+__device__ __forceinline__ f32x4 pp_scaled(const PpScale& sc, int m, int n, f32x4 v) {
+    const float sa = sc.a[m];
+    const f32x4 sw = *(const f32x4*)(sc.w + n);
+    return f32x4{v[0] * (sa * sw[0]), v[1] * (sa * sw[1]), v[2] * (sa * sw[2]), v[3] * (sa * sw[3])};
+}
+
 // NF = MFMA fragments per wave along N: 4 -> 256-column panels, 3 -> 192-column panels (n1 quadrant = one fragment)
 template <int NF>
 __device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M,
@@ -134,7 +146,18 @@ __device__ __forceinline__ void wait_vm() {
 //   end of ph3: U0(c+1) landed (and with it the older U1, U2 (c+1))  -> U3(c+1) [+ U1, U2 (c+2)] = 2 [+ 2 + n1 loads]
 // WAR: a W stage is rewritten >= 1 tile after its last read, A unit U0 one tile, U3 four slots after its last read retired.
 constexpr int PP_A_STAGE = 2 * UNIT, PP_W_BASE = 2 * PP_A_STAGE, PP_W_STAGE = 2 * UNIT;
-template <int NF>
+// F8: the operands are FP8 (e4m3fn) bytes addressed as if they were bf16 matrices of K / 2 columns - a 128-byte staged row is
+// then 128 k instead of 64 and a W piece holds, per lane, k = 16 kg .. + 15 of each 64-k half (the bf16 fragment packing of the
+// byte pairs).  The lane's two 16-byte groups (ks = 0, 1) of either operand ARE its 32-byte operand of ONE
+// v_mfma_f32_16x16x128_f8f6f4: both operands carry the same k permutation and a dot product does not care.  Everything else
+// (addresses, LDS layout, waits) is the bf16 kernel at K / 2.
+typedef int pp_i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ pp_i32x8 pp_cat(bf16x8 lo, bf16x8 hi) {
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const i32x4_ a = __builtin_bit_cast(i32x4_, lo), b = __builtin_bit_cast(i32x4_, hi);
+    return pp_i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <int NF, int F8 = 0>
 __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
     constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant = loads per wave of unit U2
     const int wr = wave >> 2, wc = wave & 3;
@@ -176,9 +199,15 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
 #define PP_MFMA(B, NI, MI0, NJ)                                                                                     \
     do {                                                                                                            \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < (NJ); ++j)            \
-            _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                                 \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0);   \
+        if constexpr (F8) {                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int f = 0; f < 4; ++f)           \
+                acc[(NI) + j][(MI0) + f] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
+                    pp_cat(B[j][0], B[j][1]), pp_cat(af[f][0], af[f][1]), acc[(NI) + j][(MI0) + f], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < (NJ); ++j)        \
+                _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                             \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0); \
+        }                                                                                                           \
         __builtin_amdgcn_s_setprio(0);                                                                              \
     } while (0)
 #define PP_READ_A(BASE)                                                                                             \
@@ -251,9 +280,10 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
 }
 
 // Epilogue: lane owns row m = .. + fr, columns n = .. + kg * 4 .. + 3 of every 16 x 16 fragment.
-template <int OUT_BF16, int ACT, int ROPE, int NF>
-__device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const float* __restrict__ bias, const float* res, int64_t ldr,
-                                            void* Cv, int64_t ldc, int M, int m0, int n0, int wave, int lane, const QkvRope& qr) {
+template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
+__device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const float* __restrict__ bias, const float* res, int64_t ldr,
+                                            void* Cv, int64_t ldc, int M, int m0, int n0, int wave, int lane, const QkvRope& qr,
+                                            const PpScale& sc = PpScale{nullptr, nullptr}) {
     static_assert(NF == 4 || ACT != RV_ACT_SILU_MUL, "the gated epilogue pairs fragments: 256-column panels only");
     constexpr int WN = NF * 16;   // columns per wave
     const int wr = wave >> 2, wc = wave & 3;
@@ -262,9 +292,12 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const flo
     for (int mi = 0; mi < 8; ++mi) {
         const int m = m0 + wr * 128 + mi * 16 + fr;
         if (m >= M) continue;
+        f32x4 acc[NF][1];   // this row block's fragments, dequantised for FP8 operands ([.][0] keeps the indexing below)
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) acc[ni][0] = F8 ? pp_scaled(sc, m, n0 + wc * WN + ni * 16 + kg * 4, acc_in[ni][mi]) : acc_in[ni][mi];
         if constexpr (ROPE) {
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni) qkv_rope_store(qr, m, n0 + wc * WN + ni * 16 + kg * 4, acc[ni][mi]);
+            for (int ni = 0; ni < NF; ++ni) qkv_rope_store(qr, m, n0 + wc * WN + ni * 16 + kg * 4, acc[ni][0]);
         } else if (ACT == RV_ACT_SILU_MUL) {
 #pragma unroll
             for (int ni = 0; ni + 1 < NF; ni += 2) {
@@ -272,7 +305,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const flo
                 const int no = (n >> 1) + kg * 4;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][0][r]) * acc[ni + 1][0][r];
                 if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -280,7 +313,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc)[NF][8], const flo
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
                 const int n = n0 + wc * WN + ni * 16 + kg * 4;
-                f32x4 v = acc[ni][mi];
+                f32x4 v = acc[ni][0];
                 if (bias) v += *(const f32x4*)(bias + n);
                 if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
@@ -362,14 +395,18 @@ __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
 }
 
 // Epilogue of one reduction unit = the fragment pair (ni = 2 nip, 2 nip + 1) x mi of wave w's sub-tile.
-template <int OUT_BF16, int ACT, int ROPE>
+template <int OUT_BF16, int ACT, int ROPE, int F8 = 0>
 __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int mi, int nip, const float* __restrict__ bias,
                                                  const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int m0, int n0, int lane,
-                                                 const QkvRope& qr) {
+                                                 const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr}) {
     const int fr = lane & 15, kg = lane >> 4;
     const int m = m0 + (w >> 2) * 128 + mi * 16 + fr;
     if (m >= M) return;
     const int nf = n0 + (w & 3) * 64 + nip * 32;   // first column of fragment ni = 2 nip
+    if constexpr (F8) {
+        v0 = pp_scaled(sc, m, nf + kg * 4, v0);
+        v1 = pp_scaled(sc, m, nf + 16 + kg * 4, v1);
+    }
     if constexpr (ROPE) {
         qkv_rope_store(qr, m, nf + kg * 4, v0);
         qkv_rope_store(qr, m, nf + 16 + kg * 4, v1);
@@ -399,10 +436,10 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
 
 // Reduce + store this workgroup's share of a shared panel: units x = j, j + c, ... of the 128 (wave, mi, ni-pair) units,
 // dealt to the 8 waves.  C participants are read per pass (ids[base .. base + C), absent ones masked); C = c for c <= 4.
-template <int C, int OUT_BF16, int ACT, int ROPE>
+template <int C, int OUT_BF16, int ACT, int ROPE, int F8 = 0>
 __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, int c, int j, int wave, int lane,
                                                 const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv, int64_t ldc,
-                                                int M, int m0, int n0, const QkvRope& qr) {
+                                                int M, int m0, int n0, const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr}) {
     constexpr int UPW = C <= 4 ? (128 + 8 * C - 1) / (8 * C) : 1;   // units per wave and pass
     const int per_pass = 8 * UPW;
     for (int q0 = 0; j + q0 * c < 128; q0 += per_pass) {
@@ -434,16 +471,17 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
             const int x = j + (q0 + wave + 8 * u) * c;
-            if (x < 128) pp_epilogue_unit<OUT_BF16, ACT, ROPE>(s[u][0], s[u][1], x >> 4, (x >> 1) & 7, x & 1, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr);
+            if (x < 128) pp_epilogue_unit<OUT_BF16, ACT, ROPE, F8>(s[u][0], s[u][1], x >> 4, (x >> 1) & 7, x & 1, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr, sc);
         }
     }
 }
 
-template <int OUT_BF16, int ACT, int ROPE, int NF>
+template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
                                                   const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                   int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
-                                                  int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr) {
+                                                  int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr,
+                                                  PpScale sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -488,10 +526,10 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pp_mainloop<NF>(acc, src, ks0, nks, smem, wave, lane);
+        pp_mainloop<NF, F8>(acc, src, ks0, nks, smem, wave, lane);
 
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
-            pp_epilogue<OUT_BF16, ACT, ROPE, NF>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
+            pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
             continue;
         }
         if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
@@ -542,10 +580,10 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         }
         __syncthreads();
         const int m0 = m0_wg, n0 = (dp_panels + panel) * PBN;
-        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
-        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
-        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
-        else pp_reduce_share<8, OUT_BF16, ACT, ROPE>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr);
+        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
+        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
+        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
+        else pp_reduce_share<8, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
     }
 }
 
@@ -595,11 +633,11 @@ int pp_teams(int64_t M) {
     return tiles_m <= per_x ? 8 * (per_x / tiles_m) : 0;
 }
 
-template <int OUT_BF16, int ACT, int ROPE, int NF>
+template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
-              int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr) {
+              int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr, PpScale sc = PpScale{nullptr, nullptr}) {
     static bool attr_set = false;
-    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF>, attr_set)) return rc;
+    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64), nk = K / PBK;
     const int TS = tiles_m;             // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle
     const int G = pp_num_cus() & ~7;
@@ -613,8 +651,8 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     int* flags = (int*)ws;
     int* status = flags + PP_HDR / 4 - 1;
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
-    hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
-                       tiles_m, TS, nk, dp_panels, (tiles_n - dp_panels) * nk, partial, flags, status, epoch, qr);
+    hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
+                       tiles_m, TS, nk, dp_panels, (tiles_n - dp_panels) * nk, partial, flags, status, epoch, qr, sc);
     return RV_OK;
 }
 
@@ -708,5 +746,41 @@ int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int6
                                                    (int)K, ws, st, r);
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_pp_qkv_rope");
+    return RV_OK;
+}
+
+// FP8 (e4m3fn) x FP8 prefill GEMM on the persistent kernel: A8 [M, K] row-major bytes with per-row scales sa [M], W8p = the
+// bf16 fragment packing of the [N, K] byte matrix taken as [N, K / 2] 16-bit words with per-column scales sw [N].  Only the
+// persistent stream-K form exists (plan of the K / 2 problem): returns RV_ERR_ARG when the shape has no plan - the caller
+// keeps its bf16 path for those.  r != nullptr: fused RoPE + KV-cache append epilogue (QKV projection).
+bool gemm_pp_fp8_supported(int64_t M, int64_t N, int64_t K, bool gated, bool rope) {
+    if (K % 128 != 0 || !gemm_pp_sk_supported(1, M, N, K / 2)) return false;
+    const int plan = gemm_pp_sk_plan(M, N, K / 2, gated);
+    return rope ? plan != 0 : plan == 4;
+}
+int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, const float* sw, const float* res, int64_t ldr, void* C,
+                int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, const QkvRope* r, void* ws, hipStream_t st) {
+    const bf16_t* a = (const bf16_t*)A8;
+    const bf16_t* w = (const bf16_t*)W8p;
+    const PpScale sc{sa, sw};
+    const int m = (int)M, n = (int)N, k2 = (int)(K / 2);
+    const int64_t lda2 = lda / 2;
+    int rc;
+    if (r) {
+        rc = gemm_pp_sk_plan(M, N, K / 2, false) == 3
+                 ? launch_sk<0, RV_ACT_NONE, 1, 3, 1>(a, lda2, w, nullptr, nullptr, 0, nullptr, 0, m, n, k2, ws, st, *r, sc)
+                 : launch_sk<0, RV_ACT_NONE, 1, 4, 1>(a, lda2, w, nullptr, nullptr, 0, nullptr, 0, m, n, k2, ws, st, *r, sc);
+    } else if (act == RV_ACT_SILU_MUL && out_dtype == RV_BF16) {
+        rc = launch_sk<1, RV_ACT_SILU_MUL, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
+    } else if (act == RV_ACT_NONE && out_dtype == RV_F32) {
+        rc = launch_sk<0, RV_ACT_NONE, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
+    } else if (act == RV_ACT_NONE && out_dtype == RV_BF16) {
+        rc = launch_sk<1, RV_ACT_NONE, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
+    } else {
+        rv_set_error("gemm_pp_fp8: unsupported epilogue (act %d, out dtype %d)", act, out_dtype);
+        return RV_ERR_ARG;
+    }
+    if (rc) return rc;
+    RV_CHECK_LAUNCH("gemm_pp_fp8");
     return RV_OK;
 }

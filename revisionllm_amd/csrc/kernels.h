@@ -88,6 +88,10 @@ int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated);   // 0 = no, 4
 bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K);
 bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K);   // long K and a tile count that fills the CUs
 size_t gemm_pp_ws_bytes();
+// FP8 x FP8 prefill GEMM (persistent stream-K form only; see gemm_pp.hip): A8 bytes [M,K] + row scales, W8p + column scales
+bool gemm_pp_fp8_supported(int64_t M, int64_t N, int64_t K, bool gated, bool rope);
+int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, const float* sw, const float* res, int64_t ldr, void* C,
+                int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, const QkvRope* r, void* ws, hipStream_t st);
 int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st);
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
@@ -99,6 +103,9 @@ int attn_oproj_decode_launch(const void* q16, const void* kc, const void* vtc, v
                              int* sync, int* status, int B, int H, int Lk, int Smax, int64_t D, float scale, hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
                 int64_t period, int64_t rows, int d, hipStream_t st);
+int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
+                    hipStream_t st);
+int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);

@@ -91,6 +91,91 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     }
 }
 
+// ---- per-row FP8 (e4m3fn, OCP) quantisation of bf16 activations for the FP8 prefill GEMMs: one wave per row;
+// scale = max|row| / 448 (1 for a zero row), q = RNE_e4m3(x / scale), both divisions IEEE f32 (hipcc divides correctly
+// rounded by default), i.e. exactly torch's CPU `x.float() / scale`.  rmsnorm_quant_kernel fuses the LlamaRMSNorm in front:
+// it quantises the bf16-ROUNDED normalised row, so it equals quant_rows_fp8(rmsnorm(x)) byte for byte. ----
+__device__ __forceinline__ uint32_t fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                             int64_t ldq, float* __restrict__ scale, int64_t rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * ldx;
+    uint8_t* qr = q + row * ldq;
+    constexpr int NV = 8;              // rows up to 8 * 512 = 4096 stay in registers; longer ones are read twice
+    bf16x8 v[NV];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 8 + i * 512;
+        v[i] = c < K ? *(const bf16x8*)(xr + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)v[i][e])));
+    }
+    for (int c = lane * 8 + NV * 512; c < K; c += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)t[e])));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c >= K) break;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)v[i][e]) / sc;
+        *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
+    }
+    for (int c = lane * 8 + NV * 512; c < K; c += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + c);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)t[e]) / sc;
+        *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
+    }
+}
+
+template <int NV>   // row of NV * 256 floats in registers (NV = 16: d = 4096)
+__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restrict__ x, int64_t x_row_stride, const float* __restrict__ w,
+                                                            uint8_t* __restrict__ q, float* __restrict__ scale, int64_t rows, int d,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_row_stride;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+        s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+    const float r = rsqrtf(wave_sum(s) / (float)d + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 ww = *(const f32x4*)(w + i * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[i][e] = bf16_to_f32(f32_to_bf16(ww[e] * (v[i][e] * r)));   // the value the bf16 path hands to its GEMM
+            amax = fmaxf(amax, fabsf(v[i][e]));
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        *(uint32_t*)(q + row * d + i * 256 + lane * 4) = fp8x4(v[i][0] / sc, v[i][1] / sc, v[i][2] / sc, v[i][3] / sc);
+}
+
 // ---- sine position table: pos[t][j], frame t+1 of T (transformer.py:35-57) ----
 __global__ void sine_pos_kernel(float* __restrict__ pos, int T, int d) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,6 +331,25 @@ int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, i
     return RV_OK;
 }
 
+int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st) {
+    RV_CHECK_ARG(x16 && q8 && scale && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "quant_rows_fp8: K, ldx, ldq must be multiples of 8");
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x16, ldx, (uint8_t*)q8, ldq,
+                       scale, rows, K);
+    RV_CHECK_LAUNCH("quant_rows_fp8");
+    return RV_OK;
+}
+
+int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
+                    hipStream_t st) {
+    RV_CHECK_ARG(d == 4096, "rmsnorm_quant: d = %d (only 4096 is instantiated)", d);
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(rmsnorm_quant_kernel<16>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (uint8_t*)q8, scale, rows,
+                       d, eps);
+    RV_CHECK_LAUNCH("rmsnorm_quant");
+    return RV_OK;
+}
+
 int k_sine_pos(float* pos, int T, int d, hipStream_t st) {
     RV_CHECK_ARG(pos && T > 0 && d > 0, "sine_pos: bad arguments");
     hipLaunchKernelGGL(sine_pos_kernel, dim3((unsigned)cdiv((int64_t)T * d, 256)), dim3(256), 0, st, pos, T, d);
@@ -307,5 +411,9 @@ extern "C" int rv_layernorm(const float* x, const float* w, const float* b, floa
 }
 extern "C" int rv_rmsnorm(const float* x, const float* w, void* y_bf16, int64_t rows, int32_t d, float eps, void* stream) {
     return k_rmsnorm(x, d, w, y_bf16, rows, d, eps, as_stream(stream));
+}
+extern "C" int rv_rmsnorm_quant_fp8(const float* x, const float* w, void* q8, float* scale, int64_t rows, int32_t d, float eps, void* stream) {
+    RV_CHECK_ARG(x && w && q8 && scale, "rv_rmsnorm_quant_fp8: null argument");
+    return k_rmsnorm_quant(x, d, w, q8, scale, rows, d, eps, as_stream(stream));
 }
 extern "C" int rv_sine_pos(float* pos, int32_t T, int32_t d, void* stream) { return k_sine_pos(pos, T, d, as_stream(stream)); }

@@ -49,8 +49,12 @@ SIGNATURES = {
     "rv_set_decode_fusion": (None, [_i32]),
     "rv_set_gemm_cus": (None, [_i32]),
     "rv_set_fp8_decode": (None, [_i32]),
+    "rv_set_fp8_prefill": (None, [_i32]),
     "rv_set_sample_variant": (None, [_i32]),
     "rv_gemm": (C.c_int, [_p, _i64, _p, _i64, C.c_int, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, _sz, _p]),
+    "rv_rmsnorm_quant_fp8": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f, _p]),
+    "rv_quant_rows_fp8": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
+    "rv_gemm_fp8": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, C.c_size_t, _p]),
     "rv_gemv_fp8": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p]),
     "rv_layernorm": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p]),
     "rv_rmsnorm": (C.c_int, [_p, _p, _p, _i64, _i32, _f, _p]),

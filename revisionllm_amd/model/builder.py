@@ -123,6 +123,7 @@ def load_pretrained_model(args, stage2=None, stage3=None, load_ckp=False):
     with open(os.path.join(model_base, "config.json")) as f:
         cfg = json.load(f)
     model = ReVisionLlamaForCausalLM(shape_from_config(cfg), max_sequence_length=cfg.get("max_sequence_length"))
+    model.fp8_prefill = bool(getattr(args, "fp8_prefill", False))  # build-defined opt-in: FP8 x FP8 prefill GEMMs
     model.fp8_decode = bool(getattr(args, "fp8_decode", False))   # build-defined opt-in: FP8 copies of the LLM weights for decode steps
     gpath = os.path.join(model_base, "generation_config.json")
     if os.path.exists(gpath):
@@ -148,7 +149,7 @@ def finalize(model):
     """Pack the (merged) host state dict into HBM and drop the host copy."""
     sd = model._host_sd
     eng = model._ensure_engine()
-    eng.load_llm(lambda n: sd[n], fp8_decode=getattr(model, "fp8_decode", False))
+    eng.load_llm(lambda n: sd[n], fp8_decode=getattr(model, "fp8_decode", False), fp8_prefill=getattr(model, "fp8_prefill", False))
     root = "model.cross_attn." if getattr(model.get_model(), "cross_attn_variant", False) else "model.mm_projector."
     proj = {k[len(root):]: v for k, v in sd.items() if k.startswith(root)}
     if proj:

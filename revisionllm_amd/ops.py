@@ -75,12 +75,25 @@ def pack_fragments_fp8(w):
     """[N,K] (any float dtype; N % 16 == 0, K % 64 == 0) -> (uint8 [N*K] in the FP8 fragment-packed layout of the decode
     kernel, f32 [N] row scales).  Byte of element (n, k): (((n>>4)*(K/64) + (k>>6))*64 + (n&15) + 16*((k>>3)&3))*16 +
     ((k>>5)&1)*8 + (k&7): a lane's 16-byte load carries its MFMA operand of two consecutive 32-k blocks."""
-    N, K = w.shape
-    assert N % 16 == 0 and K % 64 == 0
     q, scale = quantize_rows_fp8(w)
+    return pack_fp8_decode(q), scale
+
+
+def pack_fp8_decode(q):
+    """float8_e4m3fn [N,K] -> uint8 [N*K] in the decode kernel's FP8 fragment layout (see pack_fragments_fp8)."""
+    N, K = q.shape
+    assert N % 16 == 0 and K % 64 == 0
     b = q.view(torch.uint8).view(N // 16, 16, K // 64, 2, 4, 8)           # (nb, r, kc, half, kq, e)
-    packed = b.permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)            # (nb, kc, kq, r, half, e): lane = kq * 16 + r
-    return packed, scale
+    return b.permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)              # (nb, kc, kq, r, half, e): lane = kq * 16 + r
+
+
+def pack_fp8_prefill(q):
+    """float8_e4m3fn [N,K] (K % 128 == 0) -> uint8 [N*K]: the byte matrix taken as [N, K/2] 16-bit words, fragment-packed like
+    a bf16 weight (``pack_fragments``) - the operand layout of the FP8 prefill GEMM (rv_gemm_fp8)."""
+    N, K = q.shape
+    assert N % 16 == 0 and K % 128 == 0
+    words = q.contiguous().view(torch.uint8).view(torch.int16)            # [N, K/2]
+    return pack_fragments(words).view(torch.uint8).reshape(-1)
 
 
 def gemv_fp8(a, w8, scale, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None):
@@ -93,6 +106,46 @@ def gemv_fp8(a, w8, scale, bias=None, residual=None, out_dtype=torch.bfloat16, a
     hip.check(hip.lib().rv_gemv_fp8(hip.ptr(a), a.stride(0), hip.ptr(w8), hip.ptr(scale), hip.ptr(bias), hip.ptr(residual),
                                     residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0), hip.dtype_code(out),
                                     act, M, N, K, hip.stream()), "rv_gemv_fp8")
+    return out
+
+
+def pack_fragments_fp8_prefill(w):
+    """[N,K] (any float dtype; N % 16 == 0, K % 128 == 0) -> (uint8 [N*K], f32 [N] row scales) for the FP8 prefill GEMM: the
+    quantised byte matrix is taken as [N, K/2] 16-bit words and fragment-packed like a bf16 weight (``pack_fragments``)."""
+    q, scale = quantize_rows_fp8(w)
+    return pack_fp8_prefill(q), scale
+
+
+def quant_rows_fp8(x):
+    """bf16 activations [M,K] -> (e4m3fn bytes uint8 [M,K], f32 [M] row scales) on the device (rv_quant_rows_fp8)."""
+    M, K = x.shape
+    x = _c(x)
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().rv_quant_rows_fp8(hip.ptr(x), x.stride(0), hip.ptr(q), q.stride(0), hip.ptr(sc), M, K, hip.stream()), "rv_quant_rows_fp8")
+    return q, sc
+
+
+def rmsnorm_quant_fp8(x, w, eps):
+    """f32 [rows, 4096] -> (e4m3fn bytes, f32 row scales) of the bf16-rounded LlamaRMSNorm output (rv_rmsnorm_quant_fp8)."""
+    rows, d = x.shape
+    q = torch.empty(rows, d, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().rv_rmsnorm_quant_fp8(hip.ptr(_c(x)), hip.ptr(w), hip.ptr(q), hip.ptr(sc), rows, d, eps, hip.stream()), "rv_rmsnorm_quant_fp8")
+    return q, sc
+
+
+def gemm_fp8(a8, a_scale, w8p, w_scale, residual=None, out_dtype=torch.float32, act=hip.RV_ACT_NONE, out=None):
+    """FP8 x FP8 prefill GEMM: act((a8 @ w8.T) * a_scale[:, None] * w_scale[None]) + residual (rv_gemm_fp8)."""
+    M, K = a8.shape
+    N = w_scale.numel()
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=out_dtype, device=a8.device)
+    ws = stream_k_workspace(a8.device)
+    hip.check(hip.lib().rv_gemm_fp8(hip.ptr(a8), a8.stride(0), hip.ptr(a_scale), hip.ptr(w8p), hip.ptr(w_scale), hip.ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0), hip.dtype_code(out), act,
+                                    M, N, K, hip.ptr(ws), ws.numel(), hip.stream()), "rv_gemm_fp8")
     return out
 
 

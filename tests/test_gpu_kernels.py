@@ -150,6 +150,43 @@ def test_gemv_fp8_weights(dev, M, N, K, act):
         assert rel_err(yb.float().cpu(), ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1005, 4096, 4096, 0), (1005, 4096, 11008, 0), (1005, 22016, 4096, 2), (700, 4096, 11008, 0)])
+def test_gemm_fp8_prefill(dev, M, N, K, act):
+    """Opt-in FP8 x FP8 prefill GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 on the persistent ping-pong kernel): the device
+    quantiser reproduces the host quantiser's bytes and scales, and the product equals the float64 product of the same
+    quantised operands up to f32 accumulation (asymmetric random operands: a swapped or permuted k would show)."""
+    from revisionllm_amd import hip, ops
+    x = bf(feats(f"f8p.x.{M}.{K}", (M, K), bf16=True))
+    x[3] = 0                                                  # an all-zero row: scale 1, bytes 0
+    w = feats(f"f8p.w.{N}.{K}", (N, K)) * (1.0 / math.sqrt(K))
+    amax = x.float().abs().amax(dim=1)                          # the activation quantiser: IEEE f32 divisions
+    sx = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    qx = (x.float() / sx[:, None]).to(torch.float8_e4m3fn)
+    a8, sa = ops.quant_rows_fp8(x.to(dev))
+    assert torch.equal(sa.cpu(), sx) and torch.equal(a8.cpu(), qx.view(torch.uint8))
+    if K == 4096 and act == 0:                                  # fused RMSNorm + quantiser == quantiser(RMSNorm)
+        h = feats(f"f8p.h.{M}", (M, K)).to(dev)
+        wn = (1.0 + 0.1 * feats("f8p.wn", (K,))).to(dev)
+        q1, s1 = ops.rmsnorm_quant_fp8(h, wn, 1e-5)
+        q2, s2 = ops.quant_rows_fp8(ops.rmsnorm(h, wn, 1e-5))
+        assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    qw, sw_ref = ops.quantize_rows_fp8(w)
+    w8p, sw = ops.pack_fragments_fp8_prefill(w.to(dev))
+    assert torch.equal(sw.cpu(), sw_ref)
+    ref = (qx.float().double() @ qw.float().double().t()) * sx.double()[:, None] * sw_ref.double()[None]
+    if act == hip.RV_ACT_SILU_MUL:
+        r3 = ref.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
+        y = ops.gemm_fp8(a8, sa, w8p, sw, act=act, out_dtype=torch.bfloat16)
+        assert rel_err(y.float().cpu(), ref) < BF16_TOL
+    else:
+        res = feats(f"f8p.r.{M}.{N}", (M, N))
+        y = ops.gemm_fp8(a8, sa, w8p, sw, residual=res.to(dev), out_dtype=torch.float32)
+        assert rel_err(y.cpu(), ref + res.double()) < F32_TOL * 5
+        y2 = ops.gemm_fp8(a8, sa, w8p, sw, residual=res.to(dev), out_dtype=torch.float32)
+        assert torch.equal(y, y2)                             # deterministic hand-off order
+
+
 def test_gemm_strided_rows_and_inplace_residual(dev):
     from revisionllm_amd import ops
     x = bf(feats("gemm.s", (20, 5, 768), bf16=True)).to(dev)

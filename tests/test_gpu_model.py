@@ -517,6 +517,50 @@ def test_persistent_qkv_rope_epilogue_is_bit_exact():
     assert (out[6][2] - out[2][2]).abs().max() <= 5e-3 * out[6][2].abs().max()
 
 
+def test_fp8_prefill_vs_oracle_with_the_same_quantisation():
+    """Opt-in FP8 x FP8 prefill (one 7B-shaped layer, the recursion's 7-call shared-prefix prefill of 1005 rows): the oracle runs
+    the same layer on the same fake-quantised weights with its activations fake-quantised per row at the four GEMM inputs.
+    The engine is closer to that oracle than to the unquantised one, and the knob restores the bf16 prefill bit for bit."""
+    from oracle import llama
+    from revisionllm_amd import engine, hip
+    from revisionllm_amd.utils import synth
+    shape = synth.LlamaShape(hidden=4096, inter=11008, layers=1, heads=32, vocab=32000)
+    B, S, P0 = 7, 171, 32
+    h0 = feats("f8p.h0", (P0 + B * (S - P0), 4096)) * 0.02
+    logits = {}
+    for mode in ("bf16", "fp8"):
+        eng = engine.Engine(shape, device="cuda:0")
+        eng.init_synthetic(seed=1, fp8_prefill=(mode == "fp8"))
+        kv, Smax = eng.new_kv(B, S + 8, reuse=False)
+        logits[mode] = eng.llm_prefill_shared(h0.to("cuda:0"), B, P0, kv, Smax).cpu()
+        if mode == "fp8":
+            try:
+                hip.lib().rv_set_fp8_prefill(0)
+                kv, Smax = eng.new_kv(B, S + 8, reuse=False)
+                off = eng.llm_prefill_shared(h0.to("cuda:0"), B, P0, kv, Smax).cpu()
+            finally:
+                hip.lib().rv_set_fp8_prefill(1)
+            assert torch.equal(off, logits["bf16"])
+        del eng, kv
+        torch.cuda.empty_cache()
+    w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), 1).items()}
+    w = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}      # the engine binds bf16 matrices
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    emb = torch.stack([torch.cat([h0[:P0], h0[P0 + b * (S - P0):P0 + (b + 1) * (S - P0)]]) for b in range(B)])
+    w8 = llama.fp8_decode_weights(w, cfg)
+    w8["lm_head.weight"] = w["lm_head.weight"]                                               # prefill lm_head stays bf16
+    want8 = llama.forward(emb, w8, cfg, last_only=True, act_quant=llama.fp8_act_rows)[:, 0]
+    want8w = llama.forward(emb, w8, cfg, last_only=True)[:, 0]                                # weights quantised, activations not
+    want16 = llama.forward(emb, w, cfg, last_only=True)[:, 0]
+    e8, e8w, e16 = rel_err(logits["fp8"], want8), rel_err(logits["fp8"], want8w), rel_err(logits["fp8"], want16)
+    assert rel_err(logits["bf16"], want16) < 2e-2
+    # e4m3 steps are 6-12 %: an activation that differs by rounding noise between engine and oracle lands on the neighbouring
+    # code now and then.  Measured in the oracle alone: 0.2 % noise in front of the quantiser (or leaving out the bf16 rounding)
+    # moves these logits by 0.08; the engine sits 0.060 from the mirror, 0.100 from the weights-only mirror, 0.155 from the
+    # unquantised oracle.
+    assert e8 < 9e-2 and e8 < 0.8 * e8w and e8 < 0.6 * e16, (e8, e8w, e16)
+
+
 def test_multi_query_batching_on_device():
     """Two queries of one movie batched through one set of LLM passes give the records of two separate runs."""
     from revisionllm_amd import parallel
