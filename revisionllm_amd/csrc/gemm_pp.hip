@@ -756,7 +756,12 @@ int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int6
 bool gemm_pp_fp8_supported(int64_t M, int64_t N, int64_t K, bool gated, bool rope) {
     if (K % 128 != 0 || !gemm_pp_sk_supported(1, M, N, K / 2)) return false;
     const int plan = gemm_pp_sk_plan(M, N, K / 2, gated);
-    return rope ? plan != 0 : plan == 4;
+    if (rope ? plan != 0 : plan == 4) return true;
+    if (rope) return false;
+    // Two-way split panels (e.g. the N = 4096 projections at M ~ 2000: 16 panels on 32 teams) lose to the bf16 ring kernel
+    // in bf16, which is why the bf16 plan leaves them there - but the FP8 alternative is that SAME bf16 ring kernel.
+    const int64_t T = pp_teams(M), panels = N / PBN, nk = K / 2 / PBK;
+    return T > 0 && panels < T && panels * 2 <= T && panels * nk >= 8 * T;
 }
 int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, const float* sw, const float* res, int64_t ldr, void* C,
                 int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, const QkvRope* r, void* ws, hipStream_t st) {

@@ -150,7 +150,8 @@ def test_gemv_fp8_weights(dev, M, N, K, act):
         assert rel_err(yb.float().cpu(), ref) < BF16_TOL
 
 
-@pytest.mark.parametrize("M,N,K,act", [(1005, 4096, 4096, 0), (1005, 4096, 11008, 0), (1005, 22016, 4096, 2), (700, 4096, 11008, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(1005, 4096, 4096, 0), (1005, 4096, 11008, 0), (1005, 22016, 4096, 2), (700, 4096, 11008, 0),
+                                        (2010, 4096, 4096, 0), (2010, 4096, 11008, 0)])
 def test_gemm_fp8_prefill(dev, M, N, K, act):
     """Opt-in FP8 x FP8 prefill GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 on the persistent ping-pong kernel): the device
     quantiser reproduces the host quantiser's bytes and scales, and the product equals the float64 product of the same
