@@ -11,6 +11,11 @@ all-gathers (weak scaling: per-GPU work fixed).  Inputs are resident in HBM when
 
 Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, timed with HIP events on
 the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded sample, N = 1 only).
+
+The timed region is exactly K steps after W warm-up steps (and ``--settle`` untimed steps that belong to the set-up), with
+``--streams`` steps in flight.  ``value`` is the bf16 path, one video per step.  At N = 1 the same loop is then timed again in
+other configurations and reported under ``extra_measurements`` (never ``value``): FP8 decode weights, the full opt-in FP8
+LLM path (FP8 x FP8 prefill GEMMs + FP8 decode weights), two different videos batched per step, and both together.
 """
 import argparse
 import json
