@@ -90,7 +90,7 @@ int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const float* w_scale
                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* stream);
 /* Opt-in FP8 x FP8 prefill GEMM (the "fp8 MFMA LLM path" BASELINE.json configs[4] names; the reference has no counterpart, it
  * runs bf16 / fp16 - never the parity target or the headline).  rv_quant_rows_fp8: bf16 activations x16 [rows, K] -> e4m3fn bytes
- * q8 [rows, K] (row stride ldq bytes) + per-row scales max|row| / 448; q = RNE_e4m3(x / scale), IEEE f32 divisions.  rv_gemm_fp8: C = act((A8 . W8^T) * a_scale[m] * w_scale[n]) (+ residual); W8p = the [N, K] e4m3fn byte matrix
+ * q8 [rows, K] (row stride ldq bytes) + per-row scales max|row| / 448; q = RNE_e4m3(x * (1 / scale)), IEEE f32.  rv_gemm_fp8: C = act((A8 . W8^T) * a_scale[m] * w_scale[n]) (+ residual); W8p = the [N, K] e4m3fn byte matrix
  * taken as [N, K/2] 16-bit words in the bf16 fragment packing (ops.pack_fragments_fp8_prefill); v_mfma_scale_f32_16x16x128_f8f6f4
  * on the persistent 256x256 ping-pong kernel; few-row deep-K shapes only (those with a stream-K plan), act NONE or SILU_MUL. */
 /* LlamaRMSNorm + rv_quant_rows_fp8 in one pass (d = 4096): quantises the bf16-rounded normalised row, i.e. the bytes and

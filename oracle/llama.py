@@ -155,11 +155,11 @@ def fp8_rows(w):
 def fp8_act_rows(x):
     """Mirror of the build's FP8 prefill activation quantiser (rv_quant_rows_fp8): the activation is rounded to bf16 (what the
     bf16 path hands to its GEMM), then per row over the last dim: scale = max|row| / 448 (1 for a zero row), q =
-    RNE_e4m3(x / scale), IEEE f32 divisions; returns the dequantised q * scale."""
+    RNE_e4m3(x * (1 / scale)), IEEE f32; returns the dequantised q * scale."""
     xb = x.to(torch.bfloat16).float()
     amax = xb.abs().amax(dim=-1, keepdim=True)
     scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    return (xb / scale).to(torch.float8_e4m3fn).float() * scale
+    return (xb * (1.0 / scale)).to(torch.float8_e4m3fn).float() * scale
 
 
 def fp8_decode_weights(w, cfg: LlamaCfg):

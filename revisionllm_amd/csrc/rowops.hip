@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 }
 
 // ---- per-row FP8 (e4m3fn, OCP) quantisation of bf16 activations for the FP8 prefill GEMMs: one wave per row;
-// scale = max|row| / 448 (1 for a zero row), q = RNE_e4m3(x / scale), both divisions IEEE f32 (hipcc divides correctly
-// rounded by default), i.e. exactly torch's CPU `x.float() / scale`.  rmsnorm_quant_kernel fuses the LlamaRMSNorm in front:
+// scale = max|row| / 448 (1 for a zero row), q = RNE_e4m3(x * (1 / scale)): two IEEE f32 divisions per ROW (hipcc divides
+// correctly rounded by default) and one multiply per element, i.e. exactly torch's CPU `x.float() * (1.0 / scale)`.  rmsnorm_quant_kernel fuses the LlamaRMSNorm in front:
 // it quantises the bf16-ROUNDED normalised row, so it equals quant_rows_fp8(rmsnorm(x)) byte for byte. ----
 __device__ __forceinline__ uint32_t fp8x4(float a, float b, float c, float d) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
@@ -124,20 +124,21 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     amax = wave_max(amax);
     const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
     if (lane == 0) scale[row] = sc;
+    const float inv = 1.0f / sc;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane * 8 + i * 512;
         if (c >= K) break;
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)v[i][e]) / sc;
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)v[i][e]) * inv;
         *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
     }
     for (int c = lane * 8 + NV * 512; c < K; c += 512) {
         const bf16x8 t = *(const bf16x8*)(xr + c);
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)t[e]) / sc;
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)t[e]) * inv;
         *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
     }
 }
@@ -171,9 +172,10 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restr
     amax = wave_max(amax);
     const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
     if (lane == 0) scale[row] = sc;
+    const float inv = 1.0f / sc;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        *(uint32_t*)(q + row * d + i * 256 + lane * 4) = fp8x4(v[i][0] / sc, v[i][1] / sc, v[i][2] / sc, v[i][3] / sc);
+        *(uint32_t*)(q + row * d + i * 256 + lane * 4) = fp8x4(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
 }
 
 // ---- sine position table: pos[t][j], frame t+1 of T (transformer.py:35-57) ----

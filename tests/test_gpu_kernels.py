@@ -160,9 +160,9 @@ def test_gemm_fp8_prefill(dev, M, N, K, act):
     x = bf(feats(f"f8p.x.{M}.{K}", (M, K), bf16=True))
     x[3] = 0                                                  # an all-zero row: scale 1, bytes 0
     w = feats(f"f8p.w.{N}.{K}", (N, K)) * (1.0 / math.sqrt(K))
-    amax = x.float().abs().amax(dim=1)                          # the activation quantiser: IEEE f32 divisions
+    amax = x.float().abs().amax(dim=1)                          # the activation quantiser: IEEE f32, one reciprocal per row
     sx = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    qx = (x.float() / sx[:, None]).to(torch.float8_e4m3fn)
+    qx = (x.float() * (1.0 / sx)[:, None]).to(torch.float8_e4m3fn)
     a8, sa = ops.quant_rows_fp8(x.to(dev))
     assert torch.equal(sa.cpu(), sx) and torch.equal(a8.cpu(), qx.view(torch.uint8))
     if K == 4096 and act == 0:                                  # fused RMSNorm + quantiser == quantiser(RMSNorm)
