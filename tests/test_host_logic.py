@@ -163,3 +163,27 @@ def test_mm_utils_helpers(tmp_path):
     stage2.write_log(str(log), "v", "grounding", "q1", ["In video 3."], info={"iou": [1]})
     import json
     assert json.loads(open(log).read()) == {"video_id": "v", "task": "grounding", "query_id": "q1", "answer": ["In video 3."], "info": {"iou": [1]}}
+
+
+def test_fp8_quantisers_host_side():
+    """The host halves of the opt-in FP8 path: the oracle's activation fake-quantiser is idempotent, keeps the row maximum
+    exactly and a zero row at zero; the prefill weight layout is the bf16 fragment packing of the byte pairs (an operand
+    fragment = 16 rows x 64 k-bytes, lane (row, j) holding bytes 16 j .. 16 j + 15 of the 64)."""
+    from oracle import llama
+    from revisionllm_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 256, generator=g) * 3.0
+    x[2] = 0
+    y = llama.fp8_act_rows(x)
+    assert torch.equal(llama.fp8_act_rows(y), y)
+    xb = x.to(torch.bfloat16).float()
+    assert torch.equal(y.abs().amax(dim=1), xb.abs().amax(dim=1)) and torch.count_nonzero(y[2]) == 0
+    assert float((y - xb).abs().max() / xb.abs().max()) < 2 ** -4
+    w = torch.randn(32, 256, generator=g)
+    q, scale = ops.quantize_rows_fp8(w)
+    packed = ops.pack_fp8_prefill(q).view(2, 256 // 64, 64, 16)        # (n16 block, 64-byte k block, lane, byte)
+    qb = q.view(torch.uint8)
+    for (nb, kb, lane) in ((0, 0, 0), (1, 3, 37), (0, 2, 63)):
+        r, j = lane & 15, lane >> 4
+        assert torch.equal(packed[nb, kb, lane], qb[nb * 16 + r, kb * 64 + j * 16:kb * 64 + j * 16 + 16])
+    assert torch.equal(scale, w.abs().amax(dim=1).double().div(448.0).float())
