@@ -188,6 +188,18 @@ def test_gemm_fp8_prefill(dev, M, N, K, act):
         assert torch.equal(y, y2)                             # deterministic hand-off order
 
 
+def test_gemm_fp8_prefill_refuses_shapes_without_a_plan(dev):
+    """rv_gemm_fp8 exists in the persistent stream-K form only: a shape without a plan is an argument error with the
+    reason, not a silent fall back to another kernel."""
+    from revisionllm_amd import hip, ops
+    a8 = torch.zeros(64, 512, dtype=torch.uint8, device=dev)
+    sa = torch.ones(64, device=dev)
+    w8p = torch.zeros(256 * 512, dtype=torch.uint8, device=dev)
+    sw = torch.ones(256, device=dev)
+    with pytest.raises(hip.HipLibraryError, match="no persistent FP8 plan"):
+        ops.gemm_fp8(a8, sa, w8p, sw)
+
+
 def test_gemm_strided_rows_and_inplace_residual(dev):
     from revisionllm_amd import ops
     x = bf(feats("gemm.s", (20, 5, 768), bf16=True)).to(dev)
