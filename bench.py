@@ -91,7 +91,7 @@ def roofline_legs(model, n_calls, M):
     flops = 2.0 * M * s.hidden * 2 * s.inter
     # M <= 8192 rows: the persistent 256x256x64 ping-pong kernel (one 512-thread workgroup per CU), whole panels + stream-K tail
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    legs["prefill_gateup_gemm"] = dict(kernel="gemm_pp_sk<1,2,0,4>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
+    legs["prefill_gateup_gemm"] = dict(kernel="gemm_pp_sk<1,2,0,4,0>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
                                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops, grid_threads=(cus & ~7) * 512)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
     #     256 MB infinity cache cannot serve the weights
