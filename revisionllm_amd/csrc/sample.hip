@@ -493,7 +493,7 @@ __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f3
 // one block (1024 threads) per segment: column norms over frames, sims[t] = <f_t / norm, q>, sum of the k largest
 // (k <= 0: mean).  Phase 1 splits the frames over 4 thread groups per column block to keep ~T/4 loads per thread.
 template <typename T>
-__global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
+__global__ __launch_bounds__(1024) void topk_cosine_kernel_generic(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
                                                            int k, float* __restrict__ out) {
     extern __shared__ float smem[];
     float* qn = smem;            // [d] q / column norm
@@ -544,6 +544,85 @@ __global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__
     }
 }
 
+
+// The same with 16-byte loads (d a multiple of the vector width VEC = 16 B / sizeof(T)): thread t owns column chunk t % (d / VEC)
+// and walks the frames of group t / (d / VEC), so a wave reads whole 1 KiB row segments; the per-group partial sums meet in LDS
+// and are added in group order (deterministic).  The scores take one wave per frame with the same 16-byte loads, and the
+// top-k is k wave-argmax rounds (largest value, then smallest frame index: the serial scan's choice).  39 MB of bf16 features
+// for 100 segments: 157 -> ~25 us.
+template <typename T>
+__global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__ feat, const float* __restrict__ q, int Tn, int d,
+                                                           int k, float* __restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    extern __shared__ float smem[];
+    const int chunks = d / VEC, groups = 1024 / chunks;
+    float* qn = smem;                 // [d]
+    float* psum = smem + d;           // [groups][d]
+    float* sims = psum + groups * d;  // [Tn]
+    const T* f = feat + (int64_t)blockIdx.x * Tn * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto load = [&](const T* p, float (&v)[VEC]) {
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 r = *(const bf16x8*)p;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = bf16_to_f32((bf16_t)r[e]);
+        } else {
+            const f32x4 r = *(const f32x4*)p;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = r[e];
+        }
+    };
+    if (tid < chunks * groups) {
+        const int cc = tid % chunks, fg = tid / chunks;
+        float ss[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ss[e] = 0.f;
+        for (int t = fg; t < Tn; t += groups) {
+            float v[VEC];
+            load(f + (int64_t)t * d + cc * VEC, v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ss[e] += v[e] * v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) psum[fg * d + cc * VEC + e] = ss[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += 1024) {
+        float s2 = 0.f;
+        for (int g = 0; g < groups; ++g) s2 += psum[g * d + c];
+        qn[c] = q[c] / sqrtf(s2);
+    }
+    __syncthreads();
+    for (int t = wave; t < Tn; t += 16) {
+        float s1 = 0.f;
+        for (int cc = lane; cc < chunks; cc += 64) {
+            float v[VEC];
+            load(f + (int64_t)t * d + cc * VEC, v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s1 += v[e] * qn[cc * VEC + e];
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) sims[t] = s1;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float acc = 0.f;
+    if (k <= 0) {
+        for (int t = lane; t < Tn; t += 64) acc += sims[t];
+        acc = wave_sum(acc) / (float)Tn;
+    } else {
+        for (int r = 0; r < k && r < Tn; ++r) {
+            ArgMax best{-INFINITY, 0x7fffffff};
+            for (int t = lane; t < Tn; t += 64) best = better(best, ArgMax{sims[t], t});
+            best = wave_argmax(best);
+            acc += best.v;
+            if (lane == 0 && best.i < Tn) sims[best.i] = -INFINITY;
+            __builtin_amdgcn_s_waitcnt(0);   // the LDS write lands before the next round's reads (one wave: program order)
+        }
+    }
+    if (lane == 0) out[blockIdx.x] = acc;
+}
+
 }  // namespace
 
 extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
@@ -575,15 +654,22 @@ extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32
 extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
                               float* out, void* stream) {
     RV_CHECK_ARG(feat && q_cls && out && n > 0 && T > 0 && d > 0, "rv_topk_cosine: bad arguments");
-    RV_CHECK_ARG((size_t)(5 * d + T) * 4 <= 64 * 1024, "rv_topk_cosine: 5*d + T too large for LDS");
-    const size_t sm = (size_t)(5 * d + T) * sizeof(float);
-    if (feat_dtype == RV_BF16)
-        hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(1024), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
-    else if (feat_dtype == RV_F32)
-        hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(1024), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
-    else {
-        rv_set_error("rv_topk_cosine: dtype must be f32 or bf16");
-        return RV_ERR_ARG;
+    RV_CHECK_ARG(feat_dtype == RV_BF16 || feat_dtype == RV_F32, "rv_topk_cosine: dtype must be f32 or bf16");
+    const int vec = feat_dtype == RV_BF16 ? 8 : 4;
+    const int chunks = d / vec, groups = chunks > 0 && chunks <= 1024 ? 1024 / chunks : 0;
+    const size_t sm_fast = ((size_t)(groups + 1) * d + T) * sizeof(float);
+    if (d % vec == 0 && groups > 0 && sm_fast <= 64 * 1024) {
+        if (feat_dtype == RV_BF16)
+            hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(1024), sm_fast, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+        else
+            hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(1024), sm_fast, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
+    } else {
+        RV_CHECK_ARG((size_t)(5 * d + T) * 4 <= 64 * 1024, "rv_topk_cosine: 5*d + T too large for LDS");
+        const size_t sm = (size_t)(5 * d + T) * sizeof(float);
+        if (feat_dtype == RV_BF16)
+            hipLaunchKernelGGL(topk_cosine_kernel_generic<bf16_t>, dim3(n), dim3(1024), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+        else
+            hipLaunchKernelGGL(topk_cosine_kernel_generic<float>, dim3(n), dim3(1024), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
     }
     RV_CHECK_LAUNCH("rv_topk_cosine");
     return RV_OK;
