@@ -1,9 +1,12 @@
 // softmax(Q K^T * scale + mask) V with MFMA 16x16x32, head dims 96 (adapter, nn.MultiheadAttention), 128 (Llama)
 // and 64 (CLIP towers).  One wave = 16 query rows of one (batch, head); keys are walked 32 at a time with an
 // online softmax.  Both products use swapped operands so that every per-query quantity is lane-local:
-//   S^T[key][q] = K . Q^T     lane (q = lane & 15, g = lane >> 4) holds keys {g*4+r} and {16+g*4+r}
-//   O^T[d][q]   = V^T . P^T   the same 8 scores ARE the lane's B fragment (the sum over keys is
-//                             permutation invariant), V^T rows give the A fragment as two 8-byte loads
+//   S^T[key][q] = K . Q^T     row i of score tile t (t = 0, 1) is key (i >> 2) * 8 + t * 4 + (i & 3) of the 32-key block, so
+//                             lane (q = lane & 15, g = lane >> 4), which owns rows 4g + r of both tiles, holds the 8
+//                             CONSECUTIVE keys 8g .. 8g + 7
+//   O^T[d][q]   = V^T . P^T   the same 8 scores ARE the lane's B fragment (the sum over keys is permutation
+//                             invariant), and its V^T A fragment is ONE 16-byte load (8 consecutive keys of row d) - a
+//                             vector-memory instruction costs the address unit the same 16 cycles whatever it moves
 // so there is no LDS traffic and no cross-lane movement besides two shuffles for the row max.  V is
 // kept transposed in memory ([dh][keys]: the KV cache is written that way, the adapter transposes once).
 // K / V^T tiles come straight from L2 (a head's K/V is <= 64 KB at the path's sequence lengths).
@@ -30,7 +33,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     for (int c = 0; c < NC; ++c) qf[c] = *(const bf16x8*)(qp + c * 32);
 
     const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
-    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * 4;
+    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * 8;
+    const int krow = (fr >> 2) * 8 + (fr & 3);   // key of score-tile row fr within the 32-key block (+ 4 for tile 1)
     const uint8_t* pad = a.key_pad ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
 
     f32x4 o[ND];
@@ -46,19 +50,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         bf16x8 kf[2][NC];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int key = min(k0 + t * 16 + fr, a.Lk - 1);
+            const int key = min(k0 + krow + t * 4, a.Lk - 1);
             const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
         }
-        union VF { bf16x8 v; u32x2 h2[2]; };
-        VF vf[ND];
+        bf16x8 vf[ND];
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-            const bf16_t* vp = vbase + (int64_t)dt * 16 * a.vt_ds + k0;
-            vf[dt].h2[0] = *(const u32x2*)(vp);
-            vf[dt].h2[1] = *(const u32x2*)(vp + 16);
-        }
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + k0);
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -71,7 +70,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = k0 + t * 16 + g * 4 + r;
+                const int key = k0 + g * 8 + t * 4 + r;
                 bool dead = key >= a.Lk || (a.causal && key > qpos);
                 if (pad && key < a.Lk) dead = dead || pad[key];
                 const float v = dead ? -INFINITY : s[t][r] * a.scale;
@@ -101,7 +100,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
             o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt].v, pf.v, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[dt], 0, 0, 0);
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b) 
 static int attn_check(const AttnArgs& a) {
     RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");
     RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
-    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
+    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 8 == 0 && a.vt_hs % 8 == 0 && a.vt_bs % 8 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     return RV_OK;
@@ -187,7 +186,7 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st) {
 int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");
     RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
-    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 4 == 0 && a.vt_hs % 4 == 0 && a.o_rs % 4 == 0,
+    RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 8 == 0 && a.vt_hs % 8 == 0 && a.vt_bs % 8 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     const bool split = a.Lq <= 16 && !a.no_split;
