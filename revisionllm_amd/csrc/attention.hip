@@ -149,17 +149,34 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
 }
 
+// 1-D grid, XCD-aware: workgroup id lands on XCD id % 8 (private L2), so the query tiles of one (batch, head) - which read
+// the same K / V^T - get ids that differ by multiples of 8, and an XCD only ever touches 1/8 of the (batch, head) pairs.
+__device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, int& h, int& b) {
+    const int id = blockIdx.x, j = id >> 3;
+    const int pr = (j / tiles) * 8 + (id & 7);
+    if (pr >= pairs) return false;
+    bx = j % tiles;
+    h = pr % H;
+    b = pr / H;
+    return true;
+}
+__host__ inline unsigned attn_grid(int tiles, int pairs) { return (unsigned)(tiles * ((pairs + 7) / 8) * 8); }
+
 template <int DH, bool SPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
-    attn_body<DH, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
+    int bx, h, b;
+    if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;
+    attn_body<DH, SPLIT>(a, bx, h, b);
 }
 
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
 // themselves, the per-call rows attend to prefix + own keys): blockIdx.z < a.B -> problem a, else problem b.
 template <int DH>
-__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b) {
-    if ((int)blockIdx.z < a.B) attn_body<DH, false>(a, blockIdx.x, blockIdx.y, blockIdx.z);
-    else attn_body<DH, false>(b, blockIdx.x, blockIdx.y, blockIdx.z - a.B);
+__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles) {
+    int bx, h, z;
+    if (!attn_map(tiles, a.H, a.H * (a.B + b.B), bx, h, z)) return;
+    if (z < a.B) attn_body<DH, false>(a, bx, h, z);
+    else attn_body<DH, false>(b, bx, h, z - a.B);
 }
 
 }  // namespace
@@ -178,7 +195,7 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st) {
     if (int rc = attn_check(b)) return rc;
     RV_CHECK_ARG(a.dh == 128 && b.dh == 128 && a.H == b.H && a.Lq > 16 && b.Lq > 16, "attention pair: 128-wide heads, same head count, prefill lengths only");
     const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
-    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3((unsigned)tiles, (unsigned)a.H, (unsigned)(a.B + b.B)), dim3(256), 0, st, a, b);
+    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B))), dim3(256), 0, st, a, b, tiles);
     RV_CHECK_LAUNCH("attention pair");
     return RV_OK;
 }
@@ -190,19 +207,20 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
                  "attention: stride alignment");
     RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     const bool split = a.Lq <= 16 && !a.no_split;
-    dim3 grid((unsigned)cdiv(a.Lq, split ? 16 : 64), (unsigned)a.H, (unsigned)a.B);
+    const int tiles = (int)cdiv(a.Lq, split ? 16 : 64);
+    const dim3 grid(attn_grid(tiles, a.H * a.B));
     if (a.dh == 64 && !split)
-        hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 64)
-        hipLaunchKernelGGL((attn_kernel<64, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<64, true>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 96 && !split)
-        hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 96)
-        hipLaunchKernelGGL((attn_kernel<96, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<96, true>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 128 && !split)
-        hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 128)
-        hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, st, a, tiles);
     else {
         rv_set_error("attention: head dim %d unsupported (64, 96, 128)", a.dh);
         return RV_ERR_ARG;

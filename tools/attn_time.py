@@ -34,3 +34,9 @@ run("prefill rows  B=7  H=32 dh=128 Lq=139 Lk=171 causal", 7, 32, 128, 139, 171,
 run("prefill full  B=7  H=32 dh=128 Lq=171 Lk=171 causal", 7, 32, 128, 171, 171, 192, True, 0)
 run("adapter       B=100 H=8 dh=96  Lq=257 Lk=257       ", 100, 8, 96, 257, 257, 288, False, 0)
 run("decode        B=7  H=32 dh=128 Lq=1   Lk=176       ", 7, 32, 128, 1, 176, 192, False, 175)
+if len(sys.argv) > 1:   # scaling probes (latency floor vs throughput: B=1 12.7 us, B=7 24.6, B=28 73)
+    run("probe B=1 Lq=139 Lk=171", 1, 32, 128, 139, 171, 192, True, 32)
+    run("probe B=7 Lq=139 Lk=171 non-causal", 7, 32, 128, 139, 171, 192, False, 0)
+    run("probe B=7 Lq=64 Lk=64 causal", 7, 32, 128, 64, 64, 192, True, 0)
+    run("probe B=7 Lq=139 Lk=32", 7, 32, 128, 139, 32, 192, False, 0)
+    run("probe B=28 Lq=139 Lk=171 causal", 28, 32, 128, 139, 171, 192, True, 32)
