@@ -17,7 +17,9 @@ namespace {
 // SPLIT (Lq <= 16, i.e. KV-cached decode): the block's 4 waves share the same 16 queries and take key blocks
 // w, w+4, ...; their (m, l, O) partials are merged through LDS.  A decode step is pure latency (one wave would
 // walk all keys serially), so this cuts it ~4x.
-template <int DH, bool SPLIT>
+// PAD: a key-padding mask is present (the text cross-attention of the adapter); without it the per-key byte loads and their
+// branches are compiled out.
+template <int DH, bool SPLIT, bool PAD>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int b) {
     constexpr int NC = DH / 32, ND = DH / 16;
     const int lane = threadIdx.x & 63;
@@ -35,7 +37,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
     const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * 8;
     const int krow = (fr >> 2) * 8 + (fr & 3);   // key of score-tile row fr within the 32-key block (+ 4 for tile 1)
-    const uint8_t* pad = a.key_pad ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
+    const uint8_t* pad = PAD ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
 
     f32x4 o[ND];
 #pragma unroll
@@ -66,17 +68,29 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
             for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s[t], 0, 0, 0);
         }
         float mx = -INFINITY;
+        // interior block (wave-uniform): every key exists and is visible to all 16 rows - no per-element masking
+        const bool interior = !PAD && k0 + 32 <= a.Lk && (!a.causal || k0 + 31 <= a.q_pos0 + q0);
+        if (interior) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + g * 8 + t * 4 + r;
-                bool dead = key >= a.Lk || (a.causal && key > qpos);
-                if (pad && key < a.Lk) dead = dead || pad[key];
-                const float v = dead ? -INFINITY : s[t][r] * a.scale;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    s[t][r] *= a.scale;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + g * 8 + t * 4 + r;
+                    bool dead = key >= a.Lk || (a.causal && key > qpos);
+                    if (PAD && key < a.Lk) dead = dead || pad[key];
+                    const float v = dead ? -INFINITY : s[t][r] * a.scale;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
@@ -97,11 +111,12 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running maximum moved for some row of this wave
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-            o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
         }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[dt], 0, 0, 0);
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -166,7 +181,8 @@ template <int DH, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
     int bx, h, b;
     if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;
-    attn_body<DH, SPLIT>(a, bx, h, b);
+    if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b);
+    else attn_body<DH, SPLIT, false>(a, bx, h, b);
 }
 
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
@@ -175,8 +191,8 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles) {
     int bx, h, z;
     if (!attn_map(tiles, a.H, a.H * (a.B + b.B), bx, h, z)) return;
-    if (z < a.B) attn_body<DH, false>(a, bx, h, z);
-    else attn_body<DH, false>(b, bx, h, z - a.B);
+    if (z < a.B) attn_body<DH, false, false>(a, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
+    else attn_body<DH, false, false>(b, bx, h, z - a.B);
 }
 
 }  // namespace
@@ -194,6 +210,7 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st) {
     if (int rc = attn_check(a)) return rc;
     if (int rc = attn_check(b)) return rc;
     RV_CHECK_ARG(a.dh == 128 && b.dh == 128 && a.H == b.H && a.Lq > 16 && b.Lq > 16, "attention pair: 128-wide heads, same head count, prefill lengths only");
+    RV_CHECK_ARG(!a.key_pad && !b.key_pad, "attention pair: key padding is not supported");
     const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
     hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B))), dim3(256), 0, st, a, b, tiles);
     RV_CHECK_LAUNCH("attention pair");

@@ -10,6 +10,7 @@ lib, st = hip.lib(), hip.stream()
 
 def run(name, B, H, dh, Lq, Lk, Smax, causal, q_pos0):
     D = H * dh
+    torch.manual_seed(0)
     q = (torch.randn(B, Lq, D, device=dev) * 0.5).to(torch.bfloat16)
     k = (torch.randn(B, H, Smax, dh, device=dev) * 0.5).to(torch.bfloat16)
     vt = (torch.randn(B, H, dh, Smax, device=dev) * 0.5).to(torch.bfloat16)
@@ -27,7 +28,8 @@ def run(name, B, H, dh, Lq, Lk, Smax, causal, q_pos0):
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 10
     fl = 4.0 * B * H * Lq * Lk * dh * (0.5 if causal and q_pos0 == 0 else 1.0)
-    print(f"{name}: {us:7.1f} us  ({fl / us / 1e6:6.1f} TF/s nominal)")
+    import hashlib
+    print(f"{name}: {us:7.1f} us  ({fl / us / 1e6:6.1f} TF/s nominal)  out sha {hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:10]}")
 
 
 run("prefill rows  B=7  H=32 dh=128 Lq=139 Lk=171 causal", 7, 32, 128, 139, 171, 192, True, 32)
