@@ -116,6 +116,7 @@ class ReVisionLlamaForCausalLM:
         self.scores_mode = "processed"  # what transformers>=4.39 returns; "raw" = the override's intent (vtimellm_llama.py:321)
         self.dtype = torch.bfloat16
         self.uniform_fn = None  # optional (step, B) -> uniforms hook for reproducible sampling through inference()
+        self.after_prefill = None  # optional () -> None hook called between the prefill and the decode loop of generate()
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _ensure_engine(self, adapter_text=None):
@@ -253,6 +254,8 @@ class ReVisionLlamaForCausalLM:
         else:
             h = eng.splice_embed(row_map, video_rows)
             logits = eng.llm_forward(h, 0, kv, Smax)
+        if self.after_prefill is not None:   # scheduling hook (e.g. gate this call's decode steps on another stream's prefill)
+            self.after_prefill()
 
         seqs = ops.h2d(input_ids, dev, torch.long)
         unfinished = torch.ones(B, dtype=torch.int32, device=dev)
