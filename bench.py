@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=2,
+    p.add_argument("--streams", type=int, default=3,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--fp8-decode", action="store_true",
