@@ -198,6 +198,12 @@ int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float
 int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
                    float* out, void* stream);
 
+/* _topk_pooling (revisionllm/eval/similarity.py:71-94): video bf16/f32 [Nv,T,d], text f32 [Nt,d] -> out f32 [Nv,Nt,d] = SUM of
+ * the k frames of video v with the largest <f_t, text_j> (ties: smaller frame index), added in descending-similarity order;
+ * out_idx i32 [Nv,Nt,k] (the selected frames, optional).  1 <= k <= min(64, T). */
+int rv_topk_pool(const void* video, int dtype, const float* text, int32_t Nv, int32_t T, int32_t d, int32_t Nt, int32_t k,
+                 float* out, int32_t* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

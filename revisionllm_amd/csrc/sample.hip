@@ -623,6 +623,50 @@ __global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__
     if (lane == 0) out[blockIdx.x] = acc;
 }
 
+// _topk_pooling (similarity.py:71-94) for one (video, text) pair per block: sims[t] = <f_t, q>, the k frames with the largest
+// sims (ties: smaller frame index), pooled[c] = sum over the selected frames of f[t][c], added in descending-sims order.
+// 256 threads: one wave per frame for the scores, the whole block over the columns for the sum.
+template <typename T>
+__global__ __launch_bounds__(256) void topk_pool_kernel(const T* __restrict__ video, const float* __restrict__ text, int Tn, int d,
+                                                        int Nt, int k, float* __restrict__ out, int32_t* __restrict__ out_idx) {
+    extern __shared__ float smem[];
+    float* qs = smem;          // [d]
+    float* sims = smem + d;    // [Tn]
+    __shared__ int sel[64];
+    const int v = blockIdx.x, tx = blockIdx.y;
+    const T* f = video + (int64_t)v * Tn * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < d; c += 256) qs[c] = text[(int64_t)tx * d + c];
+    __syncthreads();
+    for (int t = wave; t < Tn; t += 4) {
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s += ld<T>(f + (int64_t)t * d + c) * qs[c];
+        s = wave_sum(s);
+        if (lane == 0) sims[t] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int r = 0; r < k; ++r) {
+            ArgMax best{-INFINITY, 0x7fffffff};
+            for (int t = lane; t < Tn; t += 64) best = better(best, ArgMax{sims[t], t});
+            best = wave_argmax(best);
+            if (lane == 0) {
+                sel[r] = best.i;
+                sims[best.i] = -INFINITY;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    }
+    __syncthreads();
+    float* o = out + ((int64_t)v * Nt + tx) * d;
+    for (int c = tid; c < d; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < k; ++r) a += ld<T>(f + (int64_t)sel[r] * d + c);
+        o[c] = a;
+    }
+    if (out_idx && tid < k) out_idx[((int64_t)v * Nt + tx) * k + tid] = sel[tid];
+}
+
 }  // namespace
 
 extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
@@ -672,5 +716,21 @@ extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_c
             hipLaunchKernelGGL(topk_cosine_kernel_generic<float>, dim3(n), dim3(1024), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
     }
     RV_CHECK_LAUNCH("rv_topk_cosine");
+    return RV_OK;
+}
+
+extern "C" int rv_topk_pool(const void* video, int dtype, const float* text, int32_t Nv, int32_t T, int32_t d, int32_t Nt, int32_t k,
+                            float* out, int32_t* out_idx, void* stream) {
+    RV_CHECK_ARG(video && text && out && Nv > 0 && T > 0 && d > 0 && Nt > 0, "rv_topk_pool: bad arguments");
+    RV_CHECK_ARG(dtype == RV_BF16 || dtype == RV_F32, "rv_topk_pool: dtype must be f32 or bf16");
+    RV_CHECK_ARG(k >= 1 && k <= 64 && k <= T, "rv_topk_pool: k=%d must be in [1, min(64, T=%d)]", k, T);
+    RV_CHECK_ARG(Nt <= 65535, "rv_topk_pool: at most 65535 texts per launch");
+    const size_t sm = (size_t)(d + T) * sizeof(float);
+    RV_CHECK_ARG(sm <= 64 * 1024, "rv_topk_pool: d + T too large for LDS");
+    if (dtype == RV_BF16)
+        hipLaunchKernelGGL(topk_pool_kernel<bf16_t>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const bf16_t*)video, text, T, d, Nt, k, out, out_idx);
+    else
+        hipLaunchKernelGGL(topk_pool_kernel<float>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const float*)video, text, T, d, Nt, k, out, out_idx);
+    RV_CHECK_LAUNCH("rv_topk_pool");
     return RV_OK;
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rv_sample": (C.c_int, [_p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),
     "rv_entropy_stats": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "rv_topk_cosine": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "rv_topk_pool": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
 }
 
 

@@ -234,3 +234,15 @@ def topk_cosine(feat, q_cls, k=3):
     hip.check(hip.lib().rv_topk_cosine(hip.ptr(_c(feat)), hip.dtype_code(feat), hip.ptr(_c(q_cls.float())), n, T, d, k, hip.ptr(out),
                                        hip.stream()), "rv_topk_cosine")
     return out
+
+
+def topk_pool(text_embeds, video_embeds, k, return_index=False):
+    """``_topk_pooling`` (similarity.py:71-94) on the device: text [Nt,d], video [Nv,T,d] (bf16 or f32) -> f32 [Nv,Nt,d], the SUM
+    of each video's k frames most similar to each text."""
+    Nv, T, d = video_embeds.shape
+    Nt = text_embeds.shape[0]
+    out = torch.empty(Nv, Nt, d, dtype=torch.float32, device=video_embeds.device)
+    idx = torch.empty(Nv, Nt, k, dtype=torch.int32, device=video_embeds.device) if return_index else None
+    hip.check(hip.lib().rv_topk_pool(hip.ptr(_c(video_embeds)), hip.dtype_code(video_embeds), hip.ptr(_c(text_embeds.float())), Nv, T, d,
+                                     Nt, int(k), hip.ptr(out), hip.ptr(idx), hip.stream()), "rv_topk_pool")
+    return (out, idx) if return_index else out

@@ -248,6 +248,212 @@ def g7_scores(M):
          cos_stage1_mean=torch.einsum("bd,d->b", pf, qc).mean())
 
 
+def big_model(M, shape, args, seed=SEED):
+    """Reference model at full size, filled tensor by tensor (never two copies of the 27 GB in memory).  MATRICES take
+    bf16-representable values (what the device holds), vectors stay fp32: both sides then hold identical weights and the
+    comparison isolates the arithmetic."""
+    L = M["llama"]
+    cfg = L.VTimeLLMConfig(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
+                           num_attention_heads=shape.heads, num_key_value_heads=shape.heads, vocab_size=shape.vocab,
+                           max_position_embeddings=2048, rms_norm_eps=shape.eps, rope_theta=shape.theta,
+                           pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")
+    import transformers
+    ctx = getattr(transformers.modeling_utils, "no_init_weights", None)
+    import contextlib
+    with (ctx() if ctx is not None else contextlib.nullcontext()):
+        model = L.VTimeLLMLlamaForCausalLM(cfg).eval()
+    model.get_model().initialize_vision_modules(args)
+    from revisionllm_amd.utils import hashinit
+    table = {n: (shp, a, base) for n, shp, a, base in synth.llama_spec(shape)}
+    table.update({"model.mm_projector." + n: (shp, a, base)
+                  for n, shp, a, base in synth.clip_encoder_spec(hidden=shape.hidden, text=args.clip_adapter_text)})
+    sd = model.state_dict()
+    for k in sd:
+        if "rotary" in k or "inv_freq" in k:
+            continue
+        shp, a, base = table[k]
+        assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
+        sd[k].copy_(T(hashinit.make_tensor(k, shp, seed, a, base, bf16=len(shp) > 1)))
+    return model
+
+
+class _ForceTokens:
+    """LogitsProcessor: teacher-force the continuation (used for the reference's own bf16 leg)."""
+
+    def __init__(self, forced, prompt_len):
+        self.forced, self.P = forced, prompt_len
+
+    def __call__(self, input_ids, scores):
+        step = input_ids.shape[1] - self.P
+        out = torch.full_like(scores, float("-inf"))
+        out[:, self.forced[step]] = 0
+        return out
+
+
+def g8_full_7b(M):
+    """The stage-2 recursion of ONE query at full depth through the reference itself: random-init Vicuna-7B (32 layers, fp32,
+    CPU), hierarchy ClipEncoder, W = batch = 100 windows x 256 frames, the 7 calls of e2e2.py:337-386 in its own loop order
+    (randperm, repeat_interleave, inference() with its production generate kwargs; max_new_tokens patched 1024 -> 8 and EOS
+    off, as in bench.py).  Stored per call and step: sampled token, top-64 raw logits, the kept processed scores (T=0.05,
+    top_k=50), entropies, get_entropy_statistics, 1/max, 1/mean, the cosine scores.  A second leg runs the reference in its
+    own GPU arithmetic (model.bfloat16(), e2e2.py:182) teacher-forced on the same tokens: how far the reference's bf16 path sits
+    from its fp32 path is the yardstick for the build's bf16 path."""
+    import math
+    import re
+    import time
+    import unittest.mock as mock
+    n_layers = int(os.environ.get("G8_LAYERS", "32"))     # < 32: dry run of this script (fixture goes to g8_dry_*.npz)
+    shape = synth.VICUNA_7B if n_layers == 32 else synth.LlamaShape(layers=n_layers)
+    name = "g8_full_7b" if n_layers == 32 else "g8_dry_%dL" % n_layers
+    G, W, batch, Tn, Lq = 8, 100, 100, 256, 16
+    seed = SEED
+    t0 = time.time()
+    m = big_model(M, shape, ns(), seed)
+    print("g8: model filled in %.0f s" % (time.time() - t0))
+    m.generation_config.eos_token_id = None
+    m.generation_config.top_k, m.generation_config.top_p = 50, 1.0
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    features = T(synth.features("g8.feat", (W, Tn, 768), seed, bf16=True))
+    query_feats = T(synth.features("g8.q", (Lq, 768), seed, bf16=True))
+    query_cls = T(synth.features("g8.qcls", (768,), seed, bf16=True))
+    sentence = "a man opens the door of a red car"
+    query = "During which video can we see {}?"
+    grounding_windows = list(range(W))
+    real_generate = m.generate
+    captured = {}
+
+    def short_generate(*a, **kw):
+        kw["max_new_tokens"] = G
+        kw["output_hidden_states"] = False
+        kw["output_logits"] = True
+        captured["ids"] = a[0]
+        return real_generate(*a, **kw)
+
+    pad = M["tensor_utils"].pad_sequences_1d if "tensor_utils" in M else None
+    if pad is None:
+        import importlib
+        pad = importlib.import_module("revisionllm.model.adapter.tensor_utils").pad_sequences_1d
+    torch.manual_seed(seed)
+    rec = dict(answers=[], starts=[], zooms=[], perms=[], tokens=[], raw_top_idx=[], raw_top_val=[], raw_lse=[], raw_absmax=[],
+               proc_idx=[], proc_val=[], stats=[], inv_max=[], inv_mean=[], score_cos=[], score_cos_call=[])
+    starts, indexes, hierarchy_zooms = [], [], []
+    for hierarchy_zoom in [4, 2, 1]:                         # e2e2.py:337-386, loop structure kept
+        b = batch // hierarchy_zoom
+        for i in range(math.ceil(features.shape[0] / b)):
+            t1 = time.time()
+            start = i * b
+            end = min(start + b, features.shape[0])
+            if end - start < b:
+                start = end - b
+            starts.append(start)
+            feat = features[start:end][None]
+            qf = pad(query_feats[None,].repeat(feat.shape[0], 1, 1), dtype=query_feats.dtype, device=query_feats.device, fixed_length=None)
+            idx = torch.randperm(feat.size(1))
+            feat = feat[:, idx]
+            indexes.append(idx)
+            if hierarchy_zoom > 1:
+                feat = feat.repeat_interleave(hierarchy_zoom, 1)
+            with mock.patch.object(m, "generate", short_generate):
+                answer, mo = M["inference"].inference(m, feat, qf, "<video>\n" + query.format(sentence), tok, return_list=True)
+            hierarchy_zooms.append(hierarchy_zoom)
+            scores = torch.cat([a[:, None] for a in mo["scores"]], 1)          # [1,G,V] processed
+            ent = M["entropy"].get_entropy_statistics(scores, 0, scores.shape[2])
+            raw = torch.stack(mo["logits"], 1)[0]                               # [G,V]
+            P = captured["ids"].shape[1]
+            rec["answers"].append(answer[0])
+            rec["tokens"].append(mo["sequences"][0, P:])
+            tv, ti = raw.topk(64, dim=-1)
+            rec["raw_top_idx"].append(ti.int())
+            rec["raw_top_val"].append(tv)
+            rec["raw_lse"].append(torch.logsumexp(raw.double(), -1))
+            rec["raw_absmax"].append(raw.abs().amax(-1))
+            pv, pi = scores[0].topk(50, dim=-1)
+            rec["proc_idx"].append(pi.int())
+            rec["proc_val"].append(pv)
+            rec["stats"].append(ent[0])
+            rec["inv_max"].append(1 / ent[0, 0].item())
+            rec["inv_mean"].append(1 / ent[0, 2].item())
+            matches = re.search(r"(\d+)", answer[0])
+            score = torch.tensor([0])
+            if matches:
+                from_number = int(matches.group(1)) // hierarchy_zooms[i]
+                if from_number < len(indexes[i]):
+                    from_number = indexes[i][from_number]
+                from_number = starts[i] + from_number
+                from_number = min(len(grounding_windows) - 1, max(0, from_number))
+                from_number = grounding_windows[from_number]
+                to_number = from_number
+                from_number = max(0, from_number - 1)
+                to_number = min(to_number + 1, len(feat[0]) - 1)
+                score = []
+                for n in range(from_number, to_number):
+                    feat_ = feat[:, n]
+                    pf = feat_ / feat_.norm(dim=1, keepdim=True)
+                    pf = M["similarity"]._topk_pooling(query_cls[None], pf, min(pf.shape[1], 3))[:, 0]
+                    score.append(torch.einsum("bd,d->b", pf, query_cls))
+            sc = [float(a.item()) for a in score]
+            rec["score_cos"].extend(sc)
+            rec["score_cos_call"].extend([len(rec["answers"]) - 1] * len(sc))
+            print("g8: call %d zoom %d start %d: %r  H stats %s  (%.0f s)" % (len(rec["answers"]) - 1, hierarchy_zoom, start,
+                                                                                answer[0], ent[0].tolist(), time.time() - t1), flush=True)
+    # cosine score of EVERY window (the quantity the batched recursion computes once per window)
+    f = features / features.norm(dim=1, keepdim=True)
+    pooled = M["similarity"]._topk_pooling(query_cls[None], f, 3)[:, 0]
+    cos_all = torch.einsum("bd,d->b", pooled, query_cls)
+    ids0 = captured["ids"][0].clone()
+
+    # ---- leg 2: the reference in its own GPU arithmetic (bf16), teacher-forced on the fp32 leg's tokens ----
+    bf = dict(raw_top_val_at_fp32_idx=[], raw_lse=[], proc_val_at_fp32_idx=[], stats=[], error=None)
+    try:
+        m = m.bfloat16()
+        # vtimellm_llama.py:70-71 widens images / query feats to fp32 when the model sits on the CPU ("if debug in cpu we need
+        # float32"); on the GPU they stay bf16 (e2e2.py:302-306).  Cast them back (lossless) so this leg is the GPU arithmetic.
+        m.get_model().mm_projector.register_forward_pre_hook(
+            lambda mod, args: tuple(a.bfloat16() if torch.is_tensor(a) and a.is_floating_point() else a for a in args))
+        for c, (z, start) in enumerate(zip(hierarchy_zooms, starts)):
+            b = batch // z
+            feat = features[start:start + b][None][:, indexes[c]]
+            if z > 1:
+                feat = feat.repeat_interleave(z, 1)
+            forced = rec["tokens"][c].tolist()
+            qf = query_feats[None].bfloat16()
+            g = real_generate(captured["ids"], images=feat.bfloat16(), query_feats=(qf, torch.ones(1, Lq)), do_sample=False,
+                              max_new_tokens=G, use_cache=True, output_logits=True, return_dict_in_generate=True,
+                              logits_processor=[_ForceTokens(forced, captured["ids"].shape[1])])
+            raw = torch.stack(g["logits"], 1)[0].float()
+            proc = (raw / 0.05)
+            kth = proc.topk(50, dim=-1)[0][:, -1:]
+            proc = proc.masked_fill(proc < kth, float("-inf"))
+            ent = M["entropy"].get_entropy_statistics(proc[None], 0, proc.shape[1])
+            bf["raw_top_val_at_fp32_idx"].append(raw.gather(1, rec["raw_top_idx"][c].long()))
+            bf["raw_lse"].append(torch.logsumexp(raw.double(), -1))
+            bf["proc_val_at_fp32_idx"].append(proc.gather(1, rec["proc_idx"][c].long()))
+            bf["stats"].append(ent[0])
+            print("g8/bf16: call %d H stats %s" % (c, ent[0].tolist()), flush=True)
+    except Exception as e:  # the CPU bf16 path of some op may be missing: the fp32 leg is the fixture, this one is context
+        bf["error"] = repr(e)
+        print("g8/bf16 leg failed:", bf["error"])
+    arrays = dict(prompt_ids=ids0, starts=np.array(starts), zooms=np.array(hierarchy_zooms),
+                  perms_z4=torch.stack([p for p, z in zip(indexes, hierarchy_zooms) if z == 4]),
+                  perms_z2=torch.stack([p for p, z in zip(indexes, hierarchy_zooms) if z == 2]),
+                  perms_z1=torch.stack([p for p, z in zip(indexes, hierarchy_zooms) if z == 1]),
+                  tokens=torch.stack(rec["tokens"]), raw_top_idx=torch.stack(rec["raw_top_idx"]),
+                  raw_top_val=torch.stack(rec["raw_top_val"]), raw_lse=torch.stack(rec["raw_lse"]),
+                  raw_absmax=torch.stack(rec["raw_absmax"]), proc_idx=torch.stack(rec["proc_idx"]),
+                  proc_val=torch.stack(rec["proc_val"]), stats=torch.stack(rec["stats"]), inv_max=np.array(rec["inv_max"]),
+                  inv_mean=np.array(rec["inv_mean"]), score_cos=np.array(rec["score_cos"]),
+                  score_cos_call=np.array(rec["score_cos_call"]), cos_all=cos_all)
+    if bf["error"] is None:
+        arrays.update(bf16_raw_top_val=torch.stack(bf["raw_top_val_at_fp32_idx"]), bf16_raw_lse=torch.stack(bf["raw_lse"]),
+                      bf16_proc_val=torch.stack(bf["proc_val_at_fp32_idx"]), bf16_stats=torch.stack(bf["stats"]))
+    save(name, **arrays)
+    with open(os.path.join(HERE, name.replace("full_7b", "text") + ".json"), "w") as f:
+        json.dump({"answers": rec["answers"], "sentence": sentence, "G": G, "W": W, "batch": batch, "T": Tn, "Lq": Lq,
+                   "bf16_leg_error": bf["error"],
+                   "note": "weights: synth specs, seed %d, matrices rounded to bf16-representable fp32, vectors fp32; features "
+                           "bf16-representable; sampling: torch.manual_seed(%d) before the loop" % (seed, seed)}, f, indent=1)
+
+
 def g9_driver(M):
     """Integer / string helpers of the drivers, captured from the reference functions."""
     e2, neg = M["e2e2"], M["negative"]
@@ -458,9 +664,9 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
+                  g7=g7_scores, g8=g8_full_7b, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
     for k, fn in groups.items():
-        if only and k not in only:
+        if (only and k not in only) or (not only and k == "g8"):   # g8 (27 GB, ~15 min) only on request
             continue
         fn(M)
     with open(os.path.join(HERE, "meta.json"), "w") as f:

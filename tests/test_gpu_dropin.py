@@ -1,0 +1,181 @@
+"""GPU tests of the drop-in surface under the REFERENCE'S module names: after ``install_as_revisionllm()`` the import block
+of eval_nlq_retrieval_e2e2.py:18-23 resolves to this package, ``_topk_pooling`` / ``get_entropy_statistics`` keep the
+reference's tensor contracts (checked against the oracle and the reference-generated golden G7), and the body of the
+reference's stage-2 loop (e2e2.py:337-386, restated here line by line against those names) produces the record that
+``stage2.run_query(mode="reference")`` produces."""
+import math
+import re
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import SEED, T, feats, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def as_revisionllm():
+    import revisionllm_amd
+    before = set(sys.modules)
+    finders = list(sys.meta_path)
+    revisionllm_amd.install_as_revisionllm()
+    yield
+    sys.meta_path[:] = finders
+    for k in set(sys.modules) - before:
+        if k.split(".")[0] in revisionllm_amd.ALIASES:
+            del sys.modules[k]
+
+
+def test_topk_pooling_contract(as_revisionllm, golden):
+    from revisionllm.eval.similarity import _topk_pooling
+    from oracle import scores
+    g = golden.npz("g7_scores")
+    feat = feats("g7.feat", (1, 40, 768))
+    qc = feats("g7.qcls", (768,))
+    f = feat / feat.norm(dim=1, keepdim=True)
+    pooled = _topk_pooling(qc[None].cuda(), f.cuda(), 3)
+    assert pooled.shape == (1, 1, 768) and pooled.dtype == torch.float32 and pooled.is_cuda
+    assert rel_err(pooled.cpu(), g["pooled"]) < 1e-5                       # the reference's own output
+    cos = torch.einsum("bd,d->b", pooled[:, 0], qc.cuda())
+    assert rel_err(cos.cpu(), g["cos_stage2"]) < 1e-5
+    # several videos x several texts, bf16 features (what the GPU drivers hold, e2e2.py:303), k up to the frame count
+    vid = feats("tp.vid", (5, 37, 768), bf16=True)
+    txt = feats("tp.txt", (3, 768))
+    for k in (1, 3, 37):
+        y = _topk_pooling(txt.cuda(), vid.bfloat16().cuda(), k)
+        assert y.dtype == torch.bfloat16 and y.shape == (5, 3, 768)
+        ref = scores.topk_pooling(txt, vid, k)
+        assert rel_err(y.float().cpu(), ref) < 8e-3                        # one bf16 rounding of the pooled sum
+    from revisionllm_amd import ops
+    y32, idx = ops.topk_pool(txt.cuda(), vid.cuda(), 3, return_index=True)
+    assert rel_err(y32.cpu(), scores.topk_pooling(txt, vid, 3)) < 1e-6
+    want = torch.topk(vid @ txt.t(), 3, dim=1)[1].permute(0, 2, 1)          # [Nv, Nt, k], descending similarity
+    assert torch.equal(idx.cpu().long(), want)
+    # host tensors are staged to the device and come back home
+    yh = _topk_pooling(txt, vid, 3)
+    assert not yh.is_cuda and rel_err(yh, scores.topk_pooling(txt, vid, 3)) < 1e-6
+    with pytest.raises(ValueError):
+        _topk_pooling(txt[0].cuda(), vid.cuda(), 3)
+
+
+def test_get_entropy_statistics_contract(as_revisionllm, golden):
+    from revisionllm.uncertainty.funs_get_feature_X import get_entropy_statistics
+    from oracle import scores
+    g = golden.npz("g7_scores")
+    logits = feats("g7.logits", (3, 5, 2000)) * 4.0
+    e = get_entropy_statistics(logits.cuda(), 0, logits.shape[2])
+    assert e.shape == (3, 4) and e.is_cuda
+    assert rel_err(e.cpu(), g["entropy"]) < 1e-5                           # the reference's own output
+    e1 = get_entropy_statistics(logits[:, :1].cuda(), 0, logits.shape[2])   # one step: unbiased std of one sample = NaN
+    assert torch.isnan(e1[:, 3]).all() and rel_err(e1[:, :3].cpu(), g["entropy_g1"][:, :3]) < 1e-5
+    # the q_begin/q_end slice is on the STEP axis (funs_get_feature_X.py:131); q_end == q_begin + 1 -> std = 0
+    e2 = get_entropy_statistics(logits.cuda(), 1, 4)
+    assert rel_err(e2.cpu(), scores.entropy_statistics(logits, 1, 4)) < 1e-5
+    e3 = get_entropy_statistics(logits.cuda(), 2, 3)
+    assert (e3[:, 3] == 0).all() and rel_err(e3[:, :3].cpu(), scores.entropy_statistics(logits, 2, 3)[:, :3]) < 1e-5
+    # processed scores carry -inf for filtered tokens (what e2e2.py:356 passes in)
+    sc = logits.clone()
+    sc[sc < sc.topk(50, dim=-1)[0][..., -1:]] = float("-inf")
+    e4 = get_entropy_statistics(sc.cuda(), 0, sc.shape[2])
+    assert rel_err(e4.cpu(), scores.entropy_statistics(sc)) < 1e-5
+    eh = get_entropy_statistics(logits, 0, logits.shape[2])                 # host tensor in -> host tensor out
+    assert not eh.is_cuda and rel_err(eh, g["entropy"]) < 1e-5
+
+
+def test_reference_stage2_loop_through_the_aliased_names(as_revisionllm):
+    """eval_nlq_retrieval_e2e2.py:337-386 restated against ``revisionllm.*`` (what the unmodified driver would execute after
+    ``install_as_revisionllm()``) == ``stage2.run_query(mode='reference')`` on the same permutations and draws."""
+    from revisionllm.inference import inference
+    from revisionllm.model.adapter.tensor_utils import pad_sequences_1d
+    from revisionllm.eval.similarity import _topk_pooling
+    from revisionllm.uncertainty.funs_get_feature_X import get_entropy_statistics
+    from revisionllm.model import VTimeLLMLlamaForCausalLM
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    model = VTimeLLMLlamaForCausalLM(shape, device="cuda:0")
+    model.get_model().initialize_vision_modules(SimpleNamespace(
+        clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None, clip_adapter_text=True,
+        clip_adapter_feature="cls", hierarchy=True, adapter_input_dim=768))
+    model.engine.init_synthetic(seed=SEED, llm=True, clip=True)
+    model.generation_config.eos_token_id = None
+    model.uniform_fn = lambda step, B: torch.full((B,), 0.5)
+
+    class DigitTokenizer(synth.FakeTokenizer):     # random-init models never emit digits: make every answer parse
+        def batch_decode(self, seqs, skip_special_tokens=True):
+            return ["In video %d." % (int(s[0]) % 40) for s in seqs]
+
+    tokenizer = DigitTokenizer(vocab=shape.vocab)
+    real = model.generate
+    model.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
+    W, batch = 13, 8
+    features = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
+    query_feats = feats("s2.q", (5, 768), bf16=True).to(torch.bfloat16).cuda()
+    query_cls_feats = feats("s2.qc", (768,), bf16=True).to(torch.bfloat16).cuda()
+    plan = stage2.plan_groups(W, batch)
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
+    args = SimpleNamespace(batch=batch, q_feat_dir="x", single=True)
+    grounding_windows = list(range(W))
+    sentence = "a man"
+    # ---- e2e2.py:325-386 (randperm replaced by the recorded permutation so both sides see the same shuffles) ----
+    query = 'During which video can we see {}?'
+    answers, starts, indexes, mean_entropy, max_entropy, score_cos, hierarchy_zooms = [], [], [], [], [], [], []
+    n_call = 0
+    for hierarchy_zoom in [4, 2, 1]:
+        b = args.batch // hierarchy_zoom
+        for i in range(math.ceil(features.shape[0] / b)):
+            start = i * b
+            end = min(start + b, features.shape[0])
+            if end - start < b:
+                start = end - b
+            starts.append(start)
+            feat = features[start:end][None]
+            query_feats_temp = pad_sequences_1d(query_feats[None,].repeat(feat.shape[0], 1, 1), dtype=query_feats.dtype,
+                                                device=query_feats.device, fixed_length=None)
+            idx = perms[n_call]
+            n_call += 1
+            feat = feat[:, idx.to(feat.device)]
+            indexes.append(idx)
+            if hierarchy_zoom > 1:
+                feat = feat.repeat_interleave(hierarchy_zoom, 1)
+            answer, model_output = inference(model, feat, query_feats_temp, "<video>\n" + query.format(sentence), tokenizer, return_list=True)
+            answers.extend(answer)
+            hierarchy_zooms.append(hierarchy_zoom)
+            entropy = get_entropy_statistics(torch.cat([a[:, None] for a in model_output['scores']], 1), 0, model_output['scores'][0].shape[1])
+            max_entropy.extend([1 / e[0].item() for e in entropy])
+            mean_entropy.extend([1 / e[2].item() for e in entropy])
+            matches = re.search(r"(\d+)", answer[0])
+            score = torch.tensor([0])
+            if matches:
+                from_number = int(matches.group(1))
+                from_number = from_number // hierarchy_zooms[i]
+                if from_number < len(indexes[i]):
+                    from_number = indexes[i][from_number]
+                from_number = starts[i] + from_number
+                from_number = max(0, from_number)
+                from_number = min(len(grounding_windows) - 1, from_number)
+                from_number = grounding_windows[from_number]
+                to_number = from_number
+                from_number = max(0, from_number - 1)
+                to_number = min(to_number + 1, len(feat[0]) - 1)
+                score = []
+                for n in range(from_number, to_number):
+                    feat_ = feat[:, n]
+                    proposal_features = feat_ / feat_.norm(dim=1, keepdim=True)
+                    proposal_features = _topk_pooling(query_cls_feats[None], proposal_features, min(proposal_features.shape[1], 3))[:, 0]
+                    score.append(torch.einsum('bd,d->b', proposal_features, query_cls_feats))
+            score_cos.extend([a.item() for a in score])
+    # ---- the build's own driver on the same inputs ----
+    r = stage2.run_query(model, tokenizer, features, query_feats, query_cls_feats.float(), sentence, batch=batch, perms=perms,
+                         mode="reference")
+    assert answers == r["answers"] and starts == r["starts"] and hierarchy_zooms == r["hierarchy_zooms"]
+    assert np.allclose(max_entropy, r["max_entropy"], rtol=1e-5) and np.allclose(mean_entropy, r["mean_entropy"], rtol=1e-5)
+    # the loop above normalises / pools / dots in bf16 exactly as the reference does on the GPU (e2e2.py:302-306); the driver
+    # computes the same quantity in f32 from the same bf16 features
+    assert len(score_cos) == len(r["score_cos"]) and np.allclose(score_cos, r["score_cos"], rtol=3e-2, atol=3e-2)
+    frames, hit = stage2.iou(answers, [1, 2], 250, batch, starts, indexes, True, hierarchy_zooms, grounding_windows)
+    assert frames == stage2.log_record(r, [1, 2], batch)["frames"]

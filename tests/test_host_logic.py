@@ -187,3 +187,72 @@ def test_fp8_quantisers_host_side():
         r, j = lane & 15, lane >> 4
         assert torch.equal(packed[nb, kb, lane], qb[nb * 16 + r, kb * 64 + j * 16:kb * 64 + j * 16 + 16])
     assert torch.equal(scale, w.abs().amax(dim=1).double().div(448.0).float())
+
+
+# every ``revisionllm.*`` / ``vtimellm.*`` name the reference's drivers import: eval_nlq_retrieval_e2e2.py:18-23,
+# eval_nlq_negative.py:17-22 (still under the package's older name), inference.py:7-11, demo_gradio.py, train-free builder users
+DRIVER_IMPORTS = [
+    ("revisionllm.model.builder", ["load_pretrained_model", "load_lora"]),
+    ("revisionllm.utils", ["disable_torch_init"]),
+    ("revisionllm.inference", ["inference", "inference_stage1"]),
+    ("revisionllm.model.adapter.tensor_utils", ["pad_sequences_1d"]),
+    ("revisionllm.eval.similarity", ["_topk_pooling"]),
+    ("revisionllm.uncertainty.funs_get_feature_X", ["get_entropy_statistics"]),
+    ("revisionllm.constants", ["IMAGE_TOKEN_INDEX"]),
+    ("revisionllm.conversation", ["conv_templates", "SeparatorStyle"]),
+    ("revisionllm.mm_utils", ["tokenizer_image_token", "KeywordsStoppingCriteria", "VideoExtractor"]),
+    ("revisionllm.model", ["VTimeLLMLlamaForCausalLM"]),
+    ("vtimellm.model.builder", ["load_pretrained_model"]),
+    ("vtimellm.utils", ["disable_torch_init"]),
+    ("vtimellm.inference", ["inference"]),
+    ("vtimellm.model.adapter.tensor_utils", ["pad_sequences_1d"]),
+    ("vtimellm.eval.similarity", ["_topk_pooling"]),
+    ("vtimellm.uncertainty.funs_get_feature_X", ["get_entropy_statistics"]),
+]
+
+
+def test_install_as_revisionllm_resolves_every_driver_import():
+    """After ``install_as_revisionllm()`` the import blocks of the reference's drivers resolve, to the SAME module objects as
+    ``revisionllm_amd.*`` (no second copy of module state), and names the package does not have still fail as ModuleNotFoundError.
+    Runs in a child interpreter: the alias must not leak into this test session."""
+    import subprocess
+    import sys
+    code = f"""
+import importlib, sys
+sys.path.insert(0, {ROOT!r})
+import revisionllm_amd
+assert revisionllm_amd.install_as_revisionllm() is revisionllm_amd
+for mod, names in {DRIVER_IMPORTS!r}:
+    m = importlib.import_module(mod)
+    real = importlib.import_module("revisionllm_amd" + mod[mod.index("."):])
+    assert m is real, mod
+    assert m.__name__.startswith("revisionllm_amd") and m.__spec__.name == m.__name__, (mod, m.__spec__.name)
+    for n in names:
+        assert callable(getattr(m, n)) or n in ("IMAGE_TOKEN_INDEX", "conv_templates"), (mod, n)
+import revisionllm, vtimellm
+assert revisionllm is revisionllm_amd and vtimellm is revisionllm_amd
+import revisionllm.hip, revisionllm_amd.hip
+assert revisionllm.hip is revisionllm_amd.hip
+try:
+    import revisionllm.no_such_module
+    raise SystemExit("missing module imported")
+except ModuleNotFoundError:
+    pass
+revisionllm_amd.install_as_revisionllm()          # idempotent
+assert sum(1 for f in sys.meta_path if type(f).__name__ == "_AliasFinder") == 2
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr + r.stdout
+
+
+def test_dropin_scoring_modules_refuse_without_gpu():
+    """The drop-in scoring modules are device code: without a GPU they raise instead of falling back to torch CPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU visible")
+    from revisionllm_amd.eval.similarity import _topk_pooling
+    from revisionllm_amd.uncertainty.funs_get_feature_X import get_entropy_statistics
+    with pytest.raises(hip.HipLibraryError):
+        _topk_pooling(torch.zeros(1, 8), torch.zeros(1, 4, 8), 2)
+    with pytest.raises(hip.HipLibraryError):
+        get_entropy_statistics(torch.zeros(1, 2, 16), 0, 16)
