@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--fp8-prefill", action="store_true",
                    help="extra measurement (NOT the headline): prefill GEMMs run FP8 x FP8 (activations quantised per row on the fly)")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
-    p.add_argument("--gemm-variant", type=int, default=2, help="rv_set_gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
+    p.add_argument("--gemm-variant", type=int, default=2, help="rv_ctx_set_option gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--settle", type=int, default=16,
                    help="untimed steps run as part of the set-up, before the W warm-up steps (a fresh box starts at idle clocks; ~0.5 s)")
     p.add_argument("--seed", type=int, default=0)
@@ -232,8 +232,8 @@ def main():
     # or the FP8 decode-weight copies.  The copies are resident from the start and switched off for the headline.
     extras = world == 1 and not args.no_extras and not args.fp8_decode and not args.fp8_prefill and args.queries == 1
     model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras)
-    hip.lib().rv_set_fp8_decode(1 if args.fp8_decode else 0)
-    hip.lib().rv_set_fp8_prefill(1 if args.fp8_prefill else 0)
+    model.engine.set_option("fp8_decode", 1 if args.fp8_decode else 0)
+    model.engine.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
     model.generation_config.eos_token_id = None     # forced decode length
     tok = synth.FakeTokenizer()
 
@@ -263,8 +263,8 @@ def main():
     work = {"qs": [(qf, qc, sentence)], "perms": [perms], "feats": feats}
     if args.queries > 1:
         work["qs"], work["perms"] = query_set(args.queries)
-    hip.lib().rv_set_gemm_cus(args.gemm_cus)
-    hip.lib().rv_set_gemm_tile_variant(args.gemm_variant)
+    model.engine.set_option("gemm_cus", args.gemm_cus)
+    model.engine.set_option("gemm_tile_variant", args.gemm_variant)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
 
@@ -324,8 +324,8 @@ def main():
             if nq > 1 and len(work["qs"]) != nq:
                 work["qs"], work["perms"] = query_set(nq)
                 work["feats"] = video_set(nq)
-            hip.lib().rv_set_fp8_decode(int(fp8))
-            hip.lib().rv_set_fp8_prefill(int(fp8p))
+            model.engine.set_option("fp8_decode", int(fp8))
+            model.engine.set_option("fp8_prefill", int(fp8p))
             run(args.warmup)
             sync()
             t = time.perf_counter()
@@ -347,8 +347,8 @@ def main():
                     torch.cuda.synchronize()
                 except Exception:  # noqa: BLE001
                     pass
-        hip.lib().rv_set_fp8_decode(0)
-        hip.lib().rv_set_fp8_prefill(0)
+        model.engine.set_option("fp8_decode", 0)
+        model.engine.set_option("fp8_prefill", 0)
 
     if rank == 0:
         ids1, _ = __import__("revisionllm_amd.inference", fromlist=["_prompt_ids"])._prompt_ids(
@@ -359,8 +359,8 @@ def main():
         row_map = model.build_row_map(ids1.repeat(n_calls_rank, 1), 100)
         P0 = model._common_text_prefix(row_map) if n_calls_rank > 1 else 0
         M_prefill = P0 + n_calls_rank * (S - P0)
-        hip.lib().rv_set_fp8_decode(0)
-        hip.lib().rv_set_fp8_prefill(0)
+        model.engine.set_option("fp8_decode", 0)
+        model.engine.set_option("fp8_prefill", 0)
         legs = roofline_legs(model, n_calls_rank, M_prefill)
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
                   key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (args.decode_steps - 1)))

@@ -14,7 +14,12 @@
  *   - plain C, no torch types; every pointer is a caller-owned DEVICE pointer unless marked host;
  *   - all work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises;
  *   - the library allocates nothing on the device: workspaces are caller-provided, sizes come from
- *     the *_ws_bytes queries; rv_ctx only stores pointers + configuration;
+ *     the *_ws_bytes queries; rv_ctx only stores pointers + configuration + its tunables;
+ *   - no process-wide mutable state: tunables live in the context (rv_ctx_set_option), contexts are independent and
+ *     re-entrant across threads; the only shared things are a monotonic launch counter (atomic; the hand-off flags of the
+ *     persistent GEMMs carry it, so a workspace never needs cleaning) and the thread-local error string.  At most ONE launch
+ *     that waits in-kernel for its sibling workgroups (the persistent stream-K GEMMs of a prefill with > 16 rows) may be in
+ *     flight per device at a time: callers that use several streams order those launches (Engine does, with an event);
  *   - return 0 on success, negative rv_status on error; rv_last_error() gives the message of the
  *     last failure on the calling thread;
  *   - dtypes: RV_BF16 activations/weights, RV_F32 residual streams, statistics and logits.
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 1
+#define RV_ABI_VERSION 2
 
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
 typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
@@ -53,8 +58,27 @@ int rv_abi_version(void);
 int rv_last_error(char* buf, size_t n);
 
 /* ---- context + weights ------------------------------------------------------------------- */
+/* cfg == NULL creates an OPTIONS-ONLY context: no model, nothing can be bound; it carries tunables for the building-block
+ * entry points that take an optional context (rv_gemm, rv_gemm_fp8, rv_sample). */
 int rv_ctx_create(const rv_config* cfg, rv_ctx** out);
 void rv_ctx_destroy(rv_ctx* ctx);
+/* Per-context tunables (measurement / tuning; every default is the production setting).  Keys:
+ *   "gemm_tile_variant"  packed-W GEMM family: 2 (default) = 128x128x32 3-stage LDS ring kernel + the 256x256x64 ping-pong kernel
+ *                        where it pays (stream-K for few-row deep-K problems when a workspace is given, output-tiled for long-K
+ *                        problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double
+ *                        buffer; 3 = register-double-buffered ring; 4 / 5 = ping-pong output-tiled / stream-K wherever supported
+ *   "gemm_cus"           CUs (multiple of 8; 0 = all) the persistent prefill GEMMs occupy: their 128 KiB-LDS workgroups own a CU
+ *                        each, so a smaller grid leaves whole CUs to the launches of another stream
+ *   "gemm_arows"         1 (default): short-K many-row GEMMs (the K = 768 adapter / projector family) take the A-resident kernel
+ *   "fp8_decode"         1 (default): KV-cached decode steps stream the FP8 weight copies when all of them are bound ("<name>.f8" /
+ *                        "<name>.s8" next to every LLM projection and lm_head); 0: always decode on the bf16 weights
+ *   "fp8_prefill"        1 (default): prefill passes run their QKV / o / gate-up / down GEMMs as FP8 x FP8 when the "<name>.f8p"
+ *                        copies of every layer are bound and the shape has a persistent plan; 0: always the bf16 weights
+ *   "sample_variant"     1 (default) = top-k selection through the compacted-candidate fast path when the row qualifies (V >= 1024,
+ *                        no tie across the k-th place); 0 = always the general 16-round selection.  Identical outputs.
+ * Unknown keys / out-of-range values return RV_ERR_ARG. */
+int rv_ctx_set_option(rv_ctx* ctx, const char* key, int64_t value);
+int rv_ctx_get_option(const rv_ctx* ctx, const char* key, int64_t* value);
 /* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout").  Every bf16 MATRIX
  * except llm.embed is fragment-packed (rv_gemm w_layout 1); vectors are plain f32:
  *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows; inside every head the q and k rows are
@@ -97,30 +121,17 @@ int rv_gemv_fp8(const void* A, int64_t lda, const void* W8, const float* w_scale
  * scales of rv_quant_rows_fp8(rv_rmsnorm(x)). */
 int rv_rmsnorm_quant_fp8(const float* x, const float* w, void* q8, float* scale, int64_t rows, int32_t d, float eps, void* stream);
 int rv_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int64_t K, void* stream);
-int rv_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
+int rv_gemm_fp8(const rv_ctx* ctx /* optional: tunables */, const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, size_t ws_bytes,
                 void* stream);
-/* Tuning / measurement knob (process-wide) for packed W.  2 (default) = 128x128x32 3-stage LDS ring kernel plus the
- * 256x256x64 ping-pong kernel where it pays (stream-K for few-row deep-K problems when ws is given, output-tiled for
- * long-K problems whose tile count fills the CUs); 6 = ring kernel only; 1 = 4-stage ring; 0 = 128x128x64 double buffer;
- * 3 = register-double-buffered ring; 4 / 5 = ping-pong output-tiled / stream-K wherever supported. */
+/* DEPRECATED (removed next ABI version): process-wide setters kept for one round.  They only change the DEFAULTS that contexts
+ * created afterwards start from (and that context-free calls use); existing contexts are not affected.  Use rv_ctx_set_option. */
 void rv_set_gemm_tile_variant(int32_t variant);
-/* Process-wide: number of CUs (multiple of 8; 0 = all) the persistent prefill GEMMs occupy.  Their 128 KiB-LDS workgroups own a
- * CU each, so a smaller grid leaves whole CUs to the launches of another stream (two recursions in flight: the other one's
- * HBM-bound decode GEMVs keep streaming on the free CUs while this one's prefill runs on the rest). */
 void rv_set_gemm_cus(int32_t n);
-/* Measurement knob (process-wide): 1 = the KV-cached decode step runs attention + o projection as one launch (the o weights
- * stream while the attention chain runs); 0 (default) = two launches (level on MI355X: the in-kernel hand-off costs what the
- * saved launch gains).  Same results to f32 rounding of the softmax merge. */
-void rv_set_decode_fusion(int32_t on);
-/* 1 (default): KV-cached decode steps stream the FP8 weight copies when all of them are bound ("<name>.f8" / "<name>.s8" next
- * to every LLM projection and lm_head, see Engine.load_llm(fp8_decode=True)); 0: always decode on the bf16 weights. */
 void rv_set_fp8_decode(int32_t on);
-/* 1 (default): prefill passes run their QKV / o / gate-up / down GEMMs as FP8 x FP8 (rv_gemm_fp8: activations quantised per row
- * on the fly) when the "<name>.f8p" weight copies of every layer are bound (Engine.load_llm(fp8_prefill=True)) and the shape has
- * a persistent plan; 0: always prefill on the bf16 weights.  Opt-in "fp8 MFMA LLM path", never the parity target. */
 void rv_set_fp8_prefill(int32_t on);
-int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
+void rv_set_sample_variant(int32_t v);
+int rv_gemm(const rv_ctx* ctx /* optional: tunables */, const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);
 /* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
@@ -185,10 +196,7 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  * (vtimellm_llama.py:312-338; funs_get_feature_X.py:131-132).  logits f32 [B,V].
  * out_topk_idx i32 / out_topk_val f32 [B,top_k_cap]: kept candidates in descending order (processed
  * scores), n_keep i32 [B].  top_k <= 64. */
-/* Measurement / test knob (process-wide): 1 (default) = top-k selection through the compacted-candidate fast path when the
- * row qualifies (V >= 1024, no tie across the k-th place); 0 = always the general 16-round selection.  Identical outputs. */
-void rv_set_sample_variant(int32_t v);
-int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
+int rv_sample(const rv_ctx* ctx /* optional: tunables */, const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
               int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
               int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream);
 /* get_entropy_statistics (funs_get_feature_X.py:120-146): logits f32 [B,G,V] -> [B,4] = max,min,mean,std. */

@@ -44,7 +44,11 @@ struct rv_ctx {
     const float* slm_head = nullptr;
     bool fp8_decode = false;
     bool fp8_prefill = false;   // ".f8p" copies bound for every layer projection
+    bool options_only = false;  // created without a model configuration: carries tunables for the building-block entry points
+    RvOpts opt;                 // per-context tunables (rv_ctx_set_option)
 };
+
+const RvOpts* rv_ctx_opts(const rv_ctx* c) { return c ? &c->opt : nullptr; }
 
 namespace {
 
@@ -236,7 +240,15 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
 }  // namespace
 
 extern "C" int rv_ctx_create(const rv_config* cfg, rv_ctx** out) {
-    RV_CHECK_ARG(cfg && out, "rv_ctx_create: null argument");
+    RV_CHECK_ARG(out, "rv_ctx_create: null argument");
+    if (!cfg) {   // options-only context (tunables for rv_gemm / rv_sample / ...): no model, nothing can be bound
+        rv_ctx* c = new rv_ctx();
+        memset(&c->cfg, 0, sizeof(c->cfg));
+        c->options_only = true;
+        c->opt = g_default_opts;
+        *out = c;
+        return RV_OK;
+    }
     RV_CHECK_ARG(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0, "rv_ctx_create: bad hidden/heads");
     RV_CHECK_ARG(cfg->hidden / cfg->heads == 128, "rv_ctx_create: LLM head dim must be 128 (got %d)", cfg->hidden / cfg->heads);
     RV_CHECK_ARG(cfg->hidden % 128 == 0 && cfg->inter % 128 == 0, "rv_ctx_create: hidden and inter must be multiples of 128");
@@ -244,14 +256,48 @@ extern "C" int rv_ctx_create(const rv_config* cfg, rv_ctx** out) {
     RV_CHECK_ARG(cfg->adapter_ff % 128 == 0 && cfg->adapter_layers >= 1, "rv_ctx_create: bad adapter ff/layers");
     rv_ctx* c = new rv_ctx();
     c->cfg = *cfg;
+    c->opt = g_default_opts;
     *out = c;
     return RV_OK;
 }
 
 extern "C" void rv_ctx_destroy(rv_ctx* ctx) { delete ctx; }
 
+namespace {
+int* option_slot(RvOpts& o, const char* key) {
+    const std::string k(key);
+    if (k == "gemm_tile_variant") return &o.gemm_tile_variant;
+    if (k == "gemm_cus") return &o.gemm_cus;
+    if (k == "fp8_decode") return &o.fp8_decode;
+    if (k == "fp8_prefill") return &o.fp8_prefill;
+    if (k == "sample_variant") return &o.sample_variant;
+    if (k == "gemm_arows") return &o.gemm_arows;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int rv_ctx_set_option(rv_ctx* c, const char* key, int64_t value) {
+    RV_CHECK_ARG(c && key, "rv_ctx_set_option: null argument");
+    int* slot = option_slot(c->opt, key);
+    RV_CHECK_ARG(slot, "rv_ctx_set_option: unknown option '%s'", key);
+    const std::string k(key);
+    if (k == "gemm_tile_variant") RV_CHECK_ARG(value >= 0 && value <= 6, "rv_ctx_set_option: gemm_tile_variant must be in [0, 6]");
+    if (k == "gemm_cus") RV_CHECK_ARG(value >= 0 && value % 8 == 0, "rv_ctx_set_option: gemm_cus must be a non-negative multiple of 8");
+    *slot = (int)value;
+    return RV_OK;
+}
+
+extern "C" int rv_ctx_get_option(const rv_ctx* c, const char* key, int64_t* value) {
+    RV_CHECK_ARG(c && key && value, "rv_ctx_get_option: null argument");
+    const int* slot = option_slot(const_cast<rv_ctx*>(c)->opt, key);
+    RV_CHECK_ARG(slot, "rv_ctx_get_option: unknown option '%s'", key);
+    *value = *slot;
+    return RV_OK;
+}
+
 extern "C" int rv_weights_bind(rv_ctx* c, const char* name, const void* dptr, int dtype, int64_t numel) {
     RV_CHECK_ARG(c && name && dptr && numel > 0, "rv_weights_bind: bad arguments");
+    RV_CHECK_ARG(!c->options_only, "rv_weights_bind: this context was created without a model configuration");
     RV_CHECK_ARG(((uintptr_t)dptr & 15) == 0, "rv_weights_bind: '%s' must be 16-byte aligned", name);
     c->w[name] = Tensor{dptr, dtype, numel};
     c->resolved_adapter = c->resolved_llm = c->resolved_proj = false;
@@ -260,6 +306,7 @@ extern "C" int rv_weights_bind(rv_ctx* c, const char* name, const void* dptr, in
 
 extern "C" int rv_project_dense(rv_ctx* c, const void* x_bf16, void* y, int out_dtype, int64_t rows, void* stream) {
     RV_CHECK_ARG(c && x_bf16 && y && rows > 0, "rv_project_dense: bad arguments");
+    RvOptScope scope(&c->opt);
     RV_TRY(resolve_proj(c));
     const int64_t d = c->cfg.adapter_dim, D = c->cfg.hidden;
     return rv_gemm_impl(x_bf16, d, c->proj_w, d, 1, c->proj_b, nullptr, 0, y, D, out_dtype, RV_ACT_NONE, rows, D, d, nullptr, 0, as_stream(stream));
@@ -273,6 +320,7 @@ extern "C" size_t rv_clip_encoder_ws_bytes(const rv_ctx* c, int32_t N, int32_t T
 extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const uint8_t* txt_mask, int32_t N, int32_t T,
                                int32_t Nq, int32_t Lq, int32_t feature, float* out, void* ws, size_t ws_bytes, void* stream) {
     RV_CHECK_ARG(c && x && out && ws, "rv_clip_encoder: null argument");
+    RvOptScope scope(&c->opt);
     RV_CHECK_ARG(N > 0 && T > 0, "rv_clip_encoder: empty input N=%d T=%d", N, T);
     RV_CHECK_ARG(feature == RV_FEAT_CLS || feature == RV_FEAT_ALL, "rv_clip_encoder: feature must be CLS or ALL");
     RV_TRY(resolve_adapter(c));
@@ -418,16 +466,9 @@ extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
     return carve_llm(c, nullptr, 0, 1, B * S).bytes;
 }
 
-// Measurement knob: 1 = the decode step runs attention + o projection as ONE launch (decode_fused.hip).  Measured on MI355X
-// (B = 7, 171 cached positions): 2.98 ms per step fused vs 2.96 ms with two launches - the saved launch and the overlapped
-// weight stream are paid back by the in-kernel hand-off (sc1 store -> flag -> poll -> sc1 loads: three memory round trips),
-// so it is OFF by default and kept tested.
-int g_fuse_decode_attn = 0;
-int g_use_fp8_decode = 1;   // measurement knob: 0 = ignore bound FP8 copies (decode on the bf16 weights)
-int g_use_fp8_prefill = 1;  // measurement knob: 0 = ignore bound ".f8p" copies (prefill on the bf16 weights)
-extern "C" void rv_set_fp8_decode(int32_t on) { g_use_fp8_decode = on != 0; }
-extern "C" void rv_set_fp8_prefill(int32_t on) { g_use_fp8_prefill = on != 0; }
-extern "C" void rv_set_decode_fusion(int32_t on) { g_fuse_decode_attn = on != 0; }
+// deprecated shims (one round): they only change the DEFAULTS new contexts start from; use rv_ctx_set_option
+extern "C" void rv_set_fp8_decode(int32_t on) { g_default_opts.fp8_decode = on != 0; }
+extern "C" void rv_set_fp8_prefill(int32_t on) { g_default_opts.fp8_prefill = on != 0; }
 
 namespace {
 // Rows of h: [P0 shared-prefix rows (positions 0..P0-1)] then B sequences of S rows (positions pos0..pos0+S-1, with
@@ -453,10 +494,10 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // Decode steps (M <= 16) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
     const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
-    const bool f8 = fuse_norm && c->fp8_decode && g_use_fp8_decode;   // FP8 weight copies: KV-cached decode steps only
+    const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
-    const bool p8 = !fuse_norm && M > 16 && c->fp8_prefill && g_use_fp8_prefill && w.sk_bytes >= 8192;
+    const bool p8 = !fuse_norm && M > 16 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
     const bool p8_qkv = p8 && gemm_pp_fp8_supported(M, 3 * D, D, false, true), p8_o = p8 && gemm_pp_fp8_supported(M, D, D, false, false);
     const bool p8_gu = p8 && gemm_pp_fp8_supported(M, 2 * F, D, true, false), p8_down = p8 && gemm_pp_fp8_supported(M, D, F, false, false);
     auto norm_quant = [&](const float* nw) -> int {   // RMSNorm(h) -> FP8 rows + scales (fused for d = 4096)
@@ -464,7 +505,6 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         RV_TRY(k_rmsnorm(h, D, nw, w.xn16, M, (int)D, g.rms_eps, st));
         return k_quant_rows_fp8(w.xn16, D, w.x8, D, w.sa, M, (int)D, st);
     };
-    const bool fuse_attn = !f8 && fuse_norm && g_fuse_decode_attn && attn_oproj_decode_supported(B, H, dh, D) && w.sk_bytes >= 8192;
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
     GemvNorm consume;
     consume.in_sumsq = w.ss;
@@ -511,11 +551,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.xw_out = w.xn16;
         produce.out_sumsq = w.ss;
         produce.w_next = L.norm2;
-        if (fuse_attn) {
-            // decode: attention + o projection in one launch, the o weights streaming while the attention chain runs
-            int* sync = (int*)w.sk + 1024;   // spare words [1024, 1536) of the (zero-initialised) hand-off header; status word at 2047
-            RV_TRY(attn_oproj_decode_launch(w.q16, kc, vtc, w.a16, L.wo, h, produce, sync, (int*)w.sk + 2047, B, H, pos0 + 1, Smax, D, scale, st));
-        } else {
+        {
             const int64_t r0 = P0;  // first row of the per-sequence part
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                        (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
@@ -574,6 +610,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
 extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
                               void* ws, size_t ws_bytes, void* stream) {
     RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_forward: null argument");
+    RvOptScope scope(&c->opt);
     RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_forward: empty problem");
     RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_forward: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
     return llm_forward_impl(c, h, B, S, pos0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));
@@ -587,6 +624,7 @@ extern "C" size_t rv_llm_prefill_shared_ws_bytes(const rv_ctx* c, int32_t B, int
 extern "C" int rv_llm_prefill_shared(rv_ctx* c, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t Smax, float* logits,
                                      void* ws, size_t ws_bytes, void* stream) {
     RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_prefill_shared: null argument");
+    RvOptScope scope(&c->opt);
     RV_CHECK_ARG(B > 0 && S > 0 && P0 > 0, "rv_llm_prefill_shared: empty problem");
     RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_shared: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
     return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));

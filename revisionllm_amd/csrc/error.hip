@@ -1,7 +1,7 @@
 // Thread-local error string behind rv_last_error().
 #include <stdarg.h>
 
-#include "common.h"
+#include "kernels.h"
 
 static thread_local char g_err[512] = "";
 
@@ -20,3 +20,10 @@ extern "C" int rv_last_error(char* buf, size_t n) {
     buf[n - 1] = 0;
     return RV_OK;
 }
+
+// ---- per-call option scope (see kernels.h) ----
+RvOpts g_default_opts;
+static thread_local const RvOpts* t_opts = nullptr;
+const RvOpts& rv_cur_opts() { return t_opts ? *t_opts : g_default_opts; }
+RvOptScope::RvOptScope(const RvOpts* o) : prev(t_opts) { t_opts = o; }
+RvOptScope::~RvOptScope() { t_opts = prev; }

@@ -727,23 +727,22 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 // packed W: 2 (default) = 128x128x32 3-stage ring (3 workgroups/CU) + the 256x256 ping-pong kernel where it pays;
 // 6 = ring only; 1 = 4-stage ring (2 workgroups/CU); 0 = 128x128x64 2-stage; 3 = register-double-buffered ring;
 // 4 = ping-pong output-tiled wherever supported; 5 = ping-pong stream-K wherever supported (A/B measurement knobs)
-int g_tile_variant = 2;
 
 template <int OUT_BF16, int ACT, int WP>
 void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
-    if (WP && g_tile_variant == 1) {
+    if (WP && rv_cur_opts().gemm_tile_variant == 1) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
         return;
     }
-    if (WP && g_tile_variant == 3) {
+    if (WP && rv_cur_opts().gemm_tile_variant == 3) {
         hipLaunchKernelGGL((gemm_tile_p5<OUT_BF16, ACT>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n);
         return;
     }
-    if (WP && (g_tile_variant == 2 || g_tile_variant >= 4)) {
+    if (WP && (rv_cur_opts().gemm_tile_variant == 2 || rv_cur_opts().gemm_tile_variant >= 4)) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
                            ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
         return;
@@ -800,11 +799,13 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
         RV_CHECK_LAUNCH("rv_gemm (fp8 weights)");
         return RV_OK;
     }
+    if (!gemv && !norm && (rv_cur_opts().gemm_arows & 15) && gemm_arows_supported(w_layout, act, M, N, K))
+        return gemm_arows_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, st);   // short K, many rows
     if (!gemv && gemm_pp_supported(w_layout, M, N, K)) {
         // 256x256 ping-pong kernel (gemm_pp.hip): persistent stream-K for few-row, deep-K problems (the o / down projections
         // of the prefill), output-tiled when the tile count fills the CUs; everything else stays on the 128x128 ring kernel
         void* sk_ws = (ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(w_layout, M, N, K)) ? ws : nullptr;
-        const int v = g_tile_variant;
+        const int v = rv_cur_opts().gemm_tile_variant;
         if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0) || gemm_pp_dp_profitable(M, N, K))))
             return gemm_pp_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K,
                                   (v == 5 || (v == 2 && sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0)) ? sk_ws : nullptr, st);
@@ -854,7 +855,7 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
         RV_CHECK_ARG(w_layout == 1, "gemm_qkv_rope: the prefill path takes bf16 fragment-packed weights");
         RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
         const bool sk = ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(1, M, N, K);
-        if (sk && (g_tile_variant == 5 || (g_tile_variant == 2 && gemm_pp_sk_plan(M, N, K, false) != 0)))
+        if (sk && (rv_cur_opts().gemm_tile_variant == 5 || (rv_cur_opts().gemm_tile_variant == 2 && gemm_pp_sk_plan(M, N, K, false) != 0)))
             return gemm_pp_qkv_rope(A, lda, Wp, M, N, K, r, ws, st);
         const int tiles_m = (int)cdiv(M, BM), tiles_n = N / BN;
         hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a, lda, w, nullptr, nullptr,
@@ -866,13 +867,14 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 
 int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
-extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_tile_variant = (v >= 0 && v <= 6) ? v : 2; }
+extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_default_opts.gemm_tile_variant = (v >= 0 && v <= 6) ? v : 2; }   // deprecated shim
 
 extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_pp_ws_bytes(); }
 
-extern "C" int rv_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
+extern "C" int rv_gemm(const rv_ctx* ctx, const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                        const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                        int64_t K, void* ws, size_t ws_bytes, void* stream) {
+    RvOptScope scope(rv_ctx_opts(ctx));
     return rv_gemm_impl(A, lda, W, ldw, w_layout, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K, ws, ws_bytes,
                         as_stream(stream));
 }
@@ -893,9 +895,10 @@ extern "C" int rv_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t
     return k_quant_rows_fp8(x16, ldx, q8, ldq, scale, rows, (int)K, as_stream(stream));
 }
 
-extern "C" int rv_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
+extern "C" int rv_gemm_fp8(const rv_ctx* ctx, const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
                            int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
                            size_t ws_bytes, void* stream) {
+    RvOptScope scope(rv_ctx_opts(ctx));
     RV_CHECK_ARG(A8 && a_scale && W8p && w_scale && C && ws, "rv_gemm_fp8: null argument");
     RV_CHECK_ARG(ws_bytes >= gemm_pp_ws_bytes(), "rv_gemm_fp8: workspace %zu < rv_gemm_ws_bytes() = %zu", ws_bytes, gemm_pp_ws_bytes());
     RV_CHECK_ARG(lda % 16 == 0 && gemm_pp_fp8_supported(M, N, K, act == RV_ACT_SILU_MUL, false),

@@ -439,13 +439,16 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
 template <int C, int OUT_BF16, int ACT, int ROPE, int F8 = 0>
 __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, int c, int j, int wave, int lane,
                                                 const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv, int64_t ldc,
-                                                int M, int m0, int n0, const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr}) {
+                                                int M, int m0, int n0, const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr},
+                                                float poison = 0.f) {
+    // poison: 0 normally; NaN when a participant never published its partial tile (bounded wait expired): the share is then
+    // stored as NaN instead of a silently incomplete sum
     constexpr int UPW = C <= 4 ? (128 + 8 * C - 1) / (8 * C) : 1;   // units per wave and pass
     const int per_pass = 8 * UPW;
     for (int q0 = 0; j + q0 * c < 128; q0 += per_pass) {
         f32x4 s[UPW][2];
 #pragma unroll
-        for (int u = 0; u < UPW; ++u) s[u][0] = s[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UPW; ++u) s[u][0] = s[u][1] = f32x4{poison, poison, poison, poison};
         for (int base = 0; base < c; base += C) {
             f32x4 v[UPW][C][2];
 #pragma unroll
@@ -567,27 +570,30 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
             ++c;
         }
         if (tid == 0) {
+            int gave_up = 0;
             for (int i = 0; i < c; ++i) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(flags + ids[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 24)) {
                         *status = 1;
+                        gave_up = 1;
                         break;
                     }
                 }
             }
+            ids[1024] = gave_up;   // (ids[0 .. c) hold the participants, c <= #teams <= 256)
         }
         __syncthreads();
+        const float poison = ids[1024] ? __int_as_float(0x7fc00000) : 0.f;   // a missing partial poisons this share (never a silent partial sum)
         const int m0 = m0_wg, n0 = (dp_panels + panel) * PBN;
-        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
-        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
-        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
-        else pp_reduce_share<8, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc);
+        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else pp_reduce_share<8, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
     }
 }
 
-int g_pp_cus = 0;   // 0 = every CU of the device; otherwise the persistent GEMMs use this many (a multiple of 8)
 int pp_device_cus() {
     static int n = 0;
     if (n == 0) {
@@ -599,7 +605,8 @@ int pp_device_cus() {
 }
 int pp_num_cus() {
     const int n = pp_device_cus();
-    return (g_pp_cus > 0 && g_pp_cus <= n) ? g_pp_cus : n;
+    const int want = rv_cur_opts().gemm_cus & ~7;   // 0 = every CU of the device; otherwise the persistent GEMMs use this many
+    return (want > 0 && want <= n) ? want : n;
 }
 
 template <typename Kern>
@@ -661,7 +668,7 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
 // The persistent prefill GEMMs may be told to leave CUs free (rv_set_gemm_cus): a 128 KiB-LDS workgroup owns its CU, so with a
 // grid of 192 on a 256-CU device 8 CUs per XCD stay available to whatever another stream launches (the HBM-bound decode
 // GEMVs of a second recursion in flight cannot share a CU with these workgroups: both fill the register file).
-extern "C" void rv_set_gemm_cus(int32_t n) { g_pp_cus = n > 0 ? (n & ~7) : 0; }
+extern "C" void rv_set_gemm_cus(int32_t n) { g_default_opts.gemm_cus = n > 0 ? (n & ~7) : 0; }   // deprecated shim
 
 size_t gemm_pp_ws_bytes() { return PP_HDR + (size_t)2 * pp_device_cus() * PARTIAL_F4 * sizeof(f32x4); }
 

@@ -2,6 +2,26 @@
 #pragma once
 #include "common.h"
 
+// Per-context tunables (rv_ctx_set_option).  An exported entry point opens an RvOptScope with its context's options (the
+// defaults when it has no context); the launch helpers below read them through rv_cur_opts().  The scope is thread-local
+// and lives only for the duration of the call: two contexts - or two threads - never see each other's settings.
+struct RvOpts {
+    int gemm_tile_variant = 2;  // packed-W GEMM family: 2 auto (ring + ping-pong where it pays), 6 ring only, 1 / 0 / 3 ring variants, 4 / 5 ping-pong tiled / stream-K wherever supported
+    int gemm_cus = 0;           // CUs the persistent GEMMs occupy (multiple of 8; 0 = all)
+    int fp8_decode = 1;         // use bound ".f8" decode weight copies
+    int fp8_prefill = 1;        // use bound ".f8p" prefill weight copies
+    int sample_variant = 1;     // 1 compacted-candidate top-k fast path, 0 general selection (identical outputs)
+    int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
+};
+extern RvOpts g_default_opts;   // written only by the deprecated rv_set_* shims; copied into a context at rv_ctx_create
+const RvOpts& rv_cur_opts();
+struct RvOptScope {
+    const RvOpts* prev;
+    explicit RvOptScope(const RvOpts* o);
+    ~RvOptScope();
+};
+const RvOpts* rv_ctx_opts(const rv_ctx* c);   // &c->opt, or nullptr for a null context
+
 // Optional RMSNorm fusion for the decode (M <= 16) kernel.  RMSNorm(h)[b,k] = w[k] * h[b,k] * r[b] with
 // r[b] = rsqrt(mean_k h[b,k]^2 + eps) and r factors out of the dot product: out[b,n] = r[b] * sum_k W[n,k] * (w[k] h[b,k]).
 // PRODUCER (a projection whose output is the residual stream h): besides h it writes xw = bf16(w_next * h) and, per
@@ -81,6 +101,10 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
 int gemv_blocks(int act, int64_t N);  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
+// A-resident kernel for short-K many-row problems (gemm_arows.hip): a workgroup keeps its block of A rows in LDS and walks N
+bool gemm_arows_supported(int w_layout, int act, int64_t M, int64_t N, int64_t K);
+int gemm_arows_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+                      int out_dtype, int act, int64_t M, int64_t N, int64_t K, hipStream_t st);
 // 256x256x64 ping-pong kernel (gemm_pp.hip): output-tiled, or persistent stream-K when ws != NULL and M <= 1024
 bool gemm_pp_supported(int w_layout, int64_t M, int64_t N, int64_t K);
 bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
@@ -96,11 +120,6 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st);
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st);
-// decode step: attention + o projection (+ residual, fused-RMSNorm producer) in one launch (decode_fused.hip).
-// sync: one int per workgroup (<= #CUs), zero-initialised once; status: 1 int (set non-zero if a bounded wait gave up)
-bool attn_oproj_decode_supported(int B, int H, int dh, int64_t D);
-int attn_oproj_decode_launch(const void* q16, const void* kc, const void* vtc, void* a16, const void* wo, float* h, const GemvNorm& nrm,
-                             int* sync, int* status, int B, int H, int Lk, int Smax, int64_t D, float scale, hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
                 int64_t period, int64_t rows, int d, hipStream_t st);
 int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,

@@ -10,7 +10,6 @@ namespace {
 constexpr int TPB = 1024;   // threads per row
 constexpr int ITEMS = 32;   // V <= 32768
 constexpr int KCAP = 64;
-int g_sample_variant = 1;   // host copy of the knob (rv_set_sample_variant): passed to the kernel as an argument
 
 struct ArgMax {
     float v;
@@ -669,9 +668,10 @@ __global__ __launch_bounds__(256) void topk_pool_kernel(const T* __restrict__ vi
 
 }  // namespace
 
-extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
+extern "C" int rv_sample(const rv_ctx* ctx, const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
                          int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
                          int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream) {
+    RvOptScope scope(rv_ctx_opts(ctx));
     RV_CHECK_ARG(logits && out_tokens && out_entropy_proc && out_entropy_raw && out_nkeep, "rv_sample: null output");
     RV_CHECK_ARG(B > 0 && V > 0 && V <= TPB * ITEMS, "rv_sample: V=%d exceeds %d", V, TPB * ITEMS);
     if (do_sample) {
@@ -680,12 +680,12 @@ extern "C" int rv_sample(const float* logits, int32_t B, int32_t V, const float*
         RV_CHECK_ARG(out_topk_idx && out_topk_val, "rv_sample: candidate outputs required when sampling");
     }
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(TPB), 0, as_stream(stream), logits, V, uniforms, do_sample, temperature, top_k,
-                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep, g_sample_variant);
+                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep, rv_cur_opts().sample_variant);
     RV_CHECK_LAUNCH("rv_sample");
     return RV_OK;
 }
 
-extern "C" void rv_set_sample_variant(int32_t v) { g_sample_variant = v; }
+extern "C" void rv_set_sample_variant(int32_t v) { g_default_opts.sample_variant = v; }   // deprecated shim
 
 extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream) {
     RV_CHECK_ARG(logits && out && B > 0 && G > 0 && V > 0, "rv_entropy_stats: bad arguments");

@@ -18,8 +18,12 @@ import torch
 
 
 def _npz_bytes(blob):
+    """Decode one ``np.savez[_compressed]`` blob.  ``allow_pickle=False``: feature files hold plain float arrays (the reference's
+    writers add an ``allow_pickle`` boolean array, also plain), and a data directory must not be able to run code."""
+    if blob is None:
+        raise KeyError("key not found in the feature store")
     with io.BytesIO(bytes(blob)) as reader:
-        d = np.load(reader, allow_pickle=True)
+        d = np.load(reader, allow_pickle=False)
         return {k: d[k] for k in d.files}
 
 
@@ -50,7 +54,7 @@ class FeatureStore:
         p = os.path.join(self.feat_folder, movie + ".npy")
         if os.path.exists(p):
             return np.load(p)
-        d = dict(np.load(os.path.join(self.feat_folder, movie + ".npz"), allow_pickle=True))
+        d = dict(np.load(os.path.join(self.feat_folder, movie + ".npz"), allow_pickle=False))
         return d["features"] if "features" in d else d["memory_global"]
 
     def query(self, query_id):
@@ -60,30 +64,58 @@ class FeatureStore:
         if self._qenv is not None:
             d = _npz_bytes(self._qenv.get(query_id.encode()))
         else:
-            d = dict(np.load(os.path.join(self.q_feat_dir, query_id + ".npz"), allow_pickle=True))
+            d = dict(np.load(os.path.join(self.q_feat_dir, query_id + ".npz"), allow_pickle=False))
         return d["token_features"], d["cls_features"]
+
+
+class StagedWindows:
+    """One staged window tensor: ``tensor`` bf16 [W, num_frames, 768] on the device, valid once ``event`` has completed.
+    ``wait(stream)`` orders a consumer stream after the copy and tells the caching allocator that the block is in use on that
+    stream (the tensor was allocated on the staging stream)."""
+
+    def __init__(self, tensor, event):
+        self.tensor, self.event = tensor, event
+
+    def wait(self, stream=None):
+        stream = stream or torch.cuda.current_stream(self.tensor.device)
+        stream.wait_event(self.event)
+        self.tensor.record_stream(stream)
+        return self.tensor
+
+    def __iter__(self):          # ``dev, ev = stager.stage_windows(...)``
+        return iter((self.tensor, self.event))
 
 
 class WindowStager:
     """Pinned host staging + asynchronous H2D of the window tensor [W, num_frames, 768] (bf16 on the device, as the
-    reference casts it: e2e2.py:303-306)."""
+    reference casts it: e2e2.py:303-306).  ``depth`` pinned buffers are used round-robin, each with the event of its last
+    copy: a buffer is overwritten only after that copy has completed, so the video of query i+1 (or i+depth-1) can be staged
+    while query i's copy is still in flight."""
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", depth=2):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
-        self._pinned = None
+        self._slots = [{"buf": None, "event": None} for _ in range(max(1, depth))]
+        self._next = 0
 
     def stage_windows(self, features, frame_idx):
-        """features [ctx_l, 768] numpy (any float dtype), frame_idx int32 [W, num_frames] -> (device bf16 tensor, event)."""
+        """features [ctx_l, 768] numpy (any float dtype), frame_idx int32 [W, num_frames] -> ``StagedWindows`` (unpacks as
+        ``(device bf16 tensor, event)``).  Consumers on another stream call ``.wait(stream)`` (or wait for the event and
+        ``tensor.record_stream(stream)`` themselves)."""
         W, F = frame_idx.shape
         n = W * F * features.shape[1]
-        if self._pinned is None or self._pinned.numel() < n:
-            self._pinned = torch.empty(n, dtype=torch.bfloat16).pin_memory()
-        host = self._pinned[:n].view(W, F, features.shape[1])
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % len(self._slots)
+        if slot["event"] is not None:
+            slot["event"].synchronize()          # the previous copy out of this buffer has finished reading it
+        if slot["buf"] is None or slot["buf"].numel() < n:
+            slot["buf"] = torch.empty(n, dtype=torch.bfloat16).pin_memory()     # (its predecessor is idle: waited above)
+        host = slot["buf"][:n].view(W, F, features.shape[1])
         src = torch.from_numpy(np.ascontiguousarray(features))
         host.copy_(src[torch.from_numpy(frame_idx.astype(np.int64))])
         with torch.cuda.stream(self.stream):
             dev = host.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return dev, ev
+        slot["event"] = ev
+        return StagedWindows(dev, ev)

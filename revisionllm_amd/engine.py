@@ -28,9 +28,42 @@ def _dev_packed(t, device):
     return ops.pack_fragments(_dev_bf16(t, device))
 
 
+class PersistGate:
+    """Orders the launches that need EVERY CU of a device at once.
+
+    The prefill GEMMs are PERSISTENT kernels: one workgroup per CU, and a workgroup waits in-kernel for the partial tiles of its
+    panel's other workgroups, so all of a launch's workgroups must become resident.  Two such launches running at once (calls in
+    flight on different streams, or two engines on one GPU) could each hold half the CUs and wait for the other half until the
+    bounded wait gives up; an RCCL collective kernel resident on a few CUs delays them the same way.  Whoever enqueues such a
+    launch brackets it with ``begin`` / ``end``: a device-side event wait only - decode steps and the adapter overlap freely.
+    The ordering domain is the DEVICE (its CUs are the contended resource), so by default every Engine on a device shares that
+    device's gate (``PersistGate.for_device``); an Engine can be given its own gate explicitly."""
+
+    _by_device = {}
+
+    def __init__(self):
+        self._event = None
+
+    @classmethod
+    def for_device(cls, device):
+        key = torch.device(device).index or 0
+        if key not in cls._by_device:
+            cls._by_device[key] = cls()
+        return cls._by_device[key]
+
+    def begin(self, stream=None):
+        if self._event is not None:
+            (stream or torch.cuda.current_stream()).wait_event(self._event)
+
+    def end(self, stream=None):
+        ev = torch.cuda.Event()
+        ev.record(stream or torch.cuda.current_stream())
+        self._event = ev
+
+
 class Engine:
     def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, adapter_text=True, device="cuda:0", adapter_dim=768,
-                 adapter_heads=8, adapter_ff=2048, adapter_layers=2):
+                 adapter_heads=8, adapter_ff=2048, adapter_layers=2, gate=None):
         if not torch.cuda.is_available():
             raise hip.HipLibraryError("no GPU visible: revisionllm_amd runs only on the HIP device path")
         self.lib = hip.lib()
@@ -45,6 +78,7 @@ class Engine:
         self._keep = {}      # name -> tensor (keeps device memory alive while bound)
         self._ws = {}        # workspace cache
         self.slot = 0        # workspace / KV-pool namespace: one per in-flight call stream (weights are shared, read-only)
+        self.gate = gate if gate is not None else PersistGate.for_device(self.device)
         self.has_llm = self.has_clip = self.has_linear = False
 
     def __del__(self):
@@ -54,6 +88,16 @@ class Engine:
                 self._ctx = C.c_void_p()
         except Exception:
             pass
+
+    # ---- tunables (per context: two engines in one process can differ) ---------------------------
+    def set_option(self, key, value):
+        hip.check(self.lib.rv_ctx_set_option(self._ctx, key.encode(), int(value)), f"rv_ctx_set_option({key})")
+        return self
+
+    def get_option(self, key):
+        v = C.c_int64()
+        hip.check(self.lib.rv_ctx_get_option(self._ctx, key.encode(), C.byref(v)), f"rv_ctx_get_option({key})")
+        return int(v.value)
 
     # ---- weights -------------------------------------------------------------------------------
     def bind(self, name, t):
@@ -239,21 +283,11 @@ class Engine:
                 self._ws[key] = t
         return t, Smax
 
-    # The prefill GEMMs are PERSISTENT kernels: one workgroup per CU, and a workgroup waits in-kernel for the partial tiles of
-    # its panel's other workgroups, so all of a launch's workgroups must become resident.  Two such launches running at once
-    # (calls in flight on different streams) could each hold half the CUs and wait for the other half forever, so prefills are
-    # ordered across streams with an event (device-side wait only; decode steps and the adapter overlap freely).
-    _persist_event = {}
-
     def _persist_begin(self):
-        ev = Engine._persist_event.get(self.device.index)
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+        self.gate.begin(torch.cuda.current_stream(self.device))
 
     def _persist_end(self):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        Engine._persist_event[self.device.index] = ev
+        self.gate.end(torch.cuda.current_stream(self.device))
 
     def llm_forward(self, h, pos0, kv, Smax, logits=None):
         """h f32 [B,S,D] (clobbered) -> logits f32 [B,V] of the last position; appends K/V at pos0..pos0+S-1."""

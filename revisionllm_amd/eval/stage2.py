@@ -58,6 +58,15 @@ def plan_groups(W, batch, zooms=(4, 2, 1)):
     return plan
 
 
+def group_span(W, start, end):
+    """Windows that ``features[start:end]`` selects -> (first, count).  ``start`` is NEGATIVE when a video has fewer windows than
+    the level's group size (the back-shift ``start = end - batch``, e2e2.py:342-343): the slice then counts from the end like
+    any Python / torch slice (W = 60, batch = 100: features[-40:60] = windows 20..59), the call presents fewer video tokens
+    and the negative ``start`` still enters the answer -> window arithmetic (e2e2.py:119, clamped at 0)."""
+    r = range(W)[start:end]
+    return (r.start if len(r) else 0), len(r)
+
+
 def get_ground_truth_windows(start, end, duration):
     """e2e2.py:161-170."""
     clip_len = 0.2
@@ -147,21 +156,24 @@ def window_cosine(features, query_cls, k=3):
     return ops.topk_cosine(features, query_cls, min(features.shape[1], k))
 
 
-def call_row_index(plan, perms, device):
-    """Window index of every video row of every call, concatenated: start + perm, each repeated ``zoom`` times
-    (e2e2.py:345-352 applied to CLS rows) -> (int64 device tensor, per-call row counts).  Needs only the plan, so it is
-    uploaded before the adapter is launched and the host never waits on the device between the stages."""
-    idx = [(start + p.long()).repeat_interleave(z) if z > 1 else start + p.long() for (z, start, end), p in zip(plan, perms)]
+def call_row_index(plan, perms, device, W=None):
+    """Window index of every video row of every call, concatenated: first window of the group + perm, each repeated ``zoom``
+    times (e2e2.py:345-352 applied to CLS rows) -> (int64 device tensor, per-call row counts).  Needs only the plan, so it is
+    uploaded before the adapter is launched and the host never waits on the device between the stages.  ``W`` (number of
+    windows) is needed only when a group start is negative (``group_span``)."""
+    firsts = [start if start >= 0 else group_span(W, start, end)[0] for _, start, end in plan]
+    idx = [(f + p.long()).repeat_interleave(z) if z > 1 else f + p.long() for f, (z, _, _), p in zip(firsts, plan, perms)]
     return ops.h2d(torch.cat(idx), device), [int(i.numel()) for i in idx]
 
 
 def build_call_rows(cls, plan, perms, index=None):
     """Video rows of every call: cls[start:end][perm].repeat_interleave(zoom), as views of ONE gather."""
-    idx, counts = index if index is not None else call_row_index(plan, perms, cls.device)
+    idx, counts = index if index is not None else call_row_index(plan, perms, cls.device, cls.shape[0])
     return list(cls.index_select(0, idx).split(counts))
 
 
-def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None):
+def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None,
+                 forced_tokens=None):
     """Enqueue the LLM work for the given call indices WITHOUT waiting for it (when no EOS id is configured ``generate`` never
     synchronises).  ``query`` is one prompt for all calls or a {call: prompt} mapping (several queries of one movie batched
     together).  Calls whose prompts have the same length (same number of video rows and of text tokens) run as one batched
@@ -184,9 +196,10 @@ def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_to
             sel = cs[c0:c0 + max_calls_per_generate]
             ids = torch.cat([prompt_ids(c) for c in sel], 0)
             u = None if uniforms is None else uniforms[:, sel]
+            forced = None if forced_tokens is None else forced_tokens[:, sel]       # [G, calls]: teacher forcing (parity tests)
             out = model.generate(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows, do_sample=True,
                                  temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens, output_scores=False,
-                                 return_dict_in_generate=True, uniforms=u)
+                                 return_dict_in_generate=True, uniforms=u, forced_tokens=forced)
             order.extend(sel)
             toks.append(out["sequences"][:, ids.shape[1]:])
             ents.append(out["entropy"])
@@ -223,9 +236,10 @@ def finish_calls(order, tok, ent, nst, eos):
     return res
 
 
-def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16):
+def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, forced_tokens=None):
     """Run the LLM for the given call indices and wait for the results: ``finish_calls(launch_calls(...))``."""
-    order, tok, ent, nst = launch_calls(model, tokenizer, query, rows, calls, uniforms, max_new_tokens, max_calls_per_generate)
+    order, tok, ent, nst = launch_calls(model, tokenizer, query, rows, calls, uniforms, max_new_tokens, max_calls_per_generate,
+                                        forced_tokens=forced_tokens)
     tok, ent, nst = tok.cpu(), ent.cpu(), nst.cpu()
     model.engine.check_handoff_status()   # (the host is synchronised here anyway)
     return finish_calls(order, tok, ent, nst, model.generation_config.eos_token_id)
@@ -234,6 +248,7 @@ def generate_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_
 def assemble(plan, perms, call_results, cos, tokenizer, zooms, grounding_windows, single=True):
     """Host epilogue: decode answers, invert the entropies, look up the (quirky) cosine proposals."""
     stop_str = "</s>"
+    W = len(cos)
     answers, max_ent, mean_ent, score_cos, starts, indexes, hz = [], [], [], [], [], [], []
     i_call = 0
     for z in zooms:
@@ -251,28 +266,31 @@ def assemble(plan, perms, call_results, cos, tokenizer, zooms, grounding_windows
             answers.append(text)
             max_ent.append(1 / emax)
             mean_ent.append(1 / emean)
-            n_rows = (end - start) * z
-            prop = _proposal_rows(text, n_rows, hz, indexes, starts, i, grounding_windows, single)
+            first, count = (start, end - start) if start >= 0 else group_span(W, start, end)
+            prop = _proposal_rows(text, count * z, hz, indexes, starts, i, grounding_windows, single)
             if prop is None:
                 score_cos.append(0)
-            else:  # group row n holds window start + perm[n // zoom] of THIS call
-                score_cos.extend(float(cos[start + int(idx[n // z])]) for n in prop)
+            else:  # group row n holds window first + perm[n // zoom] of THIS call
+                score_cos.extend(float(cos[first + int(idx[n // z])]) for n in prop)
             i_call += 1
     return dict(answers=answers, starts=starts, indexes=indexes, hierarchy_zooms=hz, max_entropy=max_ent,
                 mean_entropy=mean_ent, score_cos=score_cos, grounding_windows=grounding_windows, plan=plan)
 
 
-def make_perms(plan, generator=None):
-    """One permutation per call, like ``torch.randperm(feat.size(1))`` at e2e2.py:348 (global RNG unless a generator is given)."""
-    return [torch.randperm(end - start, generator=generator) for _, start, end in plan]
+def make_perms(plan, generator=None, W=None):
+    """One permutation per call, like ``torch.randperm(feat.size(1))`` at e2e2.py:348 (global RNG unless a generator is given).
+    ``W``: number of windows, needed only when a group start is negative (W < batch // zoom, see ``group_span``)."""
+    return [torch.randperm(end - start if start >= 0 else group_span(W, start, end)[1], generator=generator) for _, start, end in plan]
 
 
 def run_query(model, tokenizer, features, query_feats, query_cls, sentence, batch=100, zooms=(4, 2, 1), perms=None,
-              mode="batched", grounding_windows=None, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, single=True):
+              mode="batched", grounding_windows=None, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, single=True,
+              forced_tokens=None):
     """One query of the stage-2 recursion.  features [W,T,768] (device), query_feats [Lq,768], query_cls [768].
 
     ``perms``: one permutation per call (length batch//zoom); default ``torch.randperm`` like e2e2.py:348.
     ``uniforms`` [G, n_calls]: host-supplied sampling draws (default: torch.rand on the device).
+    ``forced_tokens`` [G, n_calls] (batched mode): teacher-force every call's continuation (parity tests against recorded runs).
     Returns the fields the reference logs (e2e2.py:411-417) + the per-call bookkeeping.
     """
     W = features.shape[0]
@@ -282,19 +300,19 @@ def run_query(model, tokenizer, features, query_feats, query_cls, sentence, batc
     if W == 0:   # video shorter than one window stride: nothing to score (the reference loops zero times)
         return dict(answers=[], starts=[], indexes=[], hierarchy_zooms=[], max_entropy=[], mean_entropy=[], score_cos=[],
                     grounding_windows=grounding_windows, plan=[])
-    if W < batch:
-        raise ValueError(f"{W} windows < batch {batch}: the reference's back-shift (e2e2.py:342-343) would index windows < 0; "
-                         "call with batch <= number of windows")
+    # W < batch // zoom: the reference's back-shift makes ``start`` negative and features[start:end] then selects FEWER windows
+    # (slice semantics, ``group_span``); such videos (< ~42 minutes at the defaults) still produce a record (e2e2.py:337-346)
     plan = plan_groups(W, batch, zooms)
-    perms = [torch.as_tensor(p).long() for p in (perms if perms is not None else make_perms(plan))]
+    perms = [torch.as_tensor(p).long() for p in (perms if perms is not None else make_perms(plan, W=W))]
     query = "<video>\n" + QUERY_TEMPLATE.format(sentence)
 
     if mode == "batched":
-        index = call_row_index(plan, perms, features.device)
+        index = call_row_index(plan, perms, features.device, W)
         cls = encode_windows(model, features, query_feats)
         cos = window_cosine(features, query_cls)
         rows = build_call_rows(cls, plan, perms, index)
-        res = generate_calls(model, tokenizer, query, rows, list(range(len(plan))), uniforms, max_new_tokens, max_calls_per_generate)
+        res = generate_calls(model, tokenizer, query, rows, list(range(len(plan))), uniforms, max_new_tokens, max_calls_per_generate,
+                             forced_tokens)
         return assemble(plan, perms, res, cos.cpu(), tokenizer, zooms, grounding_windows, single)
     if mode != "reference":
         raise ValueError(f"mode must be 'reference' or 'batched', got {mode!r}")

@@ -44,17 +44,18 @@ SIGNATURES = {
     "rv_ctx_destroy": (None, [_p]),
     "rv_weights_bind": (C.c_int, [_p, C.c_char_p, _p, C.c_int, _i64]),
     "rv_init_hash": (C.c_int, [_p, C.c_int, _i64, _u64, _f, _f, _p]),
+    "rv_ctx_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
+    "rv_ctx_get_option": (C.c_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "rv_gemm_ws_bytes": (_sz, []),
-    "rv_set_gemm_tile_variant": (None, [_i32]),
-    "rv_set_decode_fusion": (None, [_i32]),
+    "rv_set_gemm_tile_variant": (None, [_i32]),     # deprecated shims (defaults of contexts created afterwards)
     "rv_set_gemm_cus": (None, [_i32]),
     "rv_set_fp8_decode": (None, [_i32]),
     "rv_set_fp8_prefill": (None, [_i32]),
     "rv_set_sample_variant": (None, [_i32]),
-    "rv_gemm": (C.c_int, [_p, _i64, _p, _i64, C.c_int, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, _sz, _p]),
+    "rv_gemm": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, _sz, _p]),
     "rv_rmsnorm_quant_fp8": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f, _p]),
     "rv_quant_rows_fp8": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
-    "rv_gemm_fp8": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, C.c_size_t, _p]),
+    "rv_gemm_fp8": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, C.c_size_t, _p]),
     "rv_gemv_fp8": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p]),
     "rv_layernorm": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p]),
     "rv_rmsnorm": (C.c_int, [_p, _p, _p, _i64, _i32, _f, _p]),
@@ -70,7 +71,7 @@ SIGNATURES = {
     "rv_llm_forward": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_prefill_shared_ws_bytes": (_sz, [_p, _i32, _i32, _i32]),
     "rv_llm_prefill_shared": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _sz, _p]),
-    "rv_sample": (C.c_int, [_p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "rv_sample": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),
     "rv_entropy_stats": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "rv_topk_cosine": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "rv_topk_pool": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
@@ -105,6 +106,42 @@ def last_error():
 def check(rc, what):
     if rc != 0:
         raise HipLibraryError(f"{what} failed (status {rc}): {last_error()}")
+
+
+OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant")
+
+
+class Options:
+    """Owner of an OPTIONS-ONLY ``rv_ctx`` (``rv_ctx_create(NULL, ...)``): tunables for the building-block entry points that take
+    an optional context (``rv_gemm``, ``rv_gemm_fp8``, ``rv_sample``).  ``Options(gemm_tile_variant=6)``; pass it as ``ctx=``."""
+
+    def __init__(self, **kw):
+        self._ctx = C.c_void_p()
+        check(lib().rv_ctx_create(None, C.byref(self._ctx)), "rv_ctx_create(options)")
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, key, value):
+        check(lib().rv_ctx_set_option(self._ctx, key.encode(), int(value)), f"rv_ctx_set_option({key})")
+        return self
+
+    def get(self, key):
+        v = _i64()
+        check(lib().rv_ctx_get_option(self._ctx, key.encode(), C.byref(v)), f"rv_ctx_get_option({key})")
+        return int(v.value)
+
+    def __del__(self):
+        try:
+            if self._ctx and self._ctx.value:
+                lib().rv_ctx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+        except Exception:
+            pass
+
+
+def ctx_ptr(ctx):
+    """``rv_ctx*`` of an ``Options`` / ``Engine`` (or None -> NULL: the library's default tunables)."""
+    return None if ctx is None else ctx._ctx
 
 
 def ptr(t):

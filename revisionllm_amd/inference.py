@@ -31,6 +31,14 @@ def _decode(tokenizer, output_ids, input_ids, stop_str):
     return outputs
 
 
+def _check_engine(model):
+    """The host has just synchronised (decode): the cheapest place to notice that an in-kernel hand-off wait ever gave up
+    (the affected outputs are NaN-poisoned; this turns them into an exception)."""
+    eng = getattr(model, "engine", None)
+    if eng is not None:
+        eng.check_handoff_status()
+
+
 def inference(model, image, query_feats, query, tokenizer, visual_memory=None, prefix_memory=None, return_list=False):
     if visual_memory is not None:
         query = query + "<memory>"
@@ -42,6 +50,7 @@ def inference(model, image, query_feats, query, tokenizer, visual_memory=None, p
                                       prefix_memory=prefix_memory, output_scores=True, return_dict_in_generate=True,
                                       output_hidden_states=True)
     outputs = _decode(tokenizer, model_output["sequences"], input_ids, stop_str)
+    _check_engine(model)
     if len(outputs) == 1 and not return_list:
         outputs = outputs[0]
     return outputs, model_output
@@ -52,4 +61,6 @@ def inference_stage1(model, image, query, tokenizer):
     with torch.inference_mode():
         output_ids = model.generate(input_ids, images=image, query_feats=None, do_sample=True, temperature=0.05, num_beams=1,
                                     max_new_tokens=1024, use_cache=True, visual_memory=None, prefix_memory=None)
-    return _decode(tokenizer, output_ids, input_ids, stop_str)
+    outputs = _decode(tokenizer, output_ids, input_ids, stop_str)
+    _check_engine(model)
+    return outputs

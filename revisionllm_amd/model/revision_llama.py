@@ -149,7 +149,9 @@ class ReVisionLlamaForCausalLM:
         return self
 
     def to(self, *args, **kwargs):
-        """Weights live in HBM as bf16 with fp32 accumulation / residual stream; dtype moves are accepted and ignored."""
+        """Weights live in HBM as bf16 with fp32 accumulation / residual stream; dtype moves are accepted and ignored.
+        NOTE (differs from the reference): ``scores`` / ``logits`` returned by ``generate`` are float32 whatever dtype was
+        asked for here (the reference returns them in the model dtype, bf16 on the GPU)."""
         return self
 
     # ---- adapter dispatch (vtimellm_arch.py:102-147) ---------------------------------------------
@@ -168,10 +170,13 @@ class ReVisionLlamaForCausalLM:
             b, v, t, d = images.shape
             y = eng.clip_encoder(images.reshape(b * v, t, d), qf, qm, "cls")
             return y, v
+        if m.clip_adapter_feature == "cls":
+            return eng.clip_encoder(images, qf, qm, "cls"), 1
+        y = eng.clip_encoder(images, qf, qm, "all")
         if m.clip_adapter_feature == "temporal":
-            y = eng.clip_encoder(images, qf, qm, "all")[:, 1:]
-            return y.reshape(-1, self.shape.hidden), images.shape[1]
-        return eng.clip_encoder(images, qf, qm, "cls"), 1
+            return y[:, 1:].reshape(-1, self.shape.hidden), images.shape[1]
+        # any other feature value: the reference projects all T+1 rows, CLS first (transformer.py:143-144)
+        return y.reshape(-1, self.shape.hidden), images.shape[1] + 1
 
     @staticmethod
     def build_row_map(input_ids, rows_per_sample, attention_mask=None):
@@ -244,7 +249,7 @@ class ReVisionLlamaForCausalLM:
         cap = min(max_new_tokens, 64)
         kv, Smax = eng.new_kv(B, S + cap)
         P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
-        if P0 >= 16:
+        if 16 <= P0 < S:     # (P0 == S: identical text-only rows - nothing per-row is left, take the plain prefill)
             # every row starts with the same P0 text tokens (inference() repeats one prompt): under causal attention their
             # hidden states and K/V are identical for all rows, so they ride through the prefill once (rows of the
             # GEMM batch: [P0 shared ; B x (S - P0)]) and their K/V are written into every row's cache

@@ -41,9 +41,10 @@ def stream_k_workspace(device):
     return _SK_WS[key]
 
 
-def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None, w_packed=False, stream_k=None):
+def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_ACT_NONE, out=None, w_packed=False, stream_k=None, ctx=None):
     """act(a @ w.T + bias) + residual.  a [M,K] bf16 (row stride allowed), w [N,K] bf16 row-major or fragment-packed.
-    ``stream_k`` (default: on for packed W) hands the library a workspace so it may pick the persistent stream-K kernel."""
+    ``stream_k`` (default: on for packed W) hands the library a workspace so it may pick the persistent stream-K kernel.
+    ``ctx``: an ``hip.Options`` / ``Engine`` whose tunables apply (None: defaults)."""
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
@@ -51,7 +52,7 @@ def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_AC
         out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
     ws = stream_k_workspace(a.device) if (w_packed if stream_k is None else stream_k) else None
-    hip.check(hip.lib().rv_gemm(hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), int(w_packed), hip.ptr(bias), hip.ptr(residual),
+    hip.check(hip.lib().rv_gemm(hip.ctx_ptr(ctx), hip.ptr(a), a.stride(0), hip.ptr(w), w.stride(0), int(w_packed), hip.ptr(bias), hip.ptr(residual),
                                 residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0),
                                 hip.dtype_code(out), act, M, N, K, hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream()),
               "rv_gemm")
@@ -135,7 +136,7 @@ def rmsnorm_quant_fp8(x, w, eps):
     return q, sc
 
 
-def gemm_fp8(a8, a_scale, w8p, w_scale, residual=None, out_dtype=torch.float32, act=hip.RV_ACT_NONE, out=None):
+def gemm_fp8(a8, a_scale, w8p, w_scale, residual=None, out_dtype=torch.float32, act=hip.RV_ACT_NONE, out=None, ctx=None):
     """FP8 x FP8 prefill GEMM: act((a8 @ w8.T) * a_scale[:, None] * w_scale[None]) + residual (rv_gemm_fp8)."""
     M, K = a8.shape
     N = w_scale.numel()
@@ -143,7 +144,7 @@ def gemm_fp8(a8, a_scale, w8p, w_scale, residual=None, out_dtype=torch.float32, 
     if out is None:
         out = torch.empty(M, n_out, dtype=out_dtype, device=a8.device)
     ws = stream_k_workspace(a8.device)
-    hip.check(hip.lib().rv_gemm_fp8(hip.ptr(a8), a8.stride(0), hip.ptr(a_scale), hip.ptr(w8p), hip.ptr(w_scale), hip.ptr(residual),
+    hip.check(hip.lib().rv_gemm_fp8(hip.ctx_ptr(ctx), hip.ptr(a8), a8.stride(0), hip.ptr(a_scale), hip.ptr(w8p), hip.ptr(w_scale), hip.ptr(residual),
                                     residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0), hip.dtype_code(out), act,
                                     M, N, K, hip.ptr(ws), ws.numel(), hip.stream()), "rv_gemm_fp8")
     return out
@@ -202,7 +203,7 @@ def h2d(t, device, dtype=None):
     return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
 
 
-def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0):
+def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0, ctx=None):
     """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B]).
     (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""
     B, V = logits.shape
@@ -212,7 +213,7 @@ def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, to
              topk_idx=torch.empty((B, hip.TOPK_CAP), dtype=torch.int32, device=dev),
              topk_val=torch.empty((B, hip.TOPK_CAP), dtype=torch.float32, device=dev),
              n_keep=torch.empty(B, dtype=torch.int32, device=dev))
-    hip.check(hip.lib().rv_sample(hip.ptr(_c(logits)), B, V, hip.ptr(uniforms), int(do_sample), float(temperature), int(top_k),
+    hip.check(hip.lib().rv_sample(hip.ctx_ptr(ctx), hip.ptr(_c(logits)), B, V, hip.ptr(uniforms), int(do_sample), float(temperature), int(top_k),
                                   float(top_p if top_p is not None else 1.0), hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
                                   hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]),
                                   hip.stream()), "rv_sample")

@@ -140,7 +140,7 @@ def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=
     if grounding_windows is None:
         grounding_windows = list(range(W))
     dev = feats_of[0].device
-    index = [stage2.call_row_index(plan, perms[qi], dev) for qi in range(nq)]   # host inputs first: no host wait between stages
+    index = [stage2.call_row_index(plan, perms[qi], dev, W) for qi in range(nq)]   # host inputs first: no host wait between stages
     rows, prompts, cos_all = [], {}, []
     for qi, (qf, qc, sentence) in enumerate(queries):
         cls_local, cos_local = stages.encode(feats_of[qi], qf), stages.cosine(feats_of[qi], qc)

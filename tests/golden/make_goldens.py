@@ -463,8 +463,10 @@ def g9_driver(M):
                                                      e2.get_ground_truth_windows(5399.1, 5400.0, 5400.0))]
     rng = np.random.RandomState(0)
     s2 = []
-    for W, batch in ((100, 100), (33, 33), (143, 100), (290, 100)):
-        starts, idxs, zooms, answers = [], [], [], []
+    # the last two: fewer windows than the group size - the back-shifted start goes NEGATIVE and features[start:end] selects
+    # fewer windows by slice semantics (e2e2.py:342-345); the permutation has that many entries
+    for W, batch in ((100, 100), (33, 33), (143, 100), (290, 100), (60, 100), (30, 100)):
+        starts, idxs, zooms, answers, counts = [], [], [], [], []
         import math
         for z in (4, 2, 1):
             b = batch // z
@@ -474,14 +476,16 @@ def g9_driver(M):
                 if end - start < b:
                     start = end - b
                 starts.append(start)
-                idxs.append(rng.permutation(b).tolist())
+                n_sel = int(torch.zeros(W)[start:end].shape[0])        # what features[start:end] holds
+                counts.append(n_sel)
+                idxs.append(rng.permutation(n_sel).tolist())
                 zooms.append(z)
                 answers.append(["In video %d." % rng.randint(0, 100), "Not Present", "From %d to %d." % (rng.randint(0, 99), 99),
                                 "video 7"][rng.randint(0, 4)])
         gw = list(range(W))
         gt, _ = e2.get_ground_truth_windows(1000, 1400, 6000)
         frames, hit = e2.iou(answers, gt, 250, batch, starts, [torch.tensor(i) for i in idxs], True, zooms, gw)
-        s2.append(dict(W=W, batch=batch, starts=starts, indexes=idxs, zooms=zooms, answers=answers, gt=gt,
+        s2.append(dict(W=W, batch=batch, starts=starts, counts=counts, indexes=idxs, zooms=zooms, answers=answers, gt=gt,
                        frames={str(k): list(v) for k, v in frames.items()}, hit=hit))
     cases["stage2"] = s2
     outs = ["From 12 to 45.", "Not Present", "From 249 to 249.", "From 7 to 7.", "From 3 and 9.", "garbage", "From 100 to 180."]

@@ -179,3 +179,30 @@ def test_reference_stage2_loop_through_the_aliased_names(as_revisionllm):
     assert len(score_cos) == len(r["score_cos"]) and np.allclose(score_cos, r["score_cos"], rtol=3e-2, atol=3e-2)
     frames, hit = stage2.iou(answers, [1, 2], 250, batch, starts, indexes, True, hierarchy_zooms, grounding_windows)
     assert frames == stage2.log_record(r, [1, 2], batch)["frames"]
+
+
+def test_window_stager_back_to_back_videos():
+    """f-2, the device half: pinned staging + async H2D.  Two DIFFERENT videos staged back to back (the second while the
+    first copy may still be in flight) both arrive intact: bf16 values == host gather; a third staging reuses the first
+    pinned buffer only after its copy has completed; consumers on another stream are ordered by ``wait``."""
+    from revisionllm_amd.data.feature_store import WindowStager
+    from revisionllm_amd.eval import stage2
+    rs = np.random.RandomState(0)
+    vids = [rs.randn(n, 768).astype(np.float16) for n in (9000, 7000, 9500, 5200)]
+    st = WindowStager("cuda:0", depth=2)
+    staged, want = [], []
+    for v in vids:
+        _, idx = stage2.cut_windows(v.shape[0], num_frames=250)
+        staged.append(st.stage_windows(v, idx))
+        want.append(torch.from_numpy(v.astype(np.float32))[torch.from_numpy(idx.astype(np.int64))].to(torch.bfloat16))
+    assert st._slots[0]["buf"] is not None and st._slots[1]["buf"] is not None and len(st._slots) == 2
+    side = torch.cuda.Stream("cuda:0")
+    for s, w in zip(staged, want):
+        with torch.cuda.stream(side):
+            t = s.wait(side)
+            got = t.clone()
+        side.synchronize()
+        assert got.dtype == torch.bfloat16 and got.shape == w.shape and torch.equal(got.cpu(), w)
+    dev, ev = st.stage_windows(vids[0], stage2.cut_windows(9000, num_frames=250)[1])     # tuple form
+    ev.synchronize()
+    assert torch.equal(dev.cpu(), want[0])

@@ -32,7 +32,7 @@ def bf(x):
 
 def test_abi_version(dev):
     from revisionllm_amd import hip
-    assert hip.lib().rv_abi_version() == 1
+    assert hip.lib().rv_abi_version() == 2
 
 
 def test_init_hash_bit_exact(dev):
@@ -72,15 +72,14 @@ def test_gemm(dev, M, N, K, out):
         yp = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False)
         assert torch.equal(yp, y)                                    # same arithmetic, different HBM layout -> bit-identical
         for variant in (0, 1, 3, 4, 6):                              # other pipelines (4 = 256x256 ping-pong): same sums, same order
-            hip.lib().rv_set_gemm_tile_variant(variant)
-            assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False), y)
+            opt = hip.Options(gemm_tile_variant=variant, gemm_arows=0)
+            assert torch.equal(ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=False, ctx=opt), y)
         for variant in (5, 2):                                       # persistent stream-K ping-pong: forced / where the policy picks it
-            hip.lib().rv_set_gemm_tile_variant(variant)
-            ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True)
+            opt = hip.Options(gemm_tile_variant=variant)
+            ys = ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True, ctx=opt)
             assert rel_err(ys.float().cpu(), ref0) < tol
             for _ in range(3):                                       # fixed split-k summation order: deterministic (and a race screen)
-                assert torch.equal(ys, ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True))
-        hip.lib().rv_set_gemm_tile_variant(2)
+                assert torch.equal(ys, ops.gemm(ad, wpk, out_dtype=od, w_packed=True, stream_k=True, ctx=opt))
     y = ops.gemm(ad, wd, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU)
     ref = torch.relu(ref0 + bias.double()) + res.double()
     assert rel_err(y.float().cpu(), ref) < tol
@@ -91,16 +90,51 @@ def test_gemm(dev, M, N, K, out):
         ref = (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)
         assert rel_err(y.float().cpu(), ref) < tol
         for variant in (4, 5):
-            hip.lib().rv_set_gemm_tile_variant(variant)
-            ys = ops.gemm(ad, wpk, bias=None, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=True)
+            opt = hip.Options(gemm_tile_variant=variant)
+            ys = ops.gemm(ad, wpk, bias=None, out_dtype=od, act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=True, ctx=opt)
             assert rel_err(ys.float().cpu(), ref) < tol
-        hip.lib().rv_set_gemm_tile_variant(2)
         if wpk is not None:                                          # bias + relu + residual epilogue of the ping-pong kernels
             for variant in (4, 5):
-                hip.lib().rv_set_gemm_tile_variant(variant)
-                ys = ops.gemm(ad, wpk, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU, w_packed=True, stream_k=True)
+                opt = hip.Options(gemm_tile_variant=variant)
+                ys = ops.gemm(ad, wpk, bias=bias.to(dev), residual=res.to(dev), out_dtype=od, act=hip.RV_ACT_RELU, w_packed=True, stream_k=True, ctx=opt)
                 assert rel_err(ys.float().cpu(), torch.relu(ref0 + bias.double()) + res.double()) < tol
-            hip.lib().rv_set_gemm_tile_variant(2)
+
+
+@pytest.mark.parametrize("M,N,K,act,out,res", [
+    (25600, 4096, 768, 0, "bf16", False),      # dense projector, 100 windows x 256 frames (the "feature scan")
+    (25700, 1536, 768, 0, "bf16", False),      # adapter Q/K projection (100 x 257 rows)
+    (25700, 768, 768, 0, "f32", True),         # adapter out projection + residual (32-column wave slices)
+    (25700, 2048, 768, 1, "bf16", False),      # adapter FFN-1 + ReLU
+    (16385, 512, 1024, 3, "f32", False),       # K = 1024, QuickGELU, ragged rows (5 row fragments per workgroup)
+    (13000, 256, 512, 0, "bf16", True),        # 4 fragments, a partly filled last workgroup
+    (20000, 1024, 256, 1, "bf16", False),      # K = 256: one body of 8 k-steps per slice
+    (102500, 768, 768, 0, "bf16", False),      # two rounds of workgroups (100 segments x 1025 rows)
+])
+def test_gemm_a_resident_kernel_is_bit_identical_to_the_ring_kernel(dev, M, N, K, act, out, res):
+    """The A-resident kernel (gemm_arows.hip: a workgroup keeps its rows in LDS and walks N) accumulates every output in the same
+    k order with the same MFMA as the 128x128 ring kernel, so results are BIT-identical; and correct against float64."""
+    from revisionllm_amd import hip, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev) if res else None
+    od = torch.bfloat16 if out == "bf16" else torch.float32
+    wp = ops.pack_fragments(w)
+    ring = ops.gemm(a, wp, bias=bias, residual=r, out_dtype=od, act=act, w_packed=True, stream_k=False, ctx=hip.Options(gemm_arows=0))
+    rows = ops.gemm(a, wp, bias=bias, residual=r, out_dtype=od, act=act, w_packed=True, stream_k=False, ctx=hip.Options(gemm_arows=1))
+    assert torch.equal(ring, rows)
+    assert torch.equal(rows, ops.gemm(a, wp, bias=bias, residual=r, out_dtype=od, act=act, w_packed=True, stream_k=False))   # default: on
+    sel = torch.arange(0, M, max(1, M // 97), device=dev)                 # a sample of rows against float64
+    z = a[sel].double() @ w.double().t() + bias.double()
+    z = torch.relu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 3 else z)
+    if res:
+        z = z + r[sel].double()
+    assert rel_err(rows[sel].float().cpu(), z.cpu()) < (BF16_TOL if out == "bf16" else F32_TOL * 5)
+    # a strided A (row stride > K), as the engine passes views
+    big = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=dev)
+    big[:, :K] = a
+    assert torch.equal(ops.gemm(big[:, :K], wp, bias=bias, residual=r, out_dtype=od, act=act, w_packed=True, stream_k=False), rows)
 
 
 @pytest.mark.parametrize("M,N,K", [(9, 1024, 256), (771, 4096, 1024), (1000, 1024, 4096)])
@@ -116,13 +150,10 @@ def test_gemm_quick_gelu_epilogue(dev, M, N, K):
     y = ops.gemm(ad, wd, bias=bias.to(dev), act=hip.RV_ACT_QUICK_GELU)
     assert rel_err(y.float().cpu(), ref) < BF16_TOL
     wpk = ops.pack_fragments(wd)
-    try:
-        for variant in (2, 4, 5, 6):
-            hip.lib().rv_set_gemm_tile_variant(variant)
-            yp = ops.gemm(ad, wpk, bias=bias.to(dev), act=hip.RV_ACT_QUICK_GELU, out_dtype=torch.float32, w_packed=True, stream_k=True)
-            assert rel_err(yp.cpu(), ref) < F32_TOL * 5
-    finally:
-        hip.lib().rv_set_gemm_tile_variant(2)
+    for variant in (2, 4, 5, 6):
+        opt = hip.Options(gemm_tile_variant=variant)
+        yp = ops.gemm(ad, wpk, bias=bias.to(dev), act=hip.RV_ACT_QUICK_GELU, out_dtype=torch.float32, w_packed=True, stream_k=True, ctx=opt)
+        assert rel_err(yp.cpu(), ref) < F32_TOL * 5
 
 
 @pytest.mark.parametrize("M,N,K,act", [(7, 4096, 4096, 0), (1, 12288, 4096, 0), (16, 4096, 11008, 0), (7, 22016, 4096, 2), (3, 512, 1408 // 128 * 128, 0)])
@@ -416,17 +447,12 @@ def test_sample_fast_path_equals_general_path(dev):
     u = torch.tensor([0.0, 0.2, 0.4, 0.6, 0.8, 0.95, 0.9999])
     small = [feats(f"smpf.v{v}", (7, v)) * 2.0 for v in (1024, 1500, 4099, 32768)]
     small.append((small[1] * 4).round() / 4)          # short rows with ties
-    try:
-        for x in [logits, lt, flat] + small:
-            for (temp, k, p) in ((0.05, 50, 1.0), (0.05, 50, 0.6), (1.0, 64, 0.9), (0.7, 7, 1.0), (1.0, 1, 1.0)):
-                outs = []
-                for variant in (0, 1):
-                    hip.lib().rv_set_sample_variant(variant)
-                    outs.append(ops.sample(x.to(dev), u.to(dev), True, temp, k, p))
-                for name in outs[0]:
-                    assert torch.equal(outs[0][name].cpu(), outs[1][name].cpu()), (name, temp, k, p)
-    finally:
-        hip.lib().rv_set_sample_variant(1)
+    opts = [hip.Options(sample_variant=v) for v in (0, 1)]
+    for x in [logits, lt, flat] + small:
+        for (temp, k, p) in ((0.05, 50, 1.0), (0.05, 50, 0.6), (1.0, 64, 0.9), (0.7, 7, 1.0), (1.0, 1, 1.0)):
+            outs = [ops.sample(x.to(dev), u.to(dev), True, temp, k, p, ctx=o) for o in opts]
+            for name in outs[0]:
+                assert torch.equal(outs[0][name].cpu(), outs[1][name].cpu()), (name, temp, k, p)
 
 
 def test_topk_cosine(dev):

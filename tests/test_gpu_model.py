@@ -114,10 +114,10 @@ def test_fp8_decode_weights_vs_oracle_with_the_same_quantisation():
     assert rel_err(got, want8) < 3e-2
     assert rel_err(got[1:], want8[1:]) < rel_err(got[1:], want16[1:])          # it really is the quantised weights that ran
     try:
-        hip.lib().rv_set_fp8_decode(0)
+        m.engine.set_option("fp8_decode", 0)
         off = torch.stack(m.generate(ids, **kw)["logits"]).cpu()
     finally:
-        hip.lib().rv_set_fp8_decode(1)
+        m.engine.set_option("fp8_decode", 1)
     assert torch.equal(off[0], got[0]) and rel_err(off, want16) < 3e-2
 
 
@@ -417,42 +417,13 @@ def test_full_size_properties_7b(model_7b):
     from revisionllm_amd import hip
     rows7 = torch.cat([cls[torch.randperm(100, generator=torch.Generator().manual_seed(i))] for i in range(7)], 0)
     kw7 = dict(rows_per_sample=100, do_sample=False, max_new_tokens=2, return_dict_in_generate=True, output_logits=True)
-    hip.lib().rv_set_gemm_tile_variant(6)
+    eng.set_option("gemm_tile_variant", 6)
     ring = torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"])
-    hip.lib().rv_set_gemm_tile_variant(2)
+    eng.set_option("gemm_tile_variant", 2)
     auto = torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"])
     # (a different f32 summation order flips bf16 roundings; through 32 random layers that grows to ~2 % of the largest logit)
     assert torch.isfinite(auto).all() and (auto - ring).abs().max() <= 4e-2 * ring.abs().max()
     assert torch.equal(auto, torch.stack(m.generate(ids.repeat(7, 1), video_rows=rows7, **kw7)["logits"]))   # deterministic
-
-
-def test_decode_attention_oproj_fusion_matches_separate_launches(model_7b):
-    """KV-cached decode steps of the 7-call batch with attention + o projection fused into one launch (opt-in knob) against the
-    two-launch path: same K/V caches, logits equal to f32 rounding of the softmax merge (8- vs 4-way key split), greedy tokens
-    equal; and the fused path is deterministic."""
-    from revisionllm_amd import hip, ops
-    from revisionllm_amd.utils import synth
-    m = model_7b
-    dev = m.engine.device
-    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
-    qf = ops.init_hash_(torch.empty(1, 16, 768, dtype=torch.bfloat16, device=dev), "fs.q", 3, synth.SQRT3)
-    cls = m.engine.clip_encoder(feat, qf, torch.ones(1, 16), "cls")
-    ids = T(synth.synthetic_prompt_ids(72, 40, 3))[None]
-    rows7 = torch.cat([cls[torch.randperm(100, generator=torch.Generator().manual_seed(i))] for i in range(7)], 0)
-    kw = dict(rows_per_sample=100, do_sample=False, max_new_tokens=5, return_dict_in_generate=True, output_logits=True)
-    out = {}
-    try:
-        for on in (0, 1):
-            hip.lib().rv_set_decode_fusion(on)
-            out[on] = m.generate(ids.repeat(7, 1), video_rows=rows7, **kw)
-        again = m.generate(ids.repeat(7, 1), video_rows=rows7, **kw)
-    finally:
-        hip.lib().rv_set_decode_fusion(0)
-    a, b = torch.stack(out[0]["logits"]), torch.stack(out[1]["logits"])
-    assert torch.equal(a[0], b[0])                                        # prefill: untouched
-    assert (a - b).abs().max() <= 2e-2 * a.abs().max()
-    assert torch.equal(out[0]["sequences"], out[1]["sequences"])
-    assert torch.equal(b, torch.stack(again["logits"]))
 
 
 def test_recursions_in_flight_on_two_streams_match_sequential(model_7b):
@@ -506,13 +477,13 @@ def test_persistent_qkv_rope_epilogue_is_bit_exact():
     out = {}
     try:
         for v in (6, 2):
-            hip.lib().rv_set_gemm_tile_variant(v)
+            eng.set_option("gemm_tile_variant", v)
             kv, Smax = eng.new_kv(B, S + 8, reuse=False)
             logits = eng.llm_prefill_shared(h0.clone(), B, P0, kv, Smax)
             per = B * 32 * Smax * 128
             out[v] = (kv[:per].view(B, 32, Smax, 128)[:, :, :S].clone(), kv[per:2 * per].view(B, 32, 128, Smax)[..., :S].clone(), logits)
     finally:
-        hip.lib().rv_set_gemm_tile_variant(2)
+        eng.set_option("gemm_tile_variant", 2)
     assert torch.equal(out[6][0], out[2][0]) and torch.equal(out[6][1], out[2][1])
     assert (out[6][2] - out[2][2]).abs().max() <= 5e-3 * out[6][2].abs().max()
 
@@ -534,12 +505,10 @@ def test_fp8_prefill_vs_oracle_with_the_same_quantisation():
         kv, Smax = eng.new_kv(B, S + 8, reuse=False)
         logits[mode] = eng.llm_prefill_shared(h0.to("cuda:0"), B, P0, kv, Smax).cpu()
         if mode == "fp8":
-            try:
-                hip.lib().rv_set_fp8_prefill(0)
-                kv, Smax = eng.new_kv(B, S + 8, reuse=False)
-                off = eng.llm_prefill_shared(h0.to("cuda:0"), B, P0, kv, Smax).cpu()
-            finally:
-                hip.lib().rv_set_fp8_prefill(1)
+            eng.set_option("fp8_prefill", 0)
+            kv, Smax = eng.new_kv(B, S + 8, reuse=False)
+            off = eng.llm_prefill_shared(h0.to("cuda:0"), B, P0, kv, Smax).cpu()
+            eng.set_option("fp8_prefill", 1)
             assert torch.equal(off, logits["bf16"])
         del eng, kv
         torch.cuda.empty_cache()

@@ -52,7 +52,9 @@ def test_stage2_index_math_matches_reference(golden):
     for s in c["stage2"]:
         plan = stage2.plan_groups(s["W"], s["batch"])
         assert [p[1] for p in plan] == s["starts"] and [p[0] for p in plan] == s["zooms"]
+        assert [stage2.group_span(s["W"], st, e)[1] for z, st, e in plan] == s["counts"]      # torch slice semantics, negative starts too
         assert all(e - st == s["batch"] // z for z, st, e in plan)
+        assert [len(p) for p in stage2.make_perms(plan, torch.Generator().manual_seed(0), W=s["W"])] == s["counts"]
         frames, hit = stage2.iou(s["answers"], s["gt"], 250, s["batch"], s["starts"], s["indexes"], True, s["zooms"],
                                  list(range(s["W"])))
         assert {str(k): list(v) for k, v in frames.items()} == s["frames"] and hit == s["hit"]
@@ -119,9 +121,9 @@ def test_abi_exports_every_declared_symbol():
     h = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(h, name), name
-    assert hip.lib().rv_abi_version() == 1
+    assert hip.lib().rv_abi_version() == 2
     # argument validation runs on the host before any launch
-    assert hip.lib().rv_gemm(None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None, 0, None) < 0
+    assert hip.lib().rv_gemm(None, None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None, 0, None) < 0
     assert "null operand" in hip.last_error()
 
 
@@ -144,8 +146,11 @@ def test_product_has_no_cpu_fallback():
 def test_stage2_empty_and_too_short_inputs():
     rec = stage2.run_query(None, None, torch.zeros(0, 250, 768), torch.zeros(4, 768), torch.zeros(768), "x", batch=100)
     assert rec["answers"] == [] and rec["plan"] == []
-    with pytest.raises(ValueError, match="windows < batch"):
-        stage2.run_query(None, None, torch.zeros(5, 250, 768), torch.zeros(4, 768), torch.zeros(768), "x", batch=100)
+    # fewer windows than the batch: the reference's negative back-shifted start + slice semantics (e2e2.py:342-345)
+    assert stage2.plan_groups(60, 100) == [(4, 0, 25), (4, 25, 50), (4, 35, 60), (2, 0, 50), (2, 10, 60), (1, -40, 60)]
+    assert stage2.group_span(60, -40, 60) == (20, 40) and stage2.group_span(30, -70, 30) == (0, 30) and stage2.group_span(5, 0, 5) == (0, 5)
+    idx, counts = stage2.call_row_index([(1, -40, 60), (2, 10, 60)], [torch.arange(40), torch.arange(50)], "cpu", W=60)
+    assert counts == [40, 100] and idx[:40].tolist() == list(range(20, 60)) and idx[40:44].tolist() == [10, 10, 11, 11]
     assert stage2.plan_groups(0, 100) == []
     info = stage2.log_record(dict(answers=["In video 3.", "nothing"], starts=[0, 0], indexes=[[1, 0, 2, 3], [0, 1]], hierarchy_zooms=[1, 2],
                                   grounding_windows=list(range(10)), score_cos=[0.5], mean_entropy=[1.0, 2.0], max_entropy=[1.0, 2.0]),
@@ -256,3 +261,28 @@ def test_dropin_scoring_modules_refuse_without_gpu():
         _topk_pooling(torch.zeros(1, 8), torch.zeros(1, 4, 8), 2)
     with pytest.raises(hip.HipLibraryError):
         get_entropy_statistics(torch.zeros(1, 2, 16), 0, 16)
+
+
+def test_options_are_per_context():
+    """Tunables live in the context (rv_ctx_set_option): two contexts in one process differ, unknown keys / bad values are
+    argument errors, and the deprecated process-wide setters only move the defaults of contexts created afterwards."""
+    a, b = hip.Options(), hip.Options(gemm_tile_variant=6, sample_variant=0)
+    assert a.get("gemm_tile_variant") == 2 and b.get("gemm_tile_variant") == 6
+    assert a.get("sample_variant") == 1 and b.get("sample_variant") == 0
+    a.set("gemm_cus", 192)
+    assert a.get("gemm_cus") == 192 and b.get("gemm_cus") == 0
+    for key in hip.OPTION_KEYS:
+        a.get(key)
+    with pytest.raises(hip.HipLibraryError, match="unknown option"):
+        a.set("no_such_option", 1)
+    with pytest.raises(hip.HipLibraryError):
+        a.set("gemm_tile_variant", 9)
+    with pytest.raises(hip.HipLibraryError):
+        a.set("gemm_cus", 100)
+    try:
+        hip.lib().rv_set_gemm_tile_variant(6)          # deprecated shim: defaults only
+        assert a.get("gemm_tile_variant") == 2 and hip.Options().get("gemm_tile_variant") == 6
+    finally:
+        hip.lib().rv_set_gemm_tile_variant(2)
+    # an options-only context carries no model: nothing can be bound to it
+    assert hip.lib().rv_weights_bind(a._ctx, b"llm.embed", ctypes.c_void_p(256), 1, 16) < 0

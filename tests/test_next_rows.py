@@ -52,8 +52,97 @@ def test_f2_feature_store_formats(tmp_path):
     tok, cls = fs.query("q7")
     assert tok.shape == (5, 768) and cls.shape == (768,)
     assert FeatureStore(str(tmp_path)).query("q7") == (None, None)
-    with pytest.raises((ImportError, Exception)):
-        FeatureStore(str(tmp_path), vis_feat_storage="lmdb")
+    try:
+        import lmdb  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="lmdb"):
+            FeatureStore(str(tmp_path), vis_feat_storage="lmdb")
+
+
+def _dumps_npz(dump, compress=True):
+    """The reference writers' blob format (mad_clip_text_extractor.py:23-29, convert_h5_to_lmdb.py:18-25)."""
+    import io
+    with io.BytesIO() as writer:
+        (np.savez_compressed if compress else np.savez)(writer, **dump, allow_pickle=True)
+        return writer.getvalue()
+
+
+class _FakeLmdb:
+    """Dict-backed stand-in for the ``lmdb`` module surface the reader uses (``open(...).begin(buffers=True).get(key)`` returning a
+    buffer, None for a missing key) so the LMDB branch of FeatureStore runs in an image without the package."""
+
+    def __init__(self):
+        self.dbs = {}
+
+    def open(self, path, **kw):
+        db = self.dbs.setdefault(path, {})
+
+        class Txn:
+            def get(self_, key):
+                v = db.get(bytes(key))
+                return None if v is None else memoryview(v)
+
+            def put(self_, key, value):
+                db[bytes(key)] = bytes(value)
+
+            def __enter__(self_):
+                return self_
+
+            def __exit__(self_, *a):
+                return False
+
+        class Env:
+            def begin(self_, write=False, buffers=False):
+                return Txn()
+        return Env()
+
+
+def _write_stores(lmdb_mod, vdir, qdir, feats):
+    """What the reference's writers do: one savez_compressed blob per movie ("features", convert_h5_to_lmdb.py:33-37) and per
+    query ("cls_features" + "token_features", mad_clip_text_extractor.py:101-107)."""
+    env = lmdb_mod.open(vdir, map_size=1 << 30)
+    with env.begin(write=True) as txn:
+        txn.put(key="movieA".encode(), value=_dumps_npz({"features": feats.astype(np.float32)}))
+        txn.put(key="movieB".encode(), value=_dumps_npz({"memory_global": feats[:10].astype(np.float32)}))
+    env = lmdb_mod.open(qdir, map_size=1 << 30)
+    with env.begin(write=True) as txn:
+        txn.put(key="q7".encode(), value=_dumps_npz({"cls_features": feats[5].astype(np.float32), "token_features": feats[:5].astype(np.float32)}))
+
+
+def _check_stores(fs, feats):
+    assert np.array_equal(fs.video("movieA"), feats.astype(np.float32)) and fs.video("movieB").shape == (10, 768)
+    tok, cls = fs.query("q7")
+    assert np.array_equal(tok, feats[:5].astype(np.float32)) and np.array_equal(cls, feats[5].astype(np.float32))
+    with pytest.raises(KeyError):
+        fs.video("no_such_movie")
+
+
+def test_f2_lmdb_branch_with_the_reference_blob_format(tmp_path, monkeypatch):
+    """The LMDB reader path (e2e2.py:187-192,238-255) against blobs written the way the reference's writers write them; the
+    ``lmdb`` package is absent from this image, so a dict-backed module with the same surface is injected."""
+    import sys
+    fake = _FakeLmdb()
+    monkeypatch.setitem(sys.modules, "lmdb", fake)
+    feats = np.random.RandomState(1).randn(300, 768).astype(np.float16)
+    vdir, qdir = str(tmp_path / "v"), str(tmp_path / "q")
+    os.makedirs(qdir)
+    open(os.path.join(qdir, "data.mdb"), "wb").close()          # what marks a directory as an LMDB environment
+    _write_stores(fake, vdir, qdir, feats)
+    _check_stores(FeatureStore(vdir, q_feat_dir=qdir, vis_feat_storage="lmdb"), feats)
+
+
+def test_f2_real_lmdb(tmp_path):
+    lmdb = pytest.importorskip("lmdb")
+    feats = np.random.RandomState(1).randn(300, 768).astype(np.float16)
+    vdir, qdir = str(tmp_path / "v"), str(tmp_path / "q")
+    _write_stores(lmdb, vdir, qdir, feats)
+    _check_stores(FeatureStore(vdir, q_feat_dir=qdir, vis_feat_storage="lmdb"), feats)
+
+
+def test_f2_feature_files_cannot_carry_pickles(tmp_path):
+    np.savez(tmp_path / "evil.npz", features=np.array([{"a": 1}], dtype=object))
+    with pytest.raises(ValueError):
+        FeatureStore(str(tmp_path)).video("evil")
 
 
 def test_f3_checkpoint_dirs_roundtrip(tmp_path):

@@ -1,4 +1,4 @@
-"""Decode-step time (B = 7 rows, 171 cached positions, Vicuna-7B shapes) with the attention + o-projection fusion on / off."""
+"""Decode-step time (B = 7 rows, 171 cached positions, Vicuna-7B shapes)."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from types import SimpleNamespace
@@ -22,6 +22,4 @@ def ev(fn, n=20, warm=3):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 for rep in range(2):
-    for on in (0, 1):
-        hip.lib().rv_set_decode_fusion(on)
-        print("fusion", on, f"decode step {ev(lambda: eng.llm_forward(h1.clone(), S, kv, Smax)):.3f} ms", flush=True)
+    print(f"decode step {ev(lambda: eng.llm_forward(h1.clone(), S, kv, Smax)):.3f} ms", flush=True)

@@ -27,7 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     D, F, V = 4096, 11008, 32000
     for geo in ((2, 3) if "gemm" in which else ()):
-        hip.lib().rv_set_gemm_tile_variant(geo)
+        opt = hip.Options(gemm_tile_variant=geo)
         print(f"--- tile variant {geo}")
         for M in (975, 1197):
             for name, N, K, act, od in (("qkv", 3 * D, D, 0, torch.float32), ("o", D, D, 0, torch.float32),
@@ -36,15 +36,15 @@ def main():
                 w = ops.pack_fragments((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16))
                 res = torch.randn(M, N, device=dev) if name in ("o", "down") else None
                 out = torch.empty(M, N // 2 if act == 2 else N, dtype=od, device=dev)
-                us = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True))
-                us0 = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True, stream_k=False))
+                us = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True, ctx=opt))
+                us0 = timeit(lambda: ops.gemm(x, w, residual=res, out=out, act=act, w_packed=True, stream_k=False, ctx=opt))
                 print(f"gemm {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s   (tiled: {us0:7.1f} us)")
         for name, M, N, K, act in (("dense.proj", 25600, 4096, 768, 0), ("adp.qk", 25700, 1536, 768, 0), ("adp.v", 25700, 768, 768, 0), ("adp.ffn1", 25700, 2048, 768, 1),
                                    ("adp.ffn2", 25700, 768, 2048, 0)):
             x = torch.randn(M, K, device=dev).to(torch.bfloat16)
             w = ops.pack_fragments((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16))
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-            us = timeit(lambda: ops.gemm(x, w, out=out, act=act, w_packed=True))
+            us = timeit(lambda: ops.gemm(x, w, out=out, act=act, w_packed=True, ctx=opt))
             print(f"gemm {name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
     if "gemv" in which:
         for M in (1, 7, 16):

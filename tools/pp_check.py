@@ -7,11 +7,11 @@ from revisionllm_amd import hip, ops
 
 dev = torch.device("cuda:0")
 lib = hip.lib()
+OPTS = {v: hip.Options(gemm_tile_variant=v, gemm_arows=0) for v in (2, 4, 5, 6)}
 
 
 def run(variant, a, wp, **kw):
-    lib.rv_set_gemm_tile_variant(variant)
-    return ops.gemm(a, wp, w_packed=True, stream_k=(variant == 5), **kw)
+    return ops.gemm(a, wp, w_packed=True, stream_k=(variant == 5), ctx=OPTS[variant], **kw)
 
 
 def timeit(fn, n=20, warm=3):
@@ -70,5 +70,4 @@ for n in (4096, 8192):
     t2 = timeit(lambda: run(2, a, wp, out_dtype=torch.bfloat16), n=10)
     t4 = timeit(lambda: run(4, a, wp, out_dtype=torch.bfloat16), n=10)
     print(f"{n}^3: ring {2.0 * n ** 3 / t2 / 1e6:6.0f} TF | pingpong {2.0 * n ** 3 / t4 / 1e6:6.0f} TF")
-lib.rv_set_gemm_tile_variant(2)
 print("mismatching launches:", bad)

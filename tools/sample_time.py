@@ -17,7 +17,7 @@ def main():
     from revisionllm_amd import hip
     o = ops.sample(logits, u, True, 0.05, 50, 1.0)
     lib, st = hip.lib(), hip.stream()
-    args = (hip.ptr(logits), B, 32000, hip.ptr(u), 1, 0.05, 50, 1.0, hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
+    args = (None, hip.ptr(logits), B, 32000, hip.ptr(u), 1, 0.05, 50, 1.0, hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
             hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]), st)
     for _ in range(5):
         lib.rv_sample(*args)

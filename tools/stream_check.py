@@ -26,7 +26,7 @@ def main():
         clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
         adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
     model.engine.init_synthetic(seed=0, llm=True, clip=True, fp8_decode=bool(os.environ.get('REVISION_FP8')))
-    __import__('revisionllm_amd.hip', fromlist=['lib']).lib().rv_set_fp8_decode(int(os.environ.get('REVISION_FP8_ON', '0')))
+    model.engine.set_option('fp8_decode', int(os.environ.get('REVISION_FP8_ON', '0')))
     model.generation_config.eos_token_id = None
     tok = synth.FakeTokenizer()
     feats = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "bench.feat.r0", 0, synth.SQRT3)
