@@ -6,8 +6,10 @@
 One "step" = one stage-2 recursion (zoom levels 4/2/1) of one query over this rank's 100 windows
 [100 x 256 x 768] of synthetic CLIP features with random-init Vicuna-7B-shaped weights (hash-seeded, generated in
 HBM), sampling at T = 0.05, decode length forced to G = 8 (eos disabled: random-init models never emit EOS).
-N ranks process a 100*N-window video: windows block-partitioned, CLS rows and proposals exchanged by RCCL
-all-gathers (weak scaling: per-GPU work fixed).  Inputs are resident in HBM when the timed region starts.
+N ranks, ``--scaling weak`` (default): a 100*N-window video, windows block-partitioned, CLS rows and proposals exchanged by
+RCCL all-gathers (per-GPU work fixed).  ``--scaling strong``: ONE 100-window recursion per step sharded over the N ranks
+(100/N windows each, the 7 calls dealt over the ranks with a rotating start so that passes in flight keep every rank busy).
+Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, timed with HIP events on
 the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded sample, N = 1 only).
@@ -15,11 +17,14 @@ the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded 
 The timed region is exactly K steps after W warm-up steps (and ``--settle`` untimed steps that belong to the set-up), with
 ``--streams`` steps in flight.  ``value`` is the bf16 path, one video per step.  At N = 1 the same loop is then timed again in
 other configurations and reported under ``extra_measurements`` (never ``value``): FP8 decode weights, the full opt-in FP8
-LLM path (FP8 x FP8 prefill GEMMs + FP8 decode weights), two different videos batched per step, and both together.
+LLM path, two different videos batched per step, an EOS id configured (lagging device-side stop flag instead of a forced
+length), and the other BASELINE.json workloads (``stage2_long_33``, ``stage1_dense``, ``stage1_sparse``; ``--workload X`` times
+one of them alone as the line's ``value``).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from types import SimpleNamespace
@@ -31,6 +36,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+METRIC = "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B"
+SENTENCE = ("a person opens the door and walks into the kitchen while another person is sitting at the table "
+            "reading a newspaper and then both of them leave the room together")   # 20 words: with the v1 template P = 72 ids
 
 
 def parse():
@@ -38,7 +46,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--windows", type=int, default=100, help="windows (segments) per GPU")
+    p.add_argument("--workload", default="stage2_long_100", choices=["stage2_long_100", "stage2_long_33", "stage1_dense", "stage1_sparse"],
+                   help="BASELINE.json configuration timed as the line's value (default: the one the metric is quoted on)")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="N > 1: weak = 100 windows per rank (a 100*N-window video); strong = one 100-window recursion sharded over the ranks")
+    p.add_argument("--windows", type=int, default=100, help="windows (segments) per GPU (weak) / per recursion (strong)")
     p.add_argument("--frames", type=int, default=256)
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
@@ -46,6 +58,7 @@ def parse():
     p.add_argument("--streams", type=int, default=3,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
+    p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
     p.add_argument("--fp8-prefill", action="store_true",
@@ -56,9 +69,11 @@ def parse():
                    help="untimed steps run as part of the set-up, before the W warm-up steps (a fresh box starts at idle clocks; ~0.5 s)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the extra legs (two queries per step, FP8 decode weights) timed AFTER the headline")
-    p.add_argument("--cpu-layers", type=int, default=4, help="decoder layers executed by the CPU baseline sample")
-    p.add_argument("--cpu-segments", type=int, default=16, help="segments encoded by the CPU baseline sample")
+    p.add_argument("--no-extras", action="store_true", help="skip the extra legs timed AFTER the headline")
+    p.add_argument("--cpu-full", action="store_true",
+                   help="CPU baseline = the whole recursion (7 calls x (100 segment encodings + prefill + G decode steps), 32 layers) through the "
+                        "oracle, 1 warm-up + 3 repeats, median (minutes); default: ONE such call timed once, x 7 identical calls")
+    p.add_argument("--cpu-sample", action="store_true", help="CPU baseline from a sample (16 segments, 4 of 32 layers), labelled extrapolated")
     return p.parse_args()
 
 
@@ -77,7 +92,7 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def roofline_legs(model, n_calls, M):
-    """Time the path's two heavy kernels in isolation on the shapes the recursion launches them with
+    """Time the path's heavy kernels in isolation on the shapes the recursion launches them with
     (M = rows of the prefill GEMM batch: shared prompt prefix once + the rest of every call)."""
     from revisionllm_amd import hip, ops
     eng, s = model.engine, model.shape
@@ -87,7 +102,7 @@ def roofline_legs(model, n_calls, M):
     x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
     w = eng.weight("llm.L0.wgu")
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
-    ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True), 20)
+    ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True, ctx=eng), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
     # M <= 8192 rows: the persistent 256x256x64 ping-pong kernel (one 512-thread workgroup per CU), whole panels + stream-K tail
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -101,104 +116,143 @@ def roofline_legs(model, n_calls, M):
     state = {"i": 0}
 
     def gemv():
-        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True)
+        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True, ctx=eng)
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
     legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0,2>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
                                       peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
-    #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised
+    #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised.
+    #     Kernel: the A-resident GEMM (gemm_arows.hip): rows resident in LDS, A read once, C written once
     if "proj.w" not in eng._keep:
         eng.init_synthetic(seed=0, llm=False, clip=False, linear=True)
     xf = torch.randn(100 * 256, 768, device=dev).to(torch.bfloat16)
     ms = event_time_ms(lambda: eng.project_dense(xf, torch.bfloat16), 20)
     nbytes = xf.numel() * 2 + 100 * 256 * s.hidden * 2
-    legs["dense_projector_scan"] = dict(kernel="gemm_tile_p4<1,0,3,0>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
-                                        unit="GB/s", algorithmic=nbytes, grid_threads=200 * 32 * 256,
+    legs["dense_projector_scan"] = dict(kernel="gemm_arows_kernel<1,0,7,2>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
+                                        unit="GB/s", algorithmic=nbytes, grid_threads=cus * 512,
                                         tflops=2.0 * 100 * 256 * 768 * s.hidden / ms / 1e9)
+    # (4) the adapter's widest K = 768 GEMM (FFN-1 + ReLU over 100 x 257 rows), MFMA-bound
+    xa = torch.randn(100 * 257, 768, device=dev).to(torch.bfloat16)
+    if "adp.enc.0.w1" in eng._keep:
+        w1, b1 = eng.weight("adp.enc.0.w1"), eng.weight("adp.enc.0.b1")
+        oa = torch.empty(xa.shape[0], w1.shape[0], dtype=torch.bfloat16, device=dev)
+        ms = event_time_ms(lambda: ops.gemm(xa, w1, bias=b1, act=hip.RV_ACT_RELU, out=oa, w_packed=True, ctx=eng), 20)
+        fl = 2.0 * xa.shape[0] * 768 * w1.shape[0]
+        legs["adapter_ffn1_gemm"] = dict(kernel="gemm_arows_kernel<1,1,7,2>", bound="mfma", ms=ms, achieved=fl / ms / 1e9, peak=MFMA_BF16_PEAK_TF,
+                                         unit="TFLOP/s", algorithmic=fl, grid_threads=cus * 512)
     return legs
+
+
+def committed_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 def pmc_traffic(kernel, grid_threads):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE; tools/pmc_summary.py).  None if no summary matches."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
     want = kernel.replace(" ", "")
-    for row in json.load(open(path))["kernels"]:
-        if row["kernel"].replace(" ", "") == want and row["grid_threads"] == grid_threads:
-            return row["traffic_bytes_per_launch"]
+    for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        d = committed_profile(fname)
+        if d is None:
+            continue
+        for row in d["kernels"]:
+            if row["kernel"].replace(" ", "") == want and row["grid_threads"] == grid_threads:
+                return row["traffic_bytes_per_launch"]
     return None
 
 
-def cpu_baseline(args, n_calls, P):
-    """Torch-fp32 CPU oracle on a bounded sample of the same workload, extrapolated linearly:
-    adapter on ``cpu_segments`` of 100 segments; one LLM call (prefill S + G decode steps) through ``cpu_layers`` of 32
-    layers + lm_head.  recursion time = adapter(100 segs) x 7 calls' worth (the reference re-encodes per call)
-    + 7 x call time."""
-    import numpy as np
-
-    from oracle import adapter as o_adapter
-    from oracle import llama as o_llama
-    from oracle import sampling as o_sampling
-    from revisionllm_amd.utils import synth
-    torch.set_grad_enabled(False)
+def host_cpu():
     cores = os.cpu_count() or 1
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or cores
-    except Exception:
+    except Exception:  # noqa: BLE001
         pass
-    T = lambda a: torch.from_numpy(a)
-    seed, W, Tn, L = args.seed, args.windows, args.frames, args.cpu_layers
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:  # noqa: BLE001
+        pass
+    return cores, model
+
+
+def cpu_baseline(args, n_calls, P):
+    """The torch-fp32 CPU oracle (CPU restatement of load_pretrained_model -> inference) on the host cores, as the reference
+    executes the recursion: every call re-encodes its 100 video tokens (zoom duplicates included), then prefill + G decode steps.
+
+    default     ONE full call (ClipEncoder on all 100 segment rows + prefill S + G decode steps, all 32 layers) timed once after
+                a one-layer warm-up; recursion = 7 such calls (identical work per call): bounded to ~10-30 s of CPU work
+    --cpu-full  the whole recursion through ``oracle.sampling.generate`` (7 calls), 1 warm-up + 3 repeats, median
+    --cpu-sample  16 segments, 4 of 32 layers, scaled up: labelled extrapolated
+    Weights are random normal of the reference's shapes (timing only), generated with torch (multi-threaded)."""
+    from oracle import llama as o_llama
+    from oracle import sampling as o_sampling
+    from revisionllm_amd.utils import synth
+    torch.set_grad_enabled(False)
+    cores, cpu_model = host_cpu()
+    torch.set_num_threads(cores)
+    seed, W, Tn, G = args.seed, args.windows, args.frames, args.decode_steps
+    L = 4 if args.cpu_sample else 32
+    ns = 16 if args.cpu_sample else W
+    gen = torch.Generator().manual_seed(seed)
     shape = synth.LlamaShape(layers=L)
     cfg = o_llama.LlamaCfg(layers=L)
-    w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), seed).items()}
-    wa = {k[len("model.mm_projector."):]: T(v) for k, v in
-          synth.build_numpy(synth.clip_encoder_spec(), seed, prefix="model.mm_projector.").items()}
-    ns = args.cpu_segments
-    feat = T(synth.features("bench.feat.r0", (ns, Tn, 768), seed))
-    q = (T(synth.features("bench.q", (1, args.lq, 768), seed)), torch.ones(1, args.lq))
-    qf, qm = q[0].expand(ns, -1, -1), q[1].expand(ns, -1)
-    ids = T(synth.synthetic_prompt_ids(P, 40, seed))[None]
-    rows = torch.randn(1, W, shape.hidden) * 0.02
-    emb, mask, pos, _ = __import__("oracle.splice", fromlist=["splice"]).splice(ids, list(rows), w["model.embed_tokens.weight"])
+    w = {}
+    for name, shp, a, base in synth.llama_spec(shape):
+        w[name] = torch.empty(shp).normal_(0, 0.02, generator=gen) if len(shp) > 1 else torch.ones(shp)
+    wa = {}
+    for name, shp, a, base in synth.clip_encoder_spec():
+        if len(shp) > 1:
+            wa[name] = torch.empty(shp).normal_(0, a / 1.732, generator=gen)
+        else:
+            wa[name] = torch.ones(shp) if ("norm" in name and "weight" in name) else torch.zeros(shp)
+    feat = torch.empty(ns, Tn, 768).normal_(generator=gen)
+    q = (torch.empty(1, args.lq, 768).normal_(generator=gen), torch.ones(1, args.lq))
+    ids = torch.from_numpy(synth.synthetic_prompt_ids(P, 40, seed))[None]
 
-    def sample_once():
+    def one_call(n_layers=None):
+        """One LLM call as inference() drives it: adapter on the call's video rows, splice, prefill, G - 1 decode steps."""
         t0 = time.perf_counter()
-        o_adapter.clip_encoder(feat, wa, qf, qm)
-        ta = (time.perf_counter() - t0) / ns
-        t0 = time.perf_counter()
-        cache = o_llama.KVCache(L)
-        logits = o_llama.forward(emb, w, cfg, mask, pos, cache, last_only=True)[:, -1]
-        tp = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for _ in range(args.decode_steps - 1):
-            nxt = o_sampling.select_token(o_sampling.process_logits(logits, 0.05, 50, 1.0), torch.tensor([0.5]))
-            e1 = w["model.embed_tokens.weight"][nxt][:, None]
-            logits = o_llama.forward(e1, w, cfg, cache=cache)[:, -1]
-        return ta, tp, time.perf_counter() - t0
+        o_sampling.generate(ids, feat[None], q, w, wa, cfg, adapter_kw=dict(hierarchy=True), do_sample=True, temperature=0.05, top_k=50,
+                            max_new_tokens=G, eos_token_id=-1, uniforms=torch.full((G, 1), 0.5), n_layers=n_layers)
+        return time.perf_counter() - t0
 
-    # the reference leaves torch at its default thread count (= all cores); small decode GEMVs can be faster with
-    # fewer threads, so time both settings (each after a warm-up pass) and report the faster one
-    best = None
-    for nthreads in sorted({cores, min(cores, 32)}, reverse=True):
-        torch.set_num_threads(nthreads)
-        sample_once()
-        ta, tp, td = sample_once()
-        total = n_calls * (W * ta + (tp + td) * 32.0 / L)
-        if best is None or total < best[0]:
-            best = (total, nthreads, ta, tp, td)
-    t_recursion, cores, t_adapter_seg, t_prefill, t_decode = best
-    # scale the layer-proportional part to 32 layers (lm_head / embedding time is small and left unscaled)
-    scale = 32.0 / L
-    return dict(value=W / t_recursion, unit="segments/s", cores=cores, kind="port",
-                sample=(f"torch-fp32 oracle: ClipEncoder on {ns} of {W} segments ({t_adapter_seg*1e3:.0f} ms/segment), one LLM call "
-                        f"(prefill S={emb.shape[1]} {t_prefill:.2f}s + {args.decode_steps - 1} decode steps {t_decode:.2f}s) through "
-                        f"{L} of 32 layers, scaled x{scale:.0f}; recursion = {n_calls} calls x (100 segment encodings + call) "
-                        f"= {t_recursion:.1f}s as the reference executes it"))
+    info = dict(unit="segments/s", cores=cores, cpu=cpu_model, kind="port")
+    if args.cpu_full and not args.cpu_sample:
+        def recursion():
+            return sum(one_call() for _ in range(n_calls))
+        recursion()
+        times = [recursion() for _ in range(3)]
+        t_rec = statistics.median(times)
+        info.update(value=W / t_rec, extrapolated=False, repeats=3,
+                    sample=f"torch-fp32 oracle, whole recursion as the reference executes it: {n_calls} calls x (ClipEncoder on {W} segment rows + "
+                           f"prefill + {G - 1} decode steps, 32 layers), 1 warm-up + 3 repeats, median {t_rec:.1f} s (all: {[round(t, 1) for t in times]})")
+        return info
+    one_call(n_layers=1)                               # warm-up: thread pool, allocator, one layer's pass
+    t_call = one_call()
+    if args.cpu_sample:
+        t_rec = n_calls * t_call * (32.0 / L) * (W / ns)
+        info.update(value=W / t_rec, extrapolated=True,
+                    sample=f"torch-fp32 oracle SAMPLE: one call with {ns} of {W} segment rows through {L} of 32 layers ({t_call:.2f} s), scaled "
+                           f"x{32 // L} (layers) x{W // ns} (segments) x{n_calls} (calls): extrapolated, an upper bound on the time, indicative only")
+        return info
+    t_rec = n_calls * t_call
+    info.update(value=W / t_rec, extrapolated="x%d identical calls" % n_calls, repeats=1,
+                sample=f"torch-fp32 oracle: ONE full call of the recursion as the reference executes it (ClipEncoder on {W} segment rows x {Tn} frames, "
+                       f"prefill S={P - 1 + W}, {G - 1} KV-cached decode steps, all 32 layers; driven through oracle.sampling.generate = the CPU "
+                       f"restatement of inference()) timed once after a one-layer warm-up: {t_call:.1f} s; recursion = {n_calls} such calls "
+                       f"= {t_rec:.1f} s.  --cpu-full runs all {n_calls} calls, 3 repeats, median")
+    return info
 
 
 def main():
@@ -219,80 +273,93 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
-    from revisionllm_amd import hip, ops, parallel
+    from revisionllm_amd import ops, parallel, sched
     from revisionllm_amd.eval import stage2
+    from revisionllm_amd.inference import _prompt_ids
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
 
-    model = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device=dev)
-    model.get_model().initialize_vision_modules(SimpleNamespace(
-        clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
-        adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
-    # extra legs (single GPU, after the headline's timed region): the same loop with two queries of the movie per step and /
-    # or the FP8 decode-weight copies.  The copies are resident from the start and switched off for the headline.
-    extras = world == 1 and not args.no_extras and not args.fp8_decode and not args.fp8_prefill and args.queries == 1
-    model.engine.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras)
-    model.engine.set_option("fp8_decode", 1 if args.fp8_decode else 0)
-    model.engine.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
-    model.generation_config.eos_token_id = None     # forced decode length
-    tok = synth.FakeTokenizer()
+    def hier_args(**kw):
+        d = dict(clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
+                 adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None)
+        d.update(kw)
+        return SimpleNamespace(**d)
 
-    Wl, Tn = args.windows, args.frames
-    W = Wl * world
+    model = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device=dev)
+    model.get_model().initialize_vision_modules(hier_args())
+    eng = model.engine
+    headline = args.workload == "stage2_long_100"
+    # extra legs (single GPU, after the headline's timed region).  The FP8 copies are resident from the start and switched off
+    # for the headline.
+    extras = (world == 1 and headline and not args.no_extras and not args.fp8_decode and not args.fp8_prefill and args.queries == 1
+              and not args.eos)
+    eng.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras)
+    eng.set_option("fp8_decode", 1 if args.fp8_decode else 0)
+    eng.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
+    eng.set_option("gemm_cus", args.gemm_cus)
+    eng.set_option("gemm_tile_variant", args.gemm_variant)
+    model.generation_config.eos_token_id = 2 if args.eos else None     # None: forced decode length
+    tok = synth.FakeTokenizer()
+    G = args.decode_steps
+
+    # ---------------------------------------------------------------- stage-2 recursion workloads -------------------------------------
+    strong = args.scaling == "strong" and world > 1
+    batch = 33 if args.workload == "stage2_long_33" else 100
+    W = (33 if args.workload == "stage2_long_33" else args.windows) * (1 if strong else world)
+    lo, hi = parallel.shard_bounds(W, rank, world)
+    Wl, Tn = hi - lo, args.frames
     feats = ops.init_hash_(torch.empty(Wl, Tn, 768, dtype=torch.bfloat16, device=dev), f"bench.feat.r{rank}", args.seed, synth.SQRT3)
     qf = ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), "bench.q", args.seed, synth.SQRT3)
     qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "bench.qcls", args.seed, synth.SQRT3)
-    plan = stage2.plan_groups(W, 100)
+    plan = stage2.plan_groups(W, batch)
     gen = torch.Generator().manual_seed(args.seed)
     torch.manual_seed(args.seed)                    # the device-side sampling draws (torch.rand in generate)
-    perms = stage2.make_perms(plan, gen)
-    # 20 words: with the v1 template the prompt is P = 72 ids, i.e. prefill length S = 171 per call
-    sentence = ("a person opens the door and walks into the kitchen while another person is sitting at the table "
-                "reading a newspaper and then both of them leave the room together")
+    perms = stage2.make_perms(plan, gen, W=W)
     stages = parallel.HipStages(model, tok)
 
     def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
         return ([(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
-                  ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), sentence)
-                 for i in range(n)], [stage2.make_perms(plan, gen) for _ in range(n)])
+                  ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), SENTENCE)
+                 for i in range(n)], [stage2.make_perms(plan, gen, W=W) for _ in range(n)])
 
     def video_set(n):      # extra measurement: n recursions over n DIFFERENT videos (own windows, own query) in one pass
         return [ops.init_hash_(torch.empty(Wl, Tn, 768, dtype=torch.bfloat16, device=dev), f"bench.feat{i}.r{rank}", args.seed, synth.SQRT3)
                 for i in range(n)]
 
-    work = {"qs": [(qf, qc, sentence)], "perms": [perms], "feats": feats}
+    work = {"qs": [(qf, qc, SENTENCE)], "perms": [perms], "feats": feats, "W": W, "batch": batch}
     if args.queries > 1:
         work["qs"], work["perms"] = query_set(args.queries)
-    model.engine.set_option("gemm_cus", args.gemm_cus)
-    model.engine.set_option("gemm_tile_variant", args.gemm_variant)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
+    inter = sched.Interleaver()
 
     def launch():
-        kw = dict(batch=100, perms=work["perms"], max_new_tokens=args.decode_steps)
-        qs, feats = work["qs"], work["feats"]
+        """Start one step as a scheduler task bound to the next HIP stream / workspace slot."""
+        kw = dict(batch=work["batch"], perms=work["perms"], max_new_tokens=G)
+        g = parallel.launch_queries_sharded_steps(stages, tok, work["feats"], work["W"], work["qs"], **kw)
         if streams is None:
-            return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
+            return inter.add(sched.Task(g, None, eng, 0))
         k = counter["i"] % len(streams)
         counter["i"] += 1
-        model.engine.slot = k
         streams[k].wait_stream(torch.cuda.current_stream(dev))     # inputs written on the caller's stream
-        with torch.cuda.stream(streams[k]):
-            return parallel.launch_queries_sharded(stages, tok, feats, W, qs, **kw)
+        return inter.add(sched.Task(g, streams[k], eng, k))
+
+    def collect(task):
+        return parallel.collect_queries(inter.finish(task))[0]
 
     def run(n):
         """n steps.  A step's device work is enqueued before the previous steps' records are collected (``--streams`` steps in
         flight, each on its own HIP stream), so one step's HBM-bound decode launches fill the gaps of the other's MFMA-bound
         adapter / prefill and the host-side exchange / assembly overlaps device work; every step's work and record are
-        produced inside the timed region."""
+        produced inside the timed region.  With an EOS id the tasks yield at their stop-flag polls and are resumed round-robin."""
         rec, pending = None, []
         depth = max(1, args.streams)
         for _ in range(n):
             pending.append(launch())
             if len(pending) > depth:
-                rec = parallel.collect_queries(pending.pop(0))[0]
+                rec = collect(pending.pop(0))
         while pending:
-            rec = parallel.collect_queries(pending.pop(0))[0]
+            rec = collect(pending.pop(0))
         return rec
 
     def sync():
@@ -301,93 +368,186 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()       # weights / inputs were written on the default stream; the step streams do not wait for it implicitly
-    if args.settle > 0:
-        run(args.settle)
+    def timed(fn_run, steps=None, warm=None):
+        """W warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; max over ranks.  -> (seconds, last record)."""
+        steps = args.steps if steps is None else steps
+        fn_run(args.warmup if warm is None else warm)
         sync()
-    rec = run(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    rec = run(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t0 = time.perf_counter()
+        rec = fn_run(steps)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, rec
 
-    if any(e != e for e in rec["max_entropy"]) or not all(rec["answers"]):
-        raise RuntimeError(f"bench: the last record is not finite / empty: {rec['answers']} {rec['max_entropy']}")
+    # ---------------------------------------------------------------- stage-1 workloads (one window per step) --------------------------
+    def stage1_runner(kind):
+        """stage1_dense: 1 window x 256 frames -> nn.Linear projector -> 256 video tokens (S = P - 1 + 256) -> G decode steps.
+        stage1_sparse: 1 window x 1024 frames + query tokens -> ClipEncoder 'cls' -> 1 video token -> G decode steps
+        (eval_nlq_negative.py:281-298: windows are the LLM's batch rows; BASELINE configs quote 1 segment)."""
+        m1 = ReVisionLlamaForCausalLM(synth.VICUNA_7B, engine=eng)
+        if kind == "stage1_dense":
+            m1.get_model().initialize_vision_modules(hier_args(clip_adapter=False, clip_adapter_text=False, hierarchy=False))
+            if not eng.has_linear:
+                eng.init_synthetic(seed=args.seed, llm=False, clip=False, linear=True)
+            frames, qfeat = 256, None
+        else:
+            m1.get_model().initialize_vision_modules(hier_args(hierarchy=False))
+            frames = 1024
+            qfeat = (qf[None], torch.ones(1, args.lq))
+        m1.generation_config.eos_token_id = None
+        x = ops.init_hash_(torch.empty(1, frames, 768, dtype=torch.bfloat16, device=dev), f"bench.s1.{kind}", args.seed, synth.SQRT3)
+        ids = _prompt_ids("<video>\n" + "During which frames can we see {}?".format(SENTENCE), tok, 1)[0]
+        gkw = dict(images=x, query_feats=qfeat, do_sample=True, temperature=0.05, max_new_tokens=G, return_dict_in_generate=True)
+
+        def run1(n):
+            out = None
+            for i in range(n):
+                if streams is not None:
+                    k = i % len(streams)
+                    eng.slot = k
+                    streams[k].wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(streams[k]):
+                        out = m1.generate(ids, **gkw)
+                else:
+                    out = m1.generate(ids, **gkw)
+            return out
+        S = ids.shape[1] - 1 + (frames if kind == "stage1_dense" else 1)
+        return run1, dict(prompt_tokens=int(ids.shape[1]), prefill_len=int(S), frames=frames, windows_per_step=1)
+
+    sync()       # weights / inputs were written on the default stream; the step streams do not wait for it implicitly
+    if args.workload.startswith("stage1"):
+        run1, wl_cfg = stage1_runner(args.workload)
+        if args.settle > 0:
+            run1(args.settle)
+            sync()
+        dt, out1 = timed(run1)
+        if not torch.isfinite(out1["entropy"]).all():
+            raise RuntimeError("bench: non-finite entropies")
+        value, rec = args.steps * world / dt, None
+    else:
+        if args.settle > 0:
+            run(args.settle)
+            sync()
+        dt, rec = timed(run)
+        if any(e != e for e in rec["max_entropy"]) or not all(rec["answers"]):
+            raise RuntimeError(f"bench: the last record is not finite / empty: {rec['answers']} {rec['max_entropy']}")
+        value = W * args.queries * args.steps / dt
+        wl_cfg = {}
+
     extra = {}
     if extras:
-        def leg(name, nq, fp8, fp8p=False):
+        def leg(name, nq, fp8, fp8p=False, eos=False):
             if nq > 1 and len(work["qs"]) != nq:
                 work["qs"], work["perms"] = query_set(nq)
                 work["feats"] = video_set(nq)
-            model.engine.set_option("fp8_decode", int(fp8))
-            model.engine.set_option("fp8_prefill", int(fp8p))
-            run(args.warmup)
-            sync()
-            t = time.perf_counter()
-            run(args.steps)
-            sync()
-            t = time.perf_counter() - t
+            eng.set_option("fp8_decode", int(fp8))
+            eng.set_option("fp8_prefill", int(fp8p))
+            model.generation_config.eos_token_id = 2 if eos else None
+            t, _ = timed(run)
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
                            "ms_per_step": t / args.steps * 1e3, "recursions_per_step": nq,
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
                            "decode_weights": "fp8 e4m3fn, per-row scale" if fp8 else "bf16",
                            "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
-        for name, nq, fp8, fp8p in (("fp8_decode_weights", 1, True, False), ("fp8_llm_path", 1, True, True), ("two_videos_per_step", 2, False, False),
-                                    ("two_videos_per_step_fp8_decode_weights", 2, True, False), ("two_videos_per_step_fp8_llm_path", 2, True, True)):
+            if eos:
+                extra[name]["eos"] = ("EOS id 2 configured (random-init weights practically never emit it, so all G steps still run): the cost shown is "
+                                      "that of the lagging device-side stop flag (one tiny reduction + pinned D2H copy per step, looked at one step "
+                                      "later) and of the scheduler that interleaves the passes in flight instead of a per-step host sync")
+        for name, nq, fp8, fp8p, eos in (("eos_enabled", 1, False, False, True), ("fp8_decode_weights", 1, True, False, False),
+                                         ("fp8_llm_path", 1, True, True, False), ("two_videos_per_step", 2, False, False, False),
+                                         ("two_videos_per_step_fp8_decode_weights", 2, True, False, False),
+                                         ("two_videos_per_step_fp8_llm_path", 2, True, True, False)):
             try:
-                leg(name, nq, fp8, fp8p)
+                leg(name, nq, fp8, fp8p, eos)
             except Exception as e:  # noqa: BLE001 - an extra leg must never cost the headline line
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 try:
                     torch.cuda.synchronize()
                 except Exception:  # noqa: BLE001
                     pass
-        model.engine.set_option("fp8_decode", 0)
-        model.engine.set_option("fp8_prefill", 0)
+        eng.set_option("fp8_decode", 0)
+        eng.set_option("fp8_prefill", 0)
+        model.generation_config.eos_token_id = None
+        # the other BASELINE.json workloads
+        try:
+            plan33 = stage2.plan_groups(33, 33)
+            work.update(qs=[(qf, qc, SENTENCE)], W=33, batch=33, perms=[stage2.make_perms(plan33, gen, W=33)],
+                        feats=ops.init_hash_(torch.empty(33, Tn, 768, dtype=torch.bfloat16, device=dev), "bench.feat33", args.seed, synth.SQRT3))
+            t, _ = timed(run)
+            extra["workload_stage2_long_33"] = {"value": 33 * args.steps / t, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3,
+                                                "config": "33 windows x 256 frames, batch 33: 7 calls presenting 32 / 32 / 32 / 32 / 32 / 32 / 33 video tokens "
+                                                          "(8 / 16 / 33 windows x zoom 4 / 2 / 1), 1 GPU, same pipeline as the headline"}
+        except Exception as e:  # noqa: BLE001
+            extra["workload_stage2_long_33"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for kind in ("stage1_dense", "stage1_sparse"):
+            try:
+                run1, cfg1 = stage1_runner(kind)
+                t, _ = timed(run1)
+                S1 = cfg1["prefill_len"]
+                entry = {"value": args.steps / t, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3, "config": cfg1,
+                         "prefill_flops": 2.0 * S1 * 6.476e9 + 2.6e5 * S1 * S1 + 2.6e8}
+                if kind == "stage1_sparse":      # adapter alone: SURVEY 8d: 46.9 GFLOP per 1024-frame segment (MFMA-bound)
+                    x1 = ops.init_hash_(torch.empty(1, 1024, 768, dtype=torch.bfloat16, device=dev), "bench.s1.a", args.seed, synth.SQRT3)
+                    ms = event_time_ms(lambda: eng.clip_encoder(x1, qf[None], torch.ones(1, args.lq), "cls"), 10)
+                    entry["roofline"] = {"stage": "sparse adapter (ClipEncoder, 1 x 1024 frames, CLS out)", "bound": "mfma", "achieved": 46.9 / ms,
+                                         "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 46.9 / ms / MFMA_BF16_PEAK_TF, "avg_ms": ms,
+                                         "note": "ONE 1025-row sequence: 5-9 row tiles per GEMM on 256 CUs - a latency-bound chain of ~40 launches"}
+                extra["workload_" + kind] = entry
+            except Exception as e:  # noqa: BLE001
+                extra["workload_" + kind] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
 
     if rank == 0:
-        ids1, _ = __import__("revisionllm_amd.inference", fromlist=["_prompt_ids"])._prompt_ids(
-            "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence), tok, 1)
+        ids1, _ = _prompt_ids("<video>\n" + stage2.QUERY_TEMPLATE.format(SENTENCE), tok, 1)
         P = ids1.shape[1]
-        S = P - 1 + 100
+        S = P - 1 + batch
         n_calls_rank = len(parallel.deal(len(plan), 0, world))
-        row_map = model.build_row_map(ids1.repeat(n_calls_rank, 1), 100)
+        row_map = model.build_row_map(ids1.repeat(n_calls_rank, 1), batch)
         P0 = model._common_text_prefix(row_map) if n_calls_rank > 1 else 0
         M_prefill = P0 + n_calls_rank * (S - P0)
-        model.engine.set_option("fp8_decode", 0)
-        model.engine.set_option("fp8_prefill", 0)
+        eng.set_option("fp8_decode", 0)
+        eng.set_option("fp8_prefill", 0)
         legs = roofline_legs(model, n_calls_rank, M_prefill)
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
-                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (args.decode_steps - 1)))
+                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (G - 1)))
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
+        other = {k: {"kernel": v["kernel"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"], "avg_launch_ms": v["ms"],
+                     **({"tflops": v["tflops"]} if "tflops" in v else {})} for k, v in legs.items()}
+        pmc = committed_profile("r2_pmc_mfma.json")
+        if pmc is not None:
+            other["prefill_gemm_pmc"] = pmc.get("summary")
         out = {
-            "metric": "video-segments/sec (whole node), stage-2 100-seg recursion, Vicuna-7B",
-            "value": W * args.queries * args.steps / dt, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": METRIC,
+            "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16 (fp8 e4m3 LLM weights / prefill GEMMs: extra measurement)" if (args.fp8_decode or args.fp8_prefill) else "bf16", "data": "synthetic",
-            "config": {"workload": "stage2_long_100", "windows_per_gpu": Wl, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
-                       "queries_per_step": args.queries, "batch": 100, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan), "prompt_tokens": int(P),
-                       "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": args.decode_steps, "llm": "Vicuna-7B shapes, random-init (hash-seeded)",
-                       "sampling": "do_sample T=0.05 top_k=50", "recursion": "batched (CLS per window encoded once, calls batched)",
-                       "steps_in_flight": max(1, args.streams), "settle_steps": args.settle,
-                       "parallelism": f"segments x{world} + RCCL all-gather of CLS rows and proposals" if world > 1 else "single GPU"},
+            "config": {"workload": args.workload, "windows_per_gpu": Wl, "windows_total": W, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
+                       "queries_per_step": args.queries, "videos_per_step": 1, "batch": batch, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan),
+                       "prompt_tokens": int(P), "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": G,
+                       "llm": "Vicuna-7B shapes, random-init (hash-seeded)", "sampling": "do_sample T=0.05 top_k=50",
+                       "recursion": "batched (CLS per window encoded once, the 7 calls of a recursion batched in one generate)",
+                       "eos": "id 2, lagging device-side stop flag" if args.eos else "disabled (forced decode length)",
+                       "steps_in_flight": max(1, args.streams), "settle_steps": args.settle, **wl_cfg,
+                       "parallelism": (f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals"
+                                       if world > 1 else "single GPU")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,
-                         "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"],
-                         "other": {k: {"achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
-                                       "avg_launch_ms": v["ms"]} for k, v in legs.items()}},
-            "answers_sample": rec["answers"][:2] if not os.environ.get("REVISION_BENCH_ALL_ANSWERS") else rec["answers"],
+                         "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"], "other": other},
         }
+        if rec is not None:
+            out["answers_sample"] = rec["answers"][:2] if not os.environ.get("REVISION_BENCH_ALL_ANSWERS") else rec["answers"]
         if extra:
-            out["extra_measurements"] = extra       # NOT the headline: a different batch per step / reduced-precision decode weights
+            out["extra_measurements"] = extra       # NOT the headline: a different batch per step / reduced-precision weights / other workloads
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, len(plan), int(P))
+                out["cpu_baseline"] = cpu_baseline(args, len(stage2.plan_groups(100, 100)), int(P))
             except Exception as e:  # noqa: BLE001 - the reported baseline must never cost the line
                 out["cpu_baseline"] = {"value": None, "unit": "segments/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)

@@ -20,7 +20,7 @@ import re
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, sched
 from ..inference import _decode, _prompt_ids, inference
 from ..model.adapter import pad_sequences_1d
 
@@ -174,8 +174,15 @@ def build_call_rows(cls, plan, perms, index=None):
 
 def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None,
                  forced_tokens=None):
-    """Enqueue the LLM work for the given call indices WITHOUT waiting for it (when no EOS id is configured ``generate`` never
-    synchronises).  ``query`` is one prompt for all calls or a {call: prompt} mapping (several queries of one movie batched
+    """``launch_calls_steps`` driven to the end on the calling thread (waits on the host only if an EOS id is configured)."""
+    return sched.drive(launch_calls_steps(model, tokenizer, query, rows, calls, uniforms, max_new_tokens, max_calls_per_generate, width,
+                                          forced_tokens))
+
+
+def launch_calls_steps(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None,
+                       forced_tokens=None):
+    """Step generator (``revisionllm_amd.sched``): enqueue the LLM work for the given call indices WITHOUT waiting for it; with an
+    EOS id configured it yields the events of the lagging "all rows finished" flags (``generate_steps``), otherwise never.  ``query`` is one prompt for all calls or a {call: prompt} mapping (several queries of one movie batched
     together).  Calls whose prompts have the same length (same number of video rows and of text tokens) run as one batched
     generate.  -> (calls in row order, new tokens int32 [n, width], step entropies f32 [n, width], produced steps int32 [n]),
     device tensors; ``width`` defaults to the longest generate."""
@@ -197,9 +204,9 @@ def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_to
             ids = torch.cat([prompt_ids(c) for c in sel], 0)
             u = None if uniforms is None else uniforms[:, sel]
             forced = None if forced_tokens is None else forced_tokens[:, sel]       # [G, calls]: teacher forcing (parity tests)
-            out = model.generate(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows, do_sample=True,
-                                 temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens, output_scores=False,
-                                 return_dict_in_generate=True, uniforms=u, forced_tokens=forced)
+            out = yield from model.generate_steps(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows,
+                                                  do_sample=True, temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens,
+                                                  output_scores=False, return_dict_in_generate=True, uniforms=u, forced_tokens=forced)
             order.extend(sel)
             toks.append(out["sequences"][:, ids.shape[1]:])
             ents.append(out["entropy"])

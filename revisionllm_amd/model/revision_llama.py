@@ -84,7 +84,7 @@ class _Inner:
         self.pretrain_clip_adapter = getattr(a, "pretrain_clip_adapter", None)
         if self.clip_adapter_feature == "alternate":
             raise NotImplementedError("clip_adapter_feature='alternate' needs iteration_step (training-time only)")
-        eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text)
+        eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text if self.clip_adapter else None)
         if state_dict is None:
             path = self.pretrain_clip_adapter if self.clip_adapter else getattr(a, "pretrain_mm_mlp_adapter", None)
             if path is not None:
@@ -102,7 +102,10 @@ class _Inner:
 class ReVisionLlamaForCausalLM:
     """Drop-in for ``VTimeLLMLlamaForCausalLM`` on the inference path."""
 
-    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, device="cuda:0", max_sequence_length=None):
+    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, device="cuda:0", max_sequence_length=None, engine=None):
+        """``engine``: an existing ``Engine`` to share (its LLM weights, workspaces and options): a second model object with
+        another adapter topology - e.g. the dense Linear projector next to the hierarchy ClipEncoder - then costs no second copy
+        of the 13.5 GB of LLM weights."""
         self.shape = shape
         self.config = SimpleNamespace(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
                                       num_attention_heads=shape.heads, vocab_size=shape.vocab, rms_norm_eps=shape.eps,
@@ -110,8 +113,8 @@ class ReVisionLlamaForCausalLM:
         if max_sequence_length is not None:
             self.config.max_sequence_length = max_sequence_length
         self.generation_config = GenerationConfig(top_k=50, top_p=1.0, temperature=1.0, eos_token_id=2, pad_token_id=0)
-        self._device = torch.device(device)
-        self.engine = None
+        self._device = torch.device(device) if engine is None else engine.device
+        self.engine = engine
         self.model = _Inner(self)
         self.scores_mode = "processed"  # what transformers>=4.39 returns; "raw" = the override's intent (vtimellm_llama.py:321)
         self.dtype = torch.bfloat16
@@ -123,7 +126,7 @@ class ReVisionLlamaForCausalLM:
         if self.engine is None:
             self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device)
         elif adapter_text is not None and bool(adapter_text) != self.engine.adapter_text:
-            raise RuntimeError("adapter topology was already fixed for this model")
+            raise RuntimeError("the engine's ClipEncoder topology (text-conditioned layers on / off) differs from this model's")
         return self.engine
 
     def get_model(self):
@@ -207,12 +210,31 @@ class ReVisionLlamaForCausalLM:
 
     # ---- generate ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def generate(self, input_ids, images=None, query_feats=None, do_sample=False, temperature=None, num_beams=1,
-                 max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
-                 return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
-                 attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
-                 share_prefix=True, **kwargs):
-        """Prefill + KV-cached sampling loop (inference.py:45-59 kwargs).
+    def generate(self, input_ids, images=None, query_feats=None, **kwargs):
+        """Prefill + KV-cached sampling loop (inference.py:45-59 kwargs); see ``generate_steps`` for the build-defined kwargs.
+        Drives the step generator to the end, waiting on the host wherever it asks to."""
+        gen = self.generate_steps(input_ids, images=images, query_feats=query_feats, **kwargs)
+        try:
+            while True:
+                ev = next(gen)
+                if ev is not None:
+                    ev.synchronize()
+        except StopIteration as stop:
+            return stop.value
+
+    def generate_steps(self, input_ids, images=None, query_feats=None, do_sample=False, temperature=None, num_beams=1,
+                       max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
+                       return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
+                       attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
+                       share_prefix=True, eos_lookahead=1, **kwargs):
+        """``generate`` as a generator: enqueues device work and YIELDS a ``torch.cuda.Event`` whenever the host has to learn
+        something from the device before it may enqueue more - which only happens with an EOS id configured: the "all rows
+        finished" flag of step s is copied to pinned host memory asynchronously and looked at only after step s + ``eos_lookahead``
+        has been enqueued, so the device always has work queued (no per-step drain of the launch queue) and a scheduler can
+        interleave several generates on different HIP streams (``run_interleaved``): while one waits for its flag, the others'
+        launches are enqueued.  At most ``eos_lookahead`` steps are computed past the EOS step; they are cut off on the host
+        (finished rows emit the pad id from the EOS step on, exactly like HF's ``_sample`` bookkeeping).  Returns (via
+        StopIteration) what ``generate`` returns.
 
         Extra, build-defined kwargs: ``uniforms`` [G,B] (host-supplied draws for reproducible sampling; default
         ``torch.rand`` on the device), ``forced_tokens`` [G,B] (teacher forcing for parity tests),
@@ -268,15 +290,19 @@ class ReVisionLlamaForCausalLM:
         pos = S
         if do_sample and uniforms is None and self.uniform_fn is None:
             uniforms = torch.rand(max_new_tokens, B, device=dev)        # one launch instead of one per step
+        flags = []      # per step: (pinned int32 [1] = max over rows of "unfinished" after the step, event of its copy)
+        if eos is not None:
+            flag_host = torch.empty(max_new_tokens, dtype=torch.int32).pin_memory()
+        n_steps = 0
         for step in range(max_new_tokens):
             if do_sample:
                 if uniforms is not None:
                     u = uniforms[step].contiguous()
                 else:
                     u = self.uniform_fn(step, B).to(dev).float().contiguous()
-                o = ops.sample(logits, u, True, temperature, top_k, top_p)
+                o = ops.sample(logits, u, True, temperature, top_k, top_p, ctx=eng)
             else:
-                o = ops.sample(logits, None, False)
+                o = ops.sample(logits, None, False, ctx=eng)
             nxt = o["tokens"] if forced_tokens is None else forced_tokens[step].int()     # int32 [B]
             ent_p.append(o["entropy_proc"])
             ent_r.append(o["entropy_raw"])
@@ -291,15 +317,36 @@ class ReVisionLlamaForCausalLM:
             if eos is not None:   # rows that already emitted EOS keep producing the pad id (HF _sample bookkeeping)
                 nxt = nxt * unfinished + pad * (1 - unfinished)
                 unfinished = unfinished * (nxt != eos).int()
+                flag_host[step:step + 1].copy_(unfinished.max().reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                flags.append(ev)
             new_tokens.append(nxt)
-            if step == max_new_tokens - 1 or (eos is not None and int(unfinished.max()) == 0):   # the only host sync
+            n_steps = step + 1
+            if step == max_new_tokens - 1:
                 break
+            if eos is not None and step >= eos_lookahead:
+                # the flag of step (step - lookahead): its copy was enqueued ``lookahead`` steps ago - usually complete already
+                yield flags[step - eos_lookahead]
+                if int(flag_host[step - eos_lookahead]) == 0:
+                    n_steps = step - eos_lookahead + 1
+                    break
             if pos + 1 > Smax:
                 kv, Smax = self._grow_kv(kv, B, Smax, min(S + max_new_tokens, Smax * 2))
             h1 = eng.splice_embed(nxt[:, None], None)
             logits = eng.llm_forward(h1, pos, kv, Smax)
             pos += 1
+        if eos is not None and n_steps == len(new_tokens) and n_steps > 0:
+            # the steps not yet looked at: the generate may have finished inside the lookahead window
+            for s_ in range(max(0, n_steps - eos_lookahead - 1), n_steps):
+                yield flags[s_]
+                if int(flag_host[s_]) == 0:
+                    n_steps = s_ + 1
+                    break
 
+        def cut(lst):
+            return lst[:n_steps]
+        new_tokens, ent_p, ent_r, raw_steps, score_steps = cut(new_tokens), cut(ent_p), cut(ent_r), cut(raw_steps), cut(score_steps)
         seqs = torch.cat([seqs, torch.stack(new_tokens, dim=1).long()], dim=1)
         if not return_dict_in_generate:
             return seqs

@@ -13,6 +13,7 @@ tests on CPU with stand-in stages; the defaults are the HIP stages of revisionll
 import torch
 import torch.distributed as dist
 
+from . import sched
 from .eval import stage2
 from .ops import h2d as ops_h2d
 
@@ -24,9 +25,12 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def deal(n_items, rank, world):
-    """Round-robin deal of call indices (keeps the zoom levels, which have different costs, spread over ranks)."""
-    return list(range(rank, n_items, world))
+def deal(n_items, rank, world, offset=0):
+    """Round-robin deal of call indices (keeps the zoom levels, which have different costs, spread over ranks).  ``offset``
+    rotates the starting rank: consecutive passes (7 calls over 8 ranks leave one rank without a call) then leave a DIFFERENT
+    rank idle each time, so with a few passes in flight every GPU has calls queued."""
+    first = (rank - offset) % world
+    return list(range(first, n_items, world))
 
 
 def _all_gather_cat(padded, group):
@@ -102,6 +106,14 @@ class HipStages:
         """Enqueue only: -> (calls in row order, tokens int32 [n, width], entropies f32 [n, width], produced steps int32 [n])."""
         return stage2.launch_calls(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens, width=width)
 
+    def generate_steps(self, query, rows, calls, uniforms, max_new_tokens, width):
+        """``generate_async`` as a step generator (yields the EOS-flag events when an EOS id is configured; ``sched``)."""
+        return stage2.launch_calls_steps(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens, width=width)
+
+    def gate(self):
+        """The device's persistent-launch gate (engine.PersistGate): collectives are ordered against the prefill GEMMs with it."""
+        return self.model.engine.gate
+
     @property
     def eos(self):
         return self.model.generation_config.eos_token_id
@@ -116,7 +128,29 @@ class PendingQuery:
 
 def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
                            max_new_tokens=64, grounding_windows=None, group=None, single=True):
-    """Enqueue several recursions as ONE pass and return without waiting for the device.
+    """``launch_queries_sharded_steps`` driven to the end on the calling thread -> ``PendingQuery``."""
+    return sched.drive(launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, batch, zooms, perms, uniforms,
+                                                    max_new_tokens, grounding_windows, group, single))
+
+
+def _gated(stages, world, fn):
+    """Run a collective between ``begin`` / ``end`` of the device's persistent-launch gate: an RCCL kernel resident on a few CUs
+    while a one-workgroup-per-CU stream-K GEMM of another stream waits in-kernel for ALL its workgroups would stall that GEMM
+    (and, through the peer ranks waiting for this rank's contribution, the whole node) until the collective drains - so
+    collectives and prefill GEMMs are serialised on the device by the same event chain.  Device-side waits only."""
+    gate = stages.gate() if (world > 1 and hasattr(stages, "gate")) else None
+    if gate is not None:
+        gate.begin()
+    out = fn()
+    if gate is not None:
+        gate.end()
+    return out
+
+
+def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
+                                 max_new_tokens=64, grounding_windows=None, group=None, single=True):
+    """Step generator (``revisionllm_amd.sched``): enqueue several recursions as ONE pass without waiting for the device; yields
+    only the EOS-flag events of the generates (never, when no EOS id is configured).  Returns a ``PendingQuery``.
 
     ``queries`` = [(query_feats, query_cls, sentence), ...]; every recursion runs over the windows ``features_local`` (this
     rank's block of ``W``; pass a list of per-query feature tensors for recursions over different videos of the same window
@@ -144,21 +178,28 @@ def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=
     rows, prompts, cos_all = [], {}, []
     for qi, (qf, qc, sentence) in enumerate(queries):
         cls_local, cos_local = stages.encode(feats_of[qi], qf), stages.cosine(feats_of[qi], qc)
-        if world > 1:
-            cls_local = allgather_rows(cls_local, W, group)          # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
-            cos_local = allgather_rows(cos_local[:, None], W, group)[:, 0]
+        if world > 1:                                                # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
+            cls_local, cos_local = _gated(stages, world, lambda: (allgather_rows(cls_local, W, group),
+                                                                  allgather_rows(cos_local[:, None], W, group)[:, 0]))
         cos_all.append(cos_local)
         rows.extend(stage2.build_call_rows(cls_local, plan, None, index[qi]))
         for c in range(nc):
             prompts[qi * nc + c] = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
-    mine = deal(nc * nq, rank, world)
     p = PendingQuery()
+    # every rank must issue its collectives in the same order: the second exchange of a pass is issued only after those of the
+    # passes launched before it (with an EOS id the scheduler resumes passes in an order that depends on device timing)
+    p.seq = getattr(stages, "_seq_next", 0)
+    stages._seq_next = p.seq + 1
+    mine = deal(nc * nq, rank, world, offset=p.seq)
     p.args = (plan, perms, tokenizer, zooms, grounding_windows, single, nq)
     p.stages = stages
     cos = torch.stack(cos_all, 0)
     if hasattr(stages, "generate_async"):
         width = min(max_new_tokens, 128)
-        order, tok, ent, nst = stages.generate_async(prompts, rows, mine, uniforms, max_new_tokens, width)
+        if hasattr(stages, "generate_steps"):
+            order, tok, ent, nst = yield from stages.generate_steps(prompts, rows, mine, uniforms, max_new_tokens, width)
+        else:
+            order, tok, ent, nst = stages.generate_async(prompts, rows, mine, uniforms, max_new_tokens, width)
         per = -(-(nc * nq) // world)
         # wire: int32 [per, 2 + width] = (call id or -1, produced steps, tokens...) and f32 [per, width] step entropies
         tw = torch.full((per, 2 + width), -1, dtype=torch.int32, device=dev)
@@ -168,7 +209,10 @@ def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=
             tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), dev)
             tw[:n, 1], tw[:n, 2:], ew[:n] = nst.to(dev), tok.to(dev), ent.to(dev)
         if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
-            tw, ew = _all_gather_cat(tw, group), _all_gather_cat(ew, group)
+            while getattr(stages, "_seq_turn", 0) != p.seq:
+                yield sched.RETRY
+            tw, ew = _gated(stages, world, lambda: (_all_gather_cat(tw, group), _all_gather_cat(ew, group)))
+        stages._seq_turn = p.seq + 1
         if dev.type == "cuda":
             p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
             for h, t in zip(p.host, (tw, ew, cos)):
@@ -181,6 +225,7 @@ def launch_queries_sharded(stages, tokenizer, features_local, W, queries, batch=
         res = stages.generate(prompts, rows, mine, uniforms, max_new_tokens)
         if world > 1:
             res = allgather_calls(res, nc * nq, max_new_tokens, dev, group)   # exchange 2: proposals
+        stages._seq_turn = p.seq + 1
         p.res, p.cos = res, cos.cpu()
     return p
 

@@ -1,0 +1,94 @@
+"""Cooperative host-side scheduling of step generators.
+
+``generate_steps`` (and the launch generators built on it) enqueue device work and ``yield`` a ``torch.cuda.Event`` whenever
+the host must learn something from the device before enqueuing more (the EOS flag of an earlier decode step).  ``drive`` runs
+one generator to the end, blocking on each event; ``Interleaver`` keeps several of them in flight - each bound to its own HIP
+stream and engine workspace slot - and resumes whichever one's event has completed, so one recursion waiting for its flag
+never keeps the others' launches off the device.  No threads: everything is enqueued from the calling thread."""
+import torch
+
+#: yielded by a step generator that cannot continue yet for a reason other than a device event (e.g. it must issue a collective
+#: after an earlier-launched task has issued its own, so that every rank issues them in the same order): "resume me later"
+RETRY = object()
+
+
+def drive(gen):
+    """Run a step generator to completion, waiting on every event it yields; returns its return value."""
+    try:
+        while True:
+            ev = next(gen)
+            if ev is RETRY:
+                raise RuntimeError("a step generator asked to be resumed later, but nothing else is running (sched.drive)")
+            if ev is not None:
+                ev.synchronize()
+    except StopIteration as stop:
+        return stop.value
+
+
+class Task:
+    """One step generator bound to the HIP stream / engine slot its launches go to."""
+
+    def __init__(self, gen, stream=None, engine=None, slot=0):
+        self.gen, self.stream, self.engine, self.slot = gen, stream, engine, slot
+        self.waiting = None         # the event the generator asked for
+        self.done, self.result = False, None
+
+    def ready(self):
+        return not self.done and (self.waiting is None or self.waiting.query())
+
+    def advance(self):
+        """Resume until the generator yields an event that has not completed yet (or finishes).  -> True if it ran at all."""
+        if not self.ready():
+            return False
+        if self.engine is not None:
+            self.engine.slot = self.slot
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            try:
+                while True:
+                    ev = next(self.gen)
+                    if ev is RETRY:
+                        self.waiting = None
+                        return False        # no progress: let the task it waits for run
+                    if ev is not None and not ev.query():
+                        self.waiting = ev
+                        return True
+            except StopIteration as stop:
+                self.done, self.result, self.waiting = True, stop.value, None
+        return True
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class Interleaver:
+    """Tasks in launch order.  ``add`` starts a task (runs it up to its first pending event); ``finish(task)`` returns its
+    result, advancing every other ready task while it waits."""
+
+    def __init__(self):
+        self.tasks = []
+
+    def add(self, task):
+        self.tasks.append(task)
+        self.pump()
+        return task
+
+    def pump(self):
+        progressed = False
+        for t in self.tasks:
+            progressed |= t.advance()
+        return progressed
+
+    def finish(self, task):
+        while not task.done:
+            if not self.pump():
+                # nothing is ready: wait for the event of the task we want (the others keep their queued device work)
+                if task.waiting is not None:
+                    task.waiting.synchronize()
+        self.tasks.remove(task)
+        return task.result
