@@ -148,9 +148,13 @@ def _gated(stages, world, fn):
 
 
 def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, batch=100, zooms=(4, 2, 1), perms=None, uniforms=None,
-                                 max_new_tokens=64, grounding_windows=None, group=None, single=True):
+                                 max_new_tokens=64, grounding_windows=None, group=None, single=True, turn=None):
     """Step generator (``revisionllm_amd.sched``): enqueue several recursions as ONE pass without waiting for the device; yields
     only the EOS-flag events of the generates (never, when no EOS id is configured).  Returns a ``PendingQuery``.
+    ``turn`` (multi-rank, several passes in flight under ``sched.Interleaver``): the pass's ``sched.Task``; the second exchange is
+    issued only once ``turn.finishing`` is set, i.e. inside the driver's ``finish`` call - the first exchange is issued inside its
+    ``add`` call - so every rank issues its collectives in the driver's program order (RCCL / gloo require the same order on all
+    ranks; the order in which generates COMPLETE depends on device timing and may differ between ranks).
 
     ``queries`` = [(query_feats, query_cls, sentence), ...]; every recursion runs over the windows ``features_local`` (this
     rank's block of ``W``; pass a list of per-query feature tensors for recursions over different videos of the same window
@@ -186,9 +190,7 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
         for c in range(nc):
             prompts[qi * nc + c] = "<video>\n" + stage2.QUERY_TEMPLATE.format(sentence)
     p = PendingQuery()
-    # every rank must issue its collectives in the same order: the second exchange of a pass is issued only after those of the
-    # passes launched before it (with an EOS id the scheduler resumes passes in an order that depends on device timing)
-    p.seq = getattr(stages, "_seq_next", 0)
+    p.seq = getattr(stages, "_seq_next", 0)       # pass counter: rotates the call deal
     stages._seq_next = p.seq + 1
     mine = deal(nc * nq, rank, world, offset=p.seq)
     p.args = (plan, perms, tokenizer, zooms, grounding_windows, single, nq)
@@ -209,10 +211,9 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
             tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), dev)
             tw[:n, 1], tw[:n, 2:], ew[:n] = nst.to(dev), tok.to(dev), ent.to(dev)
         if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
-            while getattr(stages, "_seq_turn", 0) != p.seq:
+            while turn is not None and not turn.finishing:
                 yield sched.RETRY
             tw, ew = _gated(stages, world, lambda: (_all_gather_cat(tw, group), _all_gather_cat(ew, group)))
-        stages._seq_turn = p.seq + 1
         if dev.type == "cuda":
             p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
             for h, t in zip(p.host, (tw, ew, cos)):
@@ -225,7 +226,6 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
         res = stages.generate(prompts, rows, mine, uniforms, max_new_tokens)
         if world > 1:
             res = allgather_calls(res, nc * nq, max_new_tokens, dev, group)   # exchange 2: proposals
-        stages._seq_turn = p.seq + 1
         p.res, p.cos = res, cos.cpu()
     return p
 

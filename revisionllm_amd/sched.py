@@ -26,12 +26,16 @@ def drive(gen):
 
 
 class Task:
-    """One step generator bound to the HIP stream / engine slot its launches go to."""
+    """One step generator bound to the HIP stream / engine slot its launches go to.  ``gen`` may be a factory ``task -> generator``:
+    the generator can then read ``task.finishing`` (set once the driver has called ``Interleaver.finish`` on it) - the
+    multi-rank launch generators issue their closing collective only then, so that every rank issues its collectives in the
+    driver's program order whatever the device timing was."""
 
     def __init__(self, gen, stream=None, engine=None, slot=0):
-        self.gen, self.stream, self.engine, self.slot = gen, stream, engine, slot
+        self.stream, self.engine, self.slot = stream, engine, slot
         self.waiting = None         # the event the generator asked for
-        self.done, self.result = False, None
+        self.done, self.result, self.finishing = False, None, False
+        self.gen = gen(self) if callable(gen) else gen
 
     def ready(self):
         return not self.done and (self.waiting is None or self.waiting.query())
@@ -85,6 +89,7 @@ class Interleaver:
         return progressed
 
     def finish(self, task):
+        task.finishing = True
         while not task.done:
             if not self.pump():
                 # nothing is ready: wait for the event of the task we want (the others keep their queued device work)

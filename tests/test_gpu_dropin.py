@@ -206,3 +206,53 @@ def test_window_stager_back_to_back_videos():
     dev, ev = st.stage_windows(vids[0], stage2.cut_windows(9000, num_frames=250)[1])     # tuple form
     ev.synchronize()
     assert torch.equal(dev.cpu(), want[0])
+
+
+def test_eval_driver_end_to_end_with_resume(tmp_path):
+    """The eval entry point (eval_nlq_retrieval_e2e2.eval) on the device: feature files -> FeatureStore -> pinned staging ->
+    window cutting -> the batched recursion -> JSONL; a second run resumes (skips every logged query id) and reference mode
+    writes the same call geometry."""
+    import json
+    import os
+    from revisionllm_amd.eval import eval_nlq_retrieval_e2e2 as drv
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    rs = np.random.RandomState(4)
+    feat_dir, q_dir = tmp_path / "feats", tmp_path / "qfeats"
+    os.makedirs(feat_dir), os.makedirs(q_dir)
+    np.save(feat_dir / "movieA.npy", rs.randn(1900, 768).astype(np.float16))        # -> 14 windows of 625 frames every 125
+    ann = {}
+    for i in range(3):
+        ann[f"q{i}"] = {"movie": "movieA", "sentence": f"A man opens door {i}.", "timestamps": [30.0 * i, 30.0 * i + 8], "movie_duration": 380.0}
+        np.savez_compressed(q_dir / f"q{i}.npz", token_features=rs.randn(5 + i, 768).astype(np.float32), cls_features=rs.randn(768).astype(np.float32))
+    with open(tmp_path / "ann.json", "w") as f:
+        json.dump(ann, f)
+    shape = synth.TINY
+    model = ReVisionLlamaForCausalLM(shape, device="cuda:0")
+    model.get_model().initialize_vision_modules(SimpleNamespace(
+        clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None, clip_adapter_text=True,
+        clip_adapter_feature="cls", hierarchy=True, adapter_input_dim=768))
+    model.engine.init_synthetic(seed=SEED, llm=True, clip=True)
+    model.generation_config.eos_token_id = 2             # a real EOS id: the lagging stop flag path
+    real = model.generate_steps
+    model.generate_steps = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
+    model.generate = lambda *a, **kw: __import__("revisionllm_amd.sched", fromlist=["drive"]).drive(model.generate_steps(*a, **kw))
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    base = ["--data_path", str(tmp_path / "ann.json"), "--feat_folder", str(feat_dir), "--q_feat_dir", str(q_dir), "--batch", "8",
+            "--vis_feat_storage", "npy", "--num_frames", "32", "--debug", "True"]
+    args = drv.parse_args(base + ["--log_path", str(tmp_path / "out")])
+    written, errors = drv.eval(args, tokenizer=tok, model=model)
+    assert written == 3 and errors == []
+    recs = [json.loads(l) for l in open(tmp_path / "out" / "predictions_streaming_0.txt")]
+    W = stage2.cut_windows(1900, num_frames=32)[1].shape[0]
+    n_calls = len(stage2.plan_groups(W, 8))
+    for r in recs:
+        assert r["video_id"] == "movieA" and r["task"] == "grounding" and len(r["answer"]) == n_calls
+        assert len(r["info"]["max_entropy"]) == n_calls and all(np.isfinite(r["info"]["max_entropy"])) and r["info"]["hierarchy_zooms"][0] == 4
+    assert drv.eval(args, tokenizer=tok, model=model) == (0, [])                                   # resume
+    args_ref = drv.parse_args(base + ["--log_path", str(tmp_path / "out_ref"), "--mode", "reference"])
+    assert drv.eval(args_ref, tokenizer=tok, model=model)[0] == 3
+    ref = [json.loads(l) for l in open(tmp_path / "out_ref" / "predictions_streaming_0.txt")]
+    assert [r["info"]["hierarchy_zooms"] for r in ref] == [r["info"]["hierarchy_zooms"] for r in recs]
+    assert [r["info"]["gt"] for r in ref] == [r["info"]["gt"] for r in recs]

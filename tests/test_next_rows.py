@@ -2,6 +2,8 @@
 the feature-store reader formats (f-2), checkpoint-loader key rules through synthetic checkpoint directories (f-3),
 and the stage-1 driver's window / IoU helpers."""
 import json
+import math
+import types
 import os
 
 import numpy as np
@@ -10,7 +12,7 @@ import torch
 
 from oracle import recursion
 from revisionllm_amd.data.feature_store import FeatureStore
-from revisionllm_amd.eval import metrics, stage1
+from revisionllm_amd.eval import metrics, stage1, stage2
 from revisionllm_amd.model import builder
 
 
@@ -229,3 +231,115 @@ def test_clip_tokenizer_matches_reference_golden():
         assert [tf.encode(t) for t in g["texts"]] == g["ids_full_vocab"]
         assert tf.sot == 49406 and tf.eot == 49407
         assert tf.decode(tf.encode("a person opens the door")).strip() == "a person opens the door"
+
+
+# ---- the eval driver (eval_nlq_retrieval_e2e2.py) on CPU: argument surface, annotation formats, resume, error handling ----------
+
+def _write_eval_fixture(tmp_path, n_q=5, frames=2600):
+    rs = np.random.RandomState(3)
+    feat_dir, q_dir = tmp_path / "feats", tmp_path / "qfeats"
+    os.makedirs(feat_dir), os.makedirs(q_dir)
+    np.save(feat_dir / "movieA.npy", rs.randn(frames, 768).astype(np.float16))
+    np.save(feat_dir / "movieB.npy", rs.randn(frames + 300, 768).astype(np.float16))
+    ann = {}
+    for i in range(n_q):
+        qid = f"q{i}"
+        ann[qid] = {"movie": "movieA" if i % 2 == 0 else "movieB", "sentence": f"Someone opens door number {i}.", "timestamps": [10.0 * i, 10.0 * i + 4],
+                    "movie_duration": frames / 5.0}
+        np.savez_compressed(q_dir / f"{qid}.npz", token_features=rs.randn(6, 768).astype(np.float32), cls_features=rs.randn(768).astype(np.float32))
+    ann["short"] = {"movie": "movieA", "sentence": "x.", "timestamps": [0, 1], "movie_duration": 100.0}       # <= debug_window: skipped
+    np.savez_compressed(q_dir / "short.npz", token_features=rs.randn(3, 768).astype(np.float32), cls_features=rs.randn(768).astype(np.float32))
+    ann["broken"] = {"movie": "no_such_movie", "sentence": "x.", "timestamps": [0, 1], "movie_duration": 900.0}   # raises: recorded in errors
+    with open(tmp_path / "ann.json", "w") as f:
+        json.dump(ann, f)
+    return str(tmp_path / "ann.json"), str(feat_dir), str(q_dir)
+
+
+def test_eval_driver_argument_surface_and_formats(tmp_path):
+    from revisionllm_amd.eval import eval_nlq_retrieval_e2e2 as drv
+    a = drv.parse_args([])
+    # every flag of the reference's parser (e2e2.py:36-85), with its default type
+    ref_flags = dict(task="grounding", debug_window=125, num_frames=250, hierarchy_num_videos=33, mlp_adapter=False, ca_adapter=False, cross_attn=False,
+                     q_feat_dir=None, max_seq_length=2048, self_attn=None, ca_self_attn=None, sa_pos=1, neg_window=False, batch=1, split=0, total_split=1,
+                     topk_pool=False, adapter_input_dim=256, feature_fps=5, load_ckp=False, mad_prompt="mad_grounding", debug=False, vis_feat_storage="lmdb",
+                     clip_adapter=False, clip_adapter_text=False, clip_adapter_feature=False, hierarchy=False, score="mean_entropy", score_merge="multiply",
+                     normalize=True, hierarchy_all=False, high_res_log_path=None, single=True, zoom=1, grounding_path=None, distributed_retrieval=16, stride=5,
+                     pretrain_mm_mlp_adapter=None, pretrain_clip_adapter=None, stage3=None)
+    for k, v in ref_flags.items():
+        assert getattr(a, k) == v, k
+    for k in ("clip_path", "model_base", "stage2", "data_path", "feat_folder", "log_path"):
+        assert hasattr(a, k)
+    assert drv.parse_args(["--clip_adapter", "True", "--batch", "100"]).clip_adapter is True
+    # annotation formats (e2e2.py:203-217) and the split partition (:219-220)
+    ann, _, _ = _write_eval_fixture(tmp_path)
+    items = drv.load_items(ann)
+    assert [i for i, _ in items][:2] == ["q0", "q1"] and items[1][1]["timestamps"] == stage2.get_ground_truth_windows(10.0, 14.0, 520.0)[0]
+    with open(tmp_path / "a.jsonl", "w") as f:
+        f.write(json.dumps({"query_id": "z1", "timestamps": [0, 3], "movie_duration": 500.0}) + "\n")
+    assert drv.load_items(str(tmp_path / "a.jsonl"))[0][0] == "z1"
+    with open(tmp_path / "v.json", "w") as f:
+        json.dump({"videos": [{"query": "a dog", "timestamps": [0, 3], "movie_duration": 500.0}]}, f)
+    assert drv.load_items(str(tmp_path / "v.json"))[0][0] == "a dog"
+    js = list(range(10))
+    assert drv.split_items(js, 0, 3) == [0, 1, 2] and drv.split_items(js, 2, 3) == [6, 7, 8, 9]
+    # stage-1 pre-filter (e2e2.py:278-294), restated inline from the cited lines
+    answers = ["Not Present", "From 3 to 9.", "Not Present", "From 1 to 2.", "Not Present", "Not Present"]
+    for batch, n_windows, stride in ((8, 30, 5), (3, 30, 5), (12, 40, 4)):
+        gw = []
+        for i in [i for i, x in enumerate(answers) if x != "Not Present"]:
+            gw.extend(list(range(math.floor((i - 1) * (stride / 2)), math.ceil((i - 1) * (stride / 2) + (stride / 2)))))
+        gw = list(set(gw))
+        if batch > len(gw):
+            non = [i for i in range(n_windows) if i not in gw]
+            if len(non) > 0:
+                non = non[::int(len(non) / (batch - len(gw)))][:batch - len(gw)]
+            gw = gw + non
+            gw.sort()
+        assert drv.prefilter_windows(answers, n_windows, batch, stride) == gw
+    with pytest.raises(ValueError):       # fewer spare windows than needed: the reference's slice step is 0 there too (-> its per-query except)
+        drv.prefilter_windows(answers, 12, 20, 4)
+
+
+def test_eval_driver_resume_and_error_handling(tmp_path, monkeypatch):
+    """The loop of e2e2.py:195-236,411-421 with the device stages stubbed out: one JSONL record per query with the reference's
+    schema, videos shorter than one window skipped, a failing query recorded in ``errors`` without stopping the run, and a second
+    run skipping every query id already in the log (resume)."""
+    from revisionllm_amd.data import feature_store
+    from revisionllm_amd.eval import eval_nlq_retrieval_e2e2 as drv
+    ann, feat_dir, q_dir = _write_eval_fixture(tmp_path)
+    calls = []
+
+    class FakeStager:
+        def __init__(self, device):
+            pass
+
+        def stage_windows(self, features, frame_idx):
+            t = torch.from_numpy(features.astype(np.float32))[torch.from_numpy(frame_idx.astype(np.int64))]
+            return types.SimpleNamespace(wait=lambda: t)
+
+    def fake_run_query(model, tokenizer, windows, qf, qc, sentence, batch, mode, grounding_windows, single):
+        calls.append((sentence, tuple(windows.shape)))
+        plan = stage2.plan_groups(windows.shape[0], batch)
+        return dict(answers=["In video 3."] * len(plan), starts=[p[1] for p in plan], indexes=[list(range(p[2] - p[1])) for p in plan],
+                    hierarchy_zooms=[p[0] for p in plan], max_entropy=[1.0] * len(plan), mean_entropy=[2.0] * len(plan), score_cos=[0.5] * len(plan),
+                    grounding_windows=grounding_windows, plan=plan)
+
+    monkeypatch.setattr(feature_store, "WindowStager", FakeStager)
+    monkeypatch.setattr(stage2, "run_query", fake_run_query)
+    args = drv.parse_args(["--data_path", ann, "--feat_folder", feat_dir, "--q_feat_dir", q_dir, "--log_path", str(tmp_path / "out"), "--batch", "8",
+                           "--vis_feat_storage", "npy", "--num_frames", "250"])
+    model = types.SimpleNamespace(device=torch.device("cpu"))
+    written, errors = drv.eval(args, tokenizer=None, model=model)
+    assert written == 5 and errors == ["broken"] and len(calls) == 5
+    assert calls[0][0] == "someone opens door number 0" and calls[0][1][1:] == (250, 768)          # lower-cased, trailing '.' dropped
+    log = str(tmp_path / "out" / "predictions_streaming_0.txt")
+    recs = [json.loads(l) for l in open(log)]
+    assert [r["query_id"] for r in recs] == [f"q{i}" for i in range(5)] and recs[0]["task"] == "grounding" and recs[0]["video_id"] == "movieA"
+    assert set(recs[0]["info"]) == {"gt", "frames", "iou", "score_cos", "mean_entropy", "max_entropy", "hierarchy_zooms"}
+    # resume: nothing is recomputed, nothing appended (the failing id is retried and fails again)
+    written2, errors2 = drv.eval(args, tokenizer=None, model=model)
+    assert written2 == 0 and errors2 == ["broken"] and len(calls) == 5 and len(open(log).readlines()) == 5
+    # a torn last line (killed run) does not break the resume scan
+    with open(log, "a") as f:
+        f.write('{"video_id": "movieA", "task": "grou')
+    assert drv.done_query_ids(log) == [f"q{i}" for i in range(5)]

@@ -135,3 +135,100 @@ def test_world2_matches_world1():
         assert answers == ref["answers"] and starts == ref["starts"]
         assert emax == ref["max_entropy"] and emean == ref["mean_entropy"]
         assert cos == pytest.approx(ref["score_cos"], rel=0, abs=0)
+
+
+# ---- world 4, the headline geometry (100 windows, batch 100: 7 calls), three passes in flight through the scheduler -------------
+
+class YieldingStubStages(AsyncStubStages):
+    """Stand-in for an EOS-terminated generate: the step generator asks to be resumed a RANK- and PASS-dependent number of times
+    before it returns, so without the launch-order rule the ranks would reach their second all-gather in different orders."""
+
+    def __init__(self, rank):
+        self.rank, self.n = rank, 0
+
+    class _Event:
+        """Completes after ``polls`` queries (a device event that is still pending for a while)."""
+
+        def __init__(self, polls):
+            self.polls = polls
+
+        def query(self):
+            self.polls -= 1
+            return self.polls < 0
+
+        def synchronize(self):
+            self.polls = -1
+
+    def generate_steps(self, query, rows, calls, uniforms, max_new_tokens, width):
+        self.n += 1
+        # earlier passes wait LONGER on some ranks: later passes reach their second exchange first there
+        for k in range(1 + (self.rank + 2 * (3 - self.n)) % 5):
+            yield self._Event(polls=(self.rank * 2 + k) % 4)
+        self.finished_order = getattr(self, "finished_order", []) + [self.n]
+        return self.generate_async(query, rows, calls, uniforms, max_new_tokens, width)
+
+
+def _inputs100():
+    feats = torch.from_numpy(synth.features("par100.feat", (100, T, 768), 7))
+    qs = [(torch.from_numpy(synth.features(f"par100.q{i}", (4 + i, 768), 7)), torch.from_numpy(synth.features(f"par100.qc{i}", (768,), 7)),
+           f"query {i}") for i in range(3)]
+    plan = stage2.plan_groups(100, 100)
+    perms = [stage2.make_perms(plan, torch.Generator().manual_seed(20 + i)) for i in range(3)]
+    return feats, qs, perms
+
+
+def _worker4(rank, world, port, q):
+    from revisionllm_amd import sched
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats, qs, perms = _inputs100()
+    lo, hi = parallel.shard_bounds(100, rank, world)
+    st, tok = YieldingStubStages(rank), synth.FakeTokenizer()
+    inter = sched.Interleaver()
+    tasks = [inter.add(sched.Task(lambda t, i=i: parallel.launch_queries_sharded_steps(st, tok, feats[lo:hi], 100, [qs[i]], batch=100,
+                                                                                       perms=[perms[i]], max_new_tokens=8, turn=t)))
+             for i in range(3)]
+    recs = [parallel.collect_queries(inter.finish(t))[0] for t in reversed(tasks)][::-1]     # collected in another order than launched
+    # the call deal rotates with the pass: over three passes every rank got calls, none the same share each time
+    mine = [parallel.deal(7, rank, world, offset=s) for s in range(3)]
+    q.put((rank, [(r["answers"], r["max_entropy"], r["mean_entropy"], r["score_cos"], r["starts"]) for r in recs], mine, st.finished_order))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_three_passes_in_flight_match_world1():
+    """4 ranks x 25 windows (W = batch = 100: the headline's 7 calls dealt over 4 ranks with a rotating start), three passes in
+    flight under the cooperative scheduler with generates that yield rank-dependently: every rank issues its collectives in
+    launch order (no mismatch / hang) and ends with the 1-rank records."""
+    feats, qs, perms = _inputs100()
+    tok = synth.FakeTokenizer()
+    ref = [parallel.run_queries_sharded(AsyncStubStages(), tok, feats, 100, [qs[i]], batch=100, perms=[perms[i]], max_new_tokens=8)[0]
+           for i in range(3)]
+    assert all(len(r["answers"]) == 7 for r in ref)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shares, orders = {}, set()
+    for rank, recs, mine, finished_order in got:
+        shares[rank] = mine
+        orders.add(tuple(finished_order))
+        for (answers, emax, emean, cos, starts), want in zip(recs, ref):
+            assert answers == want["answers"] and starts == want["starts"] and cos == want["score_cos"]
+            assert all(abs(x - y) < 1e-6 for x, y in zip(emax, want["max_entropy"])) and all(abs(x - y) < 1e-6 for x, y in zip(emean, want["mean_entropy"]))
+    assert any(o != (1, 2, 3) for o in orders)      # the generates really finished out of launch order somewhere
+    for s_ in range(3):       # every pass: the 7 calls are dealt exactly once
+        assert sorted(sum((shares[r][s_] for r in range(4)), [])) == list(range(7))
+    assert len({tuple(shares[0][s_]) for s_ in range(3)}) == 3          # ... and a rank's share rotates from pass to pass
+    # 8 ranks, 7 calls: the idle rank differs from pass to pass
+    idle = [[r for r in range(8) if not parallel.deal(7, r, 8, offset=s_)] for s_ in range(8)]
+    assert all(len(i) == 1 for i in idle) and len({i[0] for i in idle}) == 8
