@@ -101,7 +101,7 @@ int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, floa
  *     Wp[(((n>>4)*(K/32) + (k>>5))*64 + (n&15) + 16*((k>>3)&3))*8 + (k&7)]      (N % 16 == 0)
  * bias f32 or NULL, residual f32 (ldr) or NULL (may alias C), out dtype RV_BF16 or RV_F32 (ldc).
  * RV_ACT_SILU_MUL: W rows are 16-row gate/up interleaved and the output has N/2 columns.  K % 64 == 0.
- * M <= 16 takes the weight-streaming (decode) kernel.  ws / ws_bytes: optional workspace of rv_gemm_ws_bytes() bytes
+ * M <= 32 takes the weight-streaming (decode) kernel (17 .. 32 rows: two MFMA column blocks per weight fragment).  ws / ws_bytes: optional workspace of rv_gemm_ws_bytes() bytes
  * enabling the persistent stream-K form of the 256x256 ping-pong kernel (packed W, N % 256 == 0, M <= 1024); its first
  * 8 KiB (hand-off flags) must be zero before the first use.  NULL -> output-tiled kernels only.  With stream-K the
  * k-summation is split across workgroups in a fixed order: results are deterministic but differ in the last bits from
@@ -189,6 +189,19 @@ int rv_llm_forward(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, vo
 size_t rv_llm_prefill_shared_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t P0, int32_t S);
 int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t Smax, float* logits,
                           void* ws, size_t ws_bytes, void* stream);
+
+/* Several generates sharing ONE KV pool of kv_rows cache rows ([L, kv_rows, H, Smax, dh] and its V^T twin), so that their decode
+ * steps can be merged into one pass over the weights (a decode step streams all 13 GB whatever the number of rows <= 32).
+ * rv_llm_prefill_pool: rv_llm_prefill_shared (P0 > 0) / rv_llm_forward prefill (P0 = 0) of B sequences whose cache rows are
+ *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
+ * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 32), row r at its OWN position row_pos[r]
+ *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified.  h f32 [R, D]
+ *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.
+ *   Workspace: rv_llm_ws_bytes(ctx, R, 1). */
+int rv_llm_prefill_pool(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows, int32_t kv_row0, int32_t Smax,
+                        float* logits, void* ws, size_t ws_bytes, void* stream);
+int rv_llm_decode_rows(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* ---- token selection + scores ----------------------------------------------------------- */
 /* HF warper chain temperature -> top-k -> top-p, inverse-CDF draw with caller uniforms (or argmax when

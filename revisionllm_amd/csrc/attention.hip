@@ -28,6 +28,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     const int q0 = SPLIT ? bx * 16 : bx * 64 + wave * 16;
     if (q0 >= a.Lq) return;
     const int kb_ = b / a.kv_div;
+    // per-row key count (merged decode steps): everything below uses Lk / q_pos0 of THIS batch row
+    const int Lk = a.row_pos ? a.row_pos[b] + 1 : a.Lk;
+    if (Lk <= 0) return;
+    const int q_pos0 = a.row_pos ? Lk - a.Lq : a.q_pos0;
 
     const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
     bf16x8 qf[NC];
@@ -43,8 +47,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
 #pragma unroll
     for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    const int qpos = a.q_pos0 + q0 + fr;
-    const int kend = a.causal ? min(a.Lk, a.q_pos0 + q0 + 16) : a.Lk;
+    const int qpos = q_pos0 + q0 + fr;
+    const int kend = a.causal ? min(Lk, q_pos0 + q0 + 16) : Lk;
 
     for (int k0 = SPLIT ? wave * 32 : 0; k0 < kend; k0 += SPLIT ? 128 : 32) {
         // issue every load of this key block up front (K rows and V^T rows are independent of the softmax), so the
@@ -52,7 +56,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         bf16x8 kf[2][NC];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int key = min(k0 + krow + t * 4, a.Lk - 1);
+            const int key = min(k0 + krow + t * 4, Lk - 1);
             const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
@@ -69,7 +73,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         }
         float mx = -INFINITY;
         // interior block (wave-uniform): every key exists and is visible to all 16 rows - no per-element masking
-        const bool interior = !PAD && k0 + 32 <= a.Lk && (!a.causal || k0 + 31 <= a.q_pos0 + q0);
+        const bool interior = !PAD && k0 + 32 <= Lk && (!a.causal || k0 + 31 <= q_pos0 + q0);
         if (interior) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -84,8 +88,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + g * 8 + t * 4 + r;
-                    bool dead = key >= a.Lk || (a.causal && key > qpos);
-                    if (PAD && key < a.Lk) dead = dead || pad[key];
+                    bool dead = key >= Lk || (a.causal && key > qpos);
+                    if (PAD && key < Lk) dead = dead || pad[key];
                     const float v = dead ? -INFINITY : s[t][r] * a.scale;
                     s[t][r] = v;
                     mx = fmaxf(mx, v);

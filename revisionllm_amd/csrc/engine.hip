@@ -453,7 +453,7 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
-    w.ss = (float*)k.take((size_t)(D / 16) * 16 * 4);
+    w.ss = (float*)k.take((size_t)2 * (D / 16) * 16 * 4);   // [<= 2 row blocks][D/16 workgroups][16]
     w.x8 = (uint8_t*)k.take((size_t)M * (F > D ? F : D));
     w.sa = (float*)k.take((size_t)M * 4);
     w.bytes = k.off;
@@ -473,8 +473,10 @@ extern "C" void rv_set_fp8_prefill(int32_t on) { g_default_opts.fp8_prefill = on
 namespace {
 // Rows of h: [P0 shared-prefix rows (positions 0..P0-1)] then B sequences of S rows (positions pos0..pos0+S-1, with
 // pos0 == P0 when P0 > 0).  P0 == 0 is the plain prefill / decode step.
+// kv_rows / kv_row0: the cache tensor holds kv_rows batch rows (0: = B) and this call's rows are kv_row0 .. kv_row0 + B - 1 of it
+// (several generates share one pool).  row_pos (device int [B], S == 1 only): every row decodes at its own position.
 int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
-                     size_t ws_bytes, hipStream_t st) {
+                     size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr) {
     RV_TRY(resolve_llm(c));
     const rv_config& g = c->cfg;
     const int64_t D = g.hidden, F = g.inter, V = g.vocab, M = (int64_t)B * S + P0;
@@ -484,20 +486,22 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         return RV_ERR_WORKSPACE;
     }
     const int H = g.heads, dh = (int)(D / H);
-    const int64_t per_layer = (int64_t)B * D * Smax;  // elements of one layer's K (= V^T)
-    bf16_t* kbase = (bf16_t*)kv;
-    bf16_t* vbase = kbase + (int64_t)g.layers * per_layer;
+    if (kv_rows <= 0) kv_rows = B;
+    const int64_t per_layer = (int64_t)kv_rows * D * Smax;  // elements of one layer's K (= V^T)
+    bf16_t* kbase = (bf16_t*)kv + (int64_t)kv_row0 * D * Smax;
+    bf16_t* vbase = (bf16_t*)kv + (int64_t)g.layers * per_layer + (int64_t)kv_row0 * D * Smax;
     const float scale = 1.0f / sqrtf((float)dh);
     // (cos, sin) table for positions [P0 ? 0 : pos0, pos0 + S)
     const int tab0 = P0 > 0 ? 0 : pos0;
-    RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
-    // Decode steps (M <= 16) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
+    if (row_pos) RV_TRY(k_rope_table_rows(w.cs, row_pos, B, dh, g.rope_theta, st));
+    else RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
+    // Decode steps (M <= 32 rows) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
-    const bool fuse_norm = S == 1 && P0 == 0 && M <= 16 && D % 128 == 0 && F % 128 == 0;
+    const bool fuse_norm = S == 1 && P0 == 0 && M <= 32 && D % 128 == 0 && F % 128 == 0;
     const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
-    const bool p8 = !fuse_norm && M > 16 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
+    const bool p8 = !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
     const bool p8_qkv = p8 && gemm_pp_fp8_supported(M, 3 * D, D, false, true), p8_o = p8 && gemm_pp_fp8_supported(M, D, D, false, false);
     const bool p8_gu = p8 && gemm_pp_fp8_supported(M, 2 * F, D, true, false), p8_down = p8 && gemm_pp_fp8_supported(M, D, F, false, false);
     auto norm_quant = [&](const float* nw) -> int {   // RMSNorm(h) -> FP8 rows + scales (fused for d = 4096)
@@ -524,6 +528,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.kc = kc;
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
+        qr.row_pos = row_pos;
         if (p8_qkv) {
             RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wqkv8p, L.sqkv, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, M, 3 * D, D, &qr, w.sk, st));
         } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
@@ -554,7 +559,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         {
             const int64_t r0 = P0;  // first row of the per-sequence part
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                       (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
+                       (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
+            a.row_pos = row_pos;
             if (!prefix_done) RV_TRY(k_attention(a, st));
             if (p8_o) {
                 RV_TRY(k_quant_rows_fp8(w.a16, D, w.x8, D, w.sa, M, (int)D, st));
@@ -628,4 +634,24 @@ extern "C" int rv_llm_prefill_shared(rv_ctx* c, float* h, int32_t B, int32_t P0,
     RV_CHECK_ARG(B > 0 && S > 0 && P0 > 0, "rv_llm_prefill_shared: empty problem");
     RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_shared: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
     return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));
+}
+
+// ---- several generates sharing one KV pool (merged decode steps) ------------------------------------------------------------
+extern "C" int rv_llm_prefill_pool(rv_ctx* c, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows, int32_t kv_row0,
+                                   int32_t Smax, float* logits, void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws, "rv_llm_prefill_pool: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(B > 0 && S > 0 && P0 >= 0, "rv_llm_prefill_pool: empty problem");
+    RV_CHECK_ARG(kv_rows >= B && kv_row0 >= 0 && kv_row0 + B <= kv_rows, "rv_llm_prefill_pool: rows %d..%d outside a pool of %d rows", kv_row0, kv_row0 + B, kv_rows);
+    RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_pool: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
+    return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), kv_rows, kv_row0, nullptr);
+}
+
+extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && row_pos && kv && logits && ws, "rv_llm_decode_rows: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(R > 0 && R <= 32, "rv_llm_decode_rows: 1 .. 32 rows per step (got %d)", R);
+    RV_CHECK_ARG(Smax % 32 == 0, "rv_llm_decode_rows: Smax=%d must be a multiple of 32", Smax);
+    return llm_forward_impl(c, h, R, 1, 0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), R, 0, row_pos);
 }

@@ -527,8 +527,9 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
     return r.v;
 }
 
-template <int NT, int WP>
-__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* xp, int kb, typename GemvW<WP>::frag (&wf)[NT], bf16x8 (&xf)[4]) {
+template <int NT, int WP, int MB>
+__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* const (&xp)[MB], int kb, typename GemvW<WP>::frag (&wf)[NT],
+                                          bf16x8 (&xf)[MB][4]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (WP == 2) {
@@ -541,7 +542,9 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *(const bf16x8*)(xp + kb * 128 + j * 32);
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[mb][j] = *(const bf16x8*)(xp[mb] + kb * 128 + j * 32);
 }
 template <int WP>
 __device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, int j) {
@@ -549,13 +552,18 @@ __device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, i
     else return w[j];
 }
 
-template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2>
+// MB = batch-row blocks of 16 (the MFMA's column operand): MB = 2 serves 17 .. 32 rows - two MFMAs per weight fragment, the
+// weights still stream exactly once (several recursions' decode steps merged into one pass).  Row b = mb * 16 + (lane & 15);
+// every per-row quantity (accumulators, epilogue, RMSNorm partial sums) is handled per block with unchanged arithmetic, so a
+// row's result does not depend on MB or on its batch-mates.  The fused-RMSNorm partials of block mb live at
+// [mb][workgroup][16] (in_sumsq + mb * in_nblk * 16, out_sumsq + mb * gridDim.x * 16).
+template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2, int MB = 1>
 __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
                                                    int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm,
                                                    QkvRope qr) {
-    __shared__ __attribute__((aligned(16))) float red[8 * NT * 256];
-    __shared__ float ssq[32][16];
+    __shared__ __attribute__((aligned(16))) float red[8 * NT * 256 * MB];
+    __shared__ float ssq[MB][32][16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, kg = lane >> 4;
@@ -563,30 +571,44 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     const int nkb = K >> 7;
     // consumer of a fused RMSNorm: the producer's partial sums of squares are fetched now (their L2 latency hides under the
     // weight stream) and added up after it
-    float ssq_pre[8];
+    float ssq_pre[MB][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = (tid >> 4) + 32 * j;
-        ssq_pre[j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[i * 16 + (tid & 15)] : 0.f;
-    }
-    f32x4 rope_pre = f32x4{0.f, 0.f, 0.f, 0.f};   // (cos, sin) of this lane's output group, fetched under the weight stream too
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = (tid >> 4) + 32 * j;
+            ssq_pre[mb][j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (tid & 15)] : 0.f;
+        }
+    f32x4 rope_pre[MB];   // (cos, sin) of this lane's output group, fetched under the weight stream too
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) rope_pre[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (ROPE) {
         static_assert(NT == 1, "the fused RoPE epilogue is instantiated for one 16-row tile per workgroup");
-        if (wave == 0 && fr < M && n0 + kg * 4 < N) rope_pre = qkv_rope_coeffs(qr, fr, n0 + kg * 4);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            if (wave == 0 && mb * 16 + fr < M && n0 + kg * 4 < N) rope_pre[mb] = qkv_rope_coeffs(qr, mb * 16 + fr, n0 + kg * 4);
     }
     // epilogue operands of the one-tile kernels (bias, residual, next norm weight): independent of the weight stream, so
     // they are fetched under it instead of as a dependent chain in the tail of every workgroup
-    f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f}, res_pre = bias_pre, wn_pre = bias_pre;
+    f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f}, wn_pre = bias_pre, res_pre[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) res_pre[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (NT == 1 && ACT != RV_ACT_SILU_MUL && ROPE == 0) {
         const int n = n0 + kg * 4;
-        if (wave == 0 && fr < M && n < N) {
+        if (wave == 0 && n < N) {
             if (bias) bias_pre = *(const f32x4*)(bias + n);
-            if (res) res_pre = *(const f32x4*)(res + (int64_t)fr * ldr + n);
             if (nrm.out_sumsq) wn_pre = *(const f32x4*)(nrm.w_next + n);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if (res && mb * 16 + fr < M) res_pre[mb] = *(const f32x4*)(res + (int64_t)(mb * 16 + fr) * ldr + n);
         }
     }
-    const int xr = fr < M ? fr : M - 1;
-    const bf16_t* xp = X + (int64_t)xr * lda + kg * 8;
+    const bf16_t* xp[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int xr = mb * 16 + fr < M ? mb * 16 + fr : M - 1;
+        xp[mb] = X + (int64_t)xr * lda + kg * 8;
+    }
     const bf16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -604,9 +626,11 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             wp[t] = W + (int64_t)n * ldw + kg * 8;
         }
     }
-    f32x4 acc[NT];
+    f32x4 acc[MB][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int kb = wave;
     // Rolling DEPTH-deep pipeline over this wave's k-blocks (wave, wave + 8, ...): a block is re-loaded as soon as its
@@ -615,10 +639,10 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     // DEPTH = 2 everywhere: 4 was measured slower on the N = 4096 projections (down 16.8 -> 18.2 us) and level elsewhere.
     {
         typename GemvW<WP>::frag wf[DEPTH][NT];
-        bf16x8 xf[DEPTH][4];
+        bf16x8 xf[DEPTH][MB][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (kb + 8 * d < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * d, wf[d], xf[d]);
+            if (kb + 8 * d < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + 8 * d, wf[d], xf[d]);
         for (; kb < nkb; kb += 8 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -626,100 +650,115 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemv_frag<WP>(wf[d][t], j), xf[d][j], acc[t], 0, 0, 0);
-                    if (kb + 8 * (d + DEPTH) < nkb) gemv_load<NT, WP>(wp, xp, kb + 8 * (d + DEPTH), wf[d], xf[d]);
+                        for (int t = 0; t < NT; ++t) {
+                            const bf16x8 wfrag = gemv_frag<WP>(wf[d][t], j);
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb)
+                                acc[mb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, xf[d][mb][j], acc[mb][t], 0, 0, 0);
+                        }
+                    if (kb + 8 * (d + DEPTH) < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + 8 * (d + DEPTH), wf[d], xf[d]);
                 }
             }
         }
     }
 
     if (nrm.in_sumsq) {  // consumer: add up the producer's partial sums of squares (fixed order -> deterministic)
-        float a = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a += ssq_pre[j];
-        for (int i = (tid >> 4) + 256; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[i * 16 + (tid & 15)];
-        ssq[tid >> 4][tid & 15] = a;
-    }
+        for (int mb = 0; mb < MB; ++mb) {
+            float a = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
-    __syncthreads();
-    if (wave != 0) return;
-    f32x4 s[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
-    }
-    const int b = fr;  // batch row
-    if constexpr (WP == 2) {   // fp8 weights: per-output-row scale (the lane owns rows n0 + t * 16 + kg * 4 .. + 3)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t * 16 + kg * 4;
-            if (n < N) s[t] *= *(const f32x4*)(nrm.w_scale + n);
+            for (int j = 0; j < 8; ++j) a += ssq_pre[mb][j];
+            for (int i = (tid >> 4) + 256; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (tid & 15)];
+            ssq[mb][tid >> 4][tid & 15] = a;
         }
     }
-    if (nrm.in_sumsq) {
-        float tot = 0.f;
 #pragma unroll
-        for (int p = 0; p < 32; ++p) tot += ssq[p][b];
-        const float rr = rsqrtf(tot * nrm.inv_d + nrm.eps);
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) s[t] *= rr;
-    }
-    if constexpr (ROPE) {
-        if (b < M) {
+        for (int t = 0; t < NT; ++t) *(f32x4*)(red + (((wave * MB + mb) * NT + t) * 64 + lane) * 4) = acc[mb][t];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        f32x4 s[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + (((w * MB + mb) * NT + t) * 64 + lane) * 4);
+        }
+        const int b = mb * 16 + fr;  // batch row
+        if constexpr (WP == 2) {   // fp8 weights: per-output-row scale (the lane owns rows n0 + t * 16 + kg * 4 .. + 3)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int n = n0 + t * 16 + kg * 4;
-                if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre);
+                if (n < N) s[t] *= *(const f32x4*)(nrm.w_scale + n);
             }
         }
-        return;
-    }
-    if (b >= M && !nrm.out_sumsq) return;
-    if (ACT == RV_ACT_SILU_MUL) {
-        const int no = blockIdx.x * 16 + kg * 4;
-        if (n0 >= N || b >= M) return;
-        float v[4];
+        if (nrm.in_sumsq) {
+            float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
-        if (OUT_BF16) {
-            u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + no) = p;
-        } else {
-            *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+            for (int p = 0; p < 32; ++p) tot += ssq[mb][p][fr];
+            const float rr = rsqrtf(__fmaf_rn(tot, nrm.inv_d, nrm.eps));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s[t] *= rr;
         }
-    } else {
-        float sq = 0.f;
+        if constexpr (ROPE) {
+            if (b < M) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t * 16 + kg * 4;
-            if (n >= N || b >= M) continue;
-            f32x4 v = s[t];
-            if (bias) v += NT == 1 ? bias_pre : *(const f32x4*)(bias + n);
-            if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
+                for (int t = 0; t < NT; ++t) {
+                    const int n = n0 + t * 16 + kg * 4;
+                    if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre[mb]);
+                }
             }
-            if (res) v += NT == 1 ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
+            continue;
+        }
+        if (b >= M && !nrm.out_sumsq) continue;
+        if (ACT == RV_ACT_SILU_MUL) {
+            const int no = blockIdx.x * 16 + kg * 4;
+            if (n0 >= N || b >= M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
             if (OUT_BF16) {
                 u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + n) = p;
+                *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + no) = p;
             } else {
-                *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
+                *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
-            if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
-                const f32x4 wn = NT == 1 ? wn_pre : *(const f32x4*)(nrm.w_next + n);
-                *(u32x2*)((bf16_t*)nrm.xw_out + (int64_t)b * N + n) =
-                    u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
-                sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + kg * 4;
+                if (n >= N || b >= M) continue;
+                f32x4 v = s[t];
+                if (bias) v += NT == 1 ? bias_pre : *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
+                }
+                if (res) v += NT == 1 ? res_pre[mb] : *(const f32x4*)(res + (int64_t)b * ldr + n);
+                if (OUT_BF16) {
+                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + n) = p;
+                } else {
+                    *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
+                }
+                if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
+                    const f32x4 wn = NT == 1 ? wn_pre : *(const f32x4*)(nrm.w_next + n);
+                    *(u32x2*)((bf16_t*)nrm.xw_out + (int64_t)b * N + n) =
+                        u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
+                    // (explicit fma chain: the contraction hipcc picks for a*a + b*b + ... may differ between template instantiations,
+                    //  and a row's sum must not depend on how many rows it is batched with)
+                    sq = __fmaf_rn(v[3], v[3], __fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], __fmaf_rn(v[0], v[0], sq))));
+                }
             }
-        }
-        if (nrm.out_sumsq) {
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            if (kg == 0) nrm.out_sumsq[blockIdx.x * 16 + b] = b < M ? sq : 0.f;
+            if (nrm.out_sumsq) {
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                if (kg == 0) nrm.out_sumsq[((int64_t)mb * gridDim.x + blockIdx.x) * 16 + fr] = b < M ? sq : 0.f;
+            }
         }
     }
 }
@@ -751,19 +790,25 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
                        C, ldc, M, N, K, tiles_m, tiles_n);
 }
 
+template <int OUT_BF16, int ACT, int WP, int MB>
+void launch_gemv_mb(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
+    if constexpr (ACT == RV_ACT_SILU_MUL) {
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
+    } else if (N >= 16384) {
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
+    } else {
+        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
+                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
+    }
+}
 template <int OUT_BF16, int ACT, int WP>
 void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
-    if constexpr (ACT == RV_ACT_SILU_MUL) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
-    } else if (N >= 16384) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
-    } else {
-        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
-                           bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
-    }
+    if (M > 16) launch_gemv_mb<OUT_BF16, ACT, WP, 2>(A, lda, W, ldw, bias, res, ldr, C, ldc, M, N, K, st, nrm);
+    else launch_gemv_mb<OUT_BF16, ACT, WP, 1>(A, lda, W, ldw, bias, res, ldr, C, ldc, M, N, K, st, nrm);
 }
 
 }  // namespace
@@ -785,11 +830,11 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "rv_gemm: dims exceed int32");
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
-    const bool gemv = (M <= 16) && (K % 128 == 0) && (N % 16 == 0);
-    RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion / fp8 weights are only available in the M <= 16 kernel");
+    const bool gemv = (M <= 32) && (K % 128 == 0) && (N % 16 == 0);   // 17 .. 32 rows: two MFMA column blocks per weight fragment
+    RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion / fp8 weights are only available in the M <= 32 kernel");
     const GemvNorm nrm = norm ? *norm : GemvNorm{};
     if (w_layout == 2) {   // fp8 weights: the weight-streaming kernel only (decode), scales ride in the norm descriptor
-        RV_CHECK_ARG(gemv && nrm.w_scale, "rv_gemm: fp8 weights need M <= 16, K %% 128 == 0 and per-row scales");
+        RV_CHECK_ARG(gemv && nrm.w_scale, "rv_gemm: fp8 weights need M <= 32, K %% 128 == 0 and per-row scales");
         const int ob8 = out_dtype == RV_BF16;
 #define RV_GEMV8(OB, AC) launch_gemv<OB, AC, 2>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st, nrm)
         if (act == RV_ACT_SILU_MUL) { if (ob8) RV_GEMV8(1, RV_ACT_SILU_MUL); else RV_GEMV8(0, RV_ACT_SILU_MUL); }
@@ -844,16 +889,24 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)Wp;
     const int N = (int)(3 * D), K = (int)D;
-    if (M <= 16 && w_layout == 2) {
+    if (M <= 32 && w_layout == 2) {
         RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");
-        hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
-                           nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
-    } else if (M <= 16) {
-        hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
-                           nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
+        if (M > 16)
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1, 2, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                               nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
+        else
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                               nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
+    } else if (M <= 32 && (r.S == 1 || M <= 16)) {     // KV-cached decode rows (17 .. 32: several recursions' steps merged)
+        if (M > 16)
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 2, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                               nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
+        else
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+                               nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
     } else {
         RV_CHECK_ARG(w_layout == 1, "gemm_qkv_rope: the prefill path takes bf16 fragment-packed weights");
-        RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 16 kernel");
+        RV_CHECK_ARG(!norm, "gemm_qkv_rope: RMSNorm fusion is only available in the M <= 32 decode kernel");
         const bool sk = ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(1, M, N, K);
         if (sk && (rv_cur_opts().gemm_tile_variant == 5 || (rv_cur_opts().gemm_tile_variant == 2 && gemm_pp_sk_plan(M, N, K, false) != 0)))
             return gemm_pp_qkv_rope(A, lda, Wp, M, N, K, r, ws, st);
@@ -906,3 +959,4 @@ extern "C" int rv_gemm_fp8(const rv_ctx* ctx, const void* A8, int64_t lda, const
                  (long long)K);
     return gemm_pp_fp8(A8, lda, a_scale, W8p, w_scale, residual, ldr, C, ldc, out_dtype, act, M, N, K, nullptr, ws, as_stream(stream));
 }
+

@@ -49,6 +49,9 @@ struct QkvRope {
     void* kc = nullptr;         // bf16 [B, H, Smax, dh]   (this layer)
     void* vtc = nullptr;        // bf16 [B, H, dh, Smax]
     int B = 0, S = 0, P0 = 0, pos0 = 0, cs_pos0 = 0, H = 0, Smax = 0;
+    // KV-cached decode of rows at DIFFERENT positions (rows of several generates merged into one step): position of row m =
+    // row_pos[m] (device array), its (cos, sin) are row m of the table; row_pos[m] < 0 = inactive row (nothing is stored)
+    const int* row_pos = nullptr;
 };
 // Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
 // qkv_rope_coeffs fetches the (cos, sin) pairs the group needs (zeros for V columns); the decode kernel calls it BEFORE its
@@ -56,10 +59,11 @@ struct QkvRope {
 static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m, int n) {
     const int D = q.H * 128;
     const int sec = n / D, p = (n - sec * D) & 127;
+    if (sec >= 2) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q.row_pos) return *(const f32x4*)(q.cs + ((int64_t)m * 64 + (p >> 1)) * 2);   // per-row table
     int pos;
     if (m < q.P0) pos = m;
     else { const int r = m - q.P0; const int b = r / q.S; pos = q.pos0 + (r - b * q.S); }
-    if (sec >= 2) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
 }
 static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) {
@@ -67,11 +71,14 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
     const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
     int b, pos;
     bool prefix = false;
-    if (m < q.P0) { b = 0; pos = m; prefix = true; }
+    if (q.row_pos) { b = m; pos = q.row_pos[m]; if (pos < 0) return; }
+    else if (m < q.P0) { b = 0; pos = m; prefix = true; }
     else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
     if (sec < 2) {
-        const float a0 = v[0] * t[0] - v[1] * t[1], b0 = v[1] * t[0] + v[0] * t[1];
-        const float a1 = v[2] * t[2] - v[3] * t[3], b1 = v[3] * t[2] + v[2] * t[3];
+        // explicit product + fma: the contraction hipcc picks for a*b - c*d may differ between the template instantiations this
+        // inlines into, and a rotated value must not depend on which kernel (or how many rows) produced it
+        const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
+        const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
         const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
         if (sec == 0) {
             *(u32x2*)((bf16_t*)q.q16 + (int64_t)m * D + hd) = o;
@@ -133,6 +140,7 @@ int k_build_x(const void* src16, const float* src32, const float* cls, const flo
 int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st);
+int k_rope_table_rows(float* cs, const int* row_pos, int rows, int dh, float theta, hipStream_t st);   // row m: position max(row_pos[m], 0)
 int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st);
 
 struct AttnArgs {
@@ -144,6 +152,9 @@ struct AttnArgs {
     int B, H, dh, Lq, Lk, causal, q_pos0, kv_div;
     float scale;
     int no_split = 0;  // 1: never use the key-split (Lq <= 16) variant - keeps a row's arithmetic identical to a full-length launch
+    // per-batch-row positions (device array [B]; KV-cached decode, Lq = 1, of rows at different positions): row b's query sits at
+    // position row_pos[b] and sees keys 0 .. row_pos[b]; row_pos[b] < 0 = inactive row (skipped).  Lk then only bounds the strides.
+    const int* row_pos = nullptr;
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
 int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st);   // two prefill problems (dh 128) in one launch

@@ -274,6 +274,18 @@ __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int 
     cs[i] = make_float2(cosf(ang), sinf(ang));
 }
 
+// per-row positions (merged decode steps): row m of the table = position max(row_pos[m], 0)
+__global__ void rope_table_rows_kernel(float2* __restrict__ cs, const int* __restrict__ row_pos, int rows, int dh, float theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dh / 2;
+    if (i >= rows * half) return;
+    const int s = i / half, j = i % half;
+    const int pos = row_pos[s] > 0 ? row_pos[s] : 0;
+    const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)dh);
+    const float ang = (float)pos * inv;
+    cs[i] = make_float2(cosf(ang), sinf(ang));
+}
+
 // ---- embedding gather + video-row splice -> f32 residual stream ----
 __global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __restrict__ map, const bf16_t* __restrict__ embed,
                                                            const float* __restrict__ video, float* __restrict__ h, int D) {
@@ -398,6 +410,12 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st) {
     hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)cdiv((int64_t)S * (dh / 2), 256)), dim3(256), 0, st, (float2*)cs, S, pos0, dh, theta);
     RV_CHECK_LAUNCH("rope_table");
+    return RV_OK;
+}
+
+int k_rope_table_rows(float* cs, const int* row_pos, int rows, int dh, float theta, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_rows_kernel, dim3((unsigned)cdiv((int64_t)rows * (dh / 2), 256)), dim3(256), 0, st, (float2*)cs, row_pos, rows, dh, theta);
+    RV_CHECK_LAUNCH("rope_table_rows");
     return RV_OK;
 }
 

@@ -320,6 +320,38 @@ class Engine:
         return logits
 
 
+    # ---- several generates sharing one KV pool: merged decode steps ---------------------------------------------------------
+    def new_kv_pool(self, rows, Smax):
+        """One cache tensor for ``rows`` sequences ([L, rows, H, Smax, 128] + its V^T twin), zero-initialised."""
+        Smax = (Smax + 31) // 32 * 32
+        nbytes = self.lib.rv_kv_bytes(self._ctx, rows, Smax)
+        return torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device), Smax
+
+    def llm_prefill_pool(self, h, B, P0, kv, kv_rows, kv_row0, Smax, logits=None):
+        """Prefill of B sequences into rows kv_row0.. of a pool: h f32 [P0 + B*S, D] (shared prefix first; P0 = 0: [B*S, D])."""
+        assert h.dtype == torch.float32 and h.is_contiguous() and (h.shape[0] - P0) % B == 0
+        S = (h.shape[0] - P0) // B
+        if logits is None:
+            logits = torch.empty(B, self.shape.vocab, dtype=torch.float32, device=self.device)
+        ws = self._workspace("llm", self.lib.rv_llm_prefill_shared_ws_bytes(self._ctx, B, P0, S))
+        self._persist_begin()
+        hip.check(self.lib.rv_llm_prefill_pool(self._ctx, hip.ptr(h), B, P0, S, hip.ptr(kv), kv_rows, kv_row0, Smax, hip.ptr(logits), hip.ptr(ws),
+                                               ws.numel(), hip.stream()), "rv_llm_prefill_pool")
+        self._persist_end()
+        return logits
+
+    def llm_decode_rows(self, h, row_pos, kv, Smax, logits=None):
+        """One merged decode step: h f32 [R, D] (clobbered), row_pos int32 [R] on the device (< 0: inactive) -> logits f32 [R, V]."""
+        R = h.shape[0]
+        assert h.dtype == torch.float32 and h.is_contiguous() and row_pos.dtype == torch.int32 and row_pos.is_cuda
+        if logits is None:
+            logits = torch.empty(R, self.shape.vocab, dtype=torch.float32, device=self.device)
+        ws = self._workspace("llm", self.lib.rv_llm_ws_bytes(self._ctx, R, 1))
+        hip.check(self.lib.rv_llm_decode_rows(self._ctx, hip.ptr(h), R, hip.ptr(row_pos), hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws), ws.numel(),
+                                              hip.stream()), "rv_llm_decode_rows")
+        return logits
+
+
 def pair_interleave_heads(w, heads):
     """Permute the rows of a q / k projection inside every head: new row 2j = dim j, new row 2j+1 = dim j + dh/2, so the
     rotate_half partners are adjacent (the fused QKV epilogue rotates them in one lane; q.k is permutation invariant)."""

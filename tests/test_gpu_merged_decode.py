@@ -1,0 +1,109 @@
+"""Merged decode steps: several generates share one KV pool and their KV-cached decode steps run as ONE pass over the weights
+(rows at different positions, up to 32 rows).  A row's results must not depend on what it is batched with."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import SEED, T, feats, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K,act", [(21, 4096, 4096, 0), (32, 22016, 4096, 2), (17, 4096, 11008, 0), (28, 32000, 4096, 0), (21, 512, 1408 // 128 * 128, 0)])
+def test_weight_streaming_kernel_17_to_32_rows(M, N, K, act):
+    """rv_gemm with 17 .. 32 rows: the weight-streaming kernel with two MFMA column blocks per weight fragment.  Rows 0 .. 15 are
+    BIT-identical to the 16-row launch of the same rows, rows 16 .. to a 16-row launch of THOSE rows; vs float64; fp8 weights too."""
+    from revisionllm_amd import hip, ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    wp = ops.pack_fragments(w)
+    res = torch.randn(M, N // 2 if act == 2 else N, generator=g).to(dev) if act == 0 else None
+    od = torch.bfloat16 if act == 2 else torch.float32
+    y = ops.gemm(a, wp, residual=res, out_dtype=od, act=act, w_packed=True)
+    lo = ops.gemm(a[:16], wp, residual=None if res is None else res[:16], out_dtype=od, act=act, w_packed=True)
+    hi = ops.gemm(a[16:], wp, residual=None if res is None else res[16:], out_dtype=od, act=act, w_packed=True)
+    assert torch.equal(y[:16], lo) and torch.equal(y[16:], hi)
+    z = a.double() @ w.double().t()
+    if act == 2:
+        z3 = z.view(M, N // 32, 2, 16)
+        z = (torch.nn.functional.silu(z3[:, :, 0]) * z3[:, :, 1]).reshape(M, N // 2)
+    else:
+        z = z + res.double()
+    assert rel_err(y.float().cpu(), z.cpu()) < (1.5e-2 if act == 2 else 1e-4)
+    assert torch.equal(y, ops.gemm(a, w, residual=res, out_dtype=od, act=act))              # row-major weights: same sums
+    w8, sc = ops.pack_fragments_fp8(w.float())
+    y8 = ops.gemv_fp8(a, w8, sc, residual=res, out_dtype=od, act=act)
+    lo8 = ops.gemv_fp8(a[:16], w8, sc, residual=None if res is None else res[:16], out_dtype=od, act=act)
+    assert torch.equal(y8[:16], lo8)
+
+
+def _engine(layers=2, vocab=2048):
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    eng = engine.Engine(synth.LlamaShape(layers=layers, vocab=vocab), adapter_text=False, device="cuda:0")
+    eng.init_synthetic(seed=SEED, llm=True, clip=False)
+    return eng
+
+
+def test_merged_decode_rows_equal_separate_generates():
+    """Three 'generates' (7, 7 and 3 rows; prompts of different lengths: 171, 171 and 140) prefilled into ONE pool and decoded by merged
+    steps (17 then, with the third group inactive, 14 active rows) against the same three run on their own caches: logits of every
+    step BIT-identical, caches bit-identical; inactive rows leave their cache untouched."""
+    eng = _engine()
+    D, V, H = 4096, 2048, 32
+    groups = [(7, 171), (7, 171), (3, 140)]
+    R, Smax = 32, 192
+    g = torch.Generator().manual_seed(3)
+    hs = [torch.randn(B, S, D, generator=g).mul(0.02).cuda() for B, S in groups]
+    steps = 4
+    toks = [[torch.randn(B, 1, D, generator=g).mul(0.02).cuda() for _ in range(steps)] for B, S in groups]
+    # --- reference: every group on its own cache
+    ref_logits, ref_kv = [], []
+    for (B, S), h, tk in zip(groups, hs, toks):
+        kv, sm = eng.new_kv(B, Smax, reuse=False)
+        assert sm == Smax
+        out = [eng.llm_forward(h.clone(), 0, kv, Smax)]
+        for s_ in range(steps):
+            out.append(eng.llm_forward(tk[s_].clone(), S + s_, kv, Smax))
+        ref_logits.append(out)
+        ref_kv.append(kv)
+    # --- pool: rows 0-6, 7-13, 14-16 (+ 15 unused rows)
+    pool, sm = eng.new_kv_pool(R, Smax)
+    row0 = [0, 7, 14]
+    pos = torch.full((R,), -1, dtype=torch.int32, device="cuda:0")
+    first = []
+    for (B, S), h, r0 in zip(groups, hs, row0):
+        first.append(eng.llm_prefill_pool(h.clone().view(B * S, D), B, 0, pool, R, r0, Smax))
+        pos[r0:r0 + B] = S
+    for gi in range(3):
+        assert torch.equal(first[gi], ref_logits[gi][0])
+    for s_ in range(steps):
+        active = [0, 1, 2] if s_ < 2 else [0, 1]          # the third group stops after two steps
+        hrow = torch.zeros(R, D, device="cuda:0")
+        p = torch.full((R,), -1, dtype=torch.int32, device="cuda:0")
+        for gi in active:
+            B, S = groups[gi]
+            hrow[row0[gi]:row0[gi] + B] = toks[gi][s_][:, 0]
+            p[row0[gi]:row0[gi] + B] = S + s_
+        logits = eng.llm_decode_rows(hrow, p, pool, Smax)
+        for gi in active:
+            B = groups[gi][0]
+            assert torch.equal(logits[row0[gi]:row0[gi] + B], ref_logits[gi][1 + s_]), (s_, gi)
+    # caches: K rows / V^T columns of every group equal its own-cache run up to the positions it wrote
+    L = 2
+    halfp = pool.numel() // 2
+    kp = pool[:halfp].view(L, R, H, Smax, 128)
+    vp = pool[halfp:].view(L, R, H, 128, Smax)
+    for gi, ((B, S), r0) in enumerate(zip(groups, row0)):
+        n = S + (2 if gi == 2 else steps)
+        half = ref_kv[gi].numel() // 2
+        kr = ref_kv[gi][:half].view(L, B, H, Smax, 128)
+        vr = ref_kv[gi][half:].view(L, B, H, 128, Smax)
+        assert torch.equal(kp[:, r0:r0 + B, :, :n], kr[:, :, :, :n]) and torch.equal(vp[:, r0:r0 + B, :, :, :n], vr[..., :n])
+    assert (kp[:, 14:17, :, 142:] == 0).all()                 # the stopped group's rows were not written after it went inactive
+    assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
