@@ -15,7 +15,9 @@ Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (domina
 the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded sample, N = 1 only).
 
 The timed region is exactly K steps after W warm-up steps (and ``--settle`` untimed steps that belong to the set-up), with
-``--streams`` steps in flight.  ``value`` is the bf16 path, one video per step.  At N = 1 the same loop is then timed again in
+``--streams`` steps in flight whose generates decode through one ``serve.DecodeServer`` (``--merge-decode``: shared KV pool,
+every decode step ONE pass over the LLM weights for the rows of all steps in flight; records identical to running them one
+by one).  ``value`` is the bf16 path, one video per step.  At N = 1 the same loop is then timed again in
 other configurations and reported under ``extra_measurements`` (never ``value``): FP8 decode weights, the full opt-in FP8
 LLM path, two different videos batched per step, an EOS id configured (lagging device-side stop flag instead of a forced
 length), and the other BASELINE.json workloads (``stage2_long_33``, ``stage1_dense``, ``stage1_sparse``; ``--workload X`` times
@@ -55,9 +57,12 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=3,
+    p.add_argument("--streams", type=int, default=4,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
+    p.add_argument("--merge-decode", type=int, default=1,
+                   help="1: the generates of the steps in flight decode through ONE serve.DecodeServer (shared KV pool, merged decode steps: "
+                        "one pass over the LLM weights per step for all of them; rows of up to 4 recursions = 28 <= 32)")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
@@ -316,6 +321,11 @@ def main():
     torch.manual_seed(args.seed)                    # the device-side sampling draws (torch.rand in generate)
     perms = stage2.make_perms(plan, gen, W=W)
     stages = parallel.HipStages(model, tok)
+    server = None
+    if args.merge_decode:
+        from revisionllm_amd import serve
+        server = serve.DecodeServer(model, rows=32, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G))
+        stages.server = server
 
     def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
         return ([(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
@@ -331,7 +341,7 @@ def main():
         work["qs"], work["perms"] = query_set(args.queries)
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
-    inter = sched.Interleaver()
+    inter = sched.Interleaver(servers=[server] if server is not None else ())
 
     def launch():
         """Start one step as a scheduler task bound to the next HIP stream / workspace slot."""
@@ -441,7 +451,8 @@ def main():
 
     extra = {}
     if extras:
-        def leg(name, nq, fp8, fp8p=False, eos=False):
+        def leg(name, nq, fp8, fp8p=False, eos=False, merged=True):
+            stages.server = server if merged else None
             if nq > 1 and len(work["qs"]) != nq:
                 work["qs"], work["perms"] = query_set(nq)
                 work["feats"] = video_set(nq)
@@ -454,16 +465,19 @@ def main():
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
                            "decode_weights": "fp8 e4m3fn, per-row scale" if fp8 else "bf16",
                            "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
+            if not merged:
+                extra[name]["decode"] = "every step in flight runs its own decode passes (no DecodeServer): the round-1 pipeline"
             if eos:
                 extra[name]["eos"] = ("EOS id 2 configured (random-init weights practically never emit it, so all G steps still run): the cost shown is "
-                                      "that of the lagging device-side stop flag (one tiny reduction + pinned D2H copy per step, looked at one step "
-                                      "later) and of the scheduler that interleaves the passes in flight instead of a per-step host sync")
-        for name, nq, fp8, fp8p, eos in (("eos_enabled", 1, False, False, True), ("fp8_decode_weights", 1, True, False, False),
-                                         ("fp8_llm_path", 1, True, True, False), ("two_videos_per_step", 2, False, False, False),
-                                         ("two_videos_per_step_fp8_decode_weights", 2, True, False, False),
-                                         ("two_videos_per_step_fp8_llm_path", 2, True, True, False)):
+                                      "that of the device-side stop flags (one tiny reduction + pinned D2H copy per generate and step, looked at when "
+                                      "the copy has landed: never a host wait)")
+        for name, nq, fp8, fp8p, eos, merged in (("eos_enabled", 1, False, False, True, True), ("separate_decode_passes", 1, False, False, False, False),
+                                                 ("fp8_decode_weights", 1, True, False, False, True),
+                                                 ("fp8_llm_path", 1, True, True, False, True), ("two_videos_per_step", 2, False, False, False, True),
+                                                 ("two_videos_per_step_fp8_decode_weights", 2, True, False, False, True),
+                                                 ("two_videos_per_step_fp8_llm_path", 2, True, True, False, True)):
             try:
-                leg(name, nq, fp8, fp8p, eos)
+                leg(name, nq, fp8, fp8p, eos, merged)
             except Exception as e:  # noqa: BLE001 - an extra leg must never cost the headline line
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 try:
@@ -473,6 +487,7 @@ def main():
         eng.set_option("fp8_decode", 0)
         eng.set_option("fp8_prefill", 0)
         model.generation_config.eos_token_id = None
+        stages.server = server
         # the other BASELINE.json workloads
         try:
             plan33 = stage2.plan_groups(33, 33)
@@ -536,6 +551,9 @@ def main():
                        "recursion": "batched (CLS per window encoded once, the 7 calls of a recursion batched in one generate)",
                        "eos": "id 2, lagging device-side stop flag" if args.eos else "disabled (forced decode length)",
                        "steps_in_flight": max(1, args.streams), "settle_steps": args.settle, **wl_cfg,
+                       "decode": ("merged: the generates of the steps in flight share one KV pool and every decode step is ONE pass over the weights for all "
+                                  "their rows (serve.DecodeServer; %.1f rows per merged step)" % (server.rows_served / max(1, server.steps_run))
+                                  if server is not None else "per step: every step in flight runs its own decode passes"),
                        "parallelism": (f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals"
                                        if world > 1 else "single GPU")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],

@@ -793,14 +793,16 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 template <int OUT_BF16, int ACT, int WP, int MB>
 void launch_gemv_mb(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                     int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
+    // MB = 2 needs > 128 VGPRs: one workgroup per CU instead of two, so it keeps the bytes in flight per CU with a deeper ring
+    constexpr int D2 = MB == 2 ? 3 : 2, D1 = MB == 2 ? 4 : 2;
     if constexpr (ACT == RV_ACT_SILU_MUL) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else if (N >= 16384) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else {
-        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP, 0, 2, MB>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP, 0, D1, MB>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     }
 }
@@ -892,14 +894,14 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
     if (M <= 32 && w_layout == 2) {
         RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");
         if (M > 16)
-            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1, 2, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1, 4, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
     } else if (M <= 32 && (r.S == 1 || M <= 16)) {     // KV-cached decode rows (17 .. 32: several recursions' steps merged)
         if (M > 16)
-            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 2, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 4, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,

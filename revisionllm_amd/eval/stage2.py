@@ -180,7 +180,7 @@ def launch_calls(model, tokenizer, query, rows, calls, uniforms=None, max_new_to
 
 
 def launch_calls_steps(model, tokenizer, query, rows, calls, uniforms=None, max_new_tokens=1024, max_calls_per_generate=16, width=None,
-                       forced_tokens=None):
+                       forced_tokens=None, server=None):
     """Step generator (``revisionllm_amd.sched``): enqueue the LLM work for the given call indices WITHOUT waiting for it; with an
     EOS id configured it yields the events of the lagging "all rows finished" flags (``generate_steps``), otherwise never.  ``query`` is one prompt for all calls or a {call: prompt} mapping (several queries of one movie batched
     together).  Calls whose prompts have the same length (same number of video rows and of text tokens) run as one batched
@@ -206,7 +206,8 @@ def launch_calls_steps(model, tokenizer, query, rows, calls, uniforms=None, max_
             forced = None if forced_tokens is None else forced_tokens[:, sel]       # [G, calls]: teacher forcing (parity tests)
             out = yield from model.generate_steps(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows,
                                                   do_sample=True, temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens,
-                                                  output_scores=False, return_dict_in_generate=True, uniforms=u, forced_tokens=forced)
+                                                  output_scores=False, return_dict_in_generate=True, uniforms=u, forced_tokens=forced,
+                                                  server=server)
             order.extend(sel)
             toks.append(out["sequences"][:, ids.shape[1]:])
             ents.append(out["entropy"])

@@ -226,7 +226,7 @@ class ReVisionLlamaForCausalLM:
                        max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
                        return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
                        attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
-                       share_prefix=True, eos_lookahead=1, **kwargs):
+                       share_prefix=True, eos_lookahead=1, server=None, **kwargs):
         """``generate`` as a generator: enqueues device work and YIELDS a ``torch.cuda.Event`` whenever the host has to learn
         something from the device before it may enqueue more - which only happens with an EOS id configured: the "all rows
         finished" flag of step s is copied to pinned host memory asynchronously and looked at only after step s + ``eos_lookahead``
@@ -239,7 +239,10 @@ class ReVisionLlamaForCausalLM:
         Extra, build-defined kwargs: ``uniforms`` [G,B] (host-supplied draws for reproducible sampling; default
         ``torch.rand`` on the device), ``forced_tokens`` [G,B] (teacher forcing for parity tests),
         ``video_rows`` / ``rows_per_sample`` (pre-encoded adapter output, used by the batched recursion),
-        ``share_prefix`` (the text prefix common to all rows goes through the prefill once; bit-identical results).
+        ``share_prefix`` (the text prefix common to all rows goes through the prefill once; bit-identical results),
+        ``server`` (a ``serve.DecodeServer``: prefill into its KV pool, then let ITS merged steps decode this generate's rows
+        together with the other generates in flight - same tokens / entropies, one pass over the weights per step for all of
+        them; only under ``sched.Interleaver(servers=[server])``; falls back to the loop below when it does not apply).
         ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
         """
         if num_beams != 1:
@@ -268,9 +271,40 @@ class ReVisionLlamaForCausalLM:
             forced_tokens = ops.h2d(forced_tokens, dev, torch.long)
         row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
         B, S = row_map.shape
+        P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
+        job = None
+        if (server is not None and not output_scores and not output_logits and self.after_prefill is None
+                and server.fits(S, max_new_tokens) and max_new_tokens >= 1):
+            job = server.reserve(B)
+        if job is not None:
+            # ---- merged-decode path: prefill into the server's pool, its merged steps do the rest ----
+            if job.free_event is not None:
+                torch.cuda.current_stream(dev).wait_event(job.free_event)       # the rows' previous owner is done with them
+            if 16 <= P0 < S:
+                flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
+                h = eng.splice_embed(flat, video_rows)[0]
+                first = eng.llm_prefill_pool(h, B, P0, server.kv, server.R, job.r0, server.Smax)
+            else:
+                h = eng.splice_embed(row_map, video_rows).view(B * S, -1)
+                first = eng.llm_prefill_pool(h, B, 0, server.kv, server.R, job.r0, server.Smax)
+            if do_sample and uniforms is None:
+                uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
+                            else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
+            ready = torch.cuda.Event()
+            ready.record()
+            yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
+            server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
+                        uniforms=uniforms if do_sample else None, forced=forced_tokens)
+            from .. import sched
+            while not job.finished:
+                yield sched.RETRY           # the scheduler pumps the server's merged steps
+            yield job.done_event
+            seqs = torch.cat([ops.h2d(input_ids, dev, torch.long), job.tokens.long()], dim=1)
+            if not return_dict_in_generate:
+                return seqs
+            return GenerateOutput(sequences=seqs, entropy=job.entropy, entropy_raw=job.entropy_raw)
         cap = min(max_new_tokens, 64)
         kv, Smax = eng.new_kv(B, S + cap)
-        P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
         if 16 <= P0 < S:     # (P0 == S: identical text-only rows - nothing per-row is left, take the plain prefill)
             # every row starts with the same P0 text tokens (inference() repeats one prompt): under causal attention their
             # hidden states and K/V are identical for all rows, so they ride through the prefill once (rows of the

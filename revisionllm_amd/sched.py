@@ -72,10 +72,12 @@ class _null:
 
 class Interleaver:
     """Tasks in launch order.  ``add`` starts a task (runs it up to its first pending event); ``finish(task)`` returns its
-    result, advancing every other ready task while it waits."""
+    result, advancing every other ready task while it waits.  ``servers``: objects with ``pump() -> bool`` / ``wait_one() -> bool``
+    (``serve.DecodeServer``: the merged decode steps of the generates in flight) that are pumped along with the tasks."""
 
-    def __init__(self):
+    def __init__(self, servers=()):
         self.tasks = []
+        self.servers = list(servers)
 
     def add(self, task):
         self.tasks.append(task)
@@ -86,14 +88,21 @@ class Interleaver:
         progressed = False
         for t in self.tasks:
             progressed |= t.advance()
+        for sv in self.servers:
+            progressed |= sv.pump()
         return progressed
 
     def finish(self, task):
         task.finishing = True
         while not task.done:
             if not self.pump():
-                # nothing is ready: wait for the event of the task we want (the others keep their queued device work)
+                # nothing is ready: wait for the event of the task we want (the others keep their queued device work), or for the
+                # oldest merged step a server has in flight (which lets it enqueue the next one)
                 if task.waiting is not None:
                     task.waiting.synchronize()
+                elif not any(sv.wait_one() for sv in self.servers):
+                    pending = [t.waiting for t in self.tasks if t.waiting is not None]
+                    if pending:
+                        pending[0].synchronize()
         self.tasks.remove(task)
         return task.result

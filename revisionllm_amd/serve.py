@@ -1,0 +1,232 @@
+"""Merged decode steps of several generates in flight ("continuous batching" of the KV-cached decode loop).
+
+A KV-cached decode step streams all 13.2 GB of LLM weights whatever the number of rows (<= 32: the weight-streaming kernel
+carries up to 32 batch rows in the MFMA's column operand), and a stage-2 recursion only brings 7 rows (its 7 calls).  With several
+recursions in flight - each on its own HIP stream - a ``DecodeServer`` gives them ONE shared KV pool and runs their decode steps
+as one pass over the weights: every generate prefills into its rows of the pool (``rv_llm_prefill_pool``), joins when its prefill
+has completed, and from then on every merged step (``rv_llm_decode_rows``: each row at its OWN position) samples one token for
+every active row.  A row's tokens / entropies are bit-identical to what its generate produces alone: per-row arithmetic does not
+depend on the batch (tests/test_gpu_merged_decode.py).
+
+Scope: generates that sample (or are teacher-forced) with the engine's token-selection kernel and need ``sequences`` + step
+entropies - what the recursion drivers use; ``output_scores`` / ``output_logits`` fall back to the classic loop.  With an EOS id
+configured a row that has emitted it produces the pad id from then on (HF's ``_sample`` bookkeeping) and a generate leaves the
+pool one step after ALL its rows have finished: its "any row unfinished" flag goes to pinned host memory after every step and is
+looked at when its copy has completed - never a host wait; the surplus step is cut off.
+Driven cooperatively from ``sched.Interleaver`` (no threads): ``pump()`` enqueues at most ``max_ahead`` merged steps ahead of
+the device so that a generate whose prefill completes can join the very next steps.
+"""
+import collections
+
+import torch
+
+from . import hip, ops
+
+
+class Job:
+    """Rows r0 .. r0 + B - 1 of the pool, owned by one generate from ``reserve`` until its results are out."""
+
+    def __init__(self, r0, B):
+        self.r0, self.B = r0, B
+        self.step, self.steps = 0, 0
+        self.uniforms = self.forced = None
+        self.joined = self.finished = False
+        self.done_event = None
+        self.tokens = self.entropy = self.entropy_raw = None
+        self.flag_host, self.flag_events = None, collections.deque()     # EOS: pinned per-step "any row unfinished" flags + their copy events
+
+
+class DecodeServer:
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97):
+        eng = model.engine
+        assert 1 <= rows <= 32
+        self.model, self.eng, self.R, self.G, self.max_ahead, self.slot = model, eng, rows, gmax, max_ahead, slot
+        dev = eng.device
+        self.kv, self.Smax = eng.new_kv_pool(rows, smax)
+        V = eng.shape.vocab
+        self.logits = torch.zeros(rows, V, dtype=torch.float32, device=dev)
+        self.pos = torch.full((rows,), -1, dtype=torch.int32, device=dev)        # next position of every row; < 0: inactive
+        self.stepidx = torch.zeros(rows, dtype=torch.int64, device=dev)          # column of the per-row outputs the next token goes to
+        self.tok_out = torch.zeros(rows, gmax, dtype=torch.int32, device=dev)
+        self.ent_out = torch.zeros(rows, gmax, dtype=torch.float32, device=dev)
+        self.entr_out = torch.zeros(rows, gmax, dtype=torch.float32, device=dev)
+        self.uni = torch.full((rows,), 0.5, dtype=torch.float32, device=dev)
+        self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)      # EOS bookkeeping: 0 once a row has emitted the EOS id
+        self.stream = torch.cuda.Stream(dev)
+        self.free = [(0, rows, None)]            # (first row, count, event after which the rows may be overwritten)
+        self.jobs = []                           # joined, not finished
+        self.draining = []                       # (EOS) all steps enqueued, waiting for their stop flags to land before the cut
+        self.in_flight = collections.deque()     # events of the merged steps enqueued and not yet seen complete
+        self.sampling = None                     # (do_sample, temperature, top_k, top_p) of the jobs in the pool (must agree)
+        self.steps_run = self.rows_served = 0
+
+    # ---- slots ---------------------------------------------------------------------------------------------------------------
+    def reserve(self, B):
+        """-> Job with B contiguous rows, or None when the pool has no room (the caller then runs its classic loop)."""
+        for i, (r0, n, ev) in enumerate(self.free):
+            if n >= B:
+                self.free[i:i + 1] = [(r0 + B, n - B, ev)] if n > B else []
+                job = Job(r0, B)
+                job.free_event = ev
+                return job
+        return None
+
+    def _release(self, job, event):
+        self.free.append((job.r0, job.B, event))
+        self.free.sort()
+        merged = []
+        for r0, n, ev in self.free:          # coalesce neighbours (their events: keep the later one = wait for both is not possible with
+            if merged and merged[-1][0] + merged[-1][1] == r0 and merged[-1][2] is ev:   # one event, so only identical events merge)
+                merged[-1] = (merged[-1][0], merged[-1][1] + n, ev)
+            else:
+                merged.append((r0, n, ev))
+        self.free = merged
+
+    def fits(self, S, max_new_tokens):
+        return S + max_new_tokens <= self.Smax and max_new_tokens <= self.G
+
+    # ---- joining -------------------------------------------------------------------------------------------------------------
+    def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None):
+        """The job's prefill has been enqueued (``ready_event`` recorded after it on the prefill's stream): hand its rows to the
+        merged steps.  ``first_logits`` [B, V]: the prefill's last-position logits; ``uniforms`` / ``forced`` [steps, B] device tensors."""
+        if self.sampling is None or not self.jobs:
+            self.sampling = sampling
+        elif self.sampling != sampling:
+            raise ValueError(f"DecodeServer: sampling settings {sampling} differ from those of the generates in the pool {self.sampling}")
+        job.steps, job.uniforms, job.forced = steps, uniforms, forced
+        r = slice(job.r0, job.r0 + job.B)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready_event)
+            self.logits[r].copy_(first_logits)
+            self.pos[r] = S
+            self.stepidx[r] = 0
+            self.unfinished[r] = 1
+        first_logits.record_stream(self.stream)
+        job.joined = True
+        self.jobs.append(job)
+
+    # ---- one merged step -----------------------------------------------------------------------------------------------------
+    def pump(self):
+        """Enqueue one merged step if there is work and the device is not already ``max_ahead`` steps behind.  -> progressed?"""
+        while self.in_flight and self.in_flight[0].query():
+            self.in_flight.popleft()
+        progressed = self._drain() if self.draining else False
+        if not self.jobs or len(self.in_flight) >= self.max_ahead:
+            return progressed
+        self._step()
+        return True
+
+    def _drain(self):
+        """Generates whose last step has been enqueued: once all their stop flags have landed, cut at the EOS step and hand over."""
+        left, done = [], False
+        for job in self.draining:
+            if all(fe.query() for _, fe in job.flag_events):
+                n = job.steps
+                for s_, _ in job.flag_events:
+                    if int(job.flag_host[s_]) == 0:
+                        n = s_ + 1
+                        break
+                prev = self.eng.slot
+                with torch.cuda.stream(self.stream):
+                    self._finish(job, n)
+                self.eng.slot = prev
+                done = True
+            else:
+                left.append(job)
+        self.draining = left
+        return done
+
+    def wait_one(self):
+        """Block until the oldest enqueued merged step has completed (called by the scheduler when nothing else can progress)."""
+        if self.in_flight:
+            self.in_flight.popleft().synchronize()
+            return True
+        if self.draining:
+            self.draining[0].flag_events[-1][1].synchronize()
+            return True
+        return False
+
+    def _finish(self, job, n):
+        """The generate has produced its ``n`` tokens: results out (clones: the rows are reused), rows inactive, slots free."""
+        r = slice(job.r0, job.r0 + job.B)
+        job.tokens = self.tok_out[r, :n].clone()
+        job.entropy = self.ent_out[r, :n].clone()
+        job.entropy_raw = self.entr_out[r, :n].clone()
+        self.pos[r] = -1
+        job.done_event = torch.cuda.Event()
+        job.done_event.record(self.stream)
+        job.finished = True
+        self._release(job, job.done_event)
+
+    def _step(self):
+        eng = self.eng
+        do_sample, temperature, top_k, top_p = self.sampling
+        gc = self.model.generation_config
+        eos, pad = gc.eos_token_id, gc.pad_token_id
+        prev_slot = eng.slot
+        eng.slot = self.slot
+        with torch.cuda.stream(self.stream):
+            if eos is not None:       # generates whose rows have ALL emitted EOS (flag copies that have landed; no host wait)
+                still = []
+                for job in self.jobs:
+                    ended = None
+                    while job.flag_events and job.flag_events[0][1].query():
+                        s_, _ = job.flag_events.popleft()
+                        if int(job.flag_host[s_]) == 0:
+                            ended = s_ + 1
+                            break
+                    if ended is not None:
+                        self._finish(job, ended)
+                    else:
+                        still.append(job)
+                self.jobs = still
+                if not self.jobs:
+                    eng.slot = prev_slot
+                    return
+            for job in self.jobs:
+                if do_sample and job.uniforms is not None:
+                    self.uni[job.r0:job.r0 + job.B].copy_(job.uniforms[job.step])
+            o = ops.sample(self.logits, self.uni if do_sample else None, do_sample, temperature, top_k, top_p, ctx=eng)
+            tokens = o["tokens"]
+            for job in self.jobs:
+                if job.forced is not None:
+                    tokens[job.r0:job.r0 + job.B] = job.forced[job.step].int()
+            active = self.pos >= 0
+            if eos is not None:       # rows that already emitted EOS keep producing the pad id
+                tokens = tokens * self.unfinished + pad * (1 - self.unfinished)
+                self.unfinished = self.unfinished * (tokens != eos).int()
+            tokens = torch.where(active, tokens, torch.zeros_like(tokens))
+            col = self.stepidx.clamp(max=self.G - 1)[:, None]          # (rows that are done keep their last index)
+            self.tok_out.scatter_(1, col, tokens[:, None])
+            self.ent_out.scatter_(1, col, o["entropy_proc"][:, None])
+            self.entr_out.scatter_(1, col, o["entropy_raw"][:, None])
+            self.stepidx += active.long()
+            self.rows_served += sum(j.B for j in self.jobs)
+            self.steps_run += 1
+            still = []
+            for job in self.jobs:
+                if eos is not None:
+                    if job.flag_host is None:
+                        job.flag_host = torch.empty(job.steps, dtype=torch.int32).pin_memory()
+                    job.flag_host[job.step:job.step + 1].copy_(self.unfinished[job.r0:job.r0 + job.B].max().reshape(1), non_blocking=True)
+                    fe = torch.cuda.Event()
+                    fe.record(self.stream)
+                    job.flag_events.append((job.step, fe))
+                job.step += 1
+                if job.step >= job.steps:          # its last token has just been sampled
+                    if eos is not None:            # an earlier step may already have ended it: decided when its flags have landed
+                        self.pos[job.r0:job.r0 + job.B] = -1
+                        self.draining.append(job)
+                    else:
+                        self._finish(job, job.steps)
+                else:
+                    still.append(job)
+            self.jobs = still
+            if self.jobs:
+                h = eng.splice_embed(tokens[:, None], None).view(self.R, -1)
+                eng.llm_decode_rows(h, self.pos, self.kv, self.Smax, logits=self.logits)
+                self.pos += (self.pos >= 0).int()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.in_flight.append(ev)
+        eng.slot = prev_slot

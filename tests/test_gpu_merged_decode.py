@@ -107,3 +107,92 @@ def test_merged_decode_rows_equal_separate_generates():
         assert torch.equal(kp[:, r0:r0 + B, :, :n], kr[:, :, :, :n]) and torch.equal(vp[:, r0:r0 + B, :, :, :n], vr[..., :n])
     assert (kp[:, 14:17, :, 142:] == 0).all()                 # the stopped group's rows were not written after it went inactive
     assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
+
+
+def _tiny_model():
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    m = ReVisionLlamaForCausalLM(synth.TINY, device="cuda:0")
+    m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None,
+                                                            pretrain_mm_mlp_adapter=None, clip_adapter_text=True, clip_adapter_feature="cls",
+                                                            hierarchy=True, adapter_input_dim=768))
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=True)
+    m.generation_config.eos_token_id = None
+    return m
+
+
+@pytest.mark.parametrize("n_passes,streams", [(3, 3), (5, 2)])
+def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams):
+    """Several stage-2 recursions in flight on their own HIP streams, their generates decoding through ONE DecodeServer (shared KV
+    pool, merged steps with rows at different positions, rows joining and leaving as prefills complete) against the same
+    recursions run one after the other through the classic loop: records identical (answers, entropies, cosine scores)."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    tok = synth.FakeTokenizer(vocab=synth.TINY.vocab)
+    st = parallel.HipStages(m, tok)
+    W, batch = 13, 8
+    feat = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
+    qfs = [feats(f"ms.q{i}", (5 + i % 3, 768), bf16=True).to(torch.bfloat16).cuda() for i in range(n_passes)]
+    qc = feats("s2.qc", (768,)).cuda()
+    plan = stage2.plan_groups(W, batch)                      # 4 + 2 + 2 calls -> generates of 8 rows (same row count per level here)
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
+    unis = [torch.rand(6, len(plan), generator=torch.Generator().manual_seed(10 + i)) for i in range(n_passes)]
+    kw = dict(batch=batch, perms=[perms], max_new_tokens=6)
+    seq = [parallel.run_queries_sharded(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], uniforms=unis[i], **kw)[0] for i in range(n_passes)]
+    server = serve.DecodeServer(m, rows=32, smax=128, gmax=16)
+    st.server = server
+    hs = [torch.cuda.Stream("cuda:0") for _ in range(streams)]
+    torch.cuda.synchronize()
+    inter = sched.Interleaver(servers=[server])
+    pending, par = [], []
+    for i in range(n_passes):
+        pending.append(inter.add(sched.Task(lambda t, i=i: parallel.launch_queries_sharded_steps(st, tok, feat, W, [(qfs[i], qc, f"query {i}")],
+                                                                                              uniforms=unis[i], turn=t, **kw),
+                                            hs[i % streams], m.engine, i % streams)))
+        if len(pending) > streams:
+            par.append(parallel.collect_queries(inter.finish(pending.pop(0)))[0])
+    while pending:
+        par.append(parallel.collect_queries(inter.finish(pending.pop(0)))[0])
+    m.engine.slot = 0
+    assert server.steps_run > 0 and server.rows_served > server.steps_run * len(plan) * 0.99      # the merged steps really carried the rows
+    if n_passes == 3:
+        assert server.rows_served > server.steps_run * len(plan)                                   # ... of more than one recursion at a time
+    for a, b in zip(seq, par):
+        assert a["answers"] == b["answers"] and a["max_entropy"] == b["max_entropy"] and a["mean_entropy"] == b["mean_entropy"]
+        assert a["score_cos"] == b["score_cos"]
+    assert not server.jobs and sum(n for _, n, _ in server.free) == 32                             # every row was given back
+
+
+def test_decode_server_with_eos_equals_classic_loop():
+    """EOS in the merged path: generates whose rows emit EOS at different steps (teacher-forced) leave the pool early; sequences and
+    entropies equal the classic loop's (pad after a row's EOS, cut at the step where all rows are done)."""
+    from revisionllm_amd import sched, serve
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    m.generation_config.eos_token_id, m.generation_config.pad_token_id = 2, 0
+    P = 40
+    ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
+    cases = []
+    forced_sets = [torch.tensor([[7, 9, 11], [2, 12, 13], [5, 14, 15], [6, 2, 2], [8, 9, 10], [8, 9, 10]]),           # ends after step 3
+                   torch.tensor([[9, 9], [9, 9], [9, 9], [9, 9], [9, 9], [9, 9]]),                                       # never ends: 6 steps
+                   torch.tensor([[2], [9], [9], [9], [9], [9]])]                                                         # ends at step 0
+    for i, forced in enumerate(forced_sets):
+        B = forced.shape[1]
+        feat = feats(f"eoss.feat{i}", (B, 6, 16, 768), bf16=True)
+        q = (feats(f"eoss.q{i}", (B, 5, 768), bf16=True), torch.ones(B, 5))
+        kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=6, forced_tokens=forced, return_dict_in_generate=True,
+                  uniforms=torch.full((6, B), 0.5))
+        cases.append((ids.repeat(B, 1), kw, m.generate(ids.repeat(B, 1), **kw)))
+    assert [c[2]["sequences"].shape[1] - P for c in cases] == [4, 6, 1]
+    server = serve.DecodeServer(m, rows=16, smax=96, gmax=8)
+    inter = sched.Interleaver(servers=[server])
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
+    tasks = [inter.add(sched.Task(m.generate_steps(c[0], server=server, **c[1]), streams[i], m.engine, i)) for i, c in enumerate(cases)]
+    outs = [inter.finish(t) for t in tasks]
+    m.engine.slot = 0
+    for (ids_, kw, want), got in zip(cases, outs):
+        assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
+        assert torch.equal(got["entropy_raw"], want["entropy_raw"])
+    assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16

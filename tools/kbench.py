@@ -47,7 +47,7 @@ def main():
             us = timeit(lambda: ops.gemm(x, w, out=out, act=act, w_packed=True, ctx=opt))
             print(f"gemm {name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
     if "gemv" in which:
-        for M in (1, 7, 16):
+        for M in (7, 16, 21, 28):
             for name, N, K, act, od in (("qkv", 3 * D, D, 0, torch.float32), ("o", D, D, 0, torch.float32),
                                         ("gateup", 2 * F, D, 2, torch.bfloat16), ("down", D, F, 0, torch.float32),
                                         ("lm_head", V, D, 0, torch.float32)):
