@@ -156,7 +156,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
                 v0 += sm_o[w][q][dc + j] * sc[w];
                 v1 += sm_o[w][q][dc + j + 1] * sc[w];
             }
-            *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
+            if (a.out_packed) *(uint32_t*)((bf16_t*)a.out + rv_xp_index(b, h * DH + dc + j)) = pack_bf16x2(v0 * inv, v1 * inv);   // (Lq = 1)
+            else *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
         }
         return;
     }

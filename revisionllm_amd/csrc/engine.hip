@@ -447,10 +447,11 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     LlmWs w;
     w.sk_bytes = gemm_pp_ws_bytes();
     w.sk = k.take(w.sk_bytes);
-    w.xn16 = (bf16_t*)k.take((size_t)M * D * 2);
+    const int64_t Mp = M < 32 ? 32 : M;   // the fragment-packed decode layout always spans 32 rows
+    w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
-    w.a16 = (bf16_t*)k.take((size_t)M * D * 2);
-    w.act16 = (bf16_t*)k.take((size_t)M * F * 2);
+    w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2);
+    w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.ss = (float*)k.take((size_t)2 * (D / 16) * 16 * 4);   // [<= 2 row blocks][D/16 workgroups][16]
@@ -510,17 +511,22 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         return k_quant_rows_fp8(w.xn16, D, w.x8, D, w.sa, M, (int)D, st);
     };
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
+    // KV-cached decode steps keep their bf16 activations (xn16, a16, act16) fragment-packed (GemvNorm::x_packed): with 17 .. 32
+    // rows the row-major operand loads would cost the address units more than the weight stream
+    const int xp = fuse_norm ? 1 : 0;
     GemvNorm consume;
     consume.in_sumsq = w.ss;
     consume.in_nblk = nb_d;
     consume.inv_d = 1.0f / (float)D;
     consume.eps = g.rms_eps;
+    consume.x_packed = xp;
+    consume.out_packed = xp;
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         if (p8_qkv) RV_TRY(norm_quant(L.norm1));
-        else if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
+        else if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st, xp));
         // fused q/k/v projection: RoPE-rotated Q -> q16, rotated K and V^T -> this layer's cache (no f32 qkv round trip)
         QkvRope qr;
         qr.cs = w.cs;
@@ -534,9 +540,12 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
             GemvNorm cq = (fuse_norm && l > 0) ? consume : GemvNorm{};
             cq.w_scale = L.sqkv;
+            cq.x_packed = xp;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv8, M, D, qr, &cq, nullptr, 0, st, 2));
         } else {
-            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, (fuse_norm && l > 0) ? &consume : nullptr, w.sk, w.sk_bytes, st));
+            GemvNorm first;       // layer 0 of a decode step: no norm to consume, but the operand layout still applies
+            first.x_packed = xp;
+            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
         if (P0 > 0) {
@@ -556,11 +565,14 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.xw_out = w.xn16;
         produce.out_sumsq = w.ss;
         produce.w_next = L.norm2;
+        produce.x_packed = xp;
+        produce.out_packed = xp;
         {
             const int64_t r0 = P0;  // first row of the per-sequence part
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
                        (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
             a.row_pos = row_pos;
+            a.out_packed = xp;
             if (!prefix_done) RV_TRY(k_attention(a, st));
             if (p8_o) {
                 RV_TRY(k_quant_rows_fp8(w.a16, D, w.x8, D, w.sa, M, (int)D, st));

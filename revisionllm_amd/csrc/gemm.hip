@@ -527,9 +527,12 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
     return r.v;
 }
 
+// x operand addressing: row-major rows (xj = 32, xkb = 128 elements per 32-k fragment / 128-k block, per-lane base = row start +
+// kg * 8) or the fragment-packed decode layout (xj = 1024, xkb = 4096: fragment (kf, mb) at (kf * 2 + mb) * 512, per-lane base =
+// mb * 512 + lane * 8; GemvNorm::x_packed)
 template <int NT, int WP, int MB>
 __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* const (&xp)[MB], int kb, typename GemvW<WP>::frag (&wf)[NT],
-                                          bf16x8 (&xf)[MB][4]) {
+                                          bf16x8 (&xf)[MB][4], int xj, int xkb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (WP == 2) {
@@ -544,7 +547,7 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[mb][j] = *(const bf16x8*)(xp[mb] + kb * 128 + j * 32);
+        for (int j = 0; j < 4; ++j) xf[mb][j] = *(const bf16x8*)(xp[mb] + (int64_t)kb * xkb + j * xj);
 }
 template <int WP>
 __device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, int j) {
@@ -557,11 +560,23 @@ __device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, i
 // every per-row quantity (accumulators, epilogue, RMSNorm partial sums) is handled per block with unchanged arithmetic, so a
 // row's result does not depend on MB or on its batch-mates.  The fused-RMSNorm partials of block mb live at
 // [mb][workgroup][16] (in_sumsq + mb * in_nblk * 16, out_sumsq + mb * gridDim.x * 16).
-template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2, int MB = 1>
-__global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
+//
+// NW = physical waves of the workgroup (8 or 4).  The k-blocks are always dealt to 8 VIRTUAL waves (block kb -> virtual wave
+// kb % 8, summed in ascending kb, the 8 partial sums added in order 0 .. 7), so the floating-point result does not depend on NW:
+// with NW = 4 a physical wave carries the two virtual waves (wave, wave + 4) in separate accumulators.  MB = 2 needs ~2x the
+// registers (<= 256 VGPRs, 2 waves per SIMD): as ONE 512-thread workgroup per CU its prologue (first loads: a full HBM latency)
+// and its tail (cross-wave reduction + epilogue) run with nothing else resident on the CU; as TWO independent 256-thread
+// workgroups the other one keeps streaming.
+template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2, int MB = 1, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
                                                    int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm,
                                                    QkvRope qr) {
+    static_assert(NW == 8 || NW == 4, "8 virtual waves on 8 or 4 physical ones");
+    static_assert(MB <= NW, "one epilogue wave per row block");
+    constexpr int VW = 8 / NW;                                      // virtual waves per physical wave
+    constexpr int U = DEPTH % VW == 0 ? DEPTH : DEPTH * VW;         // stages per trip of the main loop (ring slot u % DEPTH, virtual wave u % VW)
+    constexpr bool PRE = NW == 8;                                   // prefetch the fused-RMSNorm partial sums under the weight stream
     __shared__ __attribute__((aligned(16))) float red[8 * NT * 256 * MB];
     __shared__ float ssq[MB][32][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -569,45 +584,41 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
     const int fr = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nkb = K >> 7;
+    const int emb = wave < MB ? wave : 0;   // the row block whose epilogue this wave runs (waves >= MB leave after the reduction)
     // consumer of a fused RMSNorm: the producer's partial sums of squares are fetched now (their L2 latency hides under the
     // weight stream) and added up after it
-    float ssq_pre[MB][8];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = (tid >> 4) + 32 * j;
-            ssq_pre[mb][j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (tid & 15)] : 0.f;
-        }
-    f32x4 rope_pre[MB];   // (cos, sin) of this lane's output group, fetched under the weight stream too
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) rope_pre[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (ROPE) {
-        static_assert(NT == 1, "the fused RoPE epilogue is instantiated for one 16-row tile per workgroup");
+    float ssq_pre[PRE ? MB : 1][8];
+    if constexpr (PRE) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
-            if (wave == 0 && mb * 16 + fr < M && n0 + kg * 4 < N) rope_pre[mb] = qkv_rope_coeffs(qr, mb * 16 + fr, n0 + kg * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = (tid >> 4) + 32 * j;
+                ssq_pre[mb][j] = (nrm.in_sumsq && i < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (tid & 15)] : 0.f;
+            }
+    }
+    f32x4 rope_pre = f32x4{0.f, 0.f, 0.f, 0.f};   // (cos, sin) of this lane's output group, fetched under the weight stream too
+    if constexpr (ROPE) {
+        static_assert(NT == 1, "the fused RoPE epilogue is instantiated for one 16-row tile per workgroup");
+        if (wave < MB && emb * 16 + fr < M && n0 + kg * 4 < N) rope_pre = qkv_rope_coeffs(qr, emb * 16 + fr, n0 + kg * 4);
     }
     // epilogue operands of the one-tile kernels (bias, residual, next norm weight): independent of the weight stream, so
     // they are fetched under it instead of as a dependent chain in the tail of every workgroup
-    f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f}, wn_pre = bias_pre, res_pre[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) res_pre[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f}, wn_pre = bias_pre, res_pre = bias_pre;
     if constexpr (NT == 1 && ACT != RV_ACT_SILU_MUL && ROPE == 0) {
         const int n = n0 + kg * 4;
-        if (wave == 0 && n < N) {
+        if (wave < MB && n < N) {
             if (bias) bias_pre = *(const f32x4*)(bias + n);
             if (nrm.out_sumsq) wn_pre = *(const f32x4*)(nrm.w_next + n);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                if (res && mb * 16 + fr < M) res_pre[mb] = *(const f32x4*)(res + (int64_t)(mb * 16 + fr) * ldr + n);
+            if (res && emb * 16 + fr < M) res_pre = *(const f32x4*)(res + (int64_t)(emb * 16 + fr) * ldr + n);
         }
     }
     const bf16_t* xp[MB];
+    const int xj = nrm.x_packed ? 1024 : 32, xkb = nrm.x_packed ? 4096 : 128;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int xr = mb * 16 + fr < M ? mb * 16 + fr : M - 1;
-        xp[mb] = X + (int64_t)xr * lda + kg * 8;
+        xp[mb] = nrm.x_packed ? X + mb * 512 + lane * 8 : X + (int64_t)xr * lda + kg * 8;   // (packed: rows >= M hold stale finite data, never stored)
     }
     const bf16_t* wp[NT];
 #pragma unroll
@@ -626,27 +637,30 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
             wp[t] = W + (int64_t)n * ldw + kg * 8;
         }
     }
-    f32x4 acc[MB][NT];
+    f32x4 acc[VW][MB][NT];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int v = 0; v < VW; ++v)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[v][mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int kb = wave;
-    // Rolling DEPTH-deep pipeline over this wave's k-blocks (wave, wave + 8, ...): a block is re-loaded as soon as its
+    // Rolling DEPTH-deep pipeline over this wave's k-blocks (wave, wave + NW, ...): a block is re-loaded as soon as its
     // registers are consumed, so DEPTH - 1 .. DEPTH 128-k blocks per wave stay in flight until the very end (a batch loop
     // drains to zero between batches, and with all workgroups of a short launch in lock-step the HBM queue empties with it).
-    // DEPTH = 2 everywhere: 4 was measured slower on the N = 4096 projections (down 16.8 -> 18.2 us) and level elsewhere.
+    // The i-th block of a physical wave belongs to virtual wave wave + NW * (i % VW); U % VW == 0 keeps that static per stage.
     {
         typename GemvW<WP>::frag wf[DEPTH][NT];
         bf16x8 xf[DEPTH][MB][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (kb + 8 * d < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + 8 * d, wf[d], xf[d]);
-        for (; kb < nkb; kb += 8 * DEPTH) {
+            if (kb + NW * d < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + NW * d, wf[d], xf[d], xj, xkb);
+        for (; kb < nkb; kb += NW * U) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                if (kb + 8 * d < nkb) {
+            for (int u = 0; u < U; ++u) {
+                const int d = u % DEPTH, v = u % VW;
+                if (kb + NW * u < nkb) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -654,32 +668,50 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
                             const bf16x8 wfrag = gemv_frag<WP>(wf[d][t], j);
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb)
-                                acc[mb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, xf[d][mb][j], acc[mb][t], 0, 0, 0);
+                                acc[v][mb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, xf[d][mb][j], acc[v][mb][t], 0, 0, 0);
                         }
-                    if (kb + 8 * (d + DEPTH) < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + 8 * (d + DEPTH), wf[d], xf[d]);
+                    if (kb + NW * (u + DEPTH) < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + NW * (u + DEPTH), wf[d], xf[d], xj, xkb);
                 }
             }
         }
     }
 
-    if (nrm.in_sumsq) {  // consumer: add up the producer's partial sums of squares (fixed order -> deterministic)
+    if (nrm.in_sumsq) {  // consumer: add up the producer's partial sums of squares (fixed order -> deterministic; thread layout of
+                         // the 512-thread workgroup, two virtual threads per thread when NW = 4)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            float a = 0.f;
+        for (int q = 0; q < VW; ++q) {
+            const int vt = tid + q * NW * 64;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a += ssq_pre[mb][j];
-            for (int i = (tid >> 4) + 256; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (tid & 15)];
-            ssq[mb][tid >> 4][tid & 15] = a;
+            for (int mb = 0; mb < MB; ++mb) {
+                float a = 0.f;
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += ssq_pre[mb][j];
+                } else {
+                    float pj[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = (vt >> 4) + 32 * j;
+                        pj[j] = i < nrm.in_nblk ? nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (vt & 15)] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += pj[j];
+                }
+                for (int i = (vt >> 4) + 256; i < nrm.in_nblk; i += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + i) * 16 + (vt & 15)];
+                ssq[mb][vt >> 4][vt & 15] = a;
+            }
         }
     }
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int v = 0; v < VW; ++v)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) *(f32x4*)(red + (((wave * MB + mb) * NT + t) * 64 + lane) * 4) = acc[mb][t];
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((((wave + NW * v) * MB + mb) * NT + t) * 64 + lane) * 4) = acc[v][mb][t];
     __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+    if (wave >= MB) return;
+    {
+        const int mb = emb;      // one epilogue wave per row block
         f32x4 s[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -708,21 +740,21 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int n = n0 + t * 16 + kg * 4;
-                    if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre[mb]);
+                    if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre);
                 }
             }
-            continue;
+            return;
         }
-        if (b >= M && !nrm.out_sumsq) continue;
+        if (b >= M && !nrm.out_sumsq) return;
         if (ACT == RV_ACT_SILU_MUL) {
             const int no = blockIdx.x * 16 + kg * 4;
-            if (n0 >= N || b >= M) continue;
+            if (n0 >= N || b >= M) return;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
             if (OUT_BF16) {
                 u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + no) = p;
+                *(u32x2*)((bf16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, no) : (int64_t)b * ldc + no)) = p;
             } else {
                 *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -738,16 +770,16 @@ __global__ __launch_bounds__(512) void gemv_stream(const bf16_t* __restrict__ X,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += NT == 1 ? res_pre[mb] : *(const f32x4*)(res + (int64_t)b * ldr + n);
+                if (res) v += NT == 1 ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
                 if (OUT_BF16) {
                     u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)Cv + (int64_t)b * ldc + n) = p;
+                    *(u32x2*)((bf16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, n) : (int64_t)b * ldc + n)) = p;
                 } else {
                     *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
                 }
                 if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
                     const f32x4 wn = NT == 1 ? wn_pre : *(const f32x4*)(nrm.w_next + n);
-                    *(u32x2*)((bf16_t*)nrm.xw_out + (int64_t)b * N + n) =
+                    *(u32x2*)((bf16_t*)nrm.xw_out + (nrm.out_packed ? rv_xp_index(b, n) : (int64_t)b * N + n)) =
                         u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
                     // (explicit fma chain: the contraction hipcc picks for a*a + b*b + ... may differ between template instantiations,
                     //  and a row's sum must not depend on how many rows it is batched with)
@@ -793,16 +825,16 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 template <int OUT_BF16, int ACT, int WP, int MB>
 void launch_gemv_mb(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
                     int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
-    // MB = 2 needs > 128 VGPRs: one workgroup per CU instead of two, so it keeps the bytes in flight per CU with a deeper ring
-    constexpr int D2 = MB == 2 ? 3 : 2, D1 = MB == 2 ? 4 : 2;
+    // MB = 2 needs > 128 VGPRs (2 waves per SIMD): two independent 256-thread workgroups per CU (NW = 4) with a deeper ring
+    constexpr int D2 = MB == 2 ? 3 : 2, D1 = MB == 2 ? 4 : 2, NW = MB == 2 ? 4 : 8;
     if constexpr (ACT == RV_ACT_SILU_MUL) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB, NW>), dim3((unsigned)cdiv(N, 32)), dim3(NW * 64), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else if (N >= 16384) {
-        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB>), dim3((unsigned)cdiv(N, 32)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<2, OUT_BF16, ACT, WP, 0, D2, MB, NW>), dim3((unsigned)cdiv(N, 32)), dim3(NW * 64), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     } else {
-        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP, 0, D1, MB>), dim3((unsigned)cdiv(N, 16)), dim3(512), 0, st, A, lda, W, ldw,
+        hipLaunchKernelGGL((gemv_stream<1, OUT_BF16, ACT, WP, 0, D1, MB, NW>), dim3((unsigned)cdiv(N, 16)), dim3(NW * 64), 0, st, A, lda, W, ldw,
                            bias, res, ldr, C, ldc, M, N, K, nrm, QkvRope{});
     }
 }
@@ -894,14 +926,14 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
     if (M <= 32 && w_layout == 2) {
         RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");
         if (M > 16)
-            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1, 4, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1, 4, 2, 4>), dim3((unsigned)(N / 16)), dim3(256), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
     } else if (M <= 32 && (r.S == 1 || M <= 16)) {     // KV-cached decode rows (17 .. 32: several recursions' steps merged)
         if (M > 16)
-            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 4, 2>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
+            hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 4, 2, 4>), dim3((unsigned)(N / 16)), dim3(256), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, norm ? *norm : GemvNorm{}, r);
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,

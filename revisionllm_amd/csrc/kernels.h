@@ -35,7 +35,16 @@ struct GemvNorm {
     const float* w_next = nullptr;    // [N] norm weight of the consumer
     float* out_sumsq = nullptr;       // [gridDim.x][16]
     const float* w_scale = nullptr;   // fp8 weights (w_layout 2): per-output-row dequantisation scale [N]
+    // Fragment-packed decode activations (<= 32 rows): element (row r, k) of a [rows, K] bf16 operand lives at rv_xp_index(r, k),
+    // i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block (the two row blocks of a k-fragment adjacent).
+    // A wave then fetches its x operand of a k-step with ONE contiguous load per fragment instead of 16 row segments of 64 B -
+    // with 17 .. 32 rows the row-major x loads cost the address units more than the weight stream itself.
+    int x_packed = 0;                 // the input activation X is fragment-packed (lda ignored)
+    int out_packed = 0;               // xw_out and a bf16 C are written fragment-packed (ldc ignored for bf16 C)
 };
+__host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k) {
+    return ((((int64_t)(k >> 5) * 2 + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
+}
 
 // Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
 // (bf16 [M,D]), RoPE-rotated K into the cache and V into the transposed cache - instead of an f32 [M,3D] buffer that two
@@ -132,7 +141,8 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
 int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
-int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st);
+int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st,
+              int out_packed = 0);   // out_packed: y16 in the fragment-packed decode layout (rv_xp_index; rows <= 32)
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
@@ -155,6 +165,7 @@ struct AttnArgs {
     // per-batch-row positions (device array [B]; KV-cached decode, Lq = 1, of rows at different positions): row b's query sits at
     // position row_pos[b] and sees keys 0 .. row_pos[b]; row_pos[b] < 0 = inactive row (skipped).  Lk then only bounds the strides.
     const int* row_pos = nullptr;
+    int out_packed = 0;   // (Lq = 1 decode) the output row of batch b goes to the fragment-packed decode layout: element (b, c) at rv_xp_index(b, c)
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
 int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st);   // two prefill problems (dh 128) in one launch

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
                                                       const float* __restrict__ w, bf16_t* __restrict__ y, int64_t rows,
-                                                      int d, float eps) {
+                                                      int d, float eps, int packed) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         for (int i = 0; i < NV; ++i) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
         const float r = rsqrtf(wave_sum(s) / (float)d + eps);
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            *(u32x2*)(y + row * d + i * 256 + lane * 4) = u32x2{pack_bf16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)),
-                                                                 pack_bf16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 256 + lane * 4;
+            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c) : row * d + c)) =
+                u32x2{pack_bf16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)), pack_bf16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
+        }
     } else {
         float s = 0.f;
         for (int c = lane * 4; c < d; c += 256) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         const float r = rsqrtf(wave_sum(s) / (float)d + eps);
         for (int c = lane * 4; c < d; c += 256) {
             const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
-            *(u32x2*)(y + row * d + c) =
+            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c) : row * d + c)) =
                 u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
         }
     }
@@ -331,16 +333,17 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
     return RV_OK;
 }
 
-int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st) {
+int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed) {
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm: bad arguments");
+    RV_CHECK_ARG(!out_packed || (rows <= 32 && d % 32 == 0), "rmsnorm: the packed decode layout holds <= 32 rows");
     if (rows == 0) return RV_OK;
     const dim3 grid((unsigned)cdiv(rows, 4));
     if (d == 4096)
-        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
     else if (d == 512)
-        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
     else
-        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps);
+        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
     RV_CHECK_LAUNCH("rmsnorm");
     return RV_OK;
 }

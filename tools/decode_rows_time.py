@@ -1,0 +1,32 @@
+"""Isolated timing of merged decode steps (rv_llm_decode_rows) at 7B shapes for several row counts:
+    python tools/decode_rows_time.py [rows ...]
+Prints ms per step and the implied weight-streaming rate (13.2 GB of bf16 weights per step)."""
+import sys
+import torch
+from revisionllm_amd import engine
+from revisionllm_amd.utils import synth
+
+rows = [int(a) for a in sys.argv[1:]] or [7, 14, 16, 21, 28, 32]
+eng = engine.Engine(synth.LlamaShape(), adapter_text=False, device="cuda:0")
+eng.init_synthetic(seed=0, llm=True, clip=False)
+D, V = eng.shape.hidden, eng.shape.vocab
+Smax = 256
+wbytes = sum(t.numel() * t.element_size() for t in eng._llm_tensors()) if hasattr(eng, "_llm_tensors") else 13.2e9
+for R in rows:
+    kv, sm = eng.new_kv_pool(R, Smax)
+    pos = torch.full((R,), 180, dtype=torch.int32, device="cuda:0")
+    h0 = torch.randn(R, D, device="cuda:0") * 0.02
+    logits = torch.empty(R, V, device="cuda:0")
+    for _ in range(3):
+        eng.llm_decode_rows(h0.clone(), pos, kv, sm, logits=logits)
+    torch.cuda.synchronize()
+    n = 20
+    hs = [h0.clone() for _ in range(n)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        eng.llm_decode_rows(hs[i], pos, kv, sm, logits=logits)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print(f"rows {R:2d}: {ms:.3f} ms/step  {wbytes / ms / 1e9:.2f} TB/s  {ms / R * 1e3:.1f} us/row", flush=True)
