@@ -57,12 +57,15 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=4,
+    p.add_argument("--streams", type=int, default=8,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--merge-decode", type=int, default=1,
                    help="1: the generates of the steps in flight decode through ONE serve.DecodeServer (shared KV pool, merged decode steps: "
                         "one pass over the LLM weights per step for all of them; rows of up to 4 recursions = 28 <= 32)")
+    p.add_argument("--pools", type=int, default=2,
+                   help="KV pools of the DecodeServer; >= 2 switches on the gang policy: a pool is filled with generates first, then its merged "
+                        "steps run with all rows while the next generates prefill into the other pool")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
@@ -96,7 +99,7 @@ def event_time_ms(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def roofline_legs(model, n_calls, M):
+def roofline_legs(model, n_calls, M, dec_rows=None):
     """Time the path's heavy kernels in isolation on the shapes the recursion launches them with
     (M = rows of the prefill GEMM batch: shared prompt prefix once + the rest of every call)."""
     from revisionllm_amd import hip, ops
@@ -115,8 +118,11 @@ def roofline_legs(model, n_calls, M):
                                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops, grid_threads=(cus & ~7) * 512)
     # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
     #     256 MB infinity cache cannot serve the weights
-    xs = torch.randn(n_calls, s.hidden, device=dev).to(torch.bfloat16)
-    outs = torch.empty(n_calls, s.inter, dtype=torch.bfloat16, device=dev)
+    #     rows = what a merged decode step of the timed region carries (gang policy: a full pool of generates; <= 16 rows: the
+    #     512-thread kernel, 17 .. 32: two MFMA column blocks per weight fragment on 256-thread workgroups)
+    dec_rows = dec_rows or n_calls
+    xs = torch.randn(dec_rows, s.hidden, device=dev).to(torch.bfloat16)
+    outs = torch.empty(dec_rows, s.inter, dtype=torch.bfloat16, device=dev)
     ws = [eng.weight(f"llm.L{i}.wgu") for i in range(s.layers)]
     state = {"i": 0}
 
@@ -125,8 +131,9 @@ def roofline_legs(model, n_calls, M):
         state["i"] += 1
     ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
-    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0,2>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6,
-                                      peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, grid_threads=(2 * s.inter // 32) * 512)
+    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0,3,2,4>" if dec_rows > 16 else "gemv_stream<2,1,2,1,0,2,1,8>", bound="hbm", ms=ms,
+                                      achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, rows=dec_rows,
+                                      grid_threads=(2 * s.inter // 32) * (256 if dec_rows > 16 else 512))
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
     #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised.
     #     Kernel: the A-resident GEMM (gemm_arows.hip): rows resident in LDS, A read once, C written once
@@ -324,7 +331,7 @@ def main():
     server = None
     if args.merge_decode:
         from revisionllm_amd import serve
-        server = serve.DecodeServer(model, rows=32, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G))
+        server = serve.DecodeServer(model, rows=32, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1)
         stages.server = server
 
     def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
@@ -530,12 +537,17 @@ def main():
         M_prefill = P0 + n_calls_rank * (S - P0)
         eng.set_option("fp8_decode", 0)
         eng.set_option("fp8_prefill", 0)
-        legs = roofline_legs(model, n_calls_rank, M_prefill)
+        # generates per merged decode step of the timed region: a full pool under the gang policy, else what the run averaged
+        gang = max(1, 32 // n_calls_rank) if (server is not None and args.pools > 1) else 1
+        if server is not None and args.pools <= 1:
+            gang = max(1, min(32 // n_calls_rank, round(server.rows_served / max(1, server.steps_run) / n_calls_rank)))
+        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(32, gang * n_calls_rank))
+        # dominant = the larger share of a recursion: 32 prefill launches, or 32 x G decode launches shared by `gang` recursions
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
-                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * (G - 1)))
+                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * G / gang))
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         other = {k: {"kernel": v["kernel"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"], "avg_launch_ms": v["ms"],
-                     **({"tflops": v["tflops"]} if "tflops" in v else {})} for k, v in legs.items()}
+                     **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {})} for k, v in legs.items()}
         pmc = committed_profile("r2_pmc_mfma.json")
         if pmc is not None:
             other["prefill_gemm_pmc"] = pmc.get("summary")

@@ -274,19 +274,24 @@ class ReVisionLlamaForCausalLM:
         P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
         job = None
         if (server is not None and not output_scores and not output_logits and self.after_prefill is None
-                and server.fits(S, max_new_tokens) and max_new_tokens >= 1):
+                and server.fits(S, max_new_tokens, B) and max_new_tokens >= 1):
             job = server.reserve(B)
+            while job is None and getattr(server, "blocking", False):      # gang policy: wait for a pool to fill rather than decode alone
+                from .. import sched
+                yield sched.RETRY
+                job = server.reserve(B)
         if job is not None:
+            pool = job.pool
             # ---- merged-decode path: prefill into the server's pool, its merged steps do the rest ----
-            if job.free_event is not None:
-                torch.cuda.current_stream(dev).wait_event(job.free_event)       # the rows' previous owner is done with them
+            for ev in job.free_events:
+                torch.cuda.current_stream(dev).wait_event(ev)                   # the rows' previous owners are done with them
             if 16 <= P0 < S:
                 flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
                 h = eng.splice_embed(flat, video_rows)[0]
-                first = eng.llm_prefill_pool(h, B, P0, server.kv, server.R, job.r0, server.Smax)
+                first = eng.llm_prefill_pool(h, B, P0, pool.kv, pool.R, job.r0, pool.Smax)
             else:
                 h = eng.splice_embed(row_map, video_rows).view(B * S, -1)
-                first = eng.llm_prefill_pool(h, B, 0, server.kv, server.R, job.r0, server.Smax)
+                first = eng.llm_prefill_pool(h, B, 0, pool.kv, pool.R, job.r0, pool.Smax)
             if do_sample and uniforms is None:
                 uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
                             else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))

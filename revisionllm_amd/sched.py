@@ -73,7 +73,8 @@ class _null:
 class Interleaver:
     """Tasks in launch order.  ``add`` starts a task (runs it up to its first pending event); ``finish(task)`` returns its
     result, advancing every other ready task while it waits.  ``servers``: objects with ``pump() -> bool`` / ``wait_one() -> bool``
-    (``serve.DecodeServer``: the merged decode steps of the generates in flight) that are pumped along with the tasks."""
+    / optionally ``flush() -> bool`` (``serve.DecodeServer``: the merged decode steps of the generates in flight) that are pumped along
+    with the tasks; ``flush`` is called when neither a task nor a server has a device event left to wait for."""
 
     def __init__(self, servers=()):
         self.tasks = []
@@ -104,5 +105,9 @@ class Interleaver:
                     pending = [t.waiting for t in self.tasks if t.waiting is not None]
                     if pending:
                         pending[0].synchronize()
+                    else:       # no device event anywhere to wait for: a server holding work back (a pool still filling) must let it go
+                        for sv in self.servers:
+                            if hasattr(sv, "flush") and sv.flush():
+                                break
         self.tasks.remove(task)
         return task.result

@@ -15,6 +15,15 @@ pool one step after ALL its rows have finished: its "any row unfinished" flag go
 looked at when its copy has completed - never a host wait; the surplus step is cut off.
 Driven cooperatively from ``sched.Interleaver`` (no threads): ``pump()`` enqueues at most ``max_ahead`` merged steps ahead of
 the device so that a generate whose prefill completes can join the very next steps.
+
+Stepping policy.  ``DecodeServer(gang=False)`` (one pool) steps GREEDILY: a merged step is enqueued whenever any generate is
+in the pool, so with prefills arriving one at a time most steps carry only one or two generates' rows - and a step costs the same
+13.2 GB whatever it carries.  ``gang=True`` (``pools`` >= 2) fills a pool first: generates reserve rows in the FILLING pool and
+prefill into it; when it cannot take another one it is SEALED, and once everyone in it has joined, its steps run with all rows
+from the first to the last token, while the next generates fill the other pool (their MFMA-bound prefills overlap these
+HBM-bound steps).  A generate that finds no pool to fill waits (``sched.RETRY``) instead of decoding on its own; when the
+scheduler has nothing else to run (end of the workload; ``flush``) the filling pool is sealed as it is.  Per-row results do not depend
+on the policy.
 """
 import collections
 
@@ -36,8 +45,10 @@ class Job:
         self.flag_host, self.flag_events = None, collections.deque()     # EOS: pinned per-step "any row unfinished" flags + their copy events
 
 
-class DecodeServer:
-    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97):
+class DecodePool:
+    """One KV pool and its merged steps."""
+
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, gang=False):
         eng = model.engine
         assert 1 <= rows <= 32
         self.model, self.eng, self.R, self.G, self.max_ahead, self.slot = model, eng, rows, gmax, max_ahead, slot
@@ -53,37 +64,46 @@ class DecodeServer:
         self.uni = torch.full((rows,), 0.5, dtype=torch.float32, device=dev)
         self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)      # EOS bookkeeping: 0 once a row has emitted the EOS id
         self.stream = torch.cuda.Stream(dev)
-        self.free = [(0, rows, None)]            # (first row, count, event after which the rows may be overwritten)
+        self.free = [(0, rows, ())]              # (first row, count, events after which the rows may be overwritten)
         self.jobs = []                           # joined, not finished
         self.draining = []                       # (EOS) all steps enqueued, waiting for their stop flags to land before the cut
         self.in_flight = collections.deque()     # events of the merged steps enqueued and not yet seen complete
         self.sampling = None                     # (do_sample, temperature, top_k, top_p) of the jobs in the pool (must agree)
         self.steps_run = self.rows_served = 0
+        self.gang, self.sealed = gang, False     # gang policy: no steps before the pool is sealed and everyone in it has joined
+        self.pending = self.live = 0             # jobs reserved and not yet joined / not yet finished
 
     # ---- slots ---------------------------------------------------------------------------------------------------------------
     def reserve(self, B):
         """-> Job with B contiguous rows, or None when the pool has no room (the caller then runs its classic loop)."""
-        for i, (r0, n, ev) in enumerate(self.free):
+        for i, (r0, n, evs) in enumerate(self.free):
             if n >= B:
-                self.free[i:i + 1] = [(r0 + B, n - B, ev)] if n > B else []
+                self.free[i:i + 1] = [(r0 + B, n - B, evs)] if n > B else []
                 job = Job(r0, B)
-                job.free_event = ev
+                job.free_events = evs
+                job.pool = self
+                self.pending += 1
+                self.live += 1
                 return job
         return None
 
+    def free_rows(self):
+        return max((f[1] for f in self.free), default=0)
+
     def _release(self, job, event):
-        self.free.append((job.r0, job.B, event))
-        self.free.sort()
+        self.free.append((job.r0, job.B, (event,)))
+        self.free.sort(key=lambda f: f[0])
         merged = []
-        for r0, n, ev in self.free:          # coalesce neighbours (their events: keep the later one = wait for both is not possible with
-            if merged and merged[-1][0] + merged[-1][1] == r0 and merged[-1][2] is ev:   # one event, so only identical events merge)
-                merged[-1] = (merged[-1][0], merged[-1][1] + n, ev)
+        for r0, n, evs in self.free:         # coalesce neighbours; whoever takes the merged range waits for all their events
+            evs = tuple(e for e in evs if not e.query())
+            if merged and merged[-1][0] + merged[-1][1] == r0:
+                merged[-1] = (merged[-1][0], merged[-1][1] + n, merged[-1][2] + tuple(e for e in evs if e not in merged[-1][2]))
             else:
-                merged.append((r0, n, ev))
+                merged.append((r0, n, evs))
         self.free = merged
 
-    def fits(self, S, max_new_tokens):
-        return S + max_new_tokens <= self.Smax and max_new_tokens <= self.G
+    def fits(self, S, max_new_tokens, B=1):
+        return S + max_new_tokens <= self.Smax and max_new_tokens <= self.G and B <= self.R
 
     # ---- joining -------------------------------------------------------------------------------------------------------------
     def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None):
@@ -103,6 +123,7 @@ class DecodeServer:
             self.unfinished[r] = 1
         first_logits.record_stream(self.stream)
         job.joined = True
+        self.pending -= 1
         self.jobs.append(job)
 
     # ---- one merged step -----------------------------------------------------------------------------------------------------
@@ -112,6 +133,8 @@ class DecodeServer:
             self.in_flight.popleft()
         progressed = self._drain() if self.draining else False
         if not self.jobs or len(self.in_flight) >= self.max_ahead:
+            return progressed
+        if self.gang and (not self.sealed or self.pending > 0):      # still filling, or someone's prefill is still running
             return progressed
         self._step()
         return True
@@ -156,6 +179,7 @@ class DecodeServer:
         job.done_event = torch.cuda.Event()
         job.done_event.record(self.stream)
         job.finished = True
+        self.live -= 1
         self._release(job, job.done_event)
 
     def _step(self):
@@ -230,3 +254,97 @@ class DecodeServer:
             ev.record(self.stream)
             self.in_flight.append(ev)
         eng.slot = prev_slot
+
+
+class DecodeServer:
+    """The pools + the stepping policy (module docstring).  ``gang=False``: one pool, greedy steps.  What ``generate_steps``
+    uses: ``fits``, ``reserve`` (-> ``Job`` with ``job.pool``; ``None``: no room - wait if ``blocking`` else decode alone), ``join``;
+    what ``sched.Interleaver`` uses: ``pump`` / ``wait_one``."""
+
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False):
+        assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
+        self.pools = [DecodePool(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
+        self.gang, self.blocking, self.fill = gang, gang, 0
+        self.model = model
+
+    # -- one-pool views (tests, bench statistics)
+    @property
+    def kv(self):
+        return self.pools[0].kv
+
+    @property
+    def R(self):
+        return self.pools[0].R
+
+    @property
+    def Smax(self):
+        return self.pools[0].Smax
+
+    @property
+    def steps_run(self):
+        return sum(p.steps_run for p in self.pools)
+
+    @property
+    def rows_served(self):
+        return sum(p.rows_served for p in self.pools)
+
+    @property
+    def jobs(self):
+        return [j for p in self.pools for j in p.jobs]
+
+    @property
+    def draining(self):
+        return [j for p in self.pools for j in p.draining]
+
+    @property
+    def free(self):
+        return [f for p in self.pools for f in p.free]
+
+    def fits(self, S, max_new_tokens, B=1):
+        return self.pools[0].fits(S, max_new_tokens, B)
+
+    def reserve(self, B):
+        if not self.gang:
+            return self.pools[0].reserve(B)
+        for _ in range(2):
+            p = self.pools[self.fill]
+            if p.sealed:                        # move on to the next pool once all its generates have left
+                nxt = (self.fill + 1) % len(self.pools)
+                if self.pools[nxt].live > 0:
+                    return None
+                self.fill, p = nxt, self.pools[nxt]
+                p.sealed = False
+            job = p.reserve(B)
+            if job is None:                     # cannot take this one (B <= R: ``fits``): run what it has
+                assert p.live > 0, (B, p.free)
+                p.sealed = True
+                continue
+            if p.free_rows() < B:               # full for generates of this size: its steps start as soon as everyone has joined
+                p.sealed = True
+            return job
+        return None
+
+    def join(self, job, *a, **kw):
+        return job.pool.join(job, *a, **kw)
+
+    def pump(self):
+        progressed = False
+        for p in self.pools:
+            progressed |= p.pump()
+        return progressed
+
+    def wait_one(self):
+        for p in self.pools:
+            if p.wait_one():
+                return True
+        return False
+
+    def flush(self):
+        """Nothing is in flight anywhere and no task has a device event pending (the scheduler would spin): the partly filled
+        pool is run as it is (end of the workload, or fewer tasks in flight than a pool takes)."""
+        if self.gang:
+            p = self.pools[self.fill]
+            if not p.sealed and p.live > 0 and p.pending == 0:
+                p.sealed = True
+                return True
+        return False

@@ -121,11 +121,13 @@ def _tiny_model():
     return m
 
 
-@pytest.mark.parametrize("n_passes,streams", [(3, 3), (5, 2)])
-def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams):
+@pytest.mark.parametrize("n_passes,streams,pools", [(3, 3, 1), (5, 2, 1), (7, 6, 2), (9, 8, 3)])
+def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams, pools):
     """Several stage-2 recursions in flight on their own HIP streams, their generates decoding through ONE DecodeServer (shared KV
     pool, merged steps with rows at different positions, rows joining and leaving as prefills complete) against the same
-    recursions run one after the other through the classic loop: records identical (answers, entropies, cosine scores)."""
+    recursions run one after the other through the classic loop: records identical (answers, entropies, cosine scores).
+    ``pools`` > 1: the gang policy (a pool is filled with four 8-row generates, sealed, and stepped with all 32 rows while the
+    next recursions prefill into the other pool; the last, partly filled pool is run when nothing else is left)."""
     from revisionllm_amd import parallel, sched, serve
     from revisionllm_amd.eval import stage2
     from revisionllm_amd.utils import synth
@@ -141,7 +143,7 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     unis = [torch.rand(6, len(plan), generator=torch.Generator().manual_seed(10 + i)) for i in range(n_passes)]
     kw = dict(batch=batch, perms=[perms], max_new_tokens=6)
     seq = [parallel.run_queries_sharded(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], uniforms=unis[i], **kw)[0] for i in range(n_passes)]
-    server = serve.DecodeServer(m, rows=32, smax=128, gmax=16)
+    server = serve.DecodeServer(m, rows=32, smax=128, gmax=16, pools=pools, gang=pools > 1)
     st.server = server
     hs = [torch.cuda.Stream("cuda:0") for _ in range(streams)]
     torch.cuda.synchronize()
@@ -159,14 +161,18 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     assert server.steps_run > 0 and server.rows_served > server.steps_run * len(plan) * 0.99      # the merged steps really carried the rows
     if n_passes == 3:
         assert server.rows_served > server.steps_run * len(plan)                                   # ... of more than one recursion at a time
+    if pools > 1:
+        assert server.rows_served > server.steps_run * len(plan) * 1.5, (server.rows_served, server.steps_run)   # gangs (the three levels of a recursion are
+                                                                                                   # sequential generates, so pools also run partly filled here)
     for a, b in zip(seq, par):
         assert a["answers"] == b["answers"] and a["max_entropy"] == b["max_entropy"] and a["mean_entropy"] == b["mean_entropy"]
         assert a["score_cos"] == b["score_cos"]
-    assert not server.jobs and sum(n for _, n, _ in server.free) == 32                             # every row was given back
+    assert not server.jobs and sum(n for _, n, _ in server.free) == 32 * pools                     # every row was given back
 
 
-def test_decode_server_with_eos_equals_classic_loop():
-    """EOS in the merged path: generates whose rows emit EOS at different steps (teacher-forced) leave the pool early; sequences and
+@pytest.mark.parametrize("pools", [1, 2])
+def test_decode_server_with_eos_equals_classic_loop(pools):
+    """EOS in the merged path (``pools`` = 2: under the gang policy, the partly filled pool sealed when the scheduler runs dry): generates whose rows emit EOS at different steps (teacher-forced) leave the pool early; sequences and
     entropies equal the classic loop's (pad after a row's EOS, cut at the step where all rows are done)."""
     from revisionllm_amd import sched, serve
     from revisionllm_amd.utils import synth
@@ -186,7 +192,7 @@ def test_decode_server_with_eos_equals_classic_loop():
                   uniforms=torch.full((6, B), 0.5))
         cases.append((ids.repeat(B, 1), kw, m.generate(ids.repeat(B, 1), **kw)))
     assert [c[2]["sequences"].shape[1] - P for c in cases] == [4, 6, 1]
-    server = serve.DecodeServer(m, rows=16, smax=96, gmax=8)
+    server = serve.DecodeServer(m, rows=16, smax=96, gmax=8, pools=pools, gang=pools > 1)
     inter = sched.Interleaver(servers=[server])
     streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
     tasks = [inter.add(sched.Task(m.generate_steps(c[0], server=server, **c[1]), streams[i], m.engine, i)) for i, c in enumerate(cases)]
@@ -195,4 +201,4 @@ def test_decode_server_with_eos_equals_classic_loop():
     for (ids_, kw, want), got in zip(cases, outs):
         assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
         assert torch.equal(got["entropy_raw"], want["entropy_raw"])
-    assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16
+    assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16 * pools
