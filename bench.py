@@ -57,7 +57,7 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=8,
+    p.add_argument("--streams", type=int, default=18,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--merge-decode", type=int, default=1,
@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--pools", type=int, default=2,
                    help="KV pools of the DecodeServer; >= 2 switches on the gang policy: a pool is filled with generates first, then its merged "
                         "steps run with all rows while the next generates prefill into the other pool")
+    p.add_argument("--pool-rows", type=int, default=64,
+                   help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 128: the split-K kernel with LDS-shared activations)")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
@@ -331,7 +333,7 @@ def main():
     server = None
     if args.merge_decode:
         from revisionllm_amd import serve
-        server = serve.DecodeServer(model, rows=32, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1)
+        server = serve.DecodeServer(model, rows=args.pool_rows, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1)
         stages.server = server
 
     def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
@@ -538,10 +540,10 @@ def main():
         eng.set_option("fp8_decode", 0)
         eng.set_option("fp8_prefill", 0)
         # generates per merged decode step of the timed region: a full pool under the gang policy, else what the run averaged
-        gang = max(1, 32 // n_calls_rank) if (server is not None and args.pools > 1) else 1
+        gang = max(1, args.pool_rows // n_calls_rank) if (server is not None and args.pools > 1) else 1
         if server is not None and args.pools <= 1:
-            gang = max(1, min(32 // n_calls_rank, round(server.rows_served / max(1, server.steps_run) / n_calls_rank)))
-        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(32, gang * n_calls_rank))
+            gang = max(1, min(args.pool_rows // n_calls_rank, round(server.rows_served / max(1, server.steps_run) / n_calls_rank)))
+        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(32, gang * n_calls_rank))   # (the leg times the <= 32-row kernel; wider pools: see DESIGN.md)
         # dominant = the larger share of a recursion: 32 prefill launches, or 32 x G decode launches shared by `gang` recursions
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
                   key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * G / gang))

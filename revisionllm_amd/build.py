@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "librevision_hip.so")
-SOURCES = ["error.hip", "init.hip", "gemm.hip", "gemm_pp.hip", "gemm_arows.hip", "rowops.hip", "attention.hip", "sample.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "revision_hip.h")]
+SOURCES = ["error.hip", "init.hip", "gemm.hip", "gemm_pp.hip", "gemm_arows.hip", "gemm_rows.hip", "rowops.hip", "attention.hip", "sample.hip", "engine.hip"]
+HEADERS = ["common.h", "kernels.h", "gemv_finish.h", os.path.join("..", "..", "include", "revision_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 

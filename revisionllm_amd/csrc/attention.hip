@@ -156,7 +156,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
                 v0 += sm_o[w][q][dc + j] * sc[w];
                 v1 += sm_o[w][q][dc + j + 1] * sc[w];
             }
-            if (a.out_packed) *(uint32_t*)((bf16_t*)a.out + rv_xp_index(b, h * DH + dc + j)) = pack_bf16x2(v0 * inv, v1 * inv);   // (Lq = 1)
+            if (a.out_packed) *(uint32_t*)((bf16_t*)a.out + rv_xp_index(b, h * DH + dc + j, a.out_packed)) = pack_bf16x2(v0 * inv, v1 * inv);   // (Lq = 1)
             else *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
         }
         return;

@@ -435,6 +435,8 @@ namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
     float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
+    float* planes;   // split-K partial planes of the 33 .. 128-row decode kernel
+    int* arrive;     // ... and its arrival counters: at a FIXED offset (right behind sk) whatever the carve's row count, zero from the allocation on
     uint8_t* x8;     // FP8 prefill: the quantised GEMM operand [M, max(D, F)] ...
     float* sa;       // ... and its row scales [M]
     void* sk;
@@ -447,14 +449,16 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     LlmWs w;
     w.sk_bytes = gemm_pp_ws_bytes();
     w.sk = k.take(w.sk_bytes);
-    const int64_t Mp = M < 32 ? 32 : M;   // the fragment-packed decode layout always spans 32 rows
+    w.arrive = (int*)k.take((size_t)RV_ROWS_COUNTERS * 4);
+    const int64_t Mp = M <= 128 ? 16 * rv_xp_blocks(M) : M;   // the fragment-packed decode layout spans whole row blocks
     w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2);
     w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
-    w.ss = (float*)k.take((size_t)2 * (D / 16) * 16 * 4);   // [<= 2 row blocks][D/16 workgroups][16]
+    w.ss = (float*)k.take((size_t)8 * (D / 16) * 16 * 4);   // [<= 8 row blocks][D/16 workgroups][16]
+    w.planes = (float*)k.take(gemm_rows_ws_bytes());
     w.x8 = (uint8_t*)k.take((size_t)M * (F > D ? F : D));
     w.sa = (float*)k.take((size_t)M * 4);
     w.bytes = k.off;
@@ -498,8 +502,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     else RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
     // Decode steps (M <= 32 rows) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
-    const bool fuse_norm = S == 1 && P0 == 0 && M <= 32 && D % 128 == 0 && F % 128 == 0;
-    const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only
+    const bool fuse_norm = S == 1 && P0 == 0 && M <= 128 && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
+    const bool f8 = fuse_norm && M <= 32 && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
     const bool p8 = !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
@@ -513,7 +517,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     const int nb_d = gemv_blocks(RV_ACT_NONE, D);
     // KV-cached decode steps keep their bf16 activations (xn16, a16, act16) fragment-packed (GemvNorm::x_packed): with 17 .. 32
     // rows the row-major operand loads would cost the address units more than the weight stream
-    const int xp = fuse_norm ? 1 : 0;
+    const int xp = fuse_norm ? rv_xp_blocks(M) : 0;
     GemvNorm consume;
     consume.in_sumsq = w.ss;
     consume.in_nblk = nb_d;
@@ -521,6 +525,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.eps = g.rms_eps;
     consume.x_packed = xp;
     consume.out_packed = xp;
+    consume.planes = w.planes;
+    consume.arrive = w.arrive;
+    consume.status = (int*)w.sk + 2047;       // the hand-off status word of the workspace header (gemm_pp.hip)
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
@@ -545,6 +552,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         } else {
             GemvNorm first;       // layer 0 of a decode step: no norm to consume, but the operand layout still applies
             first.x_packed = xp;
+            first.planes = w.planes;
+            first.arrive = w.arrive;
+            first.status = consume.status;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
@@ -567,6 +577,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.w_next = L.norm2;
         produce.x_packed = xp;
         produce.out_packed = xp;
+        produce.planes = w.planes;
+        produce.arrive = w.arrive;
+        produce.status = consume.status;
         {
             const int64_t r0 = P0;  // first row of the per-sequence part
             AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
@@ -663,7 +676,7 @@ extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t*
                                   size_t ws_bytes, void* stream) {
     RV_CHECK_ARG(c && h && row_pos && kv && logits && ws, "rv_llm_decode_rows: null argument");
     RvOptScope scope(&c->opt);
-    RV_CHECK_ARG(R > 0 && R <= 32, "rv_llm_decode_rows: 1 .. 32 rows per step (got %d)", R);
+    RV_CHECK_ARG(R > 0 && R <= 128, "rv_llm_decode_rows: 1 .. 128 rows per step (got %d)", R);
     RV_CHECK_ARG(Smax % 32 == 0, "rv_llm_decode_rows: Smax=%d must be a multiple of 32", Smax);
     return llm_forward_impl(c, h, R, 1, 0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), R, 0, row_pos);
 }

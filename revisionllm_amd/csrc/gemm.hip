@@ -21,6 +21,7 @@
 // one row, so bias/residual/stores are 8/16-byte vectors and the SiLU(gate)*up epilogue is lane-local
 // (gate/up rows are interleaved in 16-row blocks in the packed weight).
 #include "kernels.h"
+#include "gemv_finish.h"
 
 namespace {
 
@@ -528,8 +529,8 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
 }
 
 // x operand addressing: row-major rows (xj = 32, xkb = 128 elements per 32-k fragment / 128-k block, per-lane base = row start +
-// kg * 8) or the fragment-packed decode layout (xj = 1024, xkb = 4096: fragment (kf, mb) at (kf * 2 + mb) * 512, per-lane base =
-// mb * 512 + lane * 8; GemvNorm::x_packed)
+// kg * 8) or the fragment-packed decode layout with mbp row blocks (xj = mbp * 512, xkb = mbp * 2048: fragment (kf, mb) at
+// (kf * mbp + mb) * 512, per-lane base = mb * 512 + lane * 8; GemvNorm::x_packed = mbp)
 template <int NT, int WP, int MB>
 __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* const (&xp)[MB], int kb, typename GemvW<WP>::frag (&wf)[NT],
                                           bf16x8 (&xf)[MB][4], int xj, int xkb) {
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
         }
     }
     const bf16_t* xp[MB];
-    const int xj = nrm.x_packed ? 1024 : 32, xkb = nrm.x_packed ? 4096 : 128;
+    const int xj = nrm.x_packed ? 1024 : 32, xkb = nrm.x_packed ? 4096 : 128;   // (<= 32 rows: two row blocks; literal strides - the loop is
+                                                                               //  specialised on them, generic ones cost ~20 address registers)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int xr = mb * 16 + fr < M ? mb * 16 + fr : M - 1;
@@ -710,89 +712,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
             for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((((wave + NW * v) * MB + mb) * NT + t) * 64 + lane) * 4) = acc[v][mb][t];
     __syncthreads();
     if (wave >= MB) return;
-    {
-        const int mb = emb;      // one epilogue wave per row block
-        f32x4 s[NT];
+    const int mb = emb;      // one epilogue wave per row block
+    f32x4 s[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+        f32x4 p[8];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s[t] += *(const f32x4*)(red + (((w * MB + mb) * NT + t) * 64 + lane) * 4);
-        }
-        const int b = mb * 16 + fr;  // batch row
-        if constexpr (WP == 2) {   // fp8 weights: per-output-row scale (the lane owns rows n0 + t * 16 + kg * 4 .. + 3)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = n0 + t * 16 + kg * 4;
-                if (n < N) s[t] *= *(const f32x4*)(nrm.w_scale + n);
-            }
-        }
-        if (nrm.in_sumsq) {
-            float tot = 0.f;
-#pragma unroll
-            for (int p = 0; p < 32; ++p) tot += ssq[mb][p][fr];
-            const float rr = rsqrtf(__fmaf_rn(tot, nrm.inv_d, nrm.eps));
-#pragma unroll
-            for (int t = 0; t < NT; ++t) s[t] *= rr;
-        }
-        if constexpr (ROPE) {
-            if (b < M) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int n = n0 + t * 16 + kg * 4;
-                    if (n < N) qkv_rope_store(qr, b, n, s[t], rope_pre);
-                }
-            }
-            return;
-        }
-        if (b >= M && !nrm.out_sumsq) return;
-        if (ACT == RV_ACT_SILU_MUL) {
-            const int no = blockIdx.x * 16 + kg * 4;
-            if (n0 >= N || b >= M) return;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = silu(s[0][r]) * s[NT - 1][r];
-            if (OUT_BF16) {
-                u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, no) : (int64_t)b * ldc + no)) = p;
-            } else {
-                *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-        } else {
-            float sq = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = n0 + t * 16 + kg * 4;
-                if (n >= N || b >= M) continue;
-                f32x4 v = s[t];
-                if (bias) v += NT == 1 ? bias_pre : *(const f32x4*)(bias + n);
-                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
-                }
-                if (res) v += NT == 1 ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
-                if (OUT_BF16) {
-                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, n) : (int64_t)b * ldc + n)) = p;
-                } else {
-                    *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
-                }
-                if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
-                    const f32x4 wn = NT == 1 ? wn_pre : *(const f32x4*)(nrm.w_next + n);
-                    *(u32x2*)((bf16_t*)nrm.xw_out + (nrm.out_packed ? rv_xp_index(b, n) : (int64_t)b * N + n)) =
-                        u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
-                    // (explicit fma chain: the contraction hipcc picks for a*a + b*b + ... may differ between template instantiations,
-                    //  and a row's sum must not depend on how many rows it is batched with)
-                    sq = __fmaf_rn(v[3], v[3], __fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], __fmaf_rn(v[0], v[0], sq))));
-                }
-            }
-            if (nrm.out_sumsq) {
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                if (kg == 0) nrm.out_sumsq[((int64_t)mb * gridDim.x + blockIdx.x) * 16 + fr] = b < M ? sq : 0.f;
-            }
-        }
+        for (int w = 0; w < 8; ++w) p[w] = *(const f32x4*)(red + (((w * MB + mb) * NT + t) * 64 + lane) * 4);
+        s[t] = gemv_tree8(p);
     }
+    float tot = 0.f;
+    if (nrm.in_sumsq) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += ssq[mb][q][fr];
+    }
+    gemv_finish<NT, OUT_BF16, ACT, WP, ROPE>(s, mb, fr, kg, blockIdx.x, gridDim.x, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, rope_pre, bias_pre, wn_pre,
+                                             res_pre, true);
 }
 
 // packed W: 2 (default) = 128x128x32 3-stage ring (3 workgroups/CU) + the 256x256 ping-pong kernel where it pays;
@@ -865,8 +800,11 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 32) && (K % 128 == 0) && (N % 16 == 0);   // 17 .. 32 rows: two MFMA column blocks per weight fragment
+    if (norm && norm->planes && M > 32 && M <= 128 && w_layout == 1)   // 33 .. 128 rows of a merged decode step: the split-K kernel
+        return gemm_rows(a, w, bias, residual, ldr, C, ldc, out_dtype, act, (int)M, (int)N, (int)K, st, *norm, nullptr);
     RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion / fp8 weights are only available in the M <= 32 kernel");
     const GemvNorm nrm = norm ? *norm : GemvNorm{};
+    RV_CHECK_ARG(!gemv || nrm.x_packed == 0 || nrm.x_packed == 2, "rv_gemm: <= 32 fragment-packed rows come in two row blocks");
     if (w_layout == 2) {   // fp8 weights: the weight-streaming kernel only (decode), scales ride in the norm descriptor
         RV_CHECK_ARG(gemv && nrm.w_scale, "rv_gemm: fp8 weights need M <= 32, K %% 128 == 0 and per-row scales");
         const int ob8 = out_dtype == RV_BF16;
@@ -931,6 +869,8 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
+    } else if (M > 32 && M <= 128 && r.S == 1 && norm && norm->planes && w_layout == 1) {
+        return gemm_rows(a, w, nullptr, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, (int)M, N, K, st, *norm, &r);
     } else if (M <= 32 && (r.S == 1 || M <= 16)) {     // KV-cached decode rows (17 .. 32: several recursions' steps merged)
         if (M > 16)
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 1, 1, 4, 2, 4>), dim3((unsigned)(N / 16)), dim3(256), 0, st, a, lda, w, (int64_t)K, nullptr,

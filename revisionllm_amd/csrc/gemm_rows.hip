@@ -1,0 +1,368 @@
+// Decode projections with 33 .. 128 rows: several pools' worth of generates merged into ONE pass over the weights.
+//
+// The <= 32-row kernel (gemv_stream, gemm.hip) re-reads the activations once per workgroup from L2; with MB = 4 / 8 row blocks
+// that is 4 - 8x the weight bytes.  Here the 4 consumer waves of a workgroup own different 16-column tiles (64 columns per
+// workgroup) and SHARE the activations: the 128-k slab of all rows (4 * MB KiB, contiguous in the fragment-packed layout,
+// kernels.h) is staged into LDS by a producer wave (LDS-DMA), while each consumer streams its own weight fragments into registers
+// (weights: HBM -> registers once; activations: L2 -> LDS once per workgroup -> registers once per wave).
+//
+// Summation order.  gemv_stream deals the k-blocks to 8 virtual waves (kb % 8, ascending kb) and adds the 8 partial sums as the
+// balanced tree gemv_tree8.  A workgroup here walks VPW of the virtual waves one after the other and folds them as adjacent
+// subtrees of that tree; with S = 8 / VPW workgroups per column group (split-K wherever N / 64 groups alone would not fill the
+// CUs) each leaves one partial plane; once all S have arrived (a monotonic arrival counter per column group and split count)
+// every one of them adds the planes for its 1 / S share of the group's (column block, row block) pairs and runs the shared
+// epilogue (gemv_finish.h) - one plane-load latency instead of a chain of them in a single last arriver.  A row's result is
+// therefore bit-identical to what the <= 32-row kernel produces for it, whatever it is batched with
+// (tests/test_gpu_merged_decode.py).
+//
+// Measured (MI355X, 63 rows, isolated): qkv 46 us, o / down 22 us, gate/up 68 us per launch - a fixed ~12 us (launch, first loads,
+// plane round trip) plus the weights at ~4.3 TB/s; a 63-row step 6.5 ms vs 4.1 ms for 28 rows on gemv_stream, i.e. 0.72 vs 1.02 ms
+// per 7-row generate (112 rows: 8.7 ms, 0.54 ms).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "gemv_finish.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
+
+// The partial planes move between workgroups (any XCD) with sc1 = agent-coherent accesses (write-through stores, L2-missing loads)
+// and a relaxed agent-scope counter - NOT with release / acquire fences: their buffer_wbl2 / buffer_inv sweep the XCD's whole L2 once
+// per workgroup and serialise the launch (measured here: 30 -> 200 us per projection; same finding as gemm_pp.hip).
+typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int RS_SC1 = 16;     // cache-policy bit 4 = sc1 on gfx940+
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rs_u32x4, v), r, (int)byte_off, 0, RS_SC1);
+}
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, RS_SC1));
+}
+
+constexpr int RS_W = 4;        // consumer waves = 16-column tiles per workgroup (64-column groups); wave RS_W is the producer
+constexpr int RS_THREADS = (RS_W + 1) * 64;
+// MB = 4 row blocks: weight ring 6 deep (5 x 4 KiB per wave in flight), 3 slabs of 16 KiB, <= 168 VGPRs -> two workgroups per CU
+// MB = 8:            weight ring 4 deep, 3 slabs of 32 KiB, one workgroup per CU
+template <int MB> struct RowsCfg { static constexpr int DW = MB == 4 ? 6 : 4, DX = MB == 4 ? 4 : 3, WPE = MB == 4 ? 3 : 2; };
+
+// FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
+//      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
+//      3 = fused q/k/v + RoPE epilogue                        4 = bf16 out, one tile per block
+//
+// Roles.  The consumer waves stream ONLY their weight fragments (registers, DW stages deep, vmcnt counts nothing else); the producer
+// wave copies the activation slabs into LDS (LDS-DMA, DX slabs deep, its own vmcnt).  vmcnt retires in order, so a wave that issued
+// both could not wait for a young slab without also waiting for every older weight load - the weight ring would be no deeper than
+// the slab ring.  One raw s_barrier per stage hands slab g to the consumers and the slot of slab g - 1 back to the producer.
+template <int MB, int VPW, int FIN>
+__global__ __attribute__((amdgpu_flat_work_group_size(RS_THREADS, RS_THREADS), amdgpu_waves_per_eu(RowsCfg<MB>::WPE, RowsCfg<MB>::WPE))) void
+rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
+            const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm, QkvRope qr) {
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    constexpr int S = 8 / VPW, LOG = VPW == 8 ? 3 : VPW == 4 ? 2 : VPW == 2 ? 1 : 0;
+    constexpr int DW = RowsCfg<MB>::DW, DX = RowsCfg<MB>::DX;
+    constexpr int SLAB = MB * 4096;                   // bytes of one 128-k slab of MB row blocks
+    constexpr int XL = MB * 4;                        // LDS-DMA fragments (1 KiB) per slab
+    static_assert((DX - 2) * XL <= 63 && (DW - 2) * 4 <= 63, "vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = blockIdx.x / S, sp = blockIdx.x % S;
+    const int nkb = K >> 7;
+    const int ntile = cg * RS_W + (wave < RS_W ? wave : 0);   // this wave's 16-column tile
+    // stage sequence: virtual waves v = sp * VPW + i, i = 0 .. VPW - 1, one after the other; virtual wave v owns k-blocks v, v + 8, ...
+    // (cnt(v) of them).  T stages in all; both roles run exactly T + (stages issued past the end as L2-hot dummies) of them.
+    auto vcount = [&](int i) -> int { return (nkb - (sp * VPW + i) + 7) >> 3; };
+    int T = 0;
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) T += vcount(i);
+
+    f32x4 acc[MB], stk[LOG ? LOG : 1][MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave == RS_W) {
+        // ---------------- producer: slab of stage g -> LDS slot g % DX ----------------
+        int pi = 0, pc = 0;     // (virtual wave index, k-block index in it) of the next slab to issue
+        auto next_kb = [&]() -> int {
+            int kb = -1;
+            if (pi < VPW) {
+                kb = sp * VPW + pi + 8 * pc;
+                if (++pc == vcount(pi)) { pc = 0; ++pi; }
+            }
+            return kb;
+        };
+        auto issue = [&](int g) {
+            const int kb = next_kb();
+            const bf16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
+            char* dst = rs_smem + (g % DX) * SLAB;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) glds16(xs + i * 512, dst + i * 1024);
+        };
+        for (int d = 0; d < DX - 1; ++d) issue(d);
+        for (int g = 0; g < T; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DX - 2) * XL) : "memory");   // slab g has landed
+            __builtin_amdgcn_s_barrier();                                          // consumers: slab g is yours, slot of slab g - 1 is mine
+            issue(g + DX - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs issued past the end must not outlive the ring's reuse below
+    } else {
+        // ---------------- consumers: weight fragments of stage g in ring slot g % DW (static: the loop is unrolled by DW) ----------------
+        const bf16_t* wp = W + (int64_t)ntile * (K >> 5) * 512 + lane * 8;
+        bf16x8 wf[DW][4];
+        int li = 0, lc = 0;     // next stage to issue
+        int ci = 0, cc = 0;     // stage being computed
+#define RS_ISSUE_W(slot)                                                                                                             \
+    do {                                                                                                                             \
+        int kb_ = -1;                                                                                                                \
+        if (li < VPW) {                                                                                                              \
+            kb_ = sp * VPW + li + 8 * lc;                                                                                            \
+            if (++lc == vcount(li)) { lc = 0; ++li; }                                                                                \
+        }                                                                                                                            \
+        const bf16_t* ws_ = kb_ >= 0 ? wp + (int64_t)kb_ * 2048 : X + lane * 8;                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) wf[slot][j_] = __builtin_nontemporal_load((const bf16x8*)(ws_ + j_ * 512)); \
+    } while (0)
+#pragma unroll
+        for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
+        for (int g0 = 0; g0 < T; g0 += DW) {
+#pragma unroll
+            for (int u = 0; u < DW; ++u) {
+                const int g = g0 + u;
+                if (g < T) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * 4) : "memory");   // the weights of stage g have landed
+                    __builtin_amdgcn_s_barrier();                                        // ... and its slab (producer)
+                    RS_ISSUE_W((u + DW - 1) % DW);
+                    {
+                        const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) {
+                                const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
+                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], xf, acc[mb], 0, 0, 0);
+                            }
+                    }
+                    if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
+                        if constexpr (VPW > 1) {
+                            bool placed = false;
+#pragma unroll
+                            for (int b = 0; b < LOG; ++b) {
+                                if (placed) continue;
+                                if ((ci >> b) & 1) {
+#pragma unroll
+                                    for (int mb = 0; mb < MB; ++mb) acc[mb] = stk[b][mb] + acc[mb];
+                                } else {
+#pragma unroll
+                                    for (int mb = 0; mb < MB; ++mb) stk[b][mb] = acc[mb];
+                                    placed = true;
+                                }
+                            }
+                            if (placed) {
+#pragma unroll
+                                for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
+                        cc = 0;
+                        ++ci;
+                    }
+                }
+            }
+        }
+#undef RS_ISSUE_W
+    }
+    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 32 MiB: 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
+    if (wave < RS_W) {
+        const unsigned off = sp * plane + ((unsigned)ntile * MB * 64 + lane) * 16;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) st_sc1(pr, off + mb * 1024, acc[mb]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through (and the trailing LDS-DMA padding stages are done)
+    __syncthreads();
+    // ---- all S workgroups of the column group have to arrive; then each finishes its share ----
+    // Arrival counter: one per (column group, log2 S), never reset - a launch adds exactly S to it (launches of one stream are
+    // ordered and every engine slot owns its workspace), so the S arrivals of this launch are old = kS .. kS + S - 1 and all of them
+    // are in once the counter reaches (k + 1) S.  No deadlock: workgroups are dispatched in blockIdx order and a group's members
+    // are adjacent, so the lowest unfinished group always has all its members resident or next in line.
+    __shared__ int gave_up;
+    if constexpr (S > 1) {
+        if (tid == 0) {
+            unsigned* cnt = (unsigned*)nrm.arrive + (LOG * (RV_ROWS_COUNTERS / 4) + cg);     // (LOG of VPW: 0 .. 2 here)
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (old / S + 1) * S;
+            unsigned spins = 0;
+            int bad = 0;
+            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {     // a member that never arrives: poison this share, flag the workspace (Engine.check_handoff_status)
+                    if (nrm.status) *nrm.status = 1;
+                    bad = 1;
+                    break;
+                }
+            }
+            gave_up = bad;
+        }
+        __syncthreads();
+    }
+    constexpr int NT = (FIN == 1 || FIN == 2) ? 2 : 1;
+    constexpr int OUT_BF16 = (FIN == 1 || FIN == 4) ? 1 : 0;
+    constexpr int ACT = FIN == 1 ? RV_ACT_SILU_MUL : RV_ACT_NONE;
+    constexpr int ROPE = FIN == 3 ? 1 : 0;
+    constexpr int BPG = RS_W / NT;                      // blocks (of NT tiles) per column group
+    constexpr int PAIRS = BPG * MB;                     // (block, row block) pairs of the group; pair p = block * MB + mb
+    constexpr int PPW = (PAIRS / S + RS_W - 1) / RS_W;  // pairs per wave of this workgroup's share {p : p % S == sp}
+    constexpr int NMB = MB > S ? MB / S : 1;            // row blocks this share touches: mb = (sp + S * i) % MB
+    const int fr = lane & 15, kg = lane >> 4;
+    const int nblk = N / (16 * NT);
+    // (1) the partial planes of this wave's pairs: agent-coherent loads, all in flight at once
+    f32x4 pl[PPW][NT][S];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = sp + S * (wave + RS_W * i);
+        const int blk = cg * BPG + p / MB, mb = p % MB;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const unsigned q = p < PAIRS ? (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16 : 0u;
+#pragma unroll
+            for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+        }
+    }
+    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), for the
+    //     row blocks of this share only
+    float* ssq = (float*)rs_smem;            // [NMB][32][16]: the slab ring is free now
+    if (nrm.in_sumsq) {
+        constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
+        float pj[NMB][VT][8];
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) {
+            const int mb = (sp + S * i) % MB;
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const int vt = tid + v * RS_THREADS;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int b = (vt >> 4) + 32 * j;
+                    pj[i][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) {
+            const int mb = (sp + S * i) % MB;
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const int vt = tid + v * RS_THREADS;
+                if (vt >= 512) continue;
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += pj[i][v][j];
+                for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)];
+                ssq[i * 512 + vt] = a;      // = [i][vt >> 4][vt & 15]
+            }
+        }
+        __syncthreads();
+    }
+    if (wave >= RS_W) return;
+    const float poison = (S > 1 && gave_up) ? __int_as_float(0x7fc00000) : 0.f;   // a missing plane never yields a silent partial sum
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = sp + S * (wave + RS_W * i);
+        if (p >= PAIRS) break;
+        const int blk = cg * BPG + p / MB, mb = p % MB;
+        f32x4 sres[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (S == 8) sres[t] = gemv_tree8(pl[i][t]);
+            else if constexpr (S == 4) sres[t] = (pl[i][t][0] + pl[i][t][1]) + (pl[i][t][2] + pl[i][t][3]);
+            else if constexpr (S == 2) sres[t] = pl[i][t][0] + pl[i][t][1];
+            else sres[t] = pl[i][t][0];
+            sres[t] += poison;
+        }
+        float tot = 0.f;
+        if (nrm.in_sumsq) {
+            const int ii = MB > S ? (mb - sp % MB + MB) % MB / S : 0;     // which of this share's row blocks
+#pragma unroll
+            for (int q = 0; q < 32; ++q) tot += ssq[(ii * 32 + q) * 16 + fr];
+        }
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemv_finish<NT, OUT_BF16, ACT, 1, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
+    }
+}
+
+int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the smallest power of two that fills the CUs, <= 8
+    const int64_t cg = N / 64;
+    int s = MBp == 8 ? 2 : 1;              // (8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit 256 VGPRs)
+    while (s < 8 && cg * s < 240) s *= 2;
+    return s;
+}
+
+template <int MB, int VPW, int FIN>
+int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
+                const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = (size_t)RowsCfg<MB>::DX * MB * 4096;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
+            return RV_ERR_HIP;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN>), dim3((unsigned)(N / 64 * (8 / VPW))), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C, ldc,
+                       M, N, K, nrm, qr);
+    return RV_OK;
+}
+template <int MB, int FIN>
+int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
+                  const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
+    switch (S) {
+        case 1: return rows_launch<MB, 8, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 2: return rows_launch<MB, 4, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 4: return rows_launch<MB, 2, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        default: return rows_launch<MB, 1, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+    }
+}
+template <int FIN>
+int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
+               int K, const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
+    return MBp == 4 ? rows_by_split<4, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
+                    : rows_by_split<8, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+}
+
+}  // namespace
+
+// S * (N / 16) tiles * MB KiB with S = rows_splits(N, MB): S * N < 2 * 240 * 128 wherever the CU fill asks for S > 2; N <= 32768, S = 2 otherwise
+size_t gemm_rows_ws_bytes() { return (size_t)(2 * 32768 / 16) * 8 * 1024; }
+
+// X: 33 .. 128 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
+// qr != nullptr: the fused q/k/v + RoPE epilogue.
+int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
+              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr) {
+    RV_CHECK_ARG(M > 32 && M <= 128 && nrm.x_packed == rv_xp_blocks(M) && nrm.planes && nrm.arrive,
+                 "gemm_rows: 33 .. 128 fragment-packed rows, a plane workspace and arrival counters");
+    RV_CHECK_ARG(N / 64 <= RV_ROWS_COUNTERS / 4, "gemm_rows: too many column groups");
+    RV_CHECK_ARG(N % 64 == 0 && K % 128 == 0 && K >= 1024 && N <= 32768, "gemm_rows: N %% 64, K %% 128, K >= 1024, N <= 32768");
+    RV_CHECK_ARG(act == RV_ACT_NONE || act == RV_ACT_SILU_MUL, "gemm_rows: no activation or SILU_MUL");
+    RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_BF16, "gemm_rows: SILU_MUL writes bf16");
+    const int MBp = nrm.x_packed, S = rows_splits(N, MBp);
+    const QkvRope q0{};
+    int rc;
+    if (qr) rc = rows_by_mb<3>(MBp, S, X, W, nullptr, nullptr, 0, nullptr, 0, M, N, K, nrm, *qr, st);
+    else if (act == RV_ACT_SILU_MUL) rc = rows_by_mb<1>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    else if (N >= 16384 && out_dtype == RV_F32) rc = rows_by_mb<2>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    else if (N < 16384 && out_dtype == RV_BF16) rc = rows_by_mb<4>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    else if (N < 16384) rc = rows_by_mb<0>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    else { rv_set_error("gemm_rows: bf16 output with N >= 16384 is not instantiated"); return RV_ERR_ARG; }
+    if (rc) return rc;
+    RV_CHECK_LAUNCH("gemm_rows");
+    return RV_OK;
+}
+
+// Measurement hook (tools/rows_time.py; not part of include/revision_hip.h): the plain f32 projection on 33 .. 128 packed rows.
+extern "C" int rv_debug_gemm_rows(const void* Xp, const void* Wp, float* C, int M, int N, int K, float* planes, int* arrive, void* stream) {
+    GemvNorm nrm;
+    nrm.x_packed = rv_xp_blocks(M);
+    nrm.planes = planes;
+    nrm.arrive = arrive;
+    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, N, RV_F32, RV_ACT_NONE, M, N, K, (hipStream_t)stream, nrm, nullptr);
+}

@@ -35,16 +35,22 @@ struct GemvNorm {
     const float* w_next = nullptr;    // [N] norm weight of the consumer
     float* out_sumsq = nullptr;       // [gridDim.x][16]
     const float* w_scale = nullptr;   // fp8 weights (w_layout 2): per-output-row dequantisation scale [N]
-    // Fragment-packed decode activations (<= 32 rows): element (row r, k) of a [rows, K] bf16 operand lives at rv_xp_index(r, k),
-    // i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block (the two row blocks of a k-fragment adjacent).
+    // Fragment-packed decode activations (<= 128 rows): element (row r, k) of a [rows, K] bf16 operand lives at
+    // rv_xp_index(r, k, mbp), i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block, the mbp row blocks
+    // (2: <= 32 rows, 4: <= 64, 8: <= 128) of a k-fragment adjacent - a 128-k slab of all rows is one contiguous 4 * mbp KiB run.
     // A wave then fetches its x operand of a k-step with ONE contiguous load per fragment instead of 16 row segments of 64 B -
     // with 17 .. 32 rows the row-major x loads cost the address units more than the weight stream itself.
-    int x_packed = 0;                 // the input activation X is fragment-packed (lda ignored)
-    int out_packed = 0;               // xw_out and a bf16 C are written fragment-packed (ldc ignored for bf16 C)
+    int x_packed = 0;                 // 0: X is row-major; 2 / 4 / 8: X is fragment-packed with that many row blocks (lda ignored)
+    int out_packed = 0;               // same for xw_out and a bf16 C (ldc ignored for bf16 C)
+    float* planes = nullptr;          // 33 .. 128 rows (split-K kernel): workspace for the partial planes, gemm_rows_ws_bytes() bytes
+    int* arrive = nullptr;            // ... and its arrival counters: RV_ROWS_COUNTERS ints, zero before the first launch
+    int* status = nullptr;            // ... and the workspace's hand-off status word (set to 1 if a bounded in-kernel wait gave up)
 };
-__host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k) {
-    return ((((int64_t)(k >> 5) * 2 + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
+__host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k, int mbp) {
+    return ((((int64_t)(k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
 }
+constexpr int RV_ROWS_COUNTERS = 2048;
+__host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows <= 32 ? 2 : rows <= 64 ? 4 : 8; }
 
 // Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
 // (bf16 [M,D]), RoPE-rotated K into the cache and V into the transposed cache - instead of an f32 [M,3D] buffer that two
@@ -116,7 +122,10 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
-int gemv_blocks(int act, int64_t N);  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
+int gemv_blocks(int act, int64_t N);
+int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
+              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr);   // gemm_rows.hip: 33 .. 128 fragment-packed rows
+size_t gemm_rows_ws_bytes();   // partial planes of the 33 .. 128-row decode kernel (any LLM shape up to N = 32768)  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
 // A-resident kernel for short-K many-row problems (gemm_arows.hip): a workgroup keeps its block of A rows in LDS and walks N
 bool gemm_arows_supported(int w_layout, int act, int64_t M, int64_t N, int64_t K);
 int gemm_arows_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
@@ -142,7 +151,7 @@ int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* 
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st,
-              int out_packed = 0);   // out_packed: y16 in the fragment-packed decode layout (rv_xp_index; rows <= 32)
+              int out_packed = 0);   // out_packed: 0, or the row blocks (2 / 4 / 8) of the fragment-packed decode layout y16 is written in (rv_xp_index)
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
@@ -165,7 +174,7 @@ struct AttnArgs {
     // per-batch-row positions (device array [B]; KV-cached decode, Lq = 1, of rows at different positions): row b's query sits at
     // position row_pos[b] and sees keys 0 .. row_pos[b]; row_pos[b] < 0 = inactive row (skipped).  Lk then only bounds the strides.
     const int* row_pos = nullptr;
-    int out_packed = 0;   // (Lq = 1 decode) the output row of batch b goes to the fragment-packed decode layout: element (b, c) at rv_xp_index(b, c)
+    int out_packed = 0;   // (Lq = 1 decode) 2 / 4 / 8: the output row of batch b goes to the fragment-packed decode layout, element (b, c) at rv_xp_index(b, c, out_packed)
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
 int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st);   // two prefill problems (dh 128) in one launch

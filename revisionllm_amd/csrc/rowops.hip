@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 256 + lane * 4;
-            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c) : row * d + c)) =
+            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
                 u32x2{pack_bf16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)), pack_bf16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
         }
     } else {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         const float r = rsqrtf(wave_sum(s) / (float)d + eps);
         for (int c = lane * 4; c < d; c += 256) {
             const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
-            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c) : row * d + c)) =
+            *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
                 u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
         }
     }
@@ -335,7 +335,7 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
 
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed) {
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm: bad arguments");
-    RV_CHECK_ARG(!out_packed || (rows <= 32 && d % 32 == 0), "rmsnorm: the packed decode layout holds <= 32 rows");
+    RV_CHECK_ARG(!out_packed || (rows <= 16 * out_packed && d % 32 == 0), "rmsnorm: the packed decode layout holds <= 16 rows per block");
     if (rows == 0) return RV_OK;
     const dim3 grid((unsigned)cdiv(rows, 4));
     if (d == 4096)

@@ -50,7 +50,7 @@ class DecodePool:
 
     def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, gang=False):
         eng = model.engine
-        assert 1 <= rows <= 32
+        assert 1 <= rows <= 128      # <= 32: the weight-streaming kernel; 33 .. 128: the split-K kernel with LDS-shared activations
         self.model, self.eng, self.R, self.G, self.max_ahead, self.slot = model, eng, rows, gmax, max_ahead, slot
         dev = eng.device
         self.kv, self.Smax = eng.new_kv_pool(rows, smax)
@@ -265,6 +265,7 @@ class DecodeServer:
         assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
         self.pools = [DecodePool(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
         self.gang, self.blocking, self.fill = gang, gang, 0
+        self.fifo_prefill, self.prefill_tail = gang, None     # gang policy: the generates' prefills run in launch order (generate_steps)
         self.model = model
 
     # -- one-pool views (tests, bench statistics)

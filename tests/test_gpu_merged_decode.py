@@ -109,6 +109,44 @@ def test_merged_decode_rows_equal_separate_generates():
     assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
 
 
+@pytest.mark.parametrize("n_groups,R", [(6, 48), (9, 64), (16, 112), (18, 128)])
+def test_wide_pools_33_to_128_rows_equal_separate_generates(n_groups, R):
+    """Merged decode steps with 33 .. 128 rows (the split-K kernel: activations shared through LDS, 1 - 8 workgroups per column group,
+    partial planes folded as subtrees of the 8-way tree): every group's logits at every step BIT-identical to the same group decoded
+    on its own cache by the <= 16-row kernel; groups at different positions, the last one leaving after two steps."""
+    eng = _engine()
+    D = 4096
+    rng = np.random.RandomState(n_groups)
+    groups = [(7, int(rng.randint(40, 120))) for _ in range(n_groups)]
+    Smax = 160
+    g = torch.Generator().manual_seed(5)
+    hs = [torch.randn(B, S, D, generator=g).mul(0.02).cuda() for B, S in groups]
+    steps = 3
+    toks = [[torch.randn(B, 1, D, generator=g).mul(0.02).cuda() for _ in range(steps)] for B, S in groups]
+    ref = []
+    for (B, S), h, tk in zip(groups, hs, toks):
+        kv, sm = eng.new_kv(B, Smax, reuse=False)
+        out = [eng.llm_forward(h.clone(), 0, kv, Smax)]
+        for s_ in range(steps):
+            out.append(eng.llm_forward(tk[s_].clone(), S + s_, kv, Smax))
+        ref.append(out)
+    pool, sm = eng.new_kv_pool(R, Smax)
+    row0 = [7 * i for i in range(n_groups)]
+    for (B, S), h, r0, want in zip(groups, hs, row0, ref):
+        assert torch.equal(eng.llm_prefill_pool(h.clone().view(B * S, D), B, 0, pool, R, r0, Smax), want[0])
+    for s_ in range(steps):
+        active = range(n_groups) if s_ < 2 else range(n_groups - 1)
+        hrow = torch.zeros(R, D, device="cuda:0")
+        p = torch.full((R,), -1, dtype=torch.int32, device="cuda:0")
+        for gi in active:
+            B, S = groups[gi]
+            hrow[row0[gi]:row0[gi] + B] = toks[gi][s_][:, 0]
+            p[row0[gi]:row0[gi] + B] = S + s_
+        logits = eng.llm_decode_rows(hrow, p, pool, Smax)
+        for gi in active:
+            assert torch.equal(logits[row0[gi]:row0[gi] + 7], ref[gi][1 + s_]), (s_, gi)
+
+
 def _tiny_model():
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth

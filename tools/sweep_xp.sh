@@ -1,10 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-for args in "--streams 3" "--streams 4" "--streams 8 --pools 2" "--streams 6 --pools 2" "--streams 10 --pools 2" "--streams 12 --pools 3"; do
+for args in "--streams 14 --pools 2 --pool-rows 49" "--streams 14 --pools 2 --pool-rows 49" "--streams 14 --pools 2 --pool-rows 49" "--streams 18 --pools 2 --pool-rows 64" "--streams 18 --pools 2 --pool-rows 64"; do
   echo "== $args"
-  timeout 300 python bench.py --steps 32 --warmup 8 --no-extras --no-cpu-baseline $args 2>&1 | tail -1 | python -c "
+  timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 $args > /tmp/b.out 2>&1; echo "rc=$?"; tail -1 /tmp/b.out | python -c "
 import sys,json
+t=sys.stdin.read()
 try:
-    d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config'].get('decode'))
-except Exception as e: print('ERR', e)"
+    d=json.loads(t); print(d['value'], d['ms_per_step'], d['config'].get('decode')[-40:])
+except Exception as e: print('ERR', e); print(open('/tmp/b.out').read()[-1500:])"
 done
