@@ -460,8 +460,17 @@ def main():
 
     extra = {}
     if extras:
+        server32 = {"s": None}
+
         def leg(name, nq, fp8, fp8p=False, eos=False, merged=True):
             stages.server = server if merged else None
+            if merged and fp8 and server is not None and args.pool_rows > 32:
+                # the FP8 weight copies are wired into the <= 32-row decode kernel only: these legs decode through 32-row pools
+                if server32["s"] is None:
+                    from revisionllm_amd import serve
+                    server32["s"] = serve.DecodeServer(model, rows=32, smax=server.Smax, gmax=max(16, G), pools=args.pools, gang=args.pools > 1, slot=110)
+                    inter.servers.append(server32["s"])
+                stages.server = server32["s"]
             if nq > 1 and len(work["qs"]) != nq:
                 work["qs"], work["perms"] = query_set(nq)
                 work["feats"] = video_set(nq)
@@ -472,7 +481,7 @@ def main():
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
                            "ms_per_step": t / args.steps * 1e3, "recursions_per_step": nq,
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
-                           "decode_weights": "fp8 e4m3fn, per-row scale" if fp8 else "bf16",
+                           "decode_weights": "fp8 e4m3fn, per-row scale (32-row pools)" if fp8 else "bf16",
                            "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
             if not merged:
                 extra[name]["decode"] = "every step in flight runs its own decode passes (no DecodeServer): the round-1 pipeline"
