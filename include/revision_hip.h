@@ -191,10 +191,11 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
                           void* ws, size_t ws_bytes, void* stream);
 
 /* Several generates sharing ONE KV pool of kv_rows cache rows ([L, kv_rows, H, Smax, dh] and its V^T twin), so that their decode
- * steps can be merged into one pass over the weights (a decode step streams all 13 GB whatever the number of rows <= 32).
+ * steps can be merged into one pass over the weights (a decode step streams all 13 GB whatever the number of rows).
  * rv_llm_prefill_pool: rv_llm_prefill_shared (P0 > 0) / rv_llm_forward prefill (P0 = 0) of B sequences whose cache rows are
  *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
- * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 32), row r at its OWN position row_pos[r]
+ * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 128: up to 32 rows take the weight-streaming kernel,
+ * 33 .. 128 the split-K kernel with LDS-shared activations; bf16 weights only above 32 rows), row r at its OWN position row_pos[r]
  *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified.  h f32 [R, D]
  *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.
  *   Workspace: rv_llm_ws_bytes(ctx, R, 1). */
