@@ -57,7 +57,7 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=18,
+    p.add_argument("--streams", type=int, default=16,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--merge-decode", type=int, default=1,
@@ -66,7 +66,10 @@ def parse():
     p.add_argument("--pools", type=int, default=2,
                    help="KV pools of the DecodeServer; >= 2 switches on the gang policy: a pool is filled with generates first, then its merged "
                         "steps run with all rows while the next generates prefill into the other pool")
-    p.add_argument("--pool-rows", type=int, default=64,
+    p.add_argument("--prefill-batch", type=int, default=4,
+                   help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
+                        "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
+    p.add_argument("--pool-rows", type=int, default=56,
                    help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 128: the split-K kernel with LDS-shared activations)")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
@@ -333,7 +336,8 @@ def main():
     server = None
     if args.merge_decode:
         from revisionllm_amd import serve
-        server = serve.DecodeServer(model, rows=args.pool_rows, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1)
+        server = serve.DecodeServer(model, rows=args.pool_rows, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1,
+                                    prefill_batch=args.prefill_batch)
         stages.server = server
 
     def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
@@ -577,6 +581,9 @@ def main():
                        "decode": ("merged: the generates of the steps in flight share one KV pool and every decode step is ONE pass over the weights for all "
                                   "their rows (serve.DecodeServer; %.1f rows per merged step)" % (server.rows_served / max(1, server.steps_run))
                                   if server is not None else "per step: every step in flight runs its own decode passes"),
+                       "prefill": ("batched: up to %d waiting prefills of the steps in flight ride in one pass (serve.DecodeServer; %.2f per pass in this run)"
+                                   % (server.prefill_batch, server.pf_tickets / max(1, server.pf_batches))
+                                   if server is not None and server.prefill_batch > 1 else "one pass per step"),
                        "parallelism": (f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals"
                                        if world > 1 else "single GPU")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],

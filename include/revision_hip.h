@@ -201,6 +201,13 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  *   Workspace: rv_llm_ws_bytes(ctx, R, 1). */
 int rv_llm_prefill_pool(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows, int32_t kv_row0, int32_t Smax,
                         float* logits, void* ws, size_t ws_bytes, void* stream);
+ /* rv_llm_prefill_pool_groups: G (<= 8) prefills of IDENTICAL geometry (B, P0, S) in one pass - the prefills of several generates in
+ *   flight batched so that the GEMMs see G * (P0 + B * S) rows.  h f32 [G * (P0 + B * S), D]: block g = [P0 shared-prefix rows ; B x S
+ *   rows] of group g, whose cache rows are kv_row0[g] .. kv_row0[g] + B - 1 (HOST array of G ints); logits f32 [G * B, V].
+ *   Workspace: rv_llm_ws_bytes(ctx, G * (P0 + B * S), 1).  Per-row results equal the separate prefills up to the summation order of the
+ *   GEMMs (the stream-K split points depend on the row count). */
+int rv_llm_prefill_pool_groups(rv_ctx* ctx, float* h, int32_t G, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows,
+                               const int32_t* kv_row0, int32_t Smax, float* logits, void* ws, size_t ws_bytes, void* stream);
 int rv_llm_decode_rows(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,
                        size_t ws_bytes, void* stream);
 

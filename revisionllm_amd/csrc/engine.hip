@@ -480,11 +480,15 @@ namespace {
 // pos0 == P0 when P0 > 0).  P0 == 0 is the plain prefill / decode step.
 // kv_rows / kv_row0: the cache tensor holds kv_rows batch rows (0: = B) and this call's rows are kv_row0 .. kv_row0 + B - 1 of it
 // (several generates share one pool).  row_pos (device int [B], S == 1 only): every row decodes at its own position.
+// G / grow (host array [G]): G prefills of identical geometry batched into one pass - h holds G blocks of [P0 ; B x S] rows, block gi's
+// cache rows are grow[gi] .. grow[gi] + B - 1 of the pool (kv_row0 is ignored then); logits [G * B, V].
 int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
-                     size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr) {
+                     size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr, int G = 1,
+                     const int* grow = nullptr) {
     RV_TRY(resolve_llm(c));
     const rv_config& g = c->cfg;
-    const int64_t D = g.hidden, F = g.inter, V = g.vocab, M = (int64_t)B * S + P0;
+    if (G > 1) kv_row0 = grow[0];
+    const int64_t D = g.hidden, F = g.inter, V = g.vocab, Mg = (int64_t)B * S + P0, M = Mg * G;
     const LlmWs w = carve_llm(c, ws, ws_bytes, 1, (int)M);
     if (w.bytes > ws_bytes) {
         rv_set_error("rv_llm_forward: workspace %zu < required %zu", ws_bytes, w.bytes);
@@ -542,6 +546,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.vtc = vtc;
         qr.B = B; qr.S = S; qr.P0 = P0; qr.pos0 = pos0; qr.cs_pos0 = tab0; qr.H = H; qr.Smax = Smax;
         qr.row_pos = row_pos;
+        qr.G = G;
+        qr.Mg = (int)Mg;
+        for (int gi = 1; gi < G; ++gi) qr.grow[gi] = grow[gi] - grow[0];
         if (p8_qkv) {
             RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wqkv8p, L.sqkv, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, M, 3 * D, D, &qr, w.sk, st));
         } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
@@ -558,12 +565,13 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
-        if (P0 > 0) {
-            AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                        (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+        for (int gi = 0; gi < G && P0 > 0; ++gi) {     // (a batch of G prefills: one launch pair per group)
+            const int64_t qo = (int64_t)gi * Mg * D, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
+            AttnArgs ap{w.q16 + qo, D, (int64_t)P0 * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
+                        (int64_t)dh * Smax, Smax, w.a16 + qo, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
             if (P0 > 16 && S > 16 && dh == 128) {   // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch)
-                AttnArgs am{w.q16 + (int64_t)P0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
-                            (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
+                AttnArgs am{w.q16 + qo + (int64_t)P0 * D, D, (int64_t)S * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co,
+                            (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + qo + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
                             S, pos0 + S, 1, pos0, 1, scale};
                 RV_TRY(k_attention_pair(ap, am, st));
                 prefix_done = true;
@@ -581,12 +589,15 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.arrive = w.arrive;
         produce.status = consume.status;
         {
-            const int64_t r0 = P0;  // first row of the per-sequence part
-            AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                       (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
-            a.row_pos = row_pos;
-            a.out_packed = xp;
-            if (!prefix_done) RV_TRY(k_attention(a, st));
+            for (int gi = 0; gi < G && !prefix_done; ++gi) {
+                const int64_t r0 = (int64_t)gi * Mg + P0;  // first row of the per-sequence part
+                const int64_t co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
+                AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
+                           (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
+                a.row_pos = row_pos;
+                a.out_packed = xp;
+                RV_TRY(k_attention(a, st));
+            }
             if (p8_o) {
                 RV_TRY(k_quant_rows_fp8(w.a16, D, w.x8, D, w.sa, M, (int)D, st));
                 RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wo8p, L.so, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, nullptr, w.sk, st));
@@ -633,8 +644,9 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         return rv_gemm_impl(w.xn16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st,
                             &consume);
     // final norm + lm_head on the last position of every sequence only
-    RV_TRY(k_rmsnorm(h + ((int64_t)P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16, B, (int)D, g.rms_eps, st));
-    return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st);
+    for (int gi = 0; gi < G; ++gi)
+        RV_TRY(k_rmsnorm(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * D, B, (int)D, g.rms_eps, st));
+    return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, (int64_t)G * B, V, D, w.sk, w.sk_bytes, st);
 }
 }  // namespace
 
@@ -670,6 +682,18 @@ extern "C" int rv_llm_prefill_pool(rv_ctx* c, float* h, int32_t B, int32_t P0, i
     RV_CHECK_ARG(kv_rows >= B && kv_row0 >= 0 && kv_row0 + B <= kv_rows, "rv_llm_prefill_pool: rows %d..%d outside a pool of %d rows", kv_row0, kv_row0 + B, kv_rows);
     RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_pool: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
     return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), kv_rows, kv_row0, nullptr);
+}
+
+extern "C" int rv_llm_prefill_pool_groups(rv_ctx* c, float* h, int32_t G, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows,
+                                          const int32_t* kv_row0, int32_t Smax, float* logits, void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws && kv_row0, "rv_llm_prefill_pool_groups: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(G >= 1 && G <= RV_MAX_PREFILL_GROUPS && B > 0 && S > 0 && P0 >= 0, "rv_llm_prefill_pool_groups: 1 .. %d groups, non-empty", RV_MAX_PREFILL_GROUPS);
+    for (int gi = 0; gi < G; ++gi)
+        RV_CHECK_ARG(kv_row0[gi] >= 0 && kv_row0[gi] + B <= kv_rows, "rv_llm_prefill_pool_groups: rows %d..%d outside a pool of %d rows", kv_row0[gi],
+                     kv_row0[gi] + B, kv_rows);
+    RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_pool_groups: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
+    return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), kv_rows, kv_row0[0], nullptr, G, kv_row0);
 }
 
 extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,

@@ -9,10 +9,9 @@
 // Summation order.  gemv_stream deals the k-blocks to 8 virtual waves (kb % 8, ascending kb) and adds the 8 partial sums as the
 // balanced tree gemv_tree8.  A workgroup here walks VPW of the virtual waves one after the other and folds them as adjacent
 // subtrees of that tree; with S = 8 / VPW workgroups per column group (split-K wherever N / 64 groups alone would not fill the
-// CUs) each leaves one partial plane; once all S have arrived (a monotonic arrival counter per column group and split count)
-// every one of them adds the planes for its 1 / S share of the group's (column block, row block) pairs and runs the shared
-// epilogue (gemv_finish.h) - one plane-load latency instead of a chain of them in a single last arriver.  A row's result is
-// therefore bit-identical to what the <= 32-row kernel produces for it, whatever it is batched with
+// CUs) each leaves one partial plane, and the LAST of them to arrive (a monotonic arrival counter per column group and split
+// count; nobody waits) adds the planes of the group's (column block, row block) pairs - all loads in flight at once - and runs the
+// shared epilogue (gemv_finish.h).  A row's result is therefore bit-identical to what the <= 32-row kernel produces for it, whatever it is batched with
 // (tests/test_gpu_merged_decode.py).
 //
 // Measured (MI355X, 63 rows, isolated): qkv 46 us, o / down 22 us, gate/up 68 us per launch - a fixed ~12 us (launch, first loads,
@@ -179,30 +178,19 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through (and the trailing LDS-DMA padding stages are done)
     __syncthreads();
-    // ---- all S workgroups of the column group have to arrive; then each finishes its share ----
-    // Arrival counter: one per (column group, log2 S), never reset - a launch adds exactly S to it (launches of one stream are
-    // ordered and every engine slot owns its workspace), so the S arrivals of this launch are old = kS .. kS + S - 1 and all of them
-    // are in once the counter reaches (k + 1) S.  No deadlock: workgroups are dispatched in blockIdx order and a group's members
-    // are adjacent, so the lowest unfinished group always has all its members resident or next in line.
-    __shared__ int gave_up;
+    // ---- the LAST of the S workgroups of the column group to arrive finishes it ----
+    // Arrival counter: one per (column group, log2 S), never reset - a launch adds exactly S to it (launches of one stream are ordered
+    // and every engine slot owns its workspace), so the last arrival of this launch is the one that reads S - 1 (mod S).  Nobody
+    // WAITS for anybody: a workgroup that spun for the others could deadlock against the stream-K prefill GEMMs of another stream,
+    // whose workgroups spin for each other too (seen: both kernels half resident, each holding the CUs the other needs).
+    __shared__ int is_last;
     if constexpr (S > 1) {
         if (tid == 0) {
             unsigned* cnt = (unsigned*)nrm.arrive + (LOG * (RV_ROWS_COUNTERS / 4) + cg);     // (LOG of VPW: 0 .. 2 here)
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (old / S + 1) * S;
-            unsigned spins = 0;
-            int bad = 0;
-            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) {     // a member that never arrives: poison this share, flag the workspace (Engine.check_handoff_status)
-                    if (nrm.status) *nrm.status = 1;
-                    bad = 1;
-                    break;
-                }
-            }
-            gave_up = bad;
+            is_last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % S == S - 1;
         }
         __syncthreads();
+        if (!is_last) return;
     }
     constexpr int NT = (FIN == 1 || FIN == 2) ? 2 : 1;
     constexpr int OUT_BF16 = (FIN == 1 || FIN == 4) ? 1 : 0;
@@ -210,64 +198,63 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     constexpr int ROPE = FIN == 3 ? 1 : 0;
     constexpr int BPG = RS_W / NT;                      // blocks (of NT tiles) per column group
     constexpr int PAIRS = BPG * MB;                     // (block, row block) pairs of the group; pair p = block * MB + mb
-    constexpr int PPW = (PAIRS / S + RS_W - 1) / RS_W;  // pairs per wave of this workgroup's share {p : p % S == sp}
-    constexpr int NMB = MB > S ? MB / S : 1;            // row blocks this share touches: mb = (sp + S * i) % MB
+    constexpr int PPW = PAIRS / RS_W;                   // pairs per consumer wave: p = wave + RS_W * i  ->  mb = p % MB
+    static_assert(PAIRS % RS_W == 0, "pairs split evenly over the consumer waves");
     const int fr = lane & 15, kg = lane >> 4;
     const int nblk = N / (16 * NT);
-    // (1) the partial planes of this wave's pairs: agent-coherent loads, all in flight at once
+    // (1) the partial planes of this wave's pairs: agent-coherent loads, all in flight at once (one memory latency, not PPW of them)
     f32x4 pl[PPW][NT][S];
+    if (wave < RS_W) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int p = sp + S * (wave + RS_W * i);
-        const int blk = cg * BPG + p / MB, mb = p % MB;
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + RS_W * i;
+            const int blk = cg * BPG + p / MB, mb = p % MB;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const unsigned q = p < PAIRS ? (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16 : 0u;
+            for (int t = 0; t < NT; ++t) {
+                const unsigned q = (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16;
 #pragma unroll
-            for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+                for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+            }
         }
     }
-    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), for the
-    //     row blocks of this share only
-    float* ssq = (float*)rs_smem;            // [NMB][32][16]: the slab ring is free now
+    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
+    //     blocks at a time (registers)
+    float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now
     if (nrm.in_sumsq) {
         constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
-        float pj[NMB][VT][8];
 #pragma unroll
-        for (int i = 0; i < NMB; ++i) {
-            const int mb = (sp + S * i) % MB;
+        for (int m0 = 0; m0 < MB; m0 += 2) {
+            float pj[2][VT][8];
 #pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const int vt = tid + v * RS_THREADS;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int b = (vt >> 4) + 32 * j;
-                    pj[i][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                for (int v = 0; v < VT; ++v) {
+                    const int vt = tid + v * RS_THREADS;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int b = (vt >> 4) + 32 * j;
+                        pj[i][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                    }
                 }
-            }
-        }
 #pragma unroll
-        for (int i = 0; i < NMB; ++i) {
-            const int mb = (sp + S * i) % MB;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const int vt = tid + v * RS_THREADS;
-                if (vt >= 512) continue;
-                float a = 0.f;
+                for (int v = 0; v < VT; ++v) {
+                    const int vt = tid + v * RS_THREADS;
+                    if (vt >= 512) continue;
+                    float a = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a += pj[i][v][j];
-                for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)];
-                ssq[i * 512 + vt] = a;      // = [i][vt >> 4][vt & 15]
-            }
+                    for (int j = 0; j < 8; ++j) a += pj[i][v][j];
+                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
+                    ssq[(m0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
+                }
         }
         __syncthreads();
     }
     if (wave >= RS_W) return;
-    const float poison = (S > 1 && gave_up) ? __int_as_float(0x7fc00000) : 0.f;   // a missing plane never yields a silent partial sum
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int p = sp + S * (wave + RS_W * i);
-        if (p >= PAIRS) break;
+        const int p = wave + RS_W * i;
         const int blk = cg * BPG + p / MB, mb = p % MB;
         f32x4 sres[NT];
 #pragma unroll
@@ -276,13 +263,11 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             else if constexpr (S == 4) sres[t] = (pl[i][t][0] + pl[i][t][1]) + (pl[i][t][2] + pl[i][t][3]);
             else if constexpr (S == 2) sres[t] = pl[i][t][0] + pl[i][t][1];
             else sres[t] = pl[i][t][0];
-            sres[t] += poison;
         }
         float tot = 0.f;
         if (nrm.in_sumsq) {
-            const int ii = MB > S ? (mb - sp % MB + MB) % MB / S : 0;     // which of this share's row blocks
 #pragma unroll
-            for (int q = 0; q < 32; ++q) tot += ssq[(ii * 32 + q) * 16 + fr];
+            for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + fr];
         }
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         gemv_finish<NT, OUT_BF16, ACT, 1, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);

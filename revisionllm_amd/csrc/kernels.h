@@ -58,6 +58,7 @@ __host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows
 // dim j+64), so the rotate_half partners (j, j+64) sit in one lane's 4 consecutive outputs; Q and K are stored in that
 // permuted order (the q.k dot product is invariant under a common permutation), V is not permuted.
 // Rows: [P0 shared-prefix rows (pos = row; K/V broadcast to all B caches)] then B sequences x S rows (pos0 + s).
+constexpr int RV_MAX_PREFILL_GROUPS = 8;
 struct QkvRope {
     const float* cs = nullptr;  // (cos, sin) table [pos - cs_pos0][dh/2]
     void* q16 = nullptr;        // bf16 [M, D]
@@ -67,6 +68,10 @@ struct QkvRope {
     // KV-cached decode of rows at DIFFERENT positions (rows of several generates merged into one step): position of row m =
     // row_pos[m] (device array), its (cos, sin) are row m of the table; row_pos[m] < 0 = inactive row (nothing is stored)
     const int* row_pos = nullptr;
+    // Several prefills of IDENTICAL geometry batched into one pass (prefills of several generates in flight: the GEMMs see G * Mg rows):
+    // rows [g * Mg, (g + 1) * Mg) are group g's [P0 prefix ; B x S] block, its cache rows start grow[g] rows after kc / vtc's
+    int G = 1, Mg = 0;
+    int grow[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 // Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
 // qkv_rope_coeffs fetches the (cos, sin) pairs the group needs (zeros for V columns); the decode kernel calls it BEFORE its
@@ -76,6 +81,7 @@ static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m,
     const int sec = n / D, p = (n - sec * D) & 127;
     if (sec >= 2) return f32x4{0.f, 0.f, 0.f, 0.f};
     if (q.row_pos) return *(const f32x4*)(q.cs + ((int64_t)m * 64 + (p >> 1)) * 2);   // per-row table
+    if (q.G > 1) m -= (m / q.Mg) * q.Mg;
     int pos;
     if (m < q.P0) pos = m;
     else { const int r = m - q.P0; const int b = r / q.S; pos = q.pos0 + (r - b * q.S); }
@@ -84,8 +90,10 @@ static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m,
 static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) {
     const int D = q.H * 128;
     const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
-    int b, pos;
+    int b, pos, goff = 0;
     bool prefix = false;
+    const int mrow = m;      // row of q16 (the batch-wide row)
+    if (q.G > 1) { const int gi = m / q.Mg; m -= gi * q.Mg; goff = q.grow[gi]; }
     if (q.row_pos) { b = m; pos = q.row_pos[m]; if (pos < 0) return; }
     else if (m < q.P0) { b = 0; pos = m; prefix = true; }
     else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
@@ -96,14 +104,14 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
         const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
         const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
         if (sec == 0) {
-            *(u32x2*)((bf16_t*)q.q16 + (int64_t)m * D + hd) = o;
+            *(u32x2*)((bf16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
         } else {
-            const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+            const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
             for (int bb = b0_; bb < b1_; ++bb)
                 *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
         }
     } else {
-        const int b0_ = prefix ? 0 : b, b1_ = prefix ? q.B : b + 1;
+        const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
         for (int bb = b0_; bb < b1_; ++bb) {
             bf16_t* dst = (bf16_t*)q.vtc + (((int64_t)bb * q.H + head) * 128 + p) * q.Smax + pos;
 #pragma unroll

@@ -340,6 +340,22 @@ class Engine:
         self._persist_end()
         return logits
 
+    def llm_prefill_pool_groups(self, h, G, B, P0, kv, kv_rows, row0s, Smax, logits=None):
+        """G prefills of identical geometry in one pass: h f32 [G * (P0 + B*S), D], block g's cache rows start at row0s[g].
+        -> logits f32 [G * B, V] (group-major)."""
+        import ctypes
+        assert h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] % G == 0 and (h.shape[0] // G - P0) % B == 0
+        S = (h.shape[0] // G - P0) // B
+        if logits is None:
+            logits = torch.empty(G * B, self.shape.vocab, dtype=torch.float32, device=self.device)
+        ws = self._workspace("llm", self.lib.rv_llm_ws_bytes(self._ctx, h.shape[0], 1))
+        rows = (ctypes.c_int32 * G)(*[int(r) for r in row0s])
+        self._persist_begin()
+        hip.check(self.lib.rv_llm_prefill_pool_groups(self._ctx, hip.ptr(h), G, B, P0, S, hip.ptr(kv), kv_rows, rows, Smax, hip.ptr(logits), hip.ptr(ws),
+                                                      ws.numel(), hip.stream()), "rv_llm_prefill_pool_groups")
+        self._persist_end()
+        return logits
+
     def llm_decode_rows(self, h, row_pos, kv, Smax, logits=None):
         """One merged decode step: h f32 [R, D] (clobbered), row_pos int32 [R] on the device (< 0: inactive) -> logits f32 [R, V]."""
         R = h.shape[0]

@@ -285,24 +285,34 @@ class ReVisionLlamaForCausalLM:
             # ---- merged-decode path: prefill into the server's pool, its merged steps do the rest ----
             for ev in job.free_events:
                 torch.cuda.current_stream(dev).wait_event(ev)                   # the rows' previous owners are done with them
-            if getattr(server, "fifo_prefill", False) and server.prefill_tail is not None:
+            batched = getattr(server, "prefill_batch", 1) > 1
+            if not batched and getattr(server, "fifo_prefill", False) and server.prefill_tail is not None:
                 # prefills in launch order: each one saturates the GPU anyway, and the pool that fills first then decodes (HBM-bound)
                 # under the NEXT pool's prefills (MFMA-bound) instead of all prefills in flight finishing together
                 torch.cuda.current_stream(dev).wait_event(server.prefill_tail)
             if 16 <= P0 < S:
                 flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
-                h = eng.splice_embed(flat, video_rows)[0]
-                first = eng.llm_prefill_pool(h, B, P0, pool.kv, pool.R, job.r0, pool.Smax)
+                h, p0 = eng.splice_embed(flat, video_rows)[0], P0
             else:
-                h = eng.splice_embed(row_map, video_rows).view(B * S, -1)
-                first = eng.llm_prefill_pool(h, B, 0, pool.kv, pool.R, job.r0, pool.Smax)
+                h, p0 = eng.splice_embed(row_map, video_rows).view(B * S, -1), 0
+            if batched:      # the server batches the waiting prefills of identical geometry into one pass (its own stream, FIFO)
+                ticket = server.submit_prefill(job, h, B, p0)
+                from .. import sched
+                while ticket.ready is None:
+                    yield sched.RETRY
+                first, ready = ticket.first, ticket.ready
+                torch.cuda.current_stream(dev).wait_event(ready)
+            else:
+                first = eng.llm_prefill_pool(h, B, p0, pool.kv, pool.R, job.r0, pool.Smax)
+                ready = None
             if do_sample and uniforms is None:
                 uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
                             else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
-            ready = torch.cuda.Event()
-            ready.record()
-            if getattr(server, "fifo_prefill", False):
-                server.prefill_tail = ready
+            if ready is None:
+                ready = torch.cuda.Event()
+                ready.record()
+                if getattr(server, "fifo_prefill", False):
+                    server.prefill_tail = ready
             yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
             server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
                         uniforms=uniforms if do_sample else None, forced=forced_tokens)

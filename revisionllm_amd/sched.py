@@ -73,7 +73,8 @@ class _null:
 class Interleaver:
     """Tasks in launch order.  ``add`` starts a task (runs it up to its first pending event); ``finish(task)`` returns its
     result, advancing every other ready task while it waits.  ``servers``: objects with ``pump() -> bool`` / ``wait_one() -> bool``
-    / optionally ``flush() -> bool`` (``serve.DecodeServer``: the merged decode steps of the generates in flight) that are pumped along
+    / optionally ``idle() -> bool`` (called whenever a pump made no progress, before the
+    scheduler blocks) and ``flush() -> bool`` (``serve.DecodeServer``: the merged decode steps of the generates in flight) that are pumped along
     with the tasks; ``flush`` is called when neither a task nor a server has a device event left to wait for."""
 
     def __init__(self, servers=()):
@@ -97,6 +98,8 @@ class Interleaver:
         task.finishing = True
         while not task.done:
             if not self.pump():
+                if any(sv.idle() for sv in self.servers if hasattr(sv, "idle")):
+                    continue        # a server let go of work it was holding back for a fuller batch
                 # nothing is ready: wait for the event of the task we want (the others keep their queued device work), or for the
                 # oldest merged step a server has in flight (which lets it enqueue the next one)
                 if task.waiting is not None:

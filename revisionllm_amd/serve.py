@@ -256,13 +256,36 @@ class DecodePool:
         eng.slot = prev_slot
 
 
+class PrefillTicket:
+    """One generate's prefill handed to the server (``DecodeServer.submit_prefill``): ``ready`` (event) / ``first`` (its last-position
+    logits [B, V]) are set once the batch it rides in has been enqueued."""
+
+    def __init__(self, job, h, B, P0, event):
+        self.job, self.h, self.B, self.P0, self.event = job, h, B, P0, event
+        self.ready = self.first = None
+
+    @property
+    def key(self):
+        return (id(self.job.pool), self.B, self.P0, self.h.shape[0])
+
+
 class DecodeServer:
     """The pools + the stepping policy (module docstring).  ``gang=False``: one pool, greedy steps.  What ``generate_steps``
     uses: ``fits``, ``reserve`` (-> ``Job`` with ``job.pool``; ``None``: no room - wait if ``blocking`` else decode alone), ``join``;
     what ``sched.Interleaver`` uses: ``pump`` / ``wait_one``."""
 
-    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False):
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False, prefill_batch=1):
+        """``prefill_batch`` > 1: the generates' LLM prefills go through the server too - up to that many waiting prefills of identical
+        geometry (rows, shared-prefix length, length) ride in ONE pass (``rv_llm_prefill_pool_groups``: the GEMMs see G x 1005 rows
+        instead of 1005, which the N = 4096 projections in particular are too small for), on one prefill stream in submission order.
+        A batch is enqueued as soon as ``prefill_batch`` tickets wait, or whatever waits when no earlier batch is still running (the
+        stream never idles for the sake of a fuller batch).  Per-row results equal the separate prefills up to GEMM summation order."""
         assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
+        assert 1 <= prefill_batch <= 8
+        self.prefill_batch, self.pf_queue, self.pf_inflight = prefill_batch, [], []
+        self.pf_stream = torch.cuda.Stream(model.engine.device) if prefill_batch > 1 else None
+        self.pf_slot = slot + 16
+        self.pf_batches = self.pf_tickets = 0
         self.pools = [DecodePool(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
         self.gang, self.blocking, self.fill = gang, gang, 0
         self.fifo_prefill, self.prefill_tail = gang, None     # gang policy: the generates' prefills run in launch order (generate_steps)
@@ -328,11 +351,66 @@ class DecodeServer:
     def join(self, job, *a, **kw):
         return job.pool.join(job, *a, **kw)
 
+    # ---- batched prefills ------------------------------------------------------------------------------------------------------
+    def submit_prefill(self, job, h, B, P0):
+        """h f32 [P0 + B * S, D] (written on the caller's current stream) -> ticket; poll ``ticket.ready``."""
+        ev = torch.cuda.Event()
+        ev.record()
+        t = PrefillTicket(job, h, B, P0, ev)
+        self.pf_queue.append(t)
+        return t
+
+    def _pump_prefill(self, partial=False, force=False):
+        """Enqueue the next batch: a FULL one any time; a partial one only when the host has nothing else to do (``partial``: every
+        launch that was imminent has been made) and no earlier batch is still running - or unconditionally (``force``)."""
+        if not self.pf_queue:
+            return False
+        self.pf_inflight = [e for e in self.pf_inflight if not e.query()]
+        lead = self.pf_queue[0]
+        n = 1
+        while n < len(self.pf_queue) and n < self.prefill_batch and self.pf_queue[n].key == lead.key:
+            n += 1
+        full = n == self.prefill_batch or n < len(self.pf_queue)      # (a ticket of another geometry behind the group closes it)
+        if not full and not force and not (partial and not self.pf_inflight):
+            return False
+        while n & (n - 1):          # 1, 2, 4 or 8 groups: their 4 / 8 / 16 / 32 row tiles of 256 divide the 32 CUs of an XCD, so the stream-K
+            n -= 1                  # teams (one per weight panel, gemm_pp.hip) leave no CU idle - 3 x 1005 rows ran 25 % slower than 4 x
+        batch, self.pf_queue = self.pf_queue[:n], self.pf_queue[n:]
+        eng, pool = self.model.engine, lead.job.pool
+        prev = eng.slot
+        eng.slot = self.pf_slot
+        with torch.cuda.stream(self.pf_stream):
+            for t in batch:
+                self.pf_stream.wait_event(t.event)
+                t.h.record_stream(self.pf_stream)
+            if n == 1:
+                logits = eng.llm_prefill_pool(lead.h, lead.B, lead.P0, pool.kv, pool.R, lead.job.r0, pool.Smax)
+            else:
+                logits = eng.llm_prefill_pool_groups(torch.cat([t.h for t in batch]), n, lead.B, lead.P0, pool.kv, pool.R,
+                                                     [t.job.r0 for t in batch], pool.Smax)
+            ev = torch.cuda.Event()
+            ev.record(self.pf_stream)
+        eng.slot = prev
+        for i, t in enumerate(batch):
+            t.first = logits[i * t.B:(i + 1) * t.B]
+            t.ready = ev
+            t.h = None
+        self.pf_inflight.append(ev)
+        self.pf_batches += 1
+        self.pf_tickets += n
+        return True
+
     def pump(self):
         progressed = False
+        if self.pf_queue:
+            progressed |= self._pump_prefill()
         for p in self.pools:
             progressed |= p.pump()
         return progressed
+
+    def idle(self):
+        """The scheduler made no progress and is about to block: what is waiting for a fuller batch goes now if the prefill stream is idle."""
+        return bool(self.pf_queue) and self._pump_prefill(partial=True)
 
     def wait_one(self):
         for p in self.pools:
@@ -343,6 +421,8 @@ class DecodeServer:
     def flush(self):
         """Nothing is in flight anywhere and no task has a device event pending (the scheduler would spin): the partly filled
         pool is run as it is (end of the workload, or fewer tasks in flight than a pool takes)."""
+        if self.pf_queue and self._pump_prefill(force=True):
+            return True
         if self.gang:
             p = self.pools[self.fill]
             if not p.sealed and p.live > 0 and p.pending == 0:

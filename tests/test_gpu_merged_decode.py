@@ -147,6 +147,38 @@ def test_wide_pools_33_to_128_rows_equal_separate_generates(n_groups, R):
             assert torch.equal(logits[row0[gi]:row0[gi] + 7], ref[gi][1 + s_]), (s_, gi)
 
 
+@pytest.mark.parametrize("G,P0", [(3, 40), (2, 0), (4, 48)])
+def test_batched_prefill_groups_match_separate_prefills(G, P0):
+    """rv_llm_prefill_pool_groups: G prefills of identical geometry ([P0 shared prefix ; 7 x S'] each) in ONE pass against the same G
+    prefills one at a time: logits and caches agree to GEMM summation order (the stream-K split points depend on the row count, so
+    not bit for bit), and with tiny prefills (the 128-row tile kernel either way) exactly."""
+    eng = _engine()
+    D, H, L = 4096, 32, 2
+    B, S, Smax, R = 7, 96, 160, 32
+    g = torch.Generator().manual_seed(11 + G)
+    hs = [torch.randn(P0 + B * S, D, generator=g).mul(0.02).cuda() for _ in range(G)]
+    row0 = [3 + 7 * i for i in range(G)]
+    pool_a, _ = eng.new_kv_pool(R, Smax)
+    pool_b, _ = eng.new_kv_pool(R, Smax)
+    sep = [eng.llm_prefill_pool(h.clone(), B, P0, pool_a, R, r0, Smax).clone() for h, r0 in zip(hs, row0)]
+    bat = eng.llm_prefill_pool_groups(torch.cat(hs).contiguous(), G, B, P0, pool_b, R, row0, Smax)
+    for gi in range(G):
+        assert rel_err(bat[gi * B:(gi + 1) * B].cpu(), sep[gi].cpu()) < 1e-2, gi       # (bf16 activations: a different f32 summation order moves roundings)
+    half = pool_a.numel() // 2
+    ka, kb = pool_a[:half].view(L, R, H, Smax, 128).float(), pool_b[:half].view(L, R, H, Smax, 128).float()
+    va, vb = pool_a[half:].view(L, R, H, 128, Smax).float(), pool_b[half:].view(L, R, H, 128, Smax).float()
+    n = P0 + S
+    assert rel_err(kb[:, :, :, :n].cpu(), ka[:, :, :, :n].cpu()) < 1e-2 and rel_err(vb[..., :n].cpu(), va[..., :n].cpu()) < 1e-2
+    assert (kb[:, :3] == 0).all() and (kb[:, 3 + 7 * G:] == 0).all() and (kb[:, :, :, n:] == 0).all()      # nothing outside the groups' rows / positions
+    # one decode step from either pool: same logits to the same tolerance
+    pos = torch.full((R,), -1, dtype=torch.int32, device="cuda:0")
+    pos[3:3 + 7 * G] = n
+    hrow = torch.randn(R, D, generator=g).mul(0.02).cuda()
+    la = eng.llm_decode_rows(hrow.clone(), pos, pool_a, Smax)
+    lb = eng.llm_decode_rows(hrow.clone(), pos, pool_b, Smax)
+    assert rel_err(lb[3:3 + 7 * G].cpu(), la[3:3 + 7 * G].cpu()) < 1e-2
+
+
 def _tiny_model():
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
@@ -159,13 +191,15 @@ def _tiny_model():
     return m
 
 
-@pytest.mark.parametrize("n_passes,streams,pools", [(3, 3, 1), (5, 2, 1), (7, 6, 2), (9, 8, 3)])
-def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams, pools):
+@pytest.mark.parametrize("n_passes,streams,pools,pbatch", [(3, 3, 1, 1), (5, 2, 1, 1), (7, 6, 2, 1), (9, 8, 3, 1), (7, 6, 2, 4)])
+def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams, pools, pbatch):
     """Several stage-2 recursions in flight on their own HIP streams, their generates decoding through ONE DecodeServer (shared KV
     pool, merged steps with rows at different positions, rows joining and leaving as prefills complete) against the same
     recursions run one after the other through the classic loop: records identical (answers, entropies, cosine scores).
     ``pools`` > 1: the gang policy (a pool is filled with four 8-row generates, sealed, and stepped with all 32 rows while the
-    next recursions prefill into the other pool; the last, partly filled pool is run when nothing else is left)."""
+    next recursions prefill into the other pool; the last, partly filled pool is run when nothing else is left).
+    ``pbatch`` > 1: the waiting prefills of identical geometry ride in one pass (``rv_llm_prefill_pool_groups``); at these sizes every
+    GEMM is on the 128-row tile kernel whatever the batch, so the records stay identical."""
     from revisionllm_amd import parallel, sched, serve
     from revisionllm_amd.eval import stage2
     from revisionllm_amd.utils import synth
@@ -181,7 +215,7 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     unis = [torch.rand(6, len(plan), generator=torch.Generator().manual_seed(10 + i)) for i in range(n_passes)]
     kw = dict(batch=batch, perms=[perms], max_new_tokens=6)
     seq = [parallel.run_queries_sharded(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], uniforms=unis[i], **kw)[0] for i in range(n_passes)]
-    server = serve.DecodeServer(m, rows=32, smax=128, gmax=16, pools=pools, gang=pools > 1)
+    server = serve.DecodeServer(m, rows=32, smax=128, gmax=16, pools=pools, gang=pools > 1, prefill_batch=pbatch)
     st.server = server
     hs = [torch.cuda.Stream("cuda:0") for _ in range(streams)]
     torch.cuda.synchronize()
@@ -199,6 +233,8 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     assert server.steps_run > 0 and server.rows_served > server.steps_run * len(plan) * 0.99      # the merged steps really carried the rows
     if n_passes == 3:
         assert server.rows_served > server.steps_run * len(plan)                                   # ... of more than one recursion at a time
+    if pbatch > 1:
+        assert server.pf_tickets > server.pf_batches > 0                                          # some prefills really rode together
     if pools > 1:
         assert server.rows_served > server.steps_run * len(plan) * 1.5, (server.rows_served, server.steps_run)   # gangs (the three levels of a recursion are
                                                                                                    # sequential generates, so pools also run partly filled here)

@@ -29,7 +29,7 @@ def main():
     for geo in ((2, 3) if "gemm" in which else ()):
         opt = hip.Options(gemm_tile_variant=geo)
         print(f"--- tile variant {geo}")
-        for M in (1005, 2010):
+        for M in (1005, 4020):
             for name, N, K, act, od in (("qkv", 3 * D, D, 0, torch.float32), ("o", D, D, 0, torch.float32),
                                         ("gateup", 2 * F, D, 2, torch.bfloat16), ("down", D, F, 0, torch.float32)):
                 x = torch.randn(M, K, device=dev).to(torch.bfloat16)
