@@ -25,6 +25,7 @@ one of them alone as the line's ``value``).
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -104,14 +105,16 @@ def event_time_ms(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def roofline_legs(model, n_calls, M, dec_rows=None):
+def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     """Time the path's heavy kernels in isolation on the shapes the recursion launches them with
     (M = rows of the prefill GEMM batch: shared prompt prefix once + the rest of every call)."""
     from revisionllm_amd import hip, ops
     eng, s = model.engine, model.shape
     dev = eng.device
     legs = {}
-    # (1) prefill gate/up GEMM + SiLU*mul epilogue: [M,4096] x [22016,4096]^T  (MFMA-bound)
+    # (1) prefill gate/up GEMM + SiLU*mul epilogue: [M,4096] x [22016,4096]^T  (MFMA-bound); M = the rows of one prefill pass of the timed
+    #     region: prefill_groups steps' prefills ride together (serve.DecodeServer, rv_llm_prefill_pool_groups)
+    M = M * prefill_groups
     x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
     w = eng.weight("llm.L0.wgu")
     out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
@@ -120,25 +123,47 @@ def roofline_legs(model, n_calls, M, dec_rows=None):
     # M <= 8192 rows: the persistent 256x256x64 ping-pong kernel (one 512-thread workgroup per CU), whole panels + stream-K tail
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     legs["prefill_gateup_gemm"] = dict(kernel="gemm_pp_sk<1,2,0,4,0>", bound="mfma", ms=ms, achieved=flops / ms / 1e9,
-                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops, grid_threads=(cus & ~7) * 512)
-    # (2) decode gate/up weight-streaming GEMV: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
-    #     256 MB infinity cache cannot serve the weights
-    #     rows = what a merged decode step of the timed region carries (gang policy: a full pool of generates; <= 16 rows: the
-    #     512-thread kernel, 17 .. 32: two MFMA column blocks per weight fragment on 256-thread workgroups)
+                                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", algorithmic=flops, grid_threads=(cus & ~7) * 512, rows=M,
+                                       prefills_per_launch=prefill_groups)
+    # (2) decode gate/up weight-streaming projection: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
+    #     256 MB infinity cache cannot serve the weights.  rows = what a merged decode step of the timed region carries (gang policy:
+    #     a full pool of generates): <= 16 rows: the 512-thread kernel, 17 .. 32: two MFMA column blocks per weight fragment on
+    #     256-thread workgroups, 33 .. 128: the split-K kernel with LDS-shared activations (gemm_rows.hip, fragment-packed rows)
     dec_rows = dec_rows or n_calls
-    xs = torch.randn(dec_rows, s.hidden, device=dev).to(torch.bfloat16)
-    outs = torch.empty(dec_rows, s.inter, dtype=torch.bfloat16, device=dev)
     ws = [eng.weight(f"llm.L{i}.wgu") for i in range(s.layers)]
     state = {"i": 0}
-
-    def gemv():
-        ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True, ctx=eng)
-        state["i"] += 1
-    ms = event_time_ms(gemv, 64, warm=4)
     nbytes = 2.0 * s.hidden * 2 * s.inter
-    legs["decode_gateup_gemv"] = dict(kernel="gemv_stream<2,1,2,1,0,3,2,4>" if dec_rows > 16 else "gemv_stream<2,1,2,1,0,2,1,8>", bound="hbm", ms=ms,
-                                      achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes, rows=dec_rows,
-                                      grid_threads=(2 * s.inter // 32) * (256 if dec_rows > 16 else 512))
+    if dec_rows <= 32:
+        xs = torch.randn(dec_rows, s.hidden, device=dev).to(torch.bfloat16)
+        outs = torch.empty(dec_rows, s.inter, dtype=torch.bfloat16, device=dev)
+
+        def gemv():
+            ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True, ctx=eng)
+            state["i"] += 1
+        kname = "gemv_stream<2,1,2,1,0,3,2,4>" if dec_rows > 16 else "gemv_stream<2,1,2,1,0,2,1,8>"
+        gthreads = (2 * s.inter // 32) * (256 if dec_rows > 16 else 512)
+    else:
+        import ctypes
+        f = hip.lib().rv_debug_gemm_rows
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+        mbp = 4 if dec_rows <= 64 else 8
+        xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(torch.bfloat16)          # fragment-packed rows (any values: timing)
+        outs = torch.empty(mbp * 16 * s.inter, dtype=torch.bfloat16, device=dev)
+        planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
+        arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
+
+        def gemv():
+            rc = f(xs.data_ptr(), ws[state["i"] % len(ws)].data_ptr(), outs.data_ptr(), dec_rows, 2 * s.inter, s.hidden, planes.data_ptr(), arrive.data_ptr(),
+                   hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
+            assert rc == 0, hip.last_error()
+            state["i"] += 1
+        split = 1 if mbp == 4 else 2
+        kname = f"rows_kernel<{mbp},{8 // split},1>"
+        gthreads = (2 * s.inter // 64) * split * 320
+    ms = event_time_ms(gemv, 64, warm=4)
+    legs["decode_gateup_gemv"] = dict(kernel=kname, bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes,
+                                      rows=dec_rows, grid_threads=gthreads)
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
     #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised.
     #     Kernel: the A-resident GEMM (gemm_arows.hip): rows resident in LDS, A read once, C written once
@@ -556,13 +581,18 @@ def main():
         gang = max(1, args.pool_rows // n_calls_rank) if (server is not None and args.pools > 1) else 1
         if server is not None and args.pools <= 1:
             gang = max(1, min(args.pool_rows // n_calls_rank, round(server.rows_served / max(1, server.steps_run) / n_calls_rank)))
-        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(32, gang * n_calls_rank))   # (the leg times the <= 32-row kernel; wider pools: see DESIGN.md)
-        # dominant = the larger share of a recursion: 32 prefill launches, or 32 x G decode launches shared by `gang` recursions
+        pf_groups = 1
+        if server is not None and server.prefill_batch > 1 and server.pf_batches:
+            pf_groups = max(server.pf_hist, key=server.pf_hist.get)       # the pass size that served most steps of this run: 1, 2, 4 or 8 prefills
+        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(128, gang * n_calls_rank), prefill_groups=pf_groups)
+        # dominant = the larger share of a recursion: 32 prefill launches shared by `pf_groups` recursions, or 32 x G decode launches
+        # shared by `gang` recursions
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),
-                  key=lambda l: l["ms"] * (32 if l["bound"] == "mfma" else 32 * G / gang))
+                  key=lambda l: l["ms"] * (32 / pf_groups if l["bound"] == "mfma" else 32 * G / gang))
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         other = {k: {"kernel": v["kernel"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"], "avg_launch_ms": v["ms"],
-                     **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {})} for k, v in legs.items()}
+                     **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {}),
+                     **({"prefills_per_launch": v["prefills_per_launch"]} if "prefills_per_launch" in v else {})} for k, v in legs.items()}
         pmc = committed_profile("r2_pmc_mfma.json")
         if pmc is not None:
             other["prefill_gemm_pmc"] = pmc.get("summary")
@@ -582,7 +612,7 @@ def main():
                                   "their rows (serve.DecodeServer; %.1f rows per merged step)" % (server.rows_served / max(1, server.steps_run))
                                   if server is not None else "per step: every step in flight runs its own decode passes"),
                        "prefill": ("batched: up to %d waiting prefills of the steps in flight ride in one pass (serve.DecodeServer; %.2f per pass in this run)"
-                                   % (server.prefill_batch, server.pf_tickets / max(1, server.pf_batches))
+                                   % (server.prefill_batch, server.pf_tickets / max(1, server.pf_batches)) + "; steps by pass size: %s" % dict(sorted(server.pf_hist.items()))
                                    if server is not None and server.prefill_batch > 1 else "one pass per step"),
                        "parallelism": (f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals"
                                        if world > 1 else "single GPU")},

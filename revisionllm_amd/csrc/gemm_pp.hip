@@ -694,8 +694,9 @@ int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated) {
     const int tiles_m = (int)cdiv(M, PBM), per_x = pp_num_cus() >> 3;
     const int64_t T = pp_teams(M), nk = K / PBK;
     if (T == 0 || K < 2048 || (per_x % tiles_m) * 10 > per_x) return 0;   // short K, or > 10 % of the CUs left without a team
-    if (!gated && N % 192 == 0 && (N / 192) % T == 0) return 3;
     const int64_t panels = N / PBN, sk_panels = panels % T;
+    if (sk_panels == 0 && panels >= T) return 4;                     // 256-column panels deal out exactly (batched prefills: 48 qkv panels on 16 teams)
+    if (!gated && N % 192 == 0 && (N / 192) % T == 0) return 3;
     if (sk_panels == 0) return 4;
     if (panels < T) {   // pure split-k: >= 4 pieces per panel with >= 8 k-tiles each, or 2 pieces of >= 64 k-tiles (one hand-off behind
                         // a long k-range: the down projection at ~2000 rows, 167 vs 194 us on the ring kernel)

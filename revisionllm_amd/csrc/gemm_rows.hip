@@ -14,8 +14,11 @@
 // shared epilogue (gemv_finish.h).  A row's result is therefore bit-identical to what the <= 32-row kernel produces for it, whatever it is batched with
 // (tests/test_gpu_merged_decode.py).
 //
-// Measured (MI355X, 63 rows, isolated): qkv 46 us, o / down 22 us, gate/up 68 us per launch - a fixed ~12 us (launch, first loads,
-// plane round trip) plus the weights at ~4.3 TB/s; a 63-row step 6.5 ms vs 4.1 ms for 28 rows on gemv_stream, i.e. 0.72 vs 1.02 ms
+// Measured (MI355X, 63 rows, isolated): qkv 46 us, o / down 22 us, gate/up 68 us per launch - a fixed ~8 us (launch, first loads,
+// finish) plus the weights at 3.2 (K = 4096) .. 4.6 TB/s (long K).  Compile-time probes: without the slab DMA and the barriers the
+// consumers' loop alone takes 55 of the gate/up launch's 58 us, the slab pipeline alone 18 us - what bounds it is the weight bytes in
+// flight (8 consumer waves x 5 stages x 4 KiB = 160 KiB per CU, all the registers the accumulator stack leaves; gemv_stream at <= 16
+// rows keeps 256 KiB in flight and streams at 5.8 TB/s); a 63-row step 6.5 ms vs 4.1 ms for 28 rows on gemv_stream, i.e. 0.72 vs 1.02 ms
 // per 7-row generate (112 rows: 8.7 ms, 0.54 ms).
 #include <hip/hip_runtime.h>
 
@@ -171,12 +174,22 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     }
     const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 32 MiB: 32-bit offsets)
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
-    if (wave < RS_W) {
-        const unsigned off = sp * plane + ((unsigned)ntile * MB * 64 + lane) * 16;
+    char* xch = rs_smem + 16384;      // S == 1: the waves' sums change hands through LDS (behind the sums-of-squares area), no plane round trip
+    if constexpr (S == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the trailing LDS-DMA padding stages are done)
+        __syncthreads();                                   // everyone is through with the slab ring
+        if (wave < RS_W) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) st_sc1(pr, off + mb * 1024, acc[mb]);
+            for (int mb = 0; mb < MB; ++mb) *(f32x4*)(xch + ((wave * MB + mb) * 64 + lane) * 16) = acc[mb];
+        }
+    } else {
+        if (wave < RS_W) {
+            const unsigned off = sp * plane + ((unsigned)ntile * MB * 64 + lane) * 16;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) st_sc1(pr, off + mb * 1024, acc[mb]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through (and the trailing LDS-DMA padding stages are done)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through (and the trailing LDS-DMA padding stages are done)
     __syncthreads();
     // ---- the LAST of the S workgroups of the column group to arrive finishes it ----
     // Arrival counter: one per (column group, log2 S), never reset - a launch adds exactly S to it (launches of one stream are ordered
@@ -211,9 +224,13 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             const int blk = cg * BPG + p / MB, mb = p % MB;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const unsigned q = (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16;
+                if constexpr (S == 1) {
+                    pl[i][t][0] = *(const f32x4*)(xch + (((p / MB * NT + t) * MB + mb) * 64 + lane) * 16);
+                } else {
+                    const unsigned q = (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16;
 #pragma unroll
-                for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+                    for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+                }
             }
         }
     }
@@ -343,11 +360,14 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
     return RV_OK;
 }
 
-// Measurement hook (tools/rows_time.py; not part of include/revision_hip.h): the plain f32 projection on 33 .. 128 packed rows.
-extern "C" int rv_debug_gemm_rows(const void* Xp, const void* Wp, float* C, int M, int N, int K, float* planes, int* arrive, void* stream) {
+// Measurement hook (tools/rows_time.py, bench.py's roofline leg; not part of include/revision_hip.h): a projection on 33 .. 128 packed rows
+// with the engine's epilogue variants (act = RV_ACT_SILU_MUL + bf16 out: the gate/up launch of a merged decode step).
+extern "C" int rv_debug_gemm_rows(const void* Xp, const void* Wp, void* C, int M, int N, int K, float* planes, int* arrive, int act, int out_dtype,
+                                  void* stream) {
     GemvNorm nrm;
     nrm.x_packed = rv_xp_blocks(M);
     nrm.planes = planes;
     nrm.arrive = arrive;
-    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, N, RV_F32, RV_ACT_NONE, M, N, K, (hipStream_t)stream, nrm, nullptr);
+    const int ldc = act == RV_ACT_SILU_MUL ? N / 2 : N;
+    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr);
 }

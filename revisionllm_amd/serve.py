@@ -286,6 +286,7 @@ class DecodeServer:
         self.pf_stream = torch.cuda.Stream(model.engine.device) if prefill_batch > 1 else None
         self.pf_slot = slot + 16
         self.pf_batches = self.pf_tickets = 0
+        self.pf_hist = {}            # groups per pass -> tickets served by passes of that size
         self.pools = [DecodePool(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
         self.gang, self.blocking, self.fill = gang, gang, 0
         self.fifo_prefill, self.prefill_tail = gang, None     # gang policy: the generates' prefills run in launch order (generate_steps)
@@ -398,6 +399,7 @@ class DecodeServer:
         self.pf_inflight.append(ev)
         self.pf_batches += 1
         self.pf_tickets += n
+        self.pf_hist[n] = self.pf_hist.get(n, 0) + n
         return True
 
     def pump(self):

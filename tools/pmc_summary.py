@@ -61,7 +61,7 @@ def sq_summary(sq_dir, grbm_dir, out_prefix, n_xcd=8, simds=1024):
     if pp:
         busy = sum(r["SQ_VALU_MFMA_BUSY_CYCLES"] * r["launches"] for r in pp)
         cyc = sum(r["kernel_cycles"] * r["launches"] for r in pp)
-        summary = {"kernels": "gemm_pp_sk<...> (the prefill projections of the recursion, M = 1005 rows)", "mfma_util": round(busy / (cyc * simds), 4),
+        summary = {"kernels": "gemm_pp_sk<...> (the prefill projections of the recursion: passes of 4 x 1005 rows)", "mfma_util": round(busy / (cyc * simds), 4),
                    "lds_bank_conflict_cycles": sum(r.get("SQ_LDS_BANK_CONFLICT", 0) for r in pp),
                    "by_kernel": {r["kernel"]: {"mfma_util": r["mfma_util"], "launches": r["launches"], "parked": r.get("frac_waves_parked_at_waitcnt_or_barrier"),
                                                "issue_stalled": r.get("frac_waves_issue_stalled")} for r in pp}}
