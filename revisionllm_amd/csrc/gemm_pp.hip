@@ -484,15 +484,19 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
                                                   const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                   int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
                                                   int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr,
-                                                  PpScale sc) {
+                                                  PpScale sc, int PG, int tiles_n) {
+    // PG > 1 (many-row problems: batched prefills): a team is tiles_m x PG workgroups - the m-tiles of PG ADJACENT panels walk the same
+    // k-range together, so an activation k-slice is fetched once per PG panels too (with one panel per team the 33 MB activation panel
+    // of a 4020-row pass is re-read for every panel: 2.5 GB of fabric traffic per gate/up launch, 20 % of its time).  The unit space,
+    // dp_panels and the hand-off then count panel GROUPS; a workgroup whose panel lies past the last one sits its items out.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int teams_per_x = (gridDim.x >> 3) / TS;
-    const int team = xcd * teams_per_x + slot / TS, tm = slot % TS;
+    const int team = xcd * teams_per_x + slot / TS, tsl = slot % TS, tm = tsl % tiles_m, pgi = tsl / tiles_m;
     const int T = 8 * teams_per_x;
-    if (tm >= tiles_m || slot >= teams_per_x * TS) return;
+    if (pgi >= PG || slot >= teams_per_x * TS) return;
     const int m0_wg = tm * PBM;
     auto ub = [&](int t) { return (int)((int64_t)t * total_units / T); };   // first unit of team t's range
     const int u_begin = ub(team), u_end = ub(team + 1);
@@ -517,7 +521,9 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         } else {
             break;
         }
-        const int n0 = panel * (NF * 64);
+        const int tpanel = panel * PG + pgi;     // this workgroup's panel of the group
+        if (tpanel >= tiles_n) continue;
+        const int n0 = tpanel * (NF * 64);
         // m0 is the same for every segment: launder it so that the row-dependent address math of the epilogue is not hoisted
         // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
         int m0 = m0_wg;
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         }
         if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
             // shared panel: publish the partial accumulators (write-through sc1 stores), then the flag
-            const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tm) * 2 + ps;
+            const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tsl) * 2 + ps;
             shared_panel[ps] = sk_panel;
             const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
             const unsigned off = (wave * 32 * 64 + lane) * 16;
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         for (int t = t0; t <= t1; ++t) {
             if (ub(t) == ub(t + 1)) continue;   // empty range: took no part
             if (t == team) j = c;
-            if (tid == 0) ids[c] = (t * TS + tm) * 2 + (ub(t) <= lo ? 1 : 0);
+            if (tid == 0) ids[c] = (t * TS + tsl) * 2 + (ub(t) <= lo ? 1 : 0);
             ++c;
         }
         if (tid == 0) {
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         }
         __syncthreads();
         const float poison = ids[1024] ? __int_as_float(0x7fc00000) : 0.f;   // a missing partial poisons this share (never a silent partial sum)
-        const int m0 = m0_wg, n0 = (dp_panels + panel) * PBN;
+        const int m0 = m0_wg, n0 = ((dp_panels + panel) * PG + pgi) * PBN;
         if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
         else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
         else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
@@ -646,9 +652,13 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     static bool attr_set = false;
     if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64), nk = K / PBK;
-    const int TS = tiles_m;             // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle
-    const int G = pp_num_cus() & ~7;
-    const int T = pp_teams(M), dp_panels = tiles_n / T * T;
+    const int G = pp_num_cus() & ~7, per_x = G >> 3;
+    // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle.  From 8 m-tiles on (batched prefills) with
+    // 256-column panels: the m-tiles of PG adjacent panels - one team per XCD (see the kernel)
+    const int PG = (NF == 4 && tiles_m >= 8 && per_x / tiles_m >= 2) ? per_x / tiles_m : 1;
+    const int TS = tiles_m * PG;
+    const int T = PG > 1 ? 8 * (per_x / TS) : pp_teams(M);
+    const int groups = (tiles_n + PG - 1) / PG, dp_panels = groups / T * T;      // (in panel groups)
     if (NF != 4 && dp_panels != tiles_n) {
         rv_set_error("gemm_pp: 192-column panels need a panel count that is a multiple of the %d teams", T);
         return RV_ERR_ARG;
@@ -659,7 +669,7 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     int* status = flags + PP_HDR / 4 - 1;
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
     hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
-                       tiles_m, TS, nk, dp_panels, (tiles_n - dp_panels) * nk, partial, flags, status, epoch, qr, sc);
+                       tiles_m, TS, nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG, tiles_n);
     return RV_OK;
 }
 
