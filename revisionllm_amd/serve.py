@@ -274,7 +274,7 @@ class DecodeServer:
     uses: ``fits``, ``reserve`` (-> ``Job`` with ``job.pool``; ``None``: no room - wait if ``blocking`` else decode alone), ``join``;
     what ``sched.Interleaver`` uses: ``pump`` / ``wait_one``."""
 
-    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False, prefill_batch=1):
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False, prefill_batch=1, pool_factory=None):
         """``prefill_batch`` > 1: the generates' LLM prefills go through the server too - up to that many waiting prefills of identical
         geometry (rows, shared-prefix length, length) ride in ONE pass (``rv_llm_prefill_pool_groups``: the GEMMs see G x 1005 rows
         instead of 1005, which the N = 4096 projections in particular are too small for), on one prefill stream in submission order.
@@ -283,11 +283,12 @@ class DecodeServer:
         assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
         assert 1 <= prefill_batch <= 8
         self.prefill_batch, self.pf_queue, self.pf_inflight = prefill_batch, [], []
-        self.pf_stream = torch.cuda.Stream(model.engine.device) if prefill_batch > 1 else None
+        self.pf_stream = torch.cuda.Stream(model.engine.device) if prefill_batch > 1 else None        # (created only when batching is on)
         self.pf_slot = slot + 16
         self.pf_batches = self.pf_tickets = 0
         self.pf_hist = {}            # groups per pass -> tickets served by passes of that size
-        self.pools = [DecodePool(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
+        make = pool_factory or DecodePool           # (tests: a stand-in without device memory)
+        self.pools = [make(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
         self.gang, self.blocking, self.fill = gang, gang, 0
         self.fifo_prefill, self.prefill_tail = gang, None     # gang policy: the generates' prefills run in launch order (generate_steps)
         self.model = model

@@ -286,3 +286,62 @@ def test_options_are_per_context():
         hip.lib().rv_set_gemm_tile_variant(2)
     # an options-only context carries no model: nothing can be bound to it
     assert hip.lib().rv_weights_bind(a._ctx, b"llm.embed", ctypes.c_void_p(256), 1, 16) < 0
+
+
+def test_decode_server_gang_policy_fills_seals_and_alternates_pools():
+    """Host logic of ``serve.DecodeServer(gang=True)`` on stand-in pools (no device): generates reserve rows in the FILLING pool, a pool
+    that cannot take another one of that size is sealed, the next reservations go to the other pool once it is idle, a generate that
+    finds no pool gets ``None`` (it waits), freed ranges coalesce, and ``flush`` seals a partly filled pool only when everyone in it
+    has joined."""
+    from revisionllm_amd import serve
+
+    class Pool:
+        def __init__(self, model, rows, smax, gmax, max_ahead, slot, gang):
+            self.R, self.Smax, self.G = rows, smax, gmax
+            self.free, self.sealed, self.pending, self.live = [(0, rows, ())], False, 0, 0
+            self.jobs, self.draining, self.steps_run, self.rows_served = [], [], 0, 0
+        reserve = serve.DecodePool.reserve
+        free_rows = serve.DecodePool.free_rows
+        fits = serve.DecodePool.fits
+
+        def release(self, job):        # what _finish + _release do to the bookkeeping (events left out)
+            self.live -= 1
+            self.free.append((job.r0, job.B, ()))
+            self.free.sort(key=lambda f: f[0])
+            merged = []
+            for r0, n, evs in self.free:
+                if merged and merged[-1][0] + merged[-1][1] == r0:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + n, ())
+                else:
+                    merged.append((r0, n, ()))
+            self.free = merged
+
+        def pump(self):
+            return False
+
+        def wait_one(self):
+            return False
+
+    sv = serve.DecodeServer(None, rows=32, smax=128, gmax=16, pools=2, gang=True, pool_factory=Pool)
+    a, b = sv.pools
+    assert sv.fits(100, 8, 7) and not sv.fits(100, 8, 33) and not sv.fits(125, 8, 7)
+    jobs = [sv.reserve(7) for _ in range(4)]
+    assert [j.r0 for j in jobs] == [0, 7, 14, 21] and all(j.pool is a for j in jobs)
+    assert a.sealed and a.pending == 4 and a.live == 4 and not b.sealed          # 4 free rows left: no room for another 7-row generate
+    jb = [sv.reserve(7) for _ in range(4)]
+    assert all(j.pool is b for j in jb) and b.sealed
+    assert sv.reserve(7) is None                                                   # both pools busy: the generate waits
+    for j in jobs:                                                                 # pool A: everyone joins, decodes, leaves
+        a.pending -= 1
+    assert not sv.flush()                                                          # A is sealed already; B still has pending joins
+    for j in jobs:
+        a.release(j)
+    assert a.free == [(0, 32, ())] and a.live == 0
+    j9 = sv.reserve(3)                                                             # A is idle: it becomes the filling pool again
+    assert j9.pool is a and not a.sealed and j9.r0 == 0
+    j10 = sv.reserve(30)                                                           # does not fit beside the 3 rows: A is sealed with what it has, B busy
+    assert j10 is None and a.sealed
+    a.sealed = False                                                               # (as if it had been the first reservation of a new fill)
+    assert not sv.flush()                                                          # its generate has not joined yet
+    a.pending -= 1
+    assert sv.flush() and a.sealed                                                 # nothing else will come: run the partly filled pool
