@@ -193,11 +193,21 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
 // themselves, the per-call rows attend to prefix + own keys): blockIdx.z < a.B -> problem a, else problem b.
 template <int DH>
-__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles) {
+__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles, AttnGroups gr) {
     int bx, h, z;
-    if (!attn_map(tiles, a.H, a.H * (a.B + b.B), bx, h, z)) return;
-    if (z < a.B) attn_body<DH, false, false>(a, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
-    else attn_body<DH, false, false>(b, bx, h, z - a.B);
+    const int per = a.B + b.B;
+    if (!attn_map(tiles, a.H, a.H * per * gr.G, bx, h, z)) return;
+    const int g = z / per;
+    z -= g * per;
+    AttnArgs& p = z < a.B ? a : b;
+    if (gr.G > 1) {      // (uniform per workgroup)
+        p.q = (const bf16_t*)p.q + gr.q_off[g];
+        p.out = (bf16_t*)p.out + gr.q_off[g];
+        p.k = (const bf16_t*)p.k + gr.kv_off[g];
+        p.vt = (const bf16_t*)p.vt + gr.kv_off[g];
+    }
+    if (z < a.B) attn_body<DH, false, false>(p, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
+    else attn_body<DH, false, false>(p, bx, h, z - a.B);
 }
 
 }  // namespace
@@ -211,13 +221,15 @@ static int attn_check(const AttnArgs& a) {
     return RV_OK;
 }
 
-int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st) {
+int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const AttnGroups* groups) {
     if (int rc = attn_check(a)) return rc;
     if (int rc = attn_check(b)) return rc;
     RV_CHECK_ARG(a.dh == 128 && b.dh == 128 && a.H == b.H && a.Lq > 16 && b.Lq > 16, "attention pair: 128-wide heads, same head count, prefill lengths only");
     RV_CHECK_ARG(!a.key_pad && !b.key_pad, "attention pair: key padding is not supported");
     const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
-    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B))), dim3(256), 0, st, a, b, tiles);
+    const AttnGroups gr = groups ? *groups : AttnGroups{};
+    RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention pair: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
+    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     RV_CHECK_LAUNCH("attention pair");
     return RV_OK;
 }

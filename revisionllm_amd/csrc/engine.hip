@@ -565,17 +565,26 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
-        for (int gi = 0; gi < G && P0 > 0; ++gi) {     // (a batch of G prefills: one launch pair per group)
-            const int64_t qo = (int64_t)gi * Mg * D, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
-            AttnArgs ap{w.q16 + qo, D, (int64_t)P0 * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
-                        (int64_t)dh * Smax, Smax, w.a16 + qo, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
-            if (P0 > 16 && S > 16 && dh == 128) {   // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch)
-                AttnArgs am{w.q16 + qo + (int64_t)P0 * D, D, (int64_t)S * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co,
-                            (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + qo + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
-                            S, pos0 + S, 1, pos0, 1, scale};
-                RV_TRY(k_attention_pair(ap, am, st));
-                prefix_done = true;
-            } else {
+        if (P0 > 0 && P0 > 16 && S > 16 && dh == 128) {
+            // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch) - for all G groups of a batched prefill
+            AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                        (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+            AttnArgs am{w.q16 + (int64_t)P0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
+                        (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
+                        S, pos0 + S, 1, pos0, 1, scale};
+            AttnGroups gr;
+            gr.G = G;
+            for (int gi = 0; gi < G; ++gi) {
+                gr.q_off[gi] = (int64_t)gi * Mg * D;
+                gr.kv_off[gi] = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
+            }
+            RV_TRY(k_attention_pair(ap, am, st, &gr));
+            prefix_done = true;
+        } else {
+            for (int gi = 0; gi < G && P0 > 0; ++gi) {
+                const int64_t qo = (int64_t)gi * Mg * D, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
+                AttnArgs ap{w.q16 + qo, D, (int64_t)P0 * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
+                            (int64_t)dh * Smax, Smax, w.a16 + qo, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
                 RV_TRY(k_attention(ap, st));
             }
         }

@@ -185,4 +185,11 @@ struct AttnArgs {
     int out_packed = 0;   // (Lq = 1 decode) 2 / 4 / 8: the output row of batch b goes to the fragment-packed decode layout, element (b, c) at rv_xp_index(b, c, out_packed)
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
-int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st);   // two prefill problems (dh 128) in one launch
+// G copies of the problem pair in one launch (batched prefills): copy g reads q / writes out at + q_off[g] elements, its K / V^T at
+// + kv_off[g] elements from the pointers in a / b
+struct AttnGroups {
+    int G = 1;
+    int64_t q_off[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t kv_off[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const AttnGroups* groups = nullptr);   // two prefill problems (dh 128) in one launch
