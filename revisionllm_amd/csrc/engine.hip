@@ -531,7 +531,6 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.out_packed = xp;
     consume.planes = w.planes;
     consume.arrive = w.arrive;
-    consume.status = (int*)w.sk + 2047;       // the hand-off status word of the workspace header (gemm_pp.hip)
     for (int l = 0; l < g.layers; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
@@ -561,7 +560,6 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             first.x_packed = xp;
             first.planes = w.planes;
             first.arrive = w.arrive;
-            first.status = consume.status;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
@@ -596,7 +594,6 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.out_packed = xp;
         produce.planes = w.planes;
         produce.arrive = w.arrive;
-        produce.status = consume.status;
         {
             for (int gi = 0; gi < G && !prefix_done; ++gi) {
                 const int64_t r0 = (int64_t)gi * Mg + P0;  // first row of the per-sequence part

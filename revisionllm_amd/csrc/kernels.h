@@ -44,7 +44,6 @@ struct GemvNorm {
     int out_packed = 0;               // same for xw_out and a bf16 C (ldc ignored for bf16 C)
     float* planes = nullptr;          // 33 .. 128 rows (split-K kernel): workspace for the partial planes, gemm_rows_ws_bytes() bytes
     int* arrive = nullptr;            // ... and its arrival counters: RV_ROWS_COUNTERS ints, zero before the first launch
-    int* status = nullptr;            // ... and the workspace's hand-off status word (set to 1 if a bounded in-kernel wait gave up)
 };
 __host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k, int mbp) {
     return ((((int64_t)(k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
