@@ -402,7 +402,7 @@ def main():
         adapter / prefill and the host-side exchange / assembly overlaps device work; every step's work and record are
         produced inside the timed region.  With an EOS id the tasks yield at their stop-flag polls and are resumed round-robin."""
         rec, pending = None, []
-        depth = max(1, args.streams)
+        depth = max(1, work.get("depth", args.streams))
         for _ in range(n):
             pending.append(launch())
             if len(pending) > depth:
@@ -535,6 +535,33 @@ def main():
         eng.set_option("fp8_prefill", 0)
         model.generation_config.eos_token_id = None
         stages.server = server
+        # steady state with wider gangs: 112-row pools (16 recursions per merged step on the 8-row-block split-K kernel), 32 steps in flight,
+        # 64 timed steps after 32 warm-up steps - what the pipeline sustains when the fill / drain of a 20-step run no longer matters
+        if server is not None and args.pools > 1 and world == 1:
+            old_streams = streams
+            try:
+                from revisionllm_amd import serve
+                if len(work["qs"]) != 1:
+                    work.update(qs=[(qf, qc, SENTENCE)], perms=[perms], feats=feats)
+                wide = serve.DecodeServer(model, rows=112, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130)
+                inter.servers.append(wide)
+                stages.server = wide
+                streams = [torch.cuda.Stream(dev) for _ in range(32)]
+                work["depth"] = 32
+                t, _ = timed(run, steps=64, warm=32)
+                extra["steady_state_112_row_pools"] = {"value": W * 64 / t, "unit": "segments/s", "ms_per_step": t / 64 * 1e3, "steps": 64, "warmup": 32,
+                                                       "steps_in_flight": 32, "rows_per_merged_step": wide.rows_served / max(1, wide.steps_run),
+                                                       "note": "same workload and kernels; longer run, wider gangs (NOT the headline: the headline keeps the contract's K / W)"}
+            except Exception as e:  # noqa: BLE001
+                extra["steady_state_112_row_pools"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+            finally:
+                work.pop("depth", None)
+                stages.server = server
+                streams = old_streams
         # the other BASELINE.json workloads
         try:
             plan33 = stage2.plan_groups(33, 33)
