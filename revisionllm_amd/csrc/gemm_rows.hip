@@ -46,7 +46,8 @@ __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
 constexpr int RS_W = 4;        // consumer waves = 16-column tiles per workgroup (64-column groups); wave RS_W is the producer
 constexpr int RS_THREADS = (RS_W + 1) * 64;
 // MB = 4 row blocks: weight ring 6 deep (5 x 4 KiB per wave in flight), 3 slabs of 16 KiB, <= 168 VGPRs -> two workgroups per CU
-// MB = 8:            weight ring 4 deep, 3 slabs of 32 KiB, one workgroup per CU
+// MB = 8:            weight ring 4 deep, 3 slabs of 32 KiB, one workgroup per CU (8 deep measured slower: 107 vs 80 us on gate/up -
+//                    with 32 LDS fragment reads per 4 KiB of weights this variant is bound by the LDS pipe, not by bytes in flight)
 template <int MB> struct RowsCfg { static constexpr int DW = MB == 4 ? 6 : 4, DX = MB == 4 ? 4 : 3, WPE = MB == 4 ? 3 : 2; };
 
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
