@@ -110,7 +110,7 @@ class HipStages:
         """``generate_async`` as a step generator (yields the EOS-flag events when an EOS id is configured; ``sched``).  With a
         ``serve.DecodeServer`` attached (``self.server``) the generates decode through its merged steps."""
         return stage2.launch_calls_steps(self.model, self.tokenizer, query, rows, calls, uniforms, max_new_tokens, width=width,
-                                         server=getattr(self, "server", None))
+                                         server=getattr(self, "server", None), forced_tokens=getattr(self, "forced_tokens", None))
 
     def gate(self):
         """The device's persistent-launch gate (engine.PersistGate): collectives are ordered against the prefill GEMMs with it."""

@@ -137,6 +137,44 @@ def test_full_depth_batched_recursion_matches_per_call(g8_run):
     assert np.median(d_max) <= np.median(b_max) + 1e-3                      # a re-ordering of f32 sums, not a different function
 
 
+@pytest.mark.parametrize("copies,pool_rows", [(4, 32), (8, 56)])
+def test_full_depth_headline_pipeline_matches_per_call(g8_run, copies, pool_rows):
+    """The pipeline the bench runs, at 7B: ``copies`` instances of the G8 recursion in flight on their own HIP streams, their prefills
+    riding up to four to a pass (``rv_llm_prefill_pool_groups``: ~4000-row GEMMs) and their decode steps merged into 28-row (two-column-
+    block GEMV) / 56-row (split-K kernel) passes of a gang-filled KV pool, teacher-forced on the reference's tokens - against the per-call
+    runs of the fixture: every instance's 1/max_entropy, 1/mean_entropy to the same bound as the batched recursion (a re-ordering of f32
+    sums), all instances of a run identical to each other where they rode in the same kind of pass."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.utils import synth
+    r, g, meta = g8_run, g8_run.g, g8_run.meta
+    m = r.model
+    tok = synth.FakeTokenizer()
+    st = parallel.HipStages(m, tok)
+    st.forced_tokens = T(g["tokens"]).t().contiguous()                      # [G, calls]
+    server = serve.DecodeServer(m, rows=pool_rows, smax=192, gmax=16, pools=2, gang=True, prefill_batch=4)
+    st.server = server
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(copies)]
+    torch.cuda.synchronize()
+    inter = sched.Interleaver(servers=[server])
+    kw = dict(batch=meta["batch"], perms=[r.perms], max_new_tokens=meta["G"])
+    tasks = [inter.add(sched.Task(lambda t: parallel.launch_queries_sharded_steps(st, tok, r.features, meta["W"], [(r.qf, r.qc, meta["sentence"])], turn=t, **kw),
+                                  streams[i], m.engine, i)) for i in range(copies)]
+    recs = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+    m.engine.slot = 0
+    assert server.pf_tickets == copies and server.pf_batches < copies       # prefills really rode together
+    assert server.rows_served >= server.steps_run * 7 * min(copies, pool_rows // 7) * 0.99      # ... and so did the decode steps
+    per_call_max = np.array([1 / float(c["stats"][0]) for c in r.calls])
+    per_call_mean = np.array([1 / float(c["stats"][2]) for c in r.calls])
+    b_max = _rel(1 / g["bf16_stats"][:, 0], g["inv_max"])
+    for rec in recs:
+        assert rec["starts"] == g["starts"].tolist() and rec["hierarchy_zooms"] == g["zooms"].tolist()
+        d_max, d_mean = _rel(rec["max_entropy"], per_call_max), _rel(rec["mean_entropy"], per_call_mean)
+        assert np.isfinite(rec["max_entropy"]).all() and np.isfinite(rec["mean_entropy"]).all()
+        assert np.median(d_max) <= np.median(b_max) + 1e-3 and np.median(d_mean) <= np.median(b_max) + 1e-3
+    print("\n[G8 headline pipeline vs per-call] copies", copies, "pool rows", pool_rows, "median rel diff 1/max_entropy",
+          [float(np.median(_rel(rec["max_entropy"], per_call_max))) for rec in recs])
+
+
 def test_7b_layer_vs_reference_g6(golden):
     """One 7B-shaped decoder layer (D 4096, F 11008, 32 heads) + the hierarchy adapter, HIP vs the REFERENCE'S own output G6
     (fp32 weights there, bf16-rounded here): prefill (65 text + 100 video tokens) and two KV-cached decode steps."""
