@@ -452,6 +452,31 @@ def main():
         ids = _prompt_ids("<video>\n" + "During which frames can we see {}?".format(SENTENCE), tok, 1)[0]
         gkw = dict(images=x, query_feats=qfeat, do_sample=True, temperature=0.05, max_new_tokens=G, return_dict_in_generate=True)
 
+        S = ids.shape[1] - 1 + (frames if kind == "stage1_dense" else 1)
+        if args.merge_decode and streams is not None:
+            # windows in flight share the weight passes like the stage-2 recursions do: one-row generates fill a 32-row KV pool
+            # (gang policy), their prefills ride four to a pass, a merged decode step serves up to 32 windows
+            from revisionllm_amd import serve
+            server1 = serve.DecodeServer(m1, rows=32, smax=(S + G + 31) // 32 * 32, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch,
+                                         slot=150)
+            inter1 = sched.Interleaver(servers=[server1])
+            streams1 = [torch.cuda.Stream(dev) for _ in range(32)]
+
+            def run1(n):
+                out, pending = None, []
+                for i in range(n):
+                    k = i % len(streams1)
+                    streams1[k].wait_stream(torch.cuda.current_stream(dev))
+                    pending.append(inter1.add(sched.Task(m1.generate_steps(ids, server=server1, **gkw), streams1[k], eng, 32 + k)))
+                    if len(pending) > len(streams1):
+                        out = inter1.finish(pending.pop(0))
+                while pending:
+                    out = inter1.finish(pending.pop(0))
+                eng.slot = 0
+                return out
+            return run1, dict(prompt_tokens=int(ids.shape[1]), prefill_len=int(S), frames=frames, windows_per_step=1, windows_in_flight=32,
+                              decode="merged (serve.DecodeServer: 32-row pools, prefills four to a pass)")
+
         def run1(n):
             out = None
             for i in range(n):
