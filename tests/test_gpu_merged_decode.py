@@ -276,3 +276,31 @@ def test_decode_server_with_eos_equals_classic_loop(pools):
         assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
         assert torch.equal(got["entropy_raw"], want["entropy_raw"])
     assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16 * pools
+
+
+def test_one_row_generates_in_flight_share_prefill_passes_and_decode_steps():
+    """The stage-1 shape of the pipeline (bench.py ``workload_stage1_*``): six ONE-row generates (own window features each, no shared
+    prefix) in flight - prefills of identical geometry ride four / two to a pass with P0 = 0, decode steps merged in a gang-filled
+    pool - against the classic loop: same sequences and entropies (tiny model: the tile GEMM serves every pass size)."""
+    from revisionllm_amd import sched, serve
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    P = 40
+    ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
+    cases = []
+    for i in range(6):
+        feat = feats(f"s1row.feat{i}", (1, 6, 16, 768), bf16=True)
+        q = (feats(f"s1row.q{i}", (1, 5, 768), bf16=True), torch.ones(1, 5))
+        kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=5, return_dict_in_generate=True,
+                  uniforms=torch.rand(5, 1, generator=torch.Generator().manual_seed(100 + i)))
+        cases.append((kw, m.generate(ids, **kw)))
+    server = serve.DecodeServer(m, rows=16, smax=96, gmax=8, pools=2, gang=True, prefill_batch=4)
+    inter = sched.Interleaver(servers=[server])
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(6)]
+    tasks = [inter.add(sched.Task(m.generate_steps(ids, server=server, **kw), streams[i], m.engine, i)) for i, (kw, _) in enumerate(cases)]
+    outs = [inter.finish(t) for t in tasks]
+    m.engine.slot = 0
+    assert server.pf_tickets == 6 and server.pf_batches <= 3 and max(server.pf_hist) >= 2          # passes of 4 + 2 (or 4 + 1 + 1)
+    assert server.rows_served > server.steps_run                                                  # merged steps carried several windows
+    for (kw, want), got in zip(cases, outs):
+        assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
