@@ -83,6 +83,12 @@ def parse_args(argv=None):
     p.add_argument("--mode", type=str, default="batched", choices=["batched", "reference"],
                    help="batched: results-preserving restructuring (default); reference: one inference() per (level, group) as the reference loops")
     p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--in_flight", type=int, default=1,
+                   help="queries processed concurrently (batched mode): > 1 runs them as scheduler tasks on their own HIP streams whose LLM prefills "
+                        "ride up to four to a pass and whose decode steps are merged (serve.DecodeServer: two KV pools filled and stepped in turn) - "
+                        "the pipeline bench.py measures; 1 = one query at a time, as the reference loops")
+    p.add_argument("--pool_rows", type=int, default=56, help="rows of a KV pool of the DecodeServer (--in_flight > 1)")
+    p.add_argument("--max_new_tokens", type=int, default=64, help="decode steps per call at most (--in_flight > 1; answers are a dozen tokens)")
     return p.parse_args(argv)
 
 
@@ -183,6 +189,8 @@ def eval(args, tokenizer=None, model=None):  # noqa: A001 - the reference's name
         for gl in load_predictions(args.grounding_path, args.distributed_retrieval):
             grounding_dict[gl["query_id"]] = gl
     errors, written = [], 0
+    if getattr(args, "in_flight", 1) > 1 and args.mode == "batched" and args.task in ("grounding", "all"):
+        return _eval_in_flight(args, tokenizer, model, store, stager, items, done, grounding_dict, prediction_path)
     for id_, data in items:
         if id_ in done:
             continue
@@ -218,6 +226,81 @@ def eval(args, tokenizer=None, model=None):  # noqa: A001 - the reference's name
             if args.debug:
                 raise
             errors.append(id_)
+    print("errors", errors)
+    return written, errors
+
+
+def _eval_in_flight(args, tokenizer, model, store, stager, items, done, grounding_dict, prediction_path):
+    """``--in_flight N``: the same per-query work as the loop in ``eval`` (features -> windows -> recursion -> one JSONL record, per-query
+    ``try / except``, records appended in annotation order), with up to N queries in flight as ``sched`` tasks: a query's feature staging
+    and adapter overlap the others' LLM passes, their prefills are batched and their decode steps merged by a ``serve.DecodeServer``."""
+    import torch
+    from .. import parallel, sched, serve
+    dev = model.device
+    stages = parallel.HipStages(model, tokenizer)
+    smax = (128 + args.batch + args.max_new_tokens + 63) // 64 * 64          # prompt (<= ~100 tokens with a long sentence) + video tokens + answer;
+                                                                             # a generate that does not fit decodes on its own (generate_steps)
+    server = serve.DecodeServer(model, rows=args.pool_rows, smax=smax, gmax=max(16, args.max_new_tokens), pools=2, gang=True, prefill_batch=4)
+    stages.server = server
+    inter = sched.Interleaver(servers=[server])
+    streams = [torch.cuda.Stream(dev) for _ in range(args.in_flight)]
+    pending, errors, written, k = [], [], 0, 0
+
+    def finish_oldest():
+        nonlocal written
+        task, id_, movie, timestamps = pending.pop(0)
+        try:
+            res = parallel.collect_queries(inter.finish(task))[0]
+            stage2.write_log(prediction_path, movie, "grounding", id_, res["answers"], info=stage2.log_record(res, timestamps, args.batch, args.num_frames, args.single))
+            written += 1
+        except Exception:  # noqa: BLE001 - the reference's per-query handler (e2e2.py:418-421)
+            if args.debug:
+                raise
+            errors.append(id_)
+            if task in inter.tasks:
+                inter.tasks.remove(task)
+
+    for id_, data in items:
+        if id_ in done:
+            continue
+        try:
+            movie = data["movie"] if "movie" in data else data["clip_id"]
+            features = store.video(movie)
+            query_feats, query_cls = store.query(id_)
+            if "movie_duration" in data and data["movie_duration"] <= args.debug_window:
+                continue
+            assert len(features) > 0, len(features)
+            _, frame_idx = stage2.cut_windows(len(features), args.debug_window, args.feature_fps, args.stride, args.num_frames)
+            if id_ in grounding_dict:
+                grounding_windows = prefilter_windows(grounding_dict[id_]["answer"], frame_idx.shape[0], args.batch, args.stride)
+                frame_idx = frame_idx[grounding_windows]
+            else:
+                grounding_windows = list(range(frame_idx.shape[0]))
+            windows = stager.stage_windows(features, frame_idx).wait()
+            qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(torch.bfloat16)
+            qc = torch.from_numpy(np.asarray(query_cls)).to(dev).float()
+            sentence = data["sentence"].strip().lower() if "sentence" in data else data["query"].strip(".?").lower()
+            if "sentence" in data and sentence.endswith("."):
+                sentence = sentence[:-1]
+            W = windows.shape[0]
+            perms = stage2.make_perms(stage2.plan_groups(W, args.batch), W=W)
+            gen = (lambda t, w=windows, W=W, q=(qf, qc, sentence), pm=perms, gw=grounding_windows:
+                   parallel.launch_queries_sharded_steps(stages, tokenizer, w, W, [q], batch=args.batch, perms=[pm], max_new_tokens=args.max_new_tokens,
+                                                         grounding_windows=gw, single=args.single, turn=t))
+            s_ = streams[k % len(streams)]
+            s_.wait_stream(torch.cuda.current_stream(dev))
+            task = inter.add(sched.Task(gen, s_, model.engine, k % len(streams)))
+            k += 1
+            pending.append((task, id_, movie, data["timestamps"]))
+        except Exception:  # noqa: BLE001
+            if args.debug:
+                raise
+            errors.append(id_)
+        while len(pending) >= args.in_flight:
+            finish_oldest()
+    while pending:
+        finish_oldest()
+    model.engine.slot = 0
     print("errors", errors)
     return written, errors
 

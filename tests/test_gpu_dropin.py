@@ -256,3 +256,14 @@ def test_eval_driver_end_to_end_with_resume(tmp_path):
     ref = [json.loads(l) for l in open(tmp_path / "out_ref" / "predictions_streaming_0.txt")]
     assert [r["info"]["hierarchy_zooms"] for r in ref] == [r["info"]["hierarchy_zooms"] for r in recs]
     assert [r["info"]["gt"] for r in ref] == [r["info"]["gt"] for r in recs]
+    # --in_flight 3: the same queries as concurrent scheduler tasks (batched prefills, merged decode steps of a gang-filled pool): same
+    # records structure, annotation order kept, resume works
+    args_if = drv.parse_args(base + ["--log_path", str(tmp_path / "out_if"), "--in_flight", "3", "--pool_rows", "32"])
+    assert drv.eval(args_if, tokenizer=tok, model=model) == (3, [])
+    pipe = [json.loads(l) for l in open(tmp_path / "out_if" / "predictions_streaming_0.txt")]
+    assert [r["query_id"] for r in pipe] == [r["query_id"] for r in recs]
+    for r in pipe:
+        assert r["video_id"] == "movieA" and len(r["answer"]) == n_calls and len(r["info"]["max_entropy"]) == n_calls
+        assert all(np.isfinite(r["info"]["max_entropy"])) and r["info"]["hierarchy_zooms"] == recs[0]["info"]["hierarchy_zooms"]
+    assert [r["info"]["gt"] for r in pipe] == [r["info"]["gt"] for r in recs]
+    assert drv.eval(args_if, tokenizer=tok, model=model) == (0, [])
