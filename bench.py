@@ -58,7 +58,7 @@ def parse():
     p.add_argument("--lq", type=int, default=16)
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--queries", type=int, default=1, help="queries of the same movie batched per step (contract default: 1)")
-    p.add_argument("--streams", type=int, default=16,
+    p.add_argument("--streams", type=int, default=20,
                    help="recursions in flight, each on its own HIP stream (workspace slot per stream, weights shared): one recursion's "
                         "HBM-bound decode steps fill the gaps of the other's MFMA-bound adapter / prefill; 1 = strictly one at a time")
     p.add_argument("--merge-decode", type=int, default=1,
@@ -70,7 +70,7 @@ def parse():
     p.add_argument("--prefill-batch", type=int, default=4,
                    help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
                         "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
-    p.add_argument("--pool-rows", type=int, default=56,
+    p.add_argument("--pool-rows", type=int, default=70,
                    help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 128: the split-K kernel with LDS-shared activations)")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
@@ -147,7 +147,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         f = hip.lib().rv_debug_gemm_rows
         f.restype = ctypes.c_int
         f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
-        mbp = 4 if dec_rows <= 64 else 8
+        mbp = 4 if dec_rows <= 64 else 5 if dec_rows <= 80 else 8
         xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(torch.bfloat16)          # fragment-packed rows (any values: timing)
         outs = torch.empty(mbp * 16 * s.inter, dtype=torch.bfloat16, device=dev)
         planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
@@ -158,7 +158,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
                    hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
-        split = 1 if mbp == 4 else 2
+        split = 2 if mbp == 8 else 1
         kname = f"rows_kernel<{mbp},{8 // split},1>"
         gthreads = (2 * s.inter // 64) * split * 320
     ms = event_time_ms(gemv, 64, warm=4)

@@ -48,7 +48,8 @@ constexpr int RS_THREADS = (RS_W + 1) * 64;
 // MB = 4 row blocks: weight ring 6 deep (5 x 4 KiB per wave in flight), 3 slabs of 16 KiB, <= 168 VGPRs -> two workgroups per CU
 // MB = 8:            weight ring 4 deep, 3 slabs of 32 KiB, one workgroup per CU (8 deep measured slower: 107 vs 80 us on gate/up -
 //                    with 32 LDS fragment reads per 4 KiB of weights this variant is bound by the LDS pipe, not by bytes in flight)
-template <int MB> struct RowsCfg { static constexpr int DW = MB == 4 ? 6 : 4, DX = MB == 4 ? 4 : 3, WPE = MB == 4 ? 3 : 2; };
+// MB = 5 (65 .. 80 rows: ten 7-row generates): as MB = 4 with 3 slabs of 20 KiB
+template <int MB> struct RowsCfg { static constexpr int DW = MB <= 5 ? 6 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2; };
 
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
@@ -212,8 +213,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     constexpr int ROPE = FIN == 3 ? 1 : 0;
     constexpr int BPG = RS_W / NT;                      // blocks (of NT tiles) per column group
     constexpr int PAIRS = BPG * MB;                     // (block, row block) pairs of the group; pair p = block * MB + mb
-    constexpr int PPW = PAIRS / RS_W;                   // pairs per consumer wave: p = wave + RS_W * i  ->  mb = p % MB
-    static_assert(PAIRS % RS_W == 0, "pairs split evenly over the consumer waves");
+    constexpr int PPW = (PAIRS + RS_W - 1) / RS_W;      // pairs per consumer wave: p = wave + RS_W * i  ->  mb = p % MB
     const int fr = lane & 15, kg = lane >> 4;
     const int nblk = N / (16 * NT);
     // (1) the partial planes of this wave's pairs: agent-coherent loads, all in flight at once (one memory latency, not PPW of them)
@@ -221,7 +221,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     if (wave < RS_W) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int p = wave + RS_W * i;
+            const int p = wave + RS_W * i < PAIRS ? wave + RS_W * i : PAIRS - 1;      // (ragged last pass: a valid pair, not used)
             const int blk = cg * BPG + p / MB, mb = p % MB;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -251,7 +251,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int b = (vt >> 4) + 32 * j;
-                        pj[i][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                        pj[i][v][j] = (m0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
                     }
                 }
 #pragma unroll
@@ -259,7 +259,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     const int vt = tid + v * RS_THREADS;
-                    if (vt >= 512) continue;
+                    if (vt >= 512 || m0 + i >= MB) continue;
                     float a = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a += pj[i][v][j];
@@ -273,6 +273,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int p = wave + RS_W * i;
+        if (p >= PAIRS) break;
         const int blk = cg * BPG + p / MB, mb = p % MB;
         f32x4 sres[NT];
 #pragma unroll
@@ -329,6 +330,7 @@ template <int FIN>
 int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
                int K, const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     return MBp == 4 ? rows_by_split<4, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
+         : MBp == 5 ? rows_by_split<5, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
                     : rows_by_split<8, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
 }
 

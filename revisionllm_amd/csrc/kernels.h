@@ -37,7 +37,7 @@ struct GemvNorm {
     const float* w_scale = nullptr;   // fp8 weights (w_layout 2): per-output-row dequantisation scale [N]
     // Fragment-packed decode activations (<= 128 rows): element (row r, k) of a [rows, K] bf16 operand lives at
     // rv_xp_index(r, k, mbp), i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block, the mbp row blocks
-    // (2: <= 32 rows, 4: <= 64, 8: <= 128) of a k-fragment adjacent - a 128-k slab of all rows is one contiguous 4 * mbp KiB run.
+    // (2: <= 32 rows, 4: <= 64, 5: <= 80, 8: <= 128) of a k-fragment adjacent - a 128-k slab of all rows is one contiguous 4 * mbp KiB run.
     // A wave then fetches its x operand of a k-step with ONE contiguous load per fragment instead of 16 row segments of 64 B -
     // with 17 .. 32 rows the row-major x loads cost the address units more than the weight stream itself.
     int x_packed = 0;                 // 0: X is row-major; 2 / 4 / 8: X is fragment-packed with that many row blocks (lda ignored)
@@ -49,7 +49,7 @@ __host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k, int mbp) {
     return ((((int64_t)(k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
 }
 constexpr int RV_ROWS_COUNTERS = 2048;
-__host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows <= 32 ? 2 : rows <= 64 ? 4 : 8; }
+__host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows <= 32 ? 2 : rows <= 64 ? 4 : rows <= 80 ? 5 : 8; }
 
 // Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
 // (bf16 [M,D]), RoPE-rotated K into the cache and V into the transposed cache - instead of an f32 [M,3D] buffer that two

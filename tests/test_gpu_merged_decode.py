@@ -109,7 +109,7 @@ def test_merged_decode_rows_equal_separate_generates():
     assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
 
 
-@pytest.mark.parametrize("n_groups,R", [(6, 48), (9, 64), (16, 112), (18, 128)])
+@pytest.mark.parametrize("n_groups,R", [(6, 48), (9, 64), (10, 70), (11, 80), (16, 112), (18, 128)])
 def test_wide_pools_33_to_128_rows_equal_separate_generates(n_groups, R):
     """Merged decode steps with 33 .. 128 rows (the split-K kernel: activations shared through LDS, 1 - 8 workgroups per column group,
     partial planes folded as subtrees of the 8-way tree): every group's logits at every step BIT-identical to the same group decoded

@@ -12,7 +12,7 @@ f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c
               ctypes.c_void_p]
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 63
-mbp = 2 if M <= 32 else 4 if M <= 64 else 8
+mbp = 2 if M <= 32 else 4 if M <= 64 else 5 if M <= 80 else 8
 planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
 arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
 for N in (4096, 12288, 22016):
