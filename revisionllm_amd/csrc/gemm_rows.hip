@@ -45,11 +45,13 @@ __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
 
 constexpr int RS_W = 4;        // consumer waves = 16-column tiles per workgroup (64-column groups); wave RS_W is the producer
 constexpr int RS_THREADS = (RS_W + 1) * 64;
-// MB = 4 row blocks: weight ring 6 deep (5 x 4 KiB per wave in flight), 3 slabs of 16 KiB, <= 168 VGPRs -> two workgroups per CU
-// MB = 8:            weight ring 4 deep, 3 slabs of 32 KiB, one workgroup per CU (8 deep measured slower: 107 vs 80 us on gate/up -
-//                    with 32 LDS fragment reads per 4 KiB of weights this variant is bound by the LDS pipe, not by bytes in flight)
-// MB = 5 (65 .. 80 rows: ten 7-row generates): as MB = 4 with 3 slabs of 20 KiB
-template <int MB> struct RowsCfg { static constexpr int DW = MB <= 5 ? 6 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2; };
+// Weight ring 4 deep (3 x 4 KiB per consumer wave in flight) everywhere.  Deeper rings were tried because the consumers' loop is bound by
+// the weight bytes in flight - and lost: at 6 deep the accumulator stack of the tree fold no longer fits the 168 VGPRs of three waves per
+// SIMD and the spills (28 - 196 B of scratch per lane) cost more than the depth gains: 56-row step 6.44 -> 6.08 ms, 70-row step 7.86 -> 6.86 ms
+// going from 6 to 4; 8 deep with 8 row blocks: gate/up 80 -> 107 us.
+// MB = 4 row blocks: 4 slabs of 16 KiB, two workgroups per CU;  MB = 5 (65 .. 80 rows: ten 7-row generates): 3 slabs of 20 KiB, two per CU;
+// MB = 8: 3 slabs of 32 KiB, one workgroup per CU
+template <int MB> struct RowsCfg { static constexpr int DW = 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2; };
 
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
@@ -295,7 +297,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 
 int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the smallest power of two that fills the CUs, <= 8
     const int64_t cg = N / 64;
-    int s = MBp == 8 ? 2 : 1;              // (8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit 256 VGPRs)
+    int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs)
     while (s < 8 && cg * s < 240) s *= 2;
     return s;
 }
