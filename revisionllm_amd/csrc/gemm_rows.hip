@@ -352,6 +352,7 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
     RV_CHECK_ARG(act == RV_ACT_NONE || act == RV_ACT_SILU_MUL, "gemm_rows: no activation or SILU_MUL");
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_BF16, "gemm_rows: SILU_MUL writes bf16");
     const int MBp = nrm.x_packed, S = rows_splits(N, MBp);
+    RV_CHECK_ARG((size_t)S * (N / 16) * MBp * 1024 <= gemm_rows_ws_bytes(), "gemm_rows: %d partial planes of N = %d do not fit the plane workspace", S, N);
     const QkvRope q0{};
     int rc;
     if (qr) rc = rows_by_mb<3>(MBp, S, X, W, nullptr, nullptr, 0, nullptr, 0, M, N, K, nrm, *qr, st);
