@@ -158,7 +158,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
                    hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
-        split = 2 if mbp == 8 else 1
+        split = 2 if mbp >= 5 else 1      # (rows_splits in gemm_rows.hip)
         kname = f"rows_kernel<{mbp},{8 // split},1>"
         gthreads = (2 * s.inter // 64) * split * 320
     ms = event_time_ms(gemv, 64, warm=4)
