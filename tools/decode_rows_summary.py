@@ -1,0 +1,19 @@
+"""Summarise gpurun_out/dr_<rows>/dr_kernel_stats.csv (tools/decode_rows_prof.sh) into profiles/r2_decode_steps.json: the kernels of an
+isolated merged decode step at several row counts."""
+import csv
+import json
+import sys
+
+out = {"what": "rocprofv3 --kernel-trace --stats of tools/decode_rows_time.py <rows> (23 isolated steps of rv_llm_decode_rows at Vicuna-7B shapes, 32 layers)",
+       "rows": {}}
+for R in sys.argv[1:]:
+    rows = list(csv.DictReader(open(f"gpurun_out/dr_{R}/dr_kernel_stats.csv")))
+    ks = []
+    for r in rows:
+        n = r["Name"].replace("void (anonymous namespace)::", "")
+        if any(t in n for t in ("rows_kernel", "gemv_stream", "attn_kernel", "rmsnorm", "sample", "splice", "rope_table")):
+            ks.append({"kernel": n.split("(")[0], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1)})
+    per_layer = sum(k["avg_us"] * k["calls"] for k in ks if k["calls"] >= 700) / 736.0
+    out["rows"][R] = {"kernels": ks[:8], "projection_and_attention_us_per_layer": round(per_layer, 1)}
+json.dump(out, open("gpurun_out/r2_decode_steps.json", "w"), indent=1)
+print(json.dumps({k: v["projection_and_attention_us_per_layer"] for k, v in out["rows"].items()}))
