@@ -48,7 +48,10 @@ constexpr int RS_THREADS = (RS_W + 1) * 64;
 // Weight ring 4 deep (3 x 4 KiB per consumer wave in flight) everywhere.  Deeper rings were tried because the consumers' loop is bound by
 // the weight bytes in flight - and lost: at 6 deep the accumulator stack of the tree fold no longer fits the 168 VGPRs of three waves per
 // SIMD and the spills (28 - 196 B of scratch per lane) cost more than the depth gains: 56-row step 6.44 -> 6.08 ms, 70-row step 7.86 -> 6.86 ms
-// going from 6 to 4; 8 deep with 8 row blocks: gate/up 80 -> 107 us.
+// going from 6 to 4; 8 deep with 8 row blocks: gate/up 80 -> 107 us.  With 4 / 5 row blocks neither the LDS reads nor the MFMAs bound the loop either
+// (compile-time probes at 70 rows: a loop-invariant activation fragment instead of the 20 LDS reads per stage - same time; one MFMA per
+// weight fragment instead of five - 5-8 % faster): the eight consumer waves of a CU simply stream their weights at 3.4 (K = 4096) .. 4.6
+// TB/s (long K) where the sixteen waves of gemv_stream reach 5.8.
 // MB = 4 row blocks: 4 slabs of 16 KiB, two workgroups per CU;  MB = 5 (65 .. 80 rows: ten 7-row generates): 3 slabs of 20 KiB, two per CU;
 // MB = 8: 3 slabs of 32 KiB, one workgroup per CU
 template <int MB> struct RowsCfg { static constexpr int DW = 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2; };
