@@ -6,10 +6,15 @@
 One "step" = one stage-2 recursion (zoom levels 4/2/1) of one query over this rank's 100 windows
 [100 x 256 x 768] of synthetic CLIP features with random-init Vicuna-7B-shaped weights (hash-seeded, generated in
 HBM), sampling at T = 0.05, decode length forced to G = 8 (eos disabled: random-init models never emit EOS).
-N ranks, ``--scaling weak`` (default): a 100*N-window video, windows block-partitioned, CLS rows and proposals exchanged by
-RCCL all-gathers (per-GPU work fixed).  ``--scaling strong``: ONE 100-window recursion per step sharded over the N ranks
-(100/N windows each, the 7 calls dealt over the ranks with a rotating start so that passes in flight keep every rank busy).
-Inputs are resident in HBM when the timed region starts.
+Every step in flight works on its OWN video, query and window permutations (hash-seeded by the step index modulo the steps in
+flight), so the prefills batched into one GEMM pass and the rows of a merged decode step are all different.
+N ranks (``--gpus N`` without a launcher: this process starts ``torch.distributed.run`` with N ranks as a child and relays rank 0's line):
+``--scaling queries`` (default; what "whole node" means here): whole recursions are dealt to the ranks - every rank runs the 1-GPU
+pipeline on its own queries, no data-path collective, ONE RCCL all-gather of the per-call proposals at the end of the timed region
+(the reference itself shards by query: e2e2.py:221-222).  ``--scaling segments``: a 100*N-window video per step, windows
+block-partitioned, CLS rows and proposals exchanged by RCCL all-gathers inside every recursion (per-GPU work fixed).
+``--scaling strong``: ONE 100-window recursion per step sharded over the N ranks (100/N windows each, the 7 calls dealt over the
+ranks with a rotating start: single-query latency).  Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0) with the contract fields plus ``roofline`` (dominant kernel, timed with HIP events on
 the launch stream) and ``cpu_baseline`` (the torch-fp32 CPU oracle on a bounded sample, N = 1 only).
@@ -51,8 +56,14 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="stage2_long_100", choices=["stage2_long_100", "stage2_long_33", "stage1_dense", "stage1_sparse"],
                    help="BASELINE.json configuration timed as the line's value (default: the one the metric is quoted on)")
-    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                   help="N > 1: weak = 100 windows per rank (a 100*N-window video); strong = one 100-window recursion sharded over the ranks")
+    p.add_argument("--scaling", default="queries", choices=["queries", "segments", "weak", "strong"],
+                   help="N > 1: queries = whole recursions dealt to the ranks (the 1-GPU pipeline x N, one final all-gather of proposals); "
+                        "segments (alias: weak) = 100 windows per rank of a 100*N-window video, two all-gathers per recursion; "
+                        "strong = one 100-window recursion sharded over the ranks")
+    p.add_argument("--identical-inputs", action="store_true",
+                   help="measurement knob: every step in flight works on the SAME video / query / permutations (the round-2 bench; identical rows "
+                        "toggle fewer bits and the power-capped GEMMs clock higher)")
+    p.add_argument("--cpu-only", action="store_true", help="time the CPU baseline alone (no GPU work) and print its JSON object")
     p.add_argument("--windows", type=int, default=100, help="windows (segments) per GPU (weak) / per recursion (strong)")
     p.add_argument("--frames", type=int, default=256)
     p.add_argument("--lq", type=int, default=16)
@@ -143,10 +154,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         kname = "gemv_stream<2,1,2,1,0,3,2,4>" if dec_rows > 16 else "gemv_stream<2,1,2,1,0,2,1,8>"
         gthreads = (2 * s.inter // 32) * (256 if dec_rows > 16 else 512)
     else:
-        import ctypes
-        f = hip.lib().rv_debug_gemm_rows
-        f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+        f = hip.lib().rv_gemm_rows
         mbp = 4 if dec_rows <= 64 else 5 if dec_rows <= 80 else 8
         xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(torch.bfloat16)          # fragment-packed rows (any values: timing)
         outs = torch.empty(mbp * 16 * s.inter, dtype=torch.bfloat16, device=dev)
@@ -154,7 +162,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
 
         def gemv():
-            rc = f(xs.data_ptr(), ws[state["i"] % len(ws)].data_ptr(), outs.data_ptr(), dec_rows, 2 * s.inter, s.hidden, planes.data_ptr(), arrive.data_ptr(),
+            rc = f(hip.ptr(xs), hip.ptr(ws[state["i"] % len(ws)]), hip.ptr(outs), dec_rows, 2 * s.inter, s.hidden, hip.ptr(planes), hip.ptr(arrive),
                    hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
@@ -163,7 +171,25 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         gthreads = (2 * s.inter // 64) * split * 320
     ms = event_time_ms(gemv, 64, warm=4)
     legs["decode_gateup_gemv"] = dict(kernel=kname, bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes,
-                                      rows=dec_rows, grid_threads=gthreads)
+                                      rows=dec_rows, grid_threads=gthreads, timing="64 back-to-back launches of this kernel alone (layers rotated); "
+                                      "inside a decode step it runs between dependent launches: see decode_step and in_step")
+    # (2b) one whole merged decode step at that row count, as rv_llm_decode_rows runs it (32 blocks x (qkv+RoPE, attention, o, gate/up, down) +
+    #      lm_head), rows at position ~ prompt + 4: algorithmic bytes = every weight once (6.607e9 x 2 B) + the rows' K / V
+    R = dec_rows
+    pos_at = 175
+    pool, smax = eng.new_kv_pool(R, 192)
+    pos = torch.full((R,), pos_at, dtype=torch.int32, device=dev)
+    hrow = (torch.randn(R, s.hidden, device=dev) * 0.02)
+    lg = torch.empty(R, s.vocab, dtype=torch.float32, device=dev)
+    prev_slot, eng.slot = eng.slot, 170
+    try:
+        ms = event_time_ms(lambda: eng.llm_decode_rows(hrow, pos, pool, smax, logits=lg), 12, warm=3)
+    finally:
+        eng.slot = prev_slot
+    step_bytes = 6.607e9 * 2 + 2.0 * s.layers * (pos_at + 1) * s.hidden * 2 * R
+    legs["decode_step"] = dict(kernel="rv_llm_decode_rows (one merged step, all its launches)", bound="hbm", ms=ms, achieved=step_bytes / ms / 1e6, peak=HBM_PEAK_GBS,
+                               unit="GB/s", algorithmic=step_bytes, rows=R, grid_threads=0)
+    del pool, lg
     # (3) the "feature scan": dense nn.Linear(768 -> 4096) projector over 100 segments x 256 frames (stage1_dense adapter);
     #     algorithmic bytes = features in + tokens out (2.49 MB / segment), weights (6.3 MB) amortised.
     #     Kernel: the A-resident GEMM (gemm_arows.hip): rows resident in LDS, A read once, C written once
@@ -199,7 +225,7 @@ def pmc_traffic(kernel, grid_threads):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE; tools/pmc_summary.py).  None if no summary matches."""
     want = kernel.replace(" ", "")
-    for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for fname in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         d = committed_profile(fname)
         if d is None:
             continue
@@ -265,22 +291,33 @@ def cpu_baseline(args, n_calls, P):
     def one_call(n_layers=None):
         """One LLM call as inference() drives it: adapter on the call's video rows, splice, prefill, G - 1 decode steps."""
         t0 = time.perf_counter()
+        tm = {}
         o_sampling.generate(ids, feat[None], q, w, wa, cfg, adapter_kw=dict(hierarchy=True), do_sample=True, temperature=0.05, top_k=50,
-                            max_new_tokens=G, eos_token_id=-1, uniforms=torch.full((G, 1), 0.5), n_layers=n_layers)
+                            max_new_tokens=G, eos_token_id=-1, uniforms=torch.full((G, 1), 0.5), n_layers=n_layers, timings=tm)
+        stage_log.append(tm)
         return time.perf_counter() - t0
+
+    stage_log = []
+
+    def stage_split(calls):
+        """Seconds per stage summed over the given calls' timing dicts (adapter = ClipEncoder on the call's rows + splice)."""
+        return {k: round(sum(c[k] for c in calls), 2) for k in ("adapter", "prefill", "decode")}
 
     info = dict(unit="segments/s", cores=cores, cpu=cpu_model, kind="port")
     if args.cpu_full and not args.cpu_sample:
         def recursion():
             return sum(one_call() for _ in range(n_calls))
         recursion()
+        del stage_log[:]
         times = [recursion() for _ in range(3)]
         t_rec = statistics.median(times)
-        info.update(value=W / t_rec, extrapolated=False, repeats=3,
+        med = times.index(t_rec)
+        info.update(value=W / t_rec, extrapolated=False, repeats=3, stage_seconds=stage_split(stage_log[med * n_calls:(med + 1) * n_calls]),
                     sample=f"torch-fp32 oracle, whole recursion as the reference executes it: {n_calls} calls x (ClipEncoder on {W} segment rows + "
                            f"prefill + {G - 1} decode steps, 32 layers), 1 warm-up + 3 repeats, median {t_rec:.1f} s (all: {[round(t, 1) for t in times]})")
         return info
     one_call(n_layers=1)                               # warm-up: thread pool, allocator, one layer's pass
+    del stage_log[:]
     t_call = one_call()
     if args.cpu_sample:
         t_rec = n_calls * t_call * (32.0 / L) * (W / ns)
@@ -290,6 +327,7 @@ def cpu_baseline(args, n_calls, P):
         return info
     t_rec = n_calls * t_call
     info.update(value=W / t_rec, extrapolated="x%d identical calls" % n_calls, repeats=1,
+                stage_seconds_per_call=stage_split(stage_log), full_run="profiles/r3_cpu_full.json (--cpu-full: all calls, 3 repeats, median)",
                 sample=f"torch-fp32 oracle: ONE full call of the recursion as the reference executes it (ClipEncoder on {W} segment rows x {Tn} frames, "
                        f"prefill S={P - 1 + W}, {G - 1} KV-cached decode steps, all 32 layers; driven through oracle.sampling.generate = the CPU "
                        f"restatement of inference()) timed once after a one-layer warm-up: {t_call:.1f} s; recursion = {n_calls} such calls "
@@ -297,9 +335,34 @@ def cpu_baseline(args, n_calls, P):
     return info
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks with ``torch.distributed.run`` as a CHILD process (this
+    process has not touched the GPU), relay what it prints and return its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.scaling == "weak":
+        args.scaling = "segments"
+    if args.cpu_only:
+        from revisionllm_amd.eval import stage2
+        print(json.dumps({"cpu_baseline": cpu_baseline(args, len(stage2.plan_groups(100, 100)), 72)}), flush=True)
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); start it as "
+                         f"`python bench.py --gpus {world}` or with torch.distributed.run --nproc-per-node {args.gpus}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -346,17 +409,47 @@ def main():
 
     # ---------------------------------------------------------------- stage-2 recursion workloads -------------------------------------
     strong = args.scaling == "strong" and world > 1
+    by_query = args.scaling == "queries" and world > 1       # whole recursions per rank: the 1-GPU pipeline on every rank
     batch = 33 if args.workload == "stage2_long_33" else 100
-    W = (33 if args.workload == "stage2_long_33" else args.windows) * (1 if strong else world)
-    lo, hi = parallel.shard_bounds(W, rank, world)
+    W = (33 if args.workload == "stage2_long_33" else args.windows) * (1 if (strong or by_query) else world)
+    lo, hi = (0, W) if by_query else parallel.shard_bounds(W, rank, world)
     Wl, Tn = hi - lo, args.frames
-    feats = ops.init_hash_(torch.empty(Wl, Tn, 768, dtype=torch.bfloat16, device=dev), f"bench.feat.r{rank}", args.seed, synth.SQRT3)
-    qf = ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), "bench.q", args.seed, synth.SQRT3)
-    qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "bench.qcls", args.seed, synth.SQRT3)
+    # queries mode: the recursion's own "world" is this rank alone (a one-rank group: the sharded driver then issues no collective)
+    own_group = None
+    if by_query:
+        groups = [dist.new_group([r]) for r in range(world)]      # (new_group is collective: every rank creates every group)
+        own_group = groups[rank]
     plan = stage2.plan_groups(W, batch)
-    gen = torch.Generator().manual_seed(args.seed)
-    torch.manual_seed(args.seed)                    # the device-side sampling draws (torch.rand in generate)
-    perms = stage2.make_perms(plan, gen, W=W)
+    torch.manual_seed(args.seed + (rank if by_query else 0))      # the device-side sampling draws (torch.rand in generate)
+
+    def hashed(shape, dtype, name):
+        return ops.init_hash_(torch.empty(*shape, dtype=dtype, device=dev), name, args.seed, synth.SQRT3)
+
+    def input_set(k, nq=1, W_=None, Wl_=None, batch_=None):
+        """The inputs of step k: ``nq`` recursions, each over its OWN video (this rank's windows of it), with its own query tokens,
+        query CLS feature, sentence (same word count: the prompts keep one geometry, the token ids differ) and window permutations.
+        Queries / permutations are identical on all ranks when a recursion is sharded over them (segments / strong), per-rank in
+        queries mode; k = 0 of rank 0 reproduces the round-2 bench's single input."""
+        W_, Wl_, batch_ = W_ or W, Wl_ or Wl, batch_ or batch
+        qtag = f".r{rank}" if by_query else ""
+        tag = "" if k == 0 else f".s{k}"
+        plan_ = stage2.plan_groups(W_, batch_)
+        g = torch.Generator().manual_seed(args.seed * 100003 + k * 17 + (rank * 7919 if by_query else 0))
+        feats_ = [hashed((Wl_, Tn, 768), torch.bfloat16, f"bench.feat{i if nq > 1 else ''}{'' if W_ == W else W_}.r{rank}{tag}") for i in range(nq)]
+        sent = SENTENCE if k == 0 else SENTENCE.replace("kitchen", f"kitchen{k}").replace("newspaper", f"newspaper{k}")
+        qs = [(hashed((args.lq, 768), torch.bfloat16, f"bench.q{i if nq > 1 else ''}{qtag}{tag}"),
+               hashed((768,), torch.float32, f"bench.qcls{i if nq > 1 else ''}{qtag}{tag}"), sent) for i in range(nq)]
+        return {"qs": qs, "perms": [stage2.make_perms(plan_, g, W=W_) for _ in range(nq)], "feats": feats_ if nq > 1 else feats_[0]}
+
+    n_sets = 1 if args.identical_inputs else max(1, args.streams)
+    sets_cache = {}
+
+    def input_sets(nq=1, **kw):
+        key = (nq, tuple(sorted(kw.items())))
+        if key not in sets_cache:
+            sets_cache[key] = [input_set(k, nq, **kw) for k in range(n_sets)]
+        return sets_cache[key]
+    qf, qc = input_sets()[0]["qs"][0][:2]
     stages = parallel.HipStages(model, tok)
     server = None
     if args.merge_decode:
@@ -365,28 +458,19 @@ def main():
                                     prefill_batch=args.prefill_batch)
         stages.server = server
 
-    def query_set(n):      # extra measurement: n queries of one movie share every decode weight pass
-        return ([(ops.init_hash_(torch.empty(args.lq, 768, dtype=torch.bfloat16, device=dev), f"bench.q{i}", args.seed, synth.SQRT3),
-                  ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"bench.qcls{i}", args.seed, synth.SQRT3), SENTENCE)
-                 for i in range(n)], [stage2.make_perms(plan, gen, W=W) for _ in range(n)])
-
-    def video_set(n):      # extra measurement: n recursions over n DIFFERENT videos (own windows, own query) in one pass
-        return [ops.init_hash_(torch.empty(Wl, Tn, 768, dtype=torch.bfloat16, device=dev), f"bench.feat{i}.r{rank}", args.seed, synth.SQRT3)
-                for i in range(n)]
-
-    work = {"qs": [(qf, qc, SENTENCE)], "perms": [perms], "feats": feats, "W": W, "batch": batch}
-    if args.queries > 1:
-        work["qs"], work["perms"] = query_set(args.queries)
+    work = {"sets": input_sets(args.queries), "W": W, "batch": batch, "G": G}
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
     inter = sched.Interleaver(servers=[server] if server is not None else ())
 
     def launch():
         """Start one step as a scheduler task bound to the next HIP stream / workspace slot."""
-        kw = dict(batch=work["batch"], perms=work["perms"], max_new_tokens=G)
+        s_ = work["sets"][counter["i"] % len(work["sets"])]
+        kw = dict(batch=work["batch"], perms=s_["perms"], max_new_tokens=work["G"], group=own_group)
         def g(task):
-            return parallel.launch_queries_sharded_steps(stages, tok, work["feats"], work["W"], work["qs"], turn=task, **kw)
+            return parallel.launch_queries_sharded_steps(stages, tok, s_["feats"], work["W"], s_["qs"], turn=task, **kw)
         if streams is None:
+            counter["i"] += 1
             return inter.add(sched.Task(g, None, eng, 0))
         k = counter["i"] % len(streams)
         counter["i"] += 1
@@ -401,14 +485,25 @@ def main():
         flight, each on its own HIP stream), so one step's HBM-bound decode launches fill the gaps of the other's MFMA-bound
         adapter / prefill and the host-side exchange / assembly overlaps device work; every step's work and record are
         produced inside the timed region.  With an EOS id the tasks yield at their stop-flag polls and are resumed round-robin."""
-        rec, pending = None, []
+        rec, pending, scores = None, [], []
         depth = max(1, work.get("depth", args.streams))
+
+        def take():
+            r = collect(pending.pop(0))
+            if by_query:
+                scores.append(r["max_entropy"] + r["mean_entropy"])
+            return r
         for _ in range(n):
             pending.append(launch())
             if len(pending) > depth:
-                rec = collect(pending.pop(0))
+                rec = take()
         while pending:
-            rec = collect(pending.pop(0))
+            rec = take()
+        if by_query and scores:
+            # the ONE exchange of this mode: the per-call proposals (1/max_entropy, 1/mean_entropy of every call of every recursion this
+            # rank ran) all-gathered over RCCL, ordered against the persistent prefill GEMMs like every collective of the path
+            mine = torch.tensor(scores, dtype=torch.float32, device=dev)
+            work["gathered"] = parallel._gated(stages, world, lambda: parallel._all_gather_cat(mine, None))
         return rec
 
     def sync():
@@ -501,7 +596,7 @@ def main():
         dt, out1 = timed(run1)
         if not torch.isfinite(out1["entropy"]).all():
             raise RuntimeError("bench: non-finite entropies")
-        value, rec = args.steps * world / dt, None
+        value, rec = args.steps * world / dt, None       # (stage-1 workloads: every rank times its own windows)
     else:
         if args.settle > 0:
             run(args.settle)
@@ -509,8 +604,10 @@ def main():
         dt, rec = timed(run)
         if any(e != e for e in rec["max_entropy"]) or not all(rec["answers"]):
             raise RuntimeError(f"bench: the last record is not finite / empty: {rec['answers']} {rec['max_entropy']}")
-        value = W * args.queries * args.steps / dt
+        value = W * args.queries * args.steps * (world if by_query else 1) / dt
         wl_cfg = {}
+        if by_query and work["gathered"].shape[0] != world * args.steps:
+            raise RuntimeError(f"bench: the final all-gather returned {tuple(work['gathered'].shape)} proposals rows for {world} ranks x {args.steps} steps")
 
     extra = {}
     if extras:
@@ -525,9 +622,7 @@ def main():
                     server32["s"] = serve.DecodeServer(model, rows=32, smax=server.Smax, gmax=max(16, G), pools=args.pools, gang=args.pools > 1, slot=110)
                     inter.servers.append(server32["s"])
                 stages.server = server32["s"]
-            if nq > 1 and len(work["qs"]) != nq:
-                work["qs"], work["perms"] = query_set(nq)
-                work["feats"] = video_set(nq)
+            work["sets"] = input_sets(nq)
             eng.set_option("fp8_decode", int(fp8))
             eng.set_option("fp8_prefill", int(fp8p))
             model.generation_config.eos_token_id = 2 if eos else None
@@ -560,14 +655,57 @@ def main():
         eng.set_option("fp8_prefill", 0)
         model.generation_config.eos_token_id = None
         stages.server = server
+        work["sets"] = input_sets(1)
+
+        def small_leg(name, fn, note):
+            try:
+                t, n = fn()
+                extra[name] = {"value": W * n / t, "unit": "segments/s", "ms_per_step": t / n * 1e3, "note": note}
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+
+        def identical():
+            work["sets"] = input_sets(1)[:1]
+            try:
+                return timed(run)[0], args.steps
+            finally:
+                work["sets"] = input_sets(1)
+        if n_sets > 1:
+            small_leg("identical_inputs_in_flight", identical,
+                      "the round-2 bench: every step in flight works on the SAME video / query / permutations (identical rows toggle fewer bits: the "
+                      "power-capped GEMMs clock higher); the headline gives every step its own inputs")
+
+        def latency():
+            work["depth"], stages.server = 1, None
+            try:
+                return timed(run, steps=8, warm=2)[0], 8
+            finally:
+                work.pop("depth", None)
+                stages.server = server
+        small_leg("one_recursion_latency", latency,
+                  "ONE recursion at a time, start to finish (no other step in flight, its own prefill and decode passes): ms_per_step = the latency of "
+                  "a single query's 100-window recursion; 8 recursions after 2 warm-up")
+
+        def prefill_only():
+            work["G"] = 1
+            try:
+                return timed(run)[0], args.steps
+            finally:
+                work["G"] = G
+        small_leg("prefill_only_G1", prefill_only,
+                  "G = 1: adapter + prefill + the first sampled token only, no KV-cached decode step (SURVEY 8d: separates the phases); same pipeline, "
+                  "same steps in flight")
         # steady state with wider gangs: 112-row pools (16 recursions per merged step on the 8-row-block split-K kernel), 32 steps in flight,
         # 64 timed steps after 32 warm-up steps - what the pipeline sustains when the fill / drain of a 20-step run no longer matters
         if server is not None and args.pools > 1 and world == 1:
             old_streams = streams
             try:
                 from revisionllm_amd import serve
-                if len(work["qs"]) != 1:
-                    work.update(qs=[(qf, qc, SENTENCE)], perms=[perms], feats=feats)
+                work["sets"] = input_sets(1)
                 wide = serve.DecodeServer(model, rows=112, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130)
                 inter.servers.append(wide)
                 stages.server = wide
@@ -589,9 +727,7 @@ def main():
                 streams = old_streams
         # the other BASELINE.json workloads
         try:
-            plan33 = stage2.plan_groups(33, 33)
-            work.update(qs=[(qf, qc, SENTENCE)], W=33, batch=33, perms=[stage2.make_perms(plan33, gen, W=33)],
-                        feats=ops.init_hash_(torch.empty(33, Tn, 768, dtype=torch.bfloat16, device=dev), "bench.feat33", args.seed, synth.SQRT3))
+            work.update(sets=input_sets(1, W_=33, Wl_=33, batch_=33), W=33, batch=33)
             t, _ = timed(run)
             extra["workload_stage2_long_33"] = {"value": 33 * args.steps / t, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3,
                                                 "config": "33 windows x 256 frames, batch 33: 9 calls (5 + 3 + 1) presenting 32 x8 / 33 video tokens "
@@ -644,16 +780,34 @@ def main():
         traffic = pmc_traffic(dom["kernel"], dom["grid_threads"])
         other = {k: {"kernel": v["kernel"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"], "avg_launch_ms": v["ms"],
                      **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {}),
+                     **({"timing": v["timing"]} if "timing" in v else {}),
                      **({"prefills_per_launch": v["prefills_per_launch"]} if "prefills_per_launch" in v else {})} for k, v in legs.items()}
-        pmc = committed_profile("r2_pmc_mfma.json")
-        if pmc is not None:
-            other["prefill_gemm_pmc"] = pmc.get("summary")
+        for fname in ("r3_pmc_mfma.json", "r2_pmc_mfma.json"):
+            pmc = committed_profile(fname)
+            if pmc is not None:
+                other["prefill_gemm_pmc"] = dict(pmc.get("summary") or {}, source="profiles/" + fname)
+                break
+        # the decode gate/up kernel INSIDE a decode step (rocprofv3 kernel trace of isolated steps, committed): the number to price it with
+        for fname in ("r3_decode_steps.json", "r2_decode_steps.json"):
+            prof = committed_profile(fname)
+            ks = [] if prof is None else prof.get("rows", {}).get(str(legs["decode_gateup_gemv"]["rows"]), {}).get("kernels", [])
+            want = legs["decode_gateup_gemv"]["kernel"].replace(" ", "")
+            row = next((r_ for r_ in ks if r_["kernel"].replace(" ", "") == want), None)
+            if row is not None:
+                nb = legs["decode_gateup_gemv"]["algorithmic"]
+                other["decode_gateup_gemv"]["in_step"] = {"avg_launch_ms": row["avg_us"] / 1e3, "achieved": nb / row["avg_us"] / 1e3, "unit": "GB/s",
+                                                          "frac": nb / row["avg_us"] / 1e3 / HBM_PEAK_GBS,
+                                                          "source": f"profiles/{fname} (rocprofv3 kernel trace of isolated {legs['decode_gateup_gemv']['rows']}-row steps)"}
+                break
         out = {
             "metric": METRIC,
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16 (fp8 e4m3 LLM weights / prefill GEMMs: extra measurement)" if (args.fp8_decode or args.fp8_prefill) else "bf16", "data": "synthetic",
-            "config": {"workload": args.workload, "windows_per_gpu": Wl, "windows_total": W, "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
+            "config": {"workload": args.workload, "windows_per_gpu": Wl, "windows_total": W * (world if by_query else 1), "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
+                       "inputs": ("every step in flight has its OWN video, query (tokens, CLS feature, sentence ids) and window permutations: %d distinct "
+                                  "input sets, step k uses set k mod %d" % (n_sets, n_sets) if n_sets > 1 else
+                                  "ONE input set shared by all steps in flight (--identical-inputs / --streams 1)"),
                        "queries_per_step": args.queries, "videos_per_step": 1, "batch": batch, "zooms": [4, 2, 1], "llm_calls_per_recursion": len(plan),
                        "prompt_tokens": int(P), "prefill_len": int(S), "shared_prefix": int(P0), "prefill_gemm_rows": int(M_prefill), "decode_steps": G,
                        "llm": "Vicuna-7B shapes, random-init (hash-seeded)", "sampling": "do_sample T=0.05 top_k=50",
@@ -666,8 +820,10 @@ def main():
                        "prefill": ("batched: up to %d waiting prefills of the steps in flight ride in one pass (serve.DecodeServer; %.2f per pass in this run)"
                                    % (server.prefill_batch, server.pf_tickets / max(1, server.pf_batches)) + "; steps by pass size: %s" % dict(sorted(server.pf_hist.items()))
                                    if server is not None and server.prefill_batch > 1 else "one pass per step"),
-                       "parallelism": (f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals"
-                                       if world > 1 else "single GPU")},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"queries x{world}: whole recursions dealt to the ranks (each rank = the 1-GPU pipeline on its own videos / queries), "
+                                       "one RCCL all-gather of the per-call proposals at the end of the timed region" if by_query else
+                                       f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals in every recursion")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,
                          "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"], "other": other},
@@ -688,4 +844,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -14,7 +14,10 @@
  *   - plain C, no torch types; every pointer is a caller-owned DEVICE pointer unless marked host;
  *   - all work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises;
  *   - the library allocates nothing on the device: workspaces are caller-provided, sizes come from
- *     the *_ws_bytes queries; rv_ctx only stores pointers + configuration + its tunables;
+ *     the *_ws_bytes queries; rv_ctx only stores pointers + configuration + its tunables.  A workspace must be ZERO when it is
+ *     handed over for the first time (its first 16 KiB hold the hand-off flags of the persistent GEMMs and the arrival counters
+ *     of the split-K decode kernel; both only ever count up, so it never needs cleaning afterwards) and must not be used by two
+ *     streams at once;
  *   - no process-wide mutable state: tunables live in the context (rv_ctx_set_option), contexts are independent and
  *     re-entrant across threads; the only shared things are a monotonic launch counter (atomic; the hand-off flags of the
  *     persistent GEMMs carry it, so a workspace never needs cleaning) and the thread-local error string.  At most ONE launch
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 2
+#define RV_ABI_VERSION 3
 
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
 typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
@@ -124,16 +127,19 @@ int rv_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float
 int rv_gemm_fp8(const rv_ctx* ctx /* optional: tunables */, const void* A8, int64_t lda, const float* a_scale, const void* W8p, const float* w_scale, const float* residual,
                 int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, size_t ws_bytes,
                 void* stream);
-/* DEPRECATED (removed next ABI version): process-wide setters kept for one round.  They only change the DEFAULTS that contexts
- * created afterwards start from (and that context-free calls use); existing contexts are not affected.  Use rv_ctx_set_option. */
-void rv_set_gemm_tile_variant(int32_t variant);
-void rv_set_gemm_cus(int32_t n);
-void rv_set_fp8_decode(int32_t on);
-void rv_set_fp8_prefill(int32_t on);
-void rv_set_sample_variant(int32_t v);
 int rv_gemm(const rv_ctx* ctx /* optional: tunables */, const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);
+/* One projection of a MERGED decode step (33 .. 128 rows; what rv_llm_decode_rows launches four times per block):
+ * C[M,N] = act(X . Wp^T), X = M bf16 rows in the fragment-packed decode layout - element (r, k) at
+ *     ((((k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7),   mbp = 4 (M <= 64), 5 (<= 80), 8 (<= 128)
+ * row blocks (16 * mbp rows allocated) -, Wp fragment-packed as for rv_gemm, C row-major (ldc = N, or N / 2 with RV_ACT_SILU_MUL, which
+ * writes bf16).  planes: workspace of rv_gemm_rows_ws_bytes() bytes; arrive: 2048 int32 arrival counters, ZERO before the first launch
+ * and private to one stream (the split-K workgroups of a column group count up in them; they are never reset, so the caller never
+ * cleans them either).  N % 64 == 0, K % 128 == 0, K >= 1024, N <= 32768. */
+size_t rv_gemm_rows_ws_bytes(void);
+int rv_gemm_rows(const void* Xp, const void* Wp, void* C, int32_t M, int32_t N, int32_t K, void* planes, int32_t* arrive, int act,
+                 int out_dtype, void* stream);
 /* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
  * x f32 [rows,d]; any of y_f32 / y_bf16 / y_pos_bf16 may be NULL; y_pos = bf16(y + pos[row % period]). */
 int rv_layernorm(const float* x, const float* w, const float* b, float* y_f32, void* y_bf16, void* y_pos_bf16,
@@ -181,6 +187,15 @@ size_t rv_llm_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t S);
 int rv_llm_forward(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, float* logits,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Blocks [layer_begin, layer_end) of the decoder stack over h f32 [B,S,D], in place: the residual stream behind block
+ * layer_end - 1, no final norm, no lm_head (rv_llm_forward = rv_llm_layers(0, L) + model.norm + lm_head on the last position).
+ * Same kernels, cache layout and workspace as rv_llm_forward: S > 1 prefill rows at positions 0..S-1 (pos0 = 0), S == 1 one
+ * KV-cached decode step at pos0 (B <= 128; above 32 rows the split-K decode kernel); only the cache planes of those blocks are
+ * touched.  This is what the per-layer parity tests drive: block l is fed the REFERENCE's input of block l
+ * (transformers LlamaDecoderLayer.forward as called from vtimellm_llama.py:79-90) and compared with the reference's output. */
+int rv_llm_layers(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, int32_t layer_begin,
+                  int32_t layer_end, void* ws, size_t ws_bytes, void* stream);
+
 /* Prefill of B sequences that start with the same P0 tokens (inference() repeats one prompt, inference.py:36): under
  * causal attention the prefix rows are identical for every sequence, so they are computed once.
  * h f32 [P0 + B*S, D]: the P0 shared rows (positions 0..P0-1) followed by S rows per sequence (positions P0..P0+S-1).
@@ -196,7 +211,8 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
  * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 128: up to 32 rows take the weight-streaming kernel,
  * 33 .. 128 the split-K kernel with LDS-shared activations; bf16 weights only above 32 rows), row r at its OWN position row_pos[r]
- *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified.  h f32 [R, D]
+ *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified; an active row
+ *   needs row_pos[r] < Smax (NOT checked: the positions live on the device).  h f32 [R, D]
  *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.
  *   Workspace: rv_llm_ws_bytes(ctx, R, 1). */
 int rv_llm_prefill_pool(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows, int32_t kv_row0, int32_t Smax,

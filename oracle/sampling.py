@@ -58,7 +58,7 @@ def select_token(scores, uniform=None):
 
 def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_kw, do_sample=False,
              temperature=1.0, top_k=0, top_p=1.0, max_new_tokens=8, eos_token_id=2, pad_token_id=0,
-             uniforms=None, forced_tokens=None, n_layers=None, w_llm_decode=None):
+             uniforms=None, forced_tokens=None, n_layers=None, w_llm_decode=None, timings=None):
     """The generate loop as driven by inference.py:45-59.
 
     Returns dict(sequences [B,P+G], logits list of G [B,V] raw, scores list of G [B,V] processed).
@@ -66,15 +66,22 @@ def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_k
     random-init models where free-running tokens would diverge on near-ties).
     ``w_llm_decode``: weights used by the KV-cached decode steps instead of ``w_llm`` (the build's opt-in FP8 decode path:
     ``oracle.llama.fp8_decode_weights``); the prefill always uses ``w_llm``.
+    ``timings``: a dict that receives the wall seconds of the three stages (``adapter``, ``prefill``, ``decode``: bench.py's cpu_baseline).
     """
+    import time
+    t0 = time.perf_counter()
     feats = _adapter.encode_images(images, w_adapter, query_feats, **adapter_kw)
     embeds, mask, pos, _ = _splice.splice(input_ids, list(feats), w_llm["model.embed_tokens.weight"])
+    t1 = time.perf_counter()
     cache = _llama.KVCache(cfg.layers)
     B = input_ids.shape[0]
     seqs = input_ids.clone()
     unfinished = torch.ones(B, dtype=torch.long)
     raw, proc = [], []
     logits = _llama.forward(embeds, w_llm, cfg, mask, pos, cache, last_only=False, n_layers=n_layers)[:, -1]
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings.update(adapter=t1 - t0, prefill=t2 - t1, decode=0.0)
     for step in range(max_new_tokens):
         raw.append(logits)
         sc = process_logits(logits, temperature, top_k, top_p) if do_sample else logits.float()
@@ -91,4 +98,6 @@ def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_k
         mask, p1 = _splice.decode_step_inputs(mask, cache.seq_len())
         e1 = w_llm["model.embed_tokens.weight"][nxt][:, None]
         logits = _llama.forward(e1, w_llm if w_llm_decode is None else w_llm_decode, cfg, mask, p1, cache, n_layers=n_layers)[:, -1]
+    if timings is not None:
+        timings["decode"] = time.perf_counter() - t2
     return {"sequences": seqs, "logits": raw, "scores": proc}

@@ -471,10 +471,6 @@ extern "C" size_t rv_llm_ws_bytes(const rv_ctx* c, int32_t B, int32_t S) {
     return carve_llm(c, nullptr, 0, 1, B * S).bytes;
 }
 
-// deprecated shims (one round): they only change the DEFAULTS new contexts start from; use rv_ctx_set_option
-extern "C" void rv_set_fp8_decode(int32_t on) { g_default_opts.fp8_decode = on != 0; }
-extern "C" void rv_set_fp8_prefill(int32_t on) { g_default_opts.fp8_prefill = on != 0; }
-
 namespace {
 // Rows of h: [P0 shared-prefix rows (positions 0..P0-1)] then B sequences of S rows (positions pos0..pos0+S-1, with
 // pos0 == P0 when P0 > 0).  P0 == 0 is the plain prefill / decode step.
@@ -482,9 +478,11 @@ namespace {
 // (several generates share one pool).  row_pos (device int [B], S == 1 only): every row decodes at its own position.
 // G / grow (host array [G]): G prefills of identical geometry batched into one pass - h holds G blocks of [P0 ; B x S] rows, block gi's
 // cache rows are grow[gi] .. grow[gi] + B - 1 of the pool (kv_row0 is ignored then); logits [G * B, V].
+// l0 / l1: only the blocks [l0, l1) run (l1 < 0: to the last one); with logits == nullptr the final norm + lm_head are skipped and h
+// is left holding the residual stream behind block l1 - 1 (rv_llm_layers).
 int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
                      size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr, int G = 1,
-                     const int* grow = nullptr) {
+                     const int* grow = nullptr, int l0 = 0, int l1 = -1) {
     RV_TRY(resolve_llm(c));
     const rv_config& g = c->cfg;
     if (G > 1) kv_row0 = grow[0];
@@ -531,12 +529,13 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.out_packed = xp;
     consume.planes = w.planes;
     consume.arrive = w.arrive;
-    for (int l = 0; l < g.layers; ++l) {
+    if (l1 < 0 || l1 > g.layers) l1 = g.layers;
+    for (int l = l0; l < l1; ++l) {
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
         if (p8_qkv) RV_TRY(norm_quant(L.norm1));
-        else if (!fuse_norm || l == 0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st, xp));
+        else if (!fuse_norm || l == l0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st, xp));
         // fused q/k/v projection: RoPE-rotated Q -> q16, rotated K and V^T -> this layer's cache (no f32 qkv round trip)
         QkvRope qr;
         qr.cs = w.cs;
@@ -551,7 +550,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         if (p8_qkv) {
             RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wqkv8p, L.sqkv, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, M, 3 * D, D, &qr, w.sk, st));
         } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
-            GemvNorm cq = (fuse_norm && l > 0) ? consume : GemvNorm{};
+            GemvNorm cq = (fuse_norm && l > l0) ? consume : GemvNorm{};
             cq.w_scale = L.sqkv;
             cq.x_packed = xp;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv8, M, D, qr, &cq, nullptr, 0, st, 2));
@@ -560,7 +559,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             first.x_packed = xp;
             first.planes = w.planes;
             first.arrive = w.arrive;
-            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > 0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
+            RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > l0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
         if (P0 > 0 && P0 > 16 && S > 16 && dh == 128) {
@@ -641,6 +640,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                                 fuse_norm ? &produce : nullptr));
         }
     }
+    if (!logits) return RV_OK;
     if (f8 && g.layers > 0) {
         GemvNorm cl = consume;
         cl.w_scale = c->slm_head;
@@ -663,6 +663,17 @@ extern "C" int rv_llm_forward(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t
     RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_forward: empty problem");
     RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_forward: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
     return llm_forward_impl(c, h, B, S, pos0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int rv_llm_layers(rv_ctx* c, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, int32_t layer_begin,
+                             int32_t layer_end, void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && kv && ws, "rv_llm_layers: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(B > 0 && S > 0 && pos0 >= 0, "rv_llm_layers: empty problem");
+    RV_CHECK_ARG(Smax % 32 == 0 && pos0 + S <= Smax, "rv_llm_layers: Smax=%d must be a multiple of 32 and >= pos0+S=%d", Smax, pos0 + S);
+    RV_CHECK_ARG(layer_begin >= 0 && layer_begin < layer_end && layer_end <= c->cfg.layers, "rv_llm_layers: blocks [%d, %d) of %d", layer_begin,
+                 layer_end, c->cfg.layers);
+    return llm_forward_impl(c, h, B, S, pos0, 0, kv, Smax, nullptr, ws, ws_bytes, as_stream(stream), 0, 0, nullptr, 1, nullptr, layer_begin, layer_end);
 }
 
 extern "C" size_t rv_llm_prefill_shared_ws_bytes(const rv_ctx* c, int32_t B, int32_t P0, int32_t S) {

@@ -22,7 +22,7 @@ extern "C" int rv_last_error(char* buf, size_t n) {
 }
 
 // ---- per-call option scope (see kernels.h) ----
-RvOpts g_default_opts;
+const RvOpts g_default_opts{};
 static thread_local const RvOpts* t_opts = nullptr;
 const RvOpts& rv_cur_opts() { return t_opts ? *t_opts : g_default_opts; }
 RvOptScope::RvOptScope(const RvOpts* o) : prev(t_opts) { t_opts = o; }

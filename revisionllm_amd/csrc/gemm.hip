@@ -895,7 +895,6 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 
 int gemv_blocks(int act, int64_t N) { return (int)((act == RV_ACT_SILU_MUL || N >= 16384) ? cdiv(N, 32) : cdiv(N, 16)); }
 
-extern "C" void rv_set_gemm_tile_variant(int32_t v) { g_default_opts.gemm_tile_variant = (v >= 0 && v <= 6) ? v : 2; }   // deprecated shim
 
 extern "C" size_t rv_gemm_ws_bytes(void) { return gemm_pp_ws_bytes(); }
 

@@ -675,10 +675,9 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
 
 }  // namespace
 
-// The persistent prefill GEMMs may be told to leave CUs free (rv_set_gemm_cus): a 128 KiB-LDS workgroup owns its CU, so with a
+// The persistent prefill GEMMs may be told to leave CUs free (option "gemm_cus"): a 128 KiB-LDS workgroup owns its CU, so with a
 // grid of 192 on a 256-CU device 8 CUs per XCD stay available to whatever another stream launches (the HBM-bound decode
 // GEMVs of a second recursion in flight cannot share a CU with these workgroups: both fill the register file).
-extern "C" void rv_set_gemm_cus(int32_t n) { g_default_opts.gemm_cus = n > 0 ? (n & ~7) : 0; }   // deprecated shim
 
 size_t gemm_pp_ws_bytes() { return PP_HDR + (size_t)2 * pp_device_cus() * PARTIAL_F4 * sizeof(f32x4); }
 

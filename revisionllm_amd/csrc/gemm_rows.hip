@@ -343,6 +343,7 @@ int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bi
 
 // S * (N / 16) tiles * MB KiB with S = rows_splits(N, MB): S * N < 2 * 240 * 128 wherever the CU fill asks for S > 2; N <= 32768, S = 2 otherwise
 size_t gemm_rows_ws_bytes() { return (size_t)(2 * 32768 / 16) * 8 * 1024; }
+extern "C" size_t rv_gemm_rows_ws_bytes(void) { return gemm_rows_ws_bytes(); }
 
 // X: 33 .. 128 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
 // qr != nullptr: the fused q/k/v + RoPE epilogue.
@@ -369,13 +370,14 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
     return RV_OK;
 }
 
-// Measurement hook (tools/rows_time.py, bench.py's roofline leg; not part of include/revision_hip.h): a projection on 33 .. 128 packed rows
-// with the engine's epilogue variants (act = RV_ACT_SILU_MUL + bf16 out: the gate/up launch of a merged decode step).
-extern "C" int rv_debug_gemm_rows(const void* Xp, const void* Wp, void* C, int M, int N, int K, float* planes, int* arrive, int act, int out_dtype,
-                                  void* stream) {
+// Building block (include/revision_hip.h): one projection of a merged decode step on 33 .. 128 fragment-packed rows, with the engine's
+// epilogue variants (act = RV_ACT_SILU_MUL + bf16 out: the gate/up launch).
+extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, void* C, int32_t M, int32_t N, int32_t K, void* planes, int32_t* arrive, int act,
+                            int out_dtype, void* stream) {
+    RV_CHECK_ARG(Xp && Wp && C && planes && arrive, "rv_gemm_rows: null argument");
     GemvNorm nrm;
     nrm.x_packed = rv_xp_blocks(M);
-    nrm.planes = planes;
+    nrm.planes = (float*)planes;
     nrm.arrive = arrive;
     const int ldc = act == RV_ACT_SILU_MUL ? N / 2 : N;
     return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr);

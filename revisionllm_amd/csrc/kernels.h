@@ -13,7 +13,7 @@ struct RvOpts {
     int sample_variant = 1;     // 1 compacted-candidate top-k fast path, 0 general selection (identical outputs)
     int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
 };
-extern RvOpts g_default_opts;   // written only by the deprecated rv_set_* shims; copied into a context at rv_ctx_create
+extern const RvOpts g_default_opts;   // the production defaults every context starts from (rv_ctx_create)
 const RvOpts& rv_cur_opts();
 struct RvOptScope {
     const RvOpts* prev;

@@ -685,7 +685,6 @@ extern "C" int rv_sample(const rv_ctx* ctx, const float* logits, int32_t B, int3
     return RV_OK;
 }
 
-extern "C" void rv_set_sample_variant(int32_t v) { g_default_opts.sample_variant = v; }   // deprecated shim
 
 extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream) {
     RV_CHECK_ARG(logits && out && B > 0 && G > 0 && V > 0, "rv_entropy_stats: bad arguments");

@@ -198,10 +198,11 @@ class Engine:
         return get
 
     def init_synthetic(self, seed=0, llm=True, clip=True, linear=False, llm_prefix="", clip_prefix="model.mm_projector.",
-                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False):
-        """Random-init weights of the reference's shapes, bit-identical to ``synth.build_numpy`` on the host."""
+                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False, cond=None):
+        """Random-init weights of the reference's shapes, bit-identical to ``synth.build_numpy`` on the host.
+        ``cond``: a ``synth.Conditioning`` (the well-conditioned LLM amplitudes of golden G8c); None = plain N(0, 0.02)."""
         if llm:
-            self.load_llm(self._synth_get(synth.llama_spec(self.shape), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill)
+            self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill)
         if clip:
             self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text), seed,
                                                    clip_prefix))
@@ -305,6 +306,20 @@ class Engine:
             self._persist_end()
         return logits
 
+
+    def llm_layers(self, h, pos0, kv, Smax, layer_begin, layer_end):
+        """Blocks [layer_begin, layer_end) over h f32 [B,S,D] IN PLACE (no final norm / lm_head): the residual stream behind the
+        last of them.  S > 1: prefill at positions 0..S-1; S == 1: one KV-cached decode step at pos0."""
+        B, S, _ = h.shape
+        assert h.dtype == torch.float32 and h.is_contiguous()
+        ws = self._workspace("llm", self.lib.rv_llm_ws_bytes(self._ctx, B, S))
+        if B * S > 16:
+            self._persist_begin()
+        hip.check(self.lib.rv_llm_layers(self._ctx, hip.ptr(h), B, S, pos0, hip.ptr(kv), Smax, layer_begin, layer_end, hip.ptr(ws), ws.numel(),
+                                         hip.stream()), "rv_llm_layers")
+        if B * S > 16:
+            self._persist_end()
+        return h
 
     def llm_prefill_shared(self, h, B, P0, kv, Smax, logits=None):
         """h f32 [P0 + B*S, D] (shared prefix rows first, then S rows per sequence) -> logits f32 [B,V]."""

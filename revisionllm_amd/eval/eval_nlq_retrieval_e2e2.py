@@ -257,8 +257,9 @@ def _eval_in_flight(args, tokenizer, model, store, stager, items, done, groundin
             if args.debug:
                 raise
             errors.append(id_)
-            if task in inter.tasks:
+            if task in inter.tasks:     # (collect_queries raised after the task had finished, or the scheduler gave up on it)
                 inter.tasks.remove(task)
+            task.cancel()               # a generate still holding rows of a KV pool gives them back (generate_steps' finally)
 
     for id_, data in items:
         if id_ in done:

@@ -47,11 +47,8 @@ SIGNATURES = {
     "rv_ctx_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
     "rv_ctx_get_option": (C.c_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "rv_gemm_ws_bytes": (_sz, []),
-    "rv_set_gemm_tile_variant": (None, [_i32]),     # deprecated shims (defaults of contexts created afterwards)
-    "rv_set_gemm_cus": (None, [_i32]),
-    "rv_set_fp8_decode": (None, [_i32]),
-    "rv_set_fp8_prefill": (None, [_i32]),
-    "rv_set_sample_variant": (None, [_i32]),
+    "rv_gemm_rows_ws_bytes": (_sz, []),
+    "rv_gemm_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, C.c_int, C.c_int, _p]),
     "rv_gemm": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, _sz, _p]),
     "rv_rmsnorm_quant_fp8": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f, _p]),
     "rv_quant_rows_fp8": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
@@ -69,6 +66,7 @@ SIGNATURES = {
     "rv_kv_bytes": (_sz, [_p, _i32, _i32]),
     "rv_llm_ws_bytes": (_sz, [_p, _i32, _i32]),
     "rv_llm_forward": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _sz, _p]),
+    "rv_llm_layers": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "rv_llm_prefill_shared_ws_bytes": (_sz, [_p, _i32, _i32, _i32]),
     "rv_llm_prefill_shared": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_prefill_pool": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),

@@ -281,49 +281,65 @@ class ReVisionLlamaForCausalLM:
                 yield sched.RETRY
                 job = server.reserve(B)
         if job is not None:
-            pool = job.pool
-            # ---- merged-decode path: prefill into the server's pool, its merged steps do the rest ----
-            for ev in job.free_events:
-                torch.cuda.current_stream(dev).wait_event(ev)                   # the rows' previous owners are done with them
-            batched = getattr(server, "prefill_batch", 1) > 1
-            if not batched and getattr(server, "fifo_prefill", False) and server.prefill_tail is not None:
-                # prefills in launch order: each one saturates the GPU anyway, and the pool that fills first then decodes (HBM-bound)
-                # under the NEXT pool's prefills (MFMA-bound) instead of all prefills in flight finishing together
-                torch.cuda.current_stream(dev).wait_event(server.prefill_tail)
-            if 16 <= P0 < S:
-                flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
-                h, p0 = eng.splice_embed(flat, video_rows)[0], P0
-            else:
-                h, p0 = eng.splice_embed(row_map, video_rows).view(B * S, -1), 0
-            if batched:      # the server batches the waiting prefills of identical geometry into one pass (its own stream, FIFO)
-                ticket = server.submit_prefill(job, h, B, p0)
-                from .. import sched
-                while ticket.ready is None:
-                    yield sched.RETRY
-                first, ready = ticket.first, ticket.ready
-                torch.cuda.current_stream(dev).wait_event(ready)
-            else:
-                first = eng.llm_prefill_pool(h, B, p0, pool.kv, pool.R, job.r0, pool.Smax)
-                ready = None
-            if do_sample and uniforms is None:
-                uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
-                            else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
-            if ready is None:
-                ready = torch.cuda.Event()
-                ready.record()
-                if getattr(server, "fifo_prefill", False):
-                    server.prefill_tail = ready
-            yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
-            server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
-                        uniforms=uniforms if do_sample else None, forced=forced_tokens)
+            try:
+                return (yield from self._generate_in_pool(server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k,
+                                                          top_p, max_new_tokens, uniforms, forced_tokens, return_dict_in_generate))
+            finally:
+                if not job.finished:        # an exception here or in a task this one was pumped from, or the task was cancelled
+                    server.abandon(job)
+        return (yield from self._generate_alone(eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
+                                                max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, output_scores, output_logits,
+                                                eos, pad, eos_lookahead))
+
+    def _generate_in_pool(self, server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
+                          max_new_tokens, uniforms, forced_tokens, return_dict_in_generate):
+        """The merged-decode path of ``generate_steps``: prefill into the server's pool, its merged steps do the rest."""
+        pool = job.pool
+        for ev in job.free_events:
+            torch.cuda.current_stream(dev).wait_event(ev)                   # the rows' previous owners are done with them
+        batched = getattr(server, "prefill_batch", 1) > 1
+        if not batched and getattr(server, "fifo_prefill", False) and server.prefill_tail is not None:
+            # prefills in launch order: each one saturates the GPU anyway, and the pool that fills first then decodes (HBM-bound)
+            # under the NEXT pool's prefills (MFMA-bound) instead of all prefills in flight finishing together
+            torch.cuda.current_stream(dev).wait_event(server.prefill_tail)
+        if 16 <= P0 < S:
+            flat = torch.cat([row_map[0, :P0], row_map[:, P0:].reshape(-1)])[None]
+            h, p0 = eng.splice_embed(flat, video_rows)[0], P0
+        else:
+            h, p0 = eng.splice_embed(row_map, video_rows).view(B * S, -1), 0
+        if batched:      # the server batches the waiting prefills of identical geometry into one pass (its own stream, FIFO)
+            ticket = server.submit_prefill(job, h, B, p0)
             from .. import sched
-            while not job.finished:
-                yield sched.RETRY           # the scheduler pumps the server's merged steps
-            yield job.done_event
-            seqs = torch.cat([ops.h2d(input_ids, dev, torch.long), job.tokens.long()], dim=1)
-            if not return_dict_in_generate:
-                return seqs
-            return GenerateOutput(sequences=seqs, entropy=job.entropy, entropy_raw=job.entropy_raw)
+            while ticket.ready is None:
+                yield sched.RETRY
+            first, ready = ticket.first, ticket.ready
+            torch.cuda.current_stream(dev).wait_event(ready)
+        else:
+            first = eng.llm_prefill_pool(h, B, p0, pool.kv, pool.R, job.r0, pool.Smax)
+            ready = None
+        if do_sample and uniforms is None:
+            uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
+                        else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record()
+            if getattr(server, "fifo_prefill", False):
+                server.prefill_tail = ready
+        yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
+        server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
+                    uniforms=uniforms if do_sample else None, forced=forced_tokens)
+        from .. import sched
+        while not job.finished:
+            yield sched.RETRY           # the scheduler pumps the server's merged steps
+        yield job.done_event
+        seqs = torch.cat([ops.h2d(input_ids, dev, torch.long), job.tokens.long()], dim=1)
+        if not return_dict_in_generate:
+            return seqs
+        return GenerateOutput(sequences=seqs, entropy=job.entropy, entropy_raw=job.entropy_raw)
+
+    def _generate_alone(self, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p, max_new_tokens,
+                        uniforms, forced_tokens, return_dict_in_generate, output_scores, output_logits, eos, pad, eos_lookahead):
+        """The classic loop of ``generate_steps``: this generate's own KV cache and decode passes."""
         cap = min(max_new_tokens, 64)
         kv, Smax = eng.new_kv(B, S + cap)
         if 16 <= P0 < S:     # (P0 == S: identical text-only rows - nothing per-row is left, take the plain prefill)

@@ -15,10 +15,15 @@ def _c(t):
 
 
 def init_hash_(t, name, seed, a, base=0.0, offset=0):
-    """Fill ``t`` in place with the hash-seeded uniform(base-a, base+a) stream of tensor ``name``."""
-    key = (hashinit.tensor_key(name, seed) + offset) & 0xFFFFFFFFFFFFFFFF
-    hip.check(hip.lib().rv_init_hash(hip.ptr(t), hip.dtype_code(t), t.numel(), key, float(hashinit.step_for(a)), float(base),
-                                     hip.stream()), "rv_init_hash")
+    """Fill ``t`` in place with the hash-seeded uniform(base-a, base+a) stream of tensor ``name``.  ``a``: one amplitude, or
+    (row_end, amplitude) pieces over the leading dimension (``hashinit.amplitude_pieces``): one launch per piece, same stream."""
+    assert t.is_contiguous()
+    key = hashinit.tensor_key(name, seed) + offset
+    flat = t.view(-1)
+    for e0, cnt, amp in hashinit.amplitude_pieces(a, tuple(t.shape)):
+        piece = flat[e0:e0 + cnt]
+        hip.check(hip.lib().rv_init_hash(hip.ptr(piece), hip.dtype_code(t), cnt, (key + e0) & 0xFFFFFFFFFFFFFFFF, float(hashinit.step_for(amp)),
+                                         float(base), hip.stream()), "rv_init_hash")
     return t
 
 
@@ -56,6 +61,44 @@ def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_AC
                                 residual.stride(0) if residual is not None else 0, hip.ptr(out), out.stride(0),
                                 hip.dtype_code(out), act, M, N, K, hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream()),
               "rv_gemm")
+    return out
+
+
+def xp_blocks(rows):
+    """Row blocks of the fragment-packed decode layout (csrc/kernels.h rv_xp_blocks)."""
+    return 2 if rows <= 32 else 4 if rows <= 64 else 5 if rows <= 80 else 8
+
+
+def pack_rows(x):
+    """[M,K] bf16 (M <= 128, K % 32 == 0) -> the fragment-packed decode layout [16 * mbp * K] (csrc/kernels.h rv_xp_index): every
+    16-row x 32-k operand fragment one contiguous 1 KiB block, the mbp row blocks of a k-fragment adjacent; rows past M are zero."""
+    M, K = x.shape
+    mbp = xp_blocks(M)
+    xp = torch.zeros(mbp * 16, K, dtype=x.dtype, device=x.device)
+    xp[:M] = x
+    return xp.view(mbp, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(-1)
+
+
+_ROWS_WS = {}
+
+
+def gemm_rows(x, wp, act=hip.RV_ACT_NONE, out_dtype=torch.float32, out=None, xp=None):
+    """One projection of a merged decode step on 33 .. 128 rows (rv_gemm_rows: the split-K kernel with LDS-shared activations).
+    x [M,K] bf16 row-major (packed here; or ``xp`` already packed), wp fragment-packed [N,K] -> row-major [M, N] (N / 2 with SILU_MUL)."""
+    M, K = x.shape
+    N = wp.shape[0]
+    key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+    if key not in _ROWS_WS:
+        _ROWS_WS[key] = (torch.zeros(hip.lib().rv_gemm_rows_ws_bytes(), dtype=torch.uint8, device=x.device),
+                         torch.zeros(2048, dtype=torch.int32, device=x.device))
+    planes, arrive = _ROWS_WS[key]
+    if xp is None:
+        xp = pack_rows(x)
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16 if act == hip.RV_ACT_SILU_MUL else out_dtype, device=x.device)
+    hip.check(hip.lib().rv_gemm_rows(hip.ptr(xp), hip.ptr(wp), hip.ptr(out), M, N, K, hip.ptr(planes), hip.ptr(arrive), act, hip.dtype_code(out),
+                                     hip.stream()), "rv_gemm_rows")
     return out
 
 

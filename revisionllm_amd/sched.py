@@ -5,6 +5,8 @@ the host must learn something from the device before enqueuing more (the EOS fla
 one generator to the end, blocking on each event; ``Interleaver`` keeps several of them in flight - each bound to its own HIP
 stream and engine workspace slot - and resumes whichever one's event has completed, so one recursion waiting for its flag
 never keeps the others' launches off the device.  No threads: everything is enqueued from the calling thread."""
+import time
+
 import torch
 
 #: yielded by a step generator that cannot continue yet for a reason other than a device event (e.g. it must issue a collective
@@ -35,6 +37,7 @@ class Task:
         self.stream, self.engine, self.slot = stream, engine, slot
         self.waiting = None         # the event the generator asked for
         self.done, self.result, self.finishing = False, None, False
+        self.error = None           # an exception raised by THIS task's generator: stored, re-raised by ``Interleaver.finish`` of this task only
         self.gen = gen(self) if callable(gen) else gen
 
     def ready(self):
@@ -59,7 +62,18 @@ class Task:
                         return True
             except StopIteration as stop:
                 self.done, self.result, self.waiting = True, stop.value, None
+            except Exception as e:  # noqa: BLE001 - whoever pumped this task is not the one to hear about it (``finish`` of THIS task is)
+                self.done, self.error, self.waiting = True, e, None
         return True
+
+    def cancel(self):
+        """Drop a task that will not be finished: closes its generator, which runs the ``finally`` blocks along its ``yield from``
+        chain (a generate in a ``serve.DecodeServer`` pool gives its rows back there)."""
+        if not self.done:
+            self.done = True
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+            with ctx:
+                self.gen.close()
 
 
 class _null:
@@ -95,7 +109,9 @@ class Interleaver:
         return progressed
 
     def finish(self, task):
+        """-> the task's result; re-raises what ITS generator raised (the other tasks' errors wait for their own ``finish``)."""
         task.finishing = True
+        stalled = 0
         while not task.done:
             if not self.pump():
                 if any(sv.idle() for sv in self.servers if hasattr(sv, "idle")):
@@ -111,6 +127,18 @@ class Interleaver:
                     else:       # no device event anywhere to wait for: a server holding work back (a pool still filling) must let it go
                         for sv in self.servers:
                             if hasattr(sv, "flush") and sv.flush():
+                                stalled = 0
                                 break
+                        else:   # nobody can move and nothing is running: say so instead of spinning (e.g. rows of a pool never given back)
+                            stalled += 1
+                            if stalled > 1000:
+                                self.tasks.remove(task)
+                                task.cancel()
+                                raise RuntimeError("sched.Interleaver: no task, server or device event can make progress (scheduler stalled)")
+                            time.sleep(1e-3)
+                        continue
+            stalled = 0
         self.tasks.remove(task)
+        if task.error is not None:
+            raise task.error
         return task.result

@@ -58,9 +58,11 @@ class DecodePool:
         self.logits = torch.zeros(rows, V, dtype=torch.float32, device=dev)
         self.pos = torch.full((rows,), -1, dtype=torch.int32, device=dev)        # next position of every row; < 0: inactive
         self.stepidx = torch.zeros(rows, dtype=torch.int64, device=dev)          # column of the per-row outputs the next token goes to
-        self.tok_out = torch.zeros(rows, gmax, dtype=torch.int32, device=dev)
-        self.ent_out = torch.zeros(rows, gmax, dtype=torch.float32, device=dev)
-        self.entr_out = torch.zeros(rows, gmax, dtype=torch.float32, device=dev)
+        # per-row outputs [rows, gmax + 1]: column gmax is a SPARE that swallows the scatter of rows that are not stepping (a merged step
+        # scatters all rows at once) - an inactive or draining row must never overwrite a column of results it still owns
+        self.tok_out = torch.zeros(rows, gmax + 1, dtype=torch.int32, device=dev)
+        self.ent_out = torch.zeros(rows, gmax + 1, dtype=torch.float32, device=dev)
+        self.entr_out = torch.zeros(rows, gmax + 1, dtype=torch.float32, device=dev)
         self.uni = torch.full((rows,), 0.5, dtype=torch.float32, device=dev)
         self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)      # EOS bookkeeping: 0 once a row has emitted the EOS id
         self.stream = torch.cuda.Stream(dev)
@@ -104,6 +106,24 @@ class DecodePool:
 
     def fits(self, S, max_new_tokens, B=1):
         return S + max_new_tokens <= self.Smax and max_new_tokens <= self.G and B <= self.R
+
+    def abandon(self, job):
+        """A generate gives up its rows before its results are out (its task raised, or was cancelled): the rows go inactive and
+        back to the free list, the pool's counts drop - a sealed gang pool must not wait for a generate that will never join or finish."""
+        if job.finished or getattr(job, "abandoned", False):
+            return
+        job.abandoned = True
+        if job.joined:
+            self.jobs = [j for j in self.jobs if j is not job]
+            self.draining = [j for j in self.draining if j is not job]
+            with torch.cuda.stream(self.stream):
+                self.pos[job.r0:job.r0 + job.B] = -1
+        else:
+            self.pending -= 1
+        self.live -= 1
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self._release(job, ev)
 
     # ---- joining -------------------------------------------------------------------------------------------------------------
     def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None):
@@ -220,7 +240,7 @@ class DecodePool:
                 tokens = tokens * self.unfinished + pad * (1 - self.unfinished)
                 self.unfinished = self.unfinished * (tokens != eos).int()
             tokens = torch.where(active, tokens, torch.zeros_like(tokens))
-            col = self.stepidx.clamp(max=self.G - 1)[:, None]          # (rows that are done keep their last index)
+            col = torch.where(active, self.stepidx.clamp(max=self.G - 1), torch.full_like(self.stepidx, self.G))[:, None]   # inactive rows -> the spare column
             self.tok_out.scatter_(1, col, tokens[:, None])
             self.ent_out.scatter_(1, col, o["entropy_proc"][:, None])
             self.entr_out.scatter_(1, col, o["entropy_raw"][:, None])
@@ -352,6 +372,11 @@ class DecodeServer:
 
     def join(self, job, *a, **kw):
         return job.pool.join(job, *a, **kw)
+
+    def abandon(self, job):
+        """Release the rows of a generate that will not complete (``generate_steps`` calls this from its ``finally``)."""
+        self.pf_queue = [t for t in self.pf_queue if t.job is not job]
+        job.pool.abandon(job)
 
     # ---- batched prefills ------------------------------------------------------------------------------------------------------
     def submit_prefill(self, job, h, B, P0):

@@ -40,7 +40,7 @@ def step_for(a: float) -> np.float32:
     return np.float32(float(a) * 2.0 ** -23)
 
 
-def hash_uniform(n: int, key: int, a: float, base: float = 0.0, offset: int = 0, chunk: int = 1 << 24):
+def hash_uniform(n: int, key: int, a: float, base: float = 0.0, offset: int = 0, chunk: int = 1 << 18):
     """fp32 array of n values uniform in [base - a, base + a)."""
     out = np.empty(n, dtype=np.float32)
     step = step_for(a)
@@ -62,7 +62,30 @@ def round_bf16(x: np.ndarray) -> np.ndarray:
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
+def amplitude_pieces(a, shape):
+    """``a`` is a float (one amplitude for the whole tensor) or a list of (row_end, amplitude) pieces over the leading dimension
+    (row_end None = to the end): -> [(first element, element count, amplitude)] over the flat index.  The pieces share ONE hash
+    stream (the key of the tensor, indexed by the flat element), so host and device fill a piece with the stream offset by its
+    first element."""
+    n = int(np.prod(shape))
+    if not isinstance(a, (list, tuple)):
+        return [(0, n, float(a))]
+    row = n // int(shape[0])
+    out, r0 = [], 0
+    for r1, amp in a:
+        r1 = int(shape[0]) if r1 is None else int(r1)
+        assert r0 < r1 <= shape[0], (a, shape)
+        out.append((r0 * row, (r1 - r0) * row, float(amp)))
+        r0 = r1
+    assert r0 == shape[0], (a, shape)
+    return out
+
+
 def make_tensor(name, shape, seed, a, base=0.0, bf16=False):
     n = int(np.prod(shape))
-    w = hash_uniform(n, tensor_key(name, seed), a, base).reshape(shape)
+    key = tensor_key(name, seed)
+    w = np.empty(n, dtype=np.float32)
+    for e0, cnt, amp in amplitude_pieces(a, shape):
+        w[e0:e0 + cnt] = hash_uniform(cnt, key, amp, base, offset=e0)
+    w = w.reshape(shape)
     return round_bf16(w) if bf16 else w

@@ -38,23 +38,55 @@ VICUNA_7B = LlamaShape()
 TINY = LlamaShape(hidden=512, inter=1408, layers=3, heads=4, vocab=512)
 
 
-def llama_spec(s: LlamaShape, std: float = 0.02) -> List[Tuple[str, tuple, float, float]]:
+@dataclass(frozen=True)
+class Conditioning:
+    """A WELL-CONDITIONED random-init Llama (golden G8c, the full-depth parity tests): same tensors, shapes and hash streams as the
+    plain ``N(0, 0.02)`` initialisation, different amplitudes, so that a rounding error made in one layer is NOT amplified by the
+    31 random layers behind it and the sampled distribution is peaked like a trained model's:
+      * the token embeddings have the RMS of the adapter's video rows (``embed_std``; plain init: 0.02 next to ~1),
+      * the two residual branches of a block (o_proj / down_proj outputs) are small next to the stream they are added to
+        (``o_scale`` / ``down_scale`` times the plain amplitude: each branch ~ 1/8 of the stream, 64 of them double its variance),
+      * lm_head: the rows of the answer vocabulary (``hot_rows``: the digits and words ``FakeTokenizer`` decodes) carry logits
+        of a few units after the T = 0.05 warper, every other row a small fraction of that (the tail of the kept top-k)."""
+    embed_std: float = 0.55              # RMS of the hierarchy adapter's CLS rows with the xavier-uniform ClipEncoder (measured 0.555)
+    o_scale: float = 0.05
+    down_scale: float = 0.025
+    hot_rows: Tuple[int, int] = (3, 21)
+    hot_std: float = 0.175 / 64.0        # logit std = hot_std * |h_normed| = hot_std * sqrt(hidden) = 0.175 -> 3.5 after / 0.05
+    cold_std: float = 0.002 / 64.0
+
+
+CONDITIONED = Conditioning()
+
+
+def llama_spec(s: LlamaShape, std: float = 0.02, cond: Conditioning = None) -> List[Tuple[str, tuple, float, float]]:
+    """``cond``: amplitudes of the well-conditioned variant (``Conditioning``); None = plain N(0, std) matrices."""
     a = std * SQRT3
-    spec = [("model.embed_tokens.weight", (s.vocab, s.hidden), a, 0.0)]
+    a_emb = a if cond is None else cond.embed_std * SQRT3
+    a_o = a if cond is None else a * cond.o_scale
+    a_down = a if cond is None else a * cond.down_scale
+    a_head = a
+    if cond is not None:
+        lo, hi = cond.hot_rows
+        hi = min(hi, s.vocab)
+        # stds are quoted for hidden = 4096 (|h_normed| = 64); keep the LOGIT scale for other widths
+        k = 64.0 / math.sqrt(s.hidden)
+        a_head = [(lo, cond.cold_std * k * SQRT3), (hi, cond.hot_std * k * SQRT3)] + ([(None, cond.cold_std * k * SQRT3)] if hi < s.vocab else [])
+    spec = [("model.embed_tokens.weight", (s.vocab, s.hidden), a_emb, 0.0)]
     for i in range(s.layers):
         p = f"model.layers.{i}."
         spec += [
             (p + "self_attn.q_proj.weight", (s.hidden, s.hidden), a, 0.0),
             (p + "self_attn.k_proj.weight", (s.hidden, s.hidden), a, 0.0),
             (p + "self_attn.v_proj.weight", (s.hidden, s.hidden), a, 0.0),
-            (p + "self_attn.o_proj.weight", (s.hidden, s.hidden), a, 0.0),
+            (p + "self_attn.o_proj.weight", (s.hidden, s.hidden), a_o, 0.0),
             (p + "mlp.gate_proj.weight", (s.inter, s.hidden), a, 0.0),
             (p + "mlp.up_proj.weight", (s.inter, s.hidden), a, 0.0),
-            (p + "mlp.down_proj.weight", (s.hidden, s.inter), a, 0.0),
+            (p + "mlp.down_proj.weight", (s.hidden, s.inter), a_down, 0.0),
             (p + "input_layernorm.weight", (s.hidden,), 0.1, 1.0),
             (p + "post_attention_layernorm.weight", (s.hidden,), 0.1, 1.0),
         ]
-    spec += [("model.norm.weight", (s.hidden,), 0.1, 1.0), ("lm_head.weight", (s.vocab, s.hidden), a, 0.0)]
+    spec += [("model.norm.weight", (s.hidden,), 0.1, 1.0), ("lm_head.weight", (s.vocab, s.hidden), a_head, 0.0)]
     return spec
 
 

@@ -248,7 +248,7 @@ def g7_scores(M):
          cos_stage1_mean=torch.einsum("bd,d->b", pf, qc).mean())
 
 
-def big_model(M, shape, args, seed=SEED):
+def big_model(M, shape, args, seed=SEED, cond=None):
     """Reference model at full size, filled tensor by tensor (never two copies of the 27 GB in memory).  MATRICES take
     bf16-representable values (what the device holds), vectors stay fp32: both sides then hold identical weights and the
     comparison isolates the arithmetic."""
@@ -264,7 +264,7 @@ def big_model(M, shape, args, seed=SEED):
         model = L.VTimeLLMLlamaForCausalLM(cfg).eval()
     model.get_model().initialize_vision_modules(args)
     from revisionllm_amd.utils import hashinit
-    table = {n: (shp, a, base) for n, shp, a, base in synth.llama_spec(shape)}
+    table = {n: (shp, a, base) for n, shp, a, base in synth.llama_spec(shape, cond=cond)}
     table.update({"model.mm_projector." + n: (shp, a, base)
                   for n, shp, a, base in synth.clip_encoder_spec(hidden=shape.hidden, text=args.clip_adapter_text)})
     sd = model.state_dict()
@@ -290,7 +290,45 @@ class _ForceTokens:
         return out
 
 
-def g8_full_7b(M):
+def hash_uniforms(name, shape, seed=SEED):
+    """Deterministic uniforms in [0, 1) from the hash stream of ``name`` (float64 arithmetic, exact in fp32)."""
+    from revisionllm_amd.utils import hashinit
+    n = int(np.prod(shape))
+    x = hashinit.hash_uniform(n, hashinit.tensor_key(name, seed), 1.0).astype(np.float64)
+    return ((x + 1.0) * 0.5).astype(np.float32).reshape(shape)
+
+
+class _InverseCdfDraw:
+    """Stand-in for ``torch.multinomial(probs, 1)`` inside HF ``_sample`` (G8c only): the draw over the reference's own ``probs`` is
+    an inverse-CDF walk in descending-probability order (ties: smaller id first) driven by a recorded uniform per call and step, so
+    the build's sampling kernel - which implements that rule - can be run FREE (not teacher-forced) against the reference's
+    tokens.  Everything in front of the draw (logits, warpers, softmax) is the reference's own code."""
+
+    def __init__(self, uniforms):
+        self.u, self.call, self.step = uniforms, 0, 0
+
+    def __call__(self, probs, num_samples=1, *a, **kw):
+        assert num_samples == 1 and probs.dim() == 2 and probs.shape[0] == 1
+        u = float(self.u[self.call, self.step])
+        self.step += 1
+        srt, idx = torch.sort(probs.float(), descending=True, stable=True, dim=-1)
+        cum = srt.cumsum(-1)
+        n_keep = int((srt > 0).sum())
+        pos = min(int((cum <= u).sum()), n_keep - 1)
+        return idx[:, pos:pos + 1]
+
+
+def g8c_full_7b(M):
+    """G8 on WELL-CONDITIONED weights (``synth.CONDITIONED``): the fixture the full-depth parity tests can FAIL against.  Same
+    recursion through the reference's own loop / ``inference()`` as G8; additionally (a) the multinomial draw is the recorded
+    inverse-CDF walk (``_InverseCdfDraw``) so tokens can be compared free-running, (b) call 0 records the hidden state at the
+    input of every layer (prefill: 8 rows x every 16th column + all row norms; first decode step: every 8th column + norm)."""
+    g8_full_7b(M, cond=synth.CONDITIONED)
+    if int(os.environ.get("G8_LAYERS", "32")) == 32:
+        g8c_windows(M)
+
+
+def g8_full_7b(M, cond=None):
     """The stage-2 recursion of ONE query at full depth through the reference itself: random-init Vicuna-7B (32 layers, fp32,
     CPU), hierarchy ClipEncoder, W = batch = 100 windows x 256 frames, the 7 calls of e2e2.py:337-386 in its own loop order
     (randperm, repeat_interleave, inference() with its production generate kwargs; max_new_tokens patched 1024 -> 8 and EOS
@@ -305,10 +343,14 @@ def g8_full_7b(M):
     n_layers = int(os.environ.get("G8_LAYERS", "32"))     # < 32: dry run of this script (fixture goes to g8_dry_*.npz)
     shape = synth.VICUNA_7B if n_layers == 32 else synth.LlamaShape(layers=n_layers)
     name = "g8_full_7b" if n_layers == 32 else "g8_dry_%dL" % n_layers
+    if cond is not None:
+        name = name.replace("g8_", "g8c_")
     G, W, batch, Tn, Lq = 8, 100, 100, 256, 16
     seed = SEED
     t0 = time.time()
-    m = big_model(M, shape, ns(), seed)
+    m = big_model(M, shape, ns(), seed, cond)
+    draw = _InverseCdfDraw(hash_uniforms("g8c.uniforms", (7, G), seed)) if cond is not None else None
+    hidden = {}
     print("g8: model filled in %.0f s" % (time.time() - t0))
     m.generation_config.eos_token_id = None
     m.generation_config.top_k, m.generation_config.top_p = 50, 1.0
@@ -324,10 +366,25 @@ def g8_full_7b(M):
 
     def short_generate(*a, **kw):
         kw["max_new_tokens"] = G
-        kw["output_hidden_states"] = False
+        kw["output_hidden_states"] = cond is not None and draw.call == 0
         kw["output_logits"] = True
         captured["ids"] = a[0]
-        return real_generate(*a, **kw)
+        if draw is None:
+            return real_generate(*a, **kw)
+        draw.step = 0
+        with mock.patch.object(torch, "multinomial", draw):
+            out = real_generate(*a, **kw)
+        assert draw.step == G, draw.step
+        if draw.call == 0:      # hidden_states[step][l]: input of layer l (l < L), [L] = model.norm(output of the last layer)
+            hs = out["hidden_states"]
+            S_ = hs[0][0].shape[1]
+            rows = sorted({0, 20, 39, 40, 90, S_ - 31, S_ - 30, S_ - 1})
+            hidden.update(hid_rows=np.array(rows), hid_prefill=torch.stack([h[0][rows][:, ::16] for h in hs[0]]),
+                          hid_prefill_norm=torch.stack([h[0].norm(dim=-1) for h in hs[0]]),
+                          hid_decode1=torch.stack([h[0, 0, ::8] for h in hs[1]]), hid_decode1_norm=torch.stack([h[0, 0].norm() for h in hs[1]]))
+            out.hidden_states = None
+        draw.call += 1
+        return out
 
     pad = M["tensor_utils"].pad_sequences_1d if "tensor_utils" in M else None
     if pad is None:
@@ -443,6 +500,8 @@ def g8_full_7b(M):
                   proc_val=torch.stack(rec["proc_val"]), stats=torch.stack(rec["stats"]), inv_max=np.array(rec["inv_max"]),
                   inv_mean=np.array(rec["inv_mean"]), score_cos=np.array(rec["score_cos"]),
                   score_cos_call=np.array(rec["score_cos_call"]), cos_all=cos_all)
+    if cond is not None:
+        arrays.update(uniforms=draw.u, **hidden)
     if bf["error"] is None:
         arrays.update(bf16_raw_top_val=torch.stack(bf["raw_top_val_at_fp32_idx"]), bf16_raw_lse=torch.stack(bf["raw_lse"]),
                       bf16_proc_val=torch.stack(bf["proc_val_at_fp32_idx"]), bf16_stats=torch.stack(bf["stats"]))
@@ -450,8 +509,29 @@ def g8_full_7b(M):
     with open(os.path.join(HERE, name.replace("full_7b", "text") + ".json"), "w") as f:
         json.dump({"answers": rec["answers"], "sentence": sentence, "G": G, "W": W, "batch": batch, "T": Tn, "Lq": Lq,
                    "bf16_leg_error": bf["error"],
+                   "conditioning": None if cond is None else {k: getattr(cond, k) for k in cond.__dataclass_fields__},
                    "note": "weights: synth specs, seed %d, matrices rounded to bf16-representable fp32, vectors fp32; features "
-                           "bf16-representable; sampling: torch.manual_seed(%d) before the loop" % (seed, seed)}, f, indent=1)
+                           "bf16-representable; sampling: torch.manual_seed(%d) before the loop%s"
+                           % (seed, seed, "" if cond is None else "; the multinomial draw = inverse-CDF walk over the reference's probs with the "
+                                                                     "stored uniforms [call, step]")}, f, indent=1)
+
+
+def g8c_windows(M, name="g8c"):
+    """The window indices the driver derives from the recorded answers of G8c, through the reference's own ``iou`` (e2e2.py:113-140)
+    and ``get_ground_truth_windows`` (:161-170): frames per call and the hit list, added to g8c_text.json (seconds; also run at the
+    end of ``g8c``)."""
+    e2 = M["e2e2"]
+    g = np.load(os.path.join(HERE, name + "_full_7b.npz"))
+    path = os.path.join(HERE, name + "_text.json")
+    with open(path) as f:
+        meta = json.load(f)
+    perms = [torch.from_numpy(p) for key in ("perms_z4", "perms_z2", "perms_z1") for p in g[key]]
+    gt, _ = e2.get_ground_truth_windows(1000, 1400, 6000)
+    frames, hit = e2.iou(meta["answers"], gt, 250, meta["batch"], g["starts"].tolist(), perms, True, g["zooms"].tolist(), list(range(meta["W"])))
+    meta.update(gt=list(gt), frames={str(k): list(v) for k, v in frames.items()}, iou=hit)
+    with open(path, "w") as f:
+        json.dump(meta, f, indent=1)
+    print("g8c windows:", meta["frames"], hit)
 
 
 def g9_driver(M):
@@ -668,9 +748,9 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
     for k, fn in groups.items():
-        if (only and k not in only) or (not only and k == "g8"):   # g8 (27 GB, ~15 min) only on request
+        if (only and k not in only) or (not only and k in ("g8", "g8c", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue
         fn(M)
     with open(os.path.join(HERE, "meta.json"), "w") as f:

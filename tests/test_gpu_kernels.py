@@ -32,7 +32,7 @@ def bf(x):
 
 def test_abi_version(dev):
     from revisionllm_amd import hip
-    assert hip.lib().rv_abi_version() == 2
+    assert hip.lib().rv_abi_version() == 3
 
 
 def test_init_hash_bit_exact(dev):
@@ -469,3 +469,25 @@ def test_topk_cosine(dev):
     assert rel_err(y.cpu(), scores.stage1_cosine(feat[0, 5:19], q)) < 1e-4
     y = ops.topk_cosine(feat[0, 5:19][None].to(dev), q.to(dev), 0)
     assert rel_err(y.cpu(), scores.stage1_cosine(feat[0, 5:19], q, topk_pool=False)) < 1e-4
+
+
+@pytest.mark.parametrize("M", [33, 56, 70, 112, 128])
+@pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 4096, 0), (4096, 11008, 0), (12288, 4096, 0), (32000, 4096, 0)])
+def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
+    """The decode projection kernel of the HEADLINE (33 .. 128 fragment-packed rows, split-K with LDS-shared activations,
+    csrc/gemm_rows.hip through rv_gemm_rows) directly against the float64 product of the same bf16 operands, for every projection
+    shape of a Vicuna-7B block + lm_head, at the row counts the bench's pools run (56, 70, 112) and the edges (33, 128)."""
+    from revisionllm_amd import hip, ops
+    g = torch.Generator().manual_seed(M * 131 + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    wp = ops.pack_fragments(w)
+    y = ops.gemm_rows(x, wp, act=act, out_dtype=torch.float32)
+    z = x.double() @ w.double().t()
+    if act == hip.RV_ACT_SILU_MUL:
+        z3 = z.view(M, N // 32, 2, 16)
+        z = (torch.nn.functional.silu(z3[:, :, 0]) * z3[:, :, 1]).reshape(M, N // 2)
+    assert y.shape == z.shape
+    assert rel_err(y.float().cpu(), z.cpu()) < (1.5e-2 if act == hip.RV_ACT_SILU_MUL else 1e-4)     # bf16 output / f32 output of f32 sums
+    # a second launch on the same (never cleaned) arrival counters gives the same bits
+    assert torch.equal(y, ops.gemm_rows(x, wp, act=act, out_dtype=torch.float32))

@@ -304,3 +304,75 @@ def test_one_row_generates_in_flight_share_prefill_passes_and_decode_steps():
     assert server.rows_served > server.steps_run                                                  # merged steps carried several windows
     for (kw, want), got in zip(cases, outs):
         assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
+
+
+def test_eos_job_running_all_its_steps_keeps_its_last_column():
+    """Regression: EOS configured, ``max_new_tokens == gmax``, greedy stepping: a generate that has produced all its
+    tokens waits in ``draining`` for its stop flags while ANOTHER generate keeps stepping in the same pool; the later merged steps
+    scatter all rows and must not touch the finished generate's last column (they used to write token 0 / a stale entropy there)."""
+    from revisionllm_amd import sched, serve
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    m.generation_config.eos_token_id, m.generation_config.pad_token_id = 2, 0
+    P, G = 40, 8
+    ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
+    cases = []
+    for i, steps in enumerate((G, G, 3)):           # two full-length generates and a short one that joins later
+        B = 2
+        feat = feats(f"eosg.feat{i}", (B, 6, 16, 768), bf16=True)
+        q = (feats(f"eosg.q{i}", (B, 5, 768), bf16=True), torch.ones(B, 5))
+        forced = torch.full((steps, B), 9 + i)
+        kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=steps, forced_tokens=forced, return_dict_in_generate=True,
+                  uniforms=torch.full((steps, B), 0.5))
+        cases.append((ids.repeat(B, 1), kw, m.generate(ids.repeat(B, 1), **kw)))
+    server = serve.DecodeServer(m, rows=16, smax=96, gmax=G, pools=1, gang=False)          # greedy: jobs step as soon as they have joined
+    inter = sched.Interleaver(servers=[server])
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
+    tasks = [inter.add(sched.Task(m.generate_steps(cases[0][0], server=server, **cases[0][1]), streams[0], m.engine, 0))]
+    for _ in range(3):                               # let the first generate get a few steps ahead of the others
+        inter.pump()
+        torch.cuda.synchronize()
+    tasks += [inter.add(sched.Task(m.generate_steps(c[0], server=server, **c[1]), streams[i], m.engine, i)) for i, c in enumerate(cases) if i > 0]
+    outs = [inter.finish(t) for t in tasks]
+    m.engine.slot = 0
+    for (ids_, kw, want), got in zip(cases, outs):
+        assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["entropy"], want["entropy"])
+    assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16
+
+
+def test_a_failing_generate_fails_alone_and_gives_its_rows_back():
+    """Regression: with several generates in flight under the gang policy, an exception in ONE task's generator is raised by
+    ``finish`` of THAT task only; its rows go back to the pool, so the pool can still seal and step for the others, and the
+    scheduler does not spin."""
+    from revisionllm_amd import sched, serve
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    P = 40
+    ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
+    server = serve.DecodeServer(m, rows=8, smax=96, gmax=8, pools=2, gang=True, prefill_batch=1)
+    inter = sched.Interleaver(servers=[server])
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(4)]
+
+    def make(i, sampling_t):
+        feat = feats(f"fail.feat{i}", (2, 6, 16, 768), bf16=True)
+        q = (feats(f"fail.q{i}", (2, 5, 768), bf16=True), torch.ones(2, 5))
+        return dict(images=feat, query_feats=q, do_sample=True, temperature=sampling_t, max_new_tokens=4, return_dict_in_generate=True,
+                    uniforms=torch.full((4, 2), 0.5))
+    kws = [make(0, 0.05), make(1, 0.7), make(2, 0.05), make(3, 0.05)]            # generate 1 asks for other sampling settings: join() raises
+    want = [m.generate(ids.repeat(2, 1), **kw) for kw in kws]
+    tasks = [inter.add(sched.Task(m.generate_steps(ids.repeat(2, 1), server=server, **kws[0]), streams[0], m.engine, 0))]
+    while not server.pools[0].jobs:                 # generate 0 joins first: its sampling settings are the pool's
+        inter.pump()
+    tasks += [inter.add(sched.Task(m.generate_steps(ids.repeat(2, 1), server=server, **kw), streams[i], m.engine, i)) for i, kw in enumerate(kws) if i > 0]
+    results = []
+    for i, t in enumerate(tasks):
+        try:
+            results.append(inter.finish(t))
+        except ValueError as e:
+            assert i == 1 and "sampling settings" in str(e)
+            results.append(None)
+    m.engine.slot = 0
+    assert [r is None for r in results] == [False, True, False, False]
+    for i in (0, 2, 3):
+        assert torch.equal(results[i]["sequences"], want[i]["sequences"]) and torch.equal(results[i]["entropy"], want[i]["entropy"])
+    assert all(p.pending == 0 and p.live == 0 for p in server.pools) and sum(n for _, n, _ in server.free) == 16

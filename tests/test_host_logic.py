@@ -121,7 +121,12 @@ def test_abi_exports_every_declared_symbol():
     h = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(h, name), name
-    assert hip.lib().rv_abi_version() == 2
+    # ... and the reverse: the library exports no C symbol of its own that the header does not declare
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b[TW] (rv_[a-z0-9_]+)$", nm, flags=re.M))
+    assert exported == declared, exported ^ declared
+    assert hip.lib().rv_abi_version() == 3
     # argument validation runs on the host before any launch
     assert hip.lib().rv_gemm(None, None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None, 0, None) < 0
     assert "null operand" in hip.last_error()
@@ -265,7 +270,7 @@ def test_dropin_scoring_modules_refuse_without_gpu():
 
 def test_options_are_per_context():
     """Tunables live in the context (rv_ctx_set_option): two contexts in one process differ, unknown keys / bad values are
-    argument errors, and the deprecated process-wide setters only move the defaults of contexts created afterwards."""
+    argument errors; nothing process-wide is left to set."""
     a, b = hip.Options(), hip.Options(gemm_tile_variant=6, sample_variant=0)
     assert a.get("gemm_tile_variant") == 2 and b.get("gemm_tile_variant") == 6
     assert a.get("sample_variant") == 1 and b.get("sample_variant") == 0
@@ -279,11 +284,7 @@ def test_options_are_per_context():
         a.set("gemm_tile_variant", 9)
     with pytest.raises(hip.HipLibraryError):
         a.set("gemm_cus", 100)
-    try:
-        hip.lib().rv_set_gemm_tile_variant(6)          # deprecated shim: defaults only
-        assert a.get("gemm_tile_variant") == 2 and hip.Options().get("gemm_tile_variant") == 6
-    finally:
-        hip.lib().rv_set_gemm_tile_variant(2)
+    assert not hasattr(hip.lib(), "rv_set_gemm_tile_variant")      # the process-wide setters of ABI 2 are gone (ABI 3)
     # an options-only context carries no model: nothing can be bound to it
     assert hip.lib().rv_weights_bind(a._ctx, b"llm.embed", ctypes.c_void_p(256), 1, 16) < 0
 
@@ -345,3 +346,37 @@ def test_decode_server_gang_policy_fills_seals_and_alternates_pools():
     assert not sv.flush()                                                          # its generate has not joined yet
     a.pending -= 1
     assert sv.flush() and a.sealed                                                 # nothing else will come: run the partly filled pool
+
+
+def test_scheduler_isolates_task_errors_and_reports_a_stall():
+    """``sched.Interleaver`` (no device): an exception in one task's generator surfaces in ``finish`` of THAT task, not of the task
+    whose ``finish`` happened to pump it; a task that can never progress makes ``finish`` raise instead of spinning."""
+    from revisionllm_amd import sched
+    closed = []
+
+    def good(n):
+        for _ in range(n):
+            yield sched.RETRY
+        return "ok"
+
+    def bad():
+        yield sched.RETRY
+        raise KeyError("boom")
+
+    def stuck():
+        try:
+            while True:
+                yield sched.RETRY
+        finally:
+            closed.append(True)
+    inter = sched.Interleaver()
+    a, b, c = (inter.add(sched.Task(g)) for g in (good(5), bad(), good(2)))
+    assert inter.finish(a) == "ok"                      # pumping b's failure along the way
+    assert b.done and isinstance(b.error, KeyError)
+    with pytest.raises(KeyError):
+        inter.finish(b)
+    assert inter.finish(c) == "ok" and not inter.tasks
+    s = inter.add(sched.Task(stuck()))
+    with pytest.raises(RuntimeError, match="stalled"):
+        inter.finish(s)
+    assert closed == [True] and not inter.tasks         # the generator was closed (its finally ran)

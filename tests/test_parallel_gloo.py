@@ -232,3 +232,108 @@ def test_world4_three_passes_in_flight_match_world1():
     # 8 ranks, 7 calls: the idle rank differs from pass to pass
     idle = [[r for r in range(8) if not parallel.deal(7, r, 8, offset=s_)] for s_ in range(8)]
     assert all(len(i) == 1 for i in idle) and len({i[0] for i in idle}) == 8
+
+
+# ---- world 2, QUERIES mode (bench.py --scaling queries): whole recursions per rank through a gang-stepping server -------------------
+
+class GangStubServer:
+    """Stand-in for ``serve.DecodeServer(gang=True)`` in front of the scheduler: generates register and wait (``sched.RETRY``) until the
+    server has a full gang of ``gang`` of them - or the scheduler, finding nothing else to do, flushes a partial one."""
+
+    def __init__(self, gang):
+        self.gang, self.waiting, self.sizes = gang, [], []
+
+    def register(self):
+        job = {"done": False}
+        self.waiting.append(job)
+        return job
+
+    def _run(self, n):
+        self.sizes.append(n)
+        for j in self.waiting[:n]:
+            j["done"] = True
+        self.waiting = self.waiting[n:]
+        return True
+
+    def pump(self):
+        return self._run(self.gang) if len(self.waiting) >= self.gang else False
+
+    def wait_one(self):
+        return False
+
+    def flush(self):
+        return self._run(len(self.waiting)) if self.waiting else False
+
+
+class GangStubStages(AsyncStubStages):
+    def __init__(self, server):
+        self.server = server
+
+    def generate_steps(self, query, rows, calls, uniforms, max_new_tokens, width):
+        from revisionllm_amd import sched
+        job = self.server.register()
+        while not job["done"]:
+            yield sched.RETRY
+        return self.generate_async(query, rows, calls, uniforms, max_new_tokens, width)
+
+
+def _query_inputs(rank, k):
+    feats = torch.from_numpy(synth.features(f"parq.feat.r{rank}.s{k}", (100, T, 768), 11))
+    q = (torch.from_numpy(synth.features(f"parq.q.r{rank}.s{k}", (4, 768), 11)), torch.from_numpy(synth.features(f"parq.qc.r{rank}.s{k}", (768,), 11)),
+         f"query {rank} {k}")
+    perms = stage2.make_perms(stage2.plan_groups(100, 100), torch.Generator().manual_seed(100 * rank + k))
+    return feats, q, perms
+
+
+def _run_rank_queries(rank, n, group, gang=3):
+    """What one rank does in queries mode: n whole recursions in flight on its OWN inputs through a gang server, world of ONE."""
+    from revisionllm_amd import sched
+    server = GangStubServer(gang)
+    st, tok = GangStubStages(server), synth.FakeTokenizer()
+    inter = sched.Interleaver(servers=[server])
+    tasks = []
+    for k in range(n):
+        feats, q, perms = _query_inputs(rank, k)
+        tasks.append(inter.add(sched.Task(lambda t, f=feats, q=q, pm=perms: parallel.launch_queries_sharded_steps(
+            st, tok, f, 100, [q], batch=100, perms=[pm], max_new_tokens=8, group=group, turn=t))))
+    recs = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+    return recs, server.sizes
+
+
+def _worker_queries(rank, world, port, q, n):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = [dist.new_group([r]) for r in range(world)]
+    recs, sizes = _run_rank_queries(rank, n, groups[rank])
+    mine = torch.tensor([r["max_entropy"] + r["mean_entropy"] for r in recs], dtype=torch.float32)
+    everyone = parallel._all_gather_cat(mine, None)                      # the ONE exchange of the mode: every rank ends with all proposals
+    q.put((rank, [r["answers"] for r in recs], everyone.tolist(), sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_queries_mode_whole_recursions_per_rank():
+    """bench.py --scaling queries on 2 ranks: every rank runs WHOLE recursions on its own inputs (a one-rank group: no collective in
+    the data path) through a gang-stepping server, 5 in flight; one final all-gather hands every rank all proposals.  Equal to the
+    same recursions run in one process."""
+    n = 5
+    ref = [_run_rank_queries(r, n, None) for r in range(2)]
+    assert ref[0][1] == [3, 2] and all(len(rec["answers"]) == 7 for rec in ref[0][0])      # a full gang of 3, then the flushed rest
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_queries, args=(r, 2, port, q, n)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_all = [rec["max_entropy"] + rec["mean_entropy"] for r in range(2) for rec in ref[r][0]]
+    for rank, answers, everyone, sizes in got:
+        assert answers == [rec["answers"] for rec in ref[rank][0]] and sizes == [3, 2]
+        assert len(everyone) == 2 * n and all(abs(a - b) < 1e-6 for row, wrow in zip(everyone, want_all) for a, b in zip(row, wrow))
+    assert got[0][1] != got[1][1]                                         # the two ranks really worked on different queries

@@ -6,10 +6,7 @@ import torch
 from revisionllm_amd import hip
 
 lib = hip.lib()
-f = lib.rv_debug_gemm_rows
-f.restype = ctypes.c_int
-f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-              ctypes.c_void_p]
+f = lib.rv_gemm_rows
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 63
 mbp = 2 if M <= 32 else 4 if M <= 64 else 5 if M <= 80 else 8
@@ -24,7 +21,7 @@ for N in (4096, 12288, 22016):
         i = [0]
 
         def run():
-            rc = f(x.data_ptr(), ws[i[0] % nw].data_ptr(), c.data_ptr(), M, N, K, planes.data_ptr(), arrive.data_ptr(), hip.RV_ACT_NONE, hip.RV_F32, hip.stream())
+            rc = f(hip.ptr(x), hip.ptr(ws[i[0] % nw]), hip.ptr(c), M, N, K, hip.ptr(planes), hip.ptr(arrive), hip.RV_ACT_NONE, hip.RV_F32, hip.stream())
             assert rc == 0, hip.last_error()
             i[0] += 1
         for _ in range(4):
