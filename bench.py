@@ -162,7 +162,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
 
         def gemv():
-            rc = f(hip.ptr(xs), hip.ptr(ws[state["i"] % len(ws)]), hip.ptr(outs), dec_rows, 2 * s.inter, s.hidden, hip.ptr(planes), hip.ptr(arrive),
+            rc = f(hip.ptr(xs), hip.ptr(ws[state["i"] % len(ws)]), None, hip.ptr(outs), dec_rows, 2 * s.inter, s.hidden, hip.ptr(planes), hip.ptr(arrive),
                    hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
@@ -402,6 +402,11 @@ def main():
     eng.set_option("fp8_decode", 1 if args.fp8_decode else 0)
     eng.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
     eng.set_option("gemm_cus", args.gemm_cus)
+    shared_gpu = world > max(torch.cuda.device_count(), 1)
+    if shared_gpu:
+        # plumbing run (several ranks on ONE GPU, e.g. REVISION_DIST_BACKEND=gloo on a 1-GPU box): the persistent stream-K prefill GEMMs
+        # wait in-kernel for ALL their workgroups, and two PROCESSES on one device would each hold half the CUs - output-tiled kernels only
+        args.gemm_variant = 6
     eng.set_option("gemm_tile_variant", args.gemm_variant)
     model.generation_config.eos_token_id = 2 if args.eos else None     # None: forced decode length
     tok = synth.FakeTokenizer()
@@ -557,19 +562,42 @@ def main():
             inter1 = sched.Interleaver(servers=[server1])
             streams1 = [torch.cuda.Stream(dev) for _ in range(32)]
 
+            # every window in flight is its OWN window (32 distinct ones, window i of a step group = set i); the adapter of a group of
+            # windows runs as ONE call over [group, frames, 768] - the reference's stage-1 driver hands inference() a batch of windows
+            # too (eval_nlq_negative.py:281-298) - and each window then decodes as its own one-row generate through the server
+            NB = len(streams1)
+            xs = ops.init_hash_(torch.empty(NB, frames, 768, dtype=torch.bfloat16, device=dev), f"bench.s1.{kind}.windows", args.seed, synth.SQRT3)
+            enc_stream = torch.cuda.Stream(dev)
+            gkw1 = {k_: v_ for k_, v_ in gkw.items() if k_ not in ("images", "query_feats")}
+
             def run1(n):
                 out, pending = None, []
-                for i in range(n):
-                    k = i % len(streams1)
-                    streams1[k].wait_stream(torch.cuda.current_stream(dev))
-                    pending.append(inter1.add(sched.Task(m1.generate_steps(ids, server=server1, **gkw), streams1[k], eng, 32 + k)))
-                    if len(pending) > len(streams1):
-                        out = inter1.finish(pending.pop(0))
+                for base in range(0, n, NB):
+                    nb = min(NB, n - base)
+                    enc_stream.wait_stream(torch.cuda.current_stream(dev))
+                    prev_slot, eng.slot = eng.slot, 31
+                    with torch.cuda.stream(enc_stream):
+                        qb = None if qfeat is None else (qf[None].expand(nb, -1, -1).contiguous(), torch.ones(nb, args.lq))
+                        rows, rps = m1.encode_images(xs[:nb], qb)
+                        rows = rows.view(nb, rps, -1)
+                        enc_done = torch.cuda.Event()
+                        enc_done.record()
+                    eng.slot = prev_slot
+                    rows.record_stream(enc_stream)
+                    for i in range(nb):
+                        k = (base + i) % NB
+                        streams1[k].wait_event(enc_done)
+                        pending.append(inter1.add(sched.Task(m1.generate_steps(ids, video_rows=rows[i], rows_per_sample=rps, server=server1, **gkw1),
+                                                             streams1[k], eng, 32 + k)))
+                        if len(pending) > NB:
+                            out = inter1.finish(pending.pop(0))
                 while pending:
                     out = inter1.finish(pending.pop(0))
                 eng.slot = 0
                 return out
             return run1, dict(prompt_tokens=int(ids.shape[1]), prefill_len=int(S), frames=frames, windows_per_step=1, windows_in_flight=32,
+                              inputs="32 distinct windows in flight",
+                              adapter="one call per group of up to 32 windows in flight ([32, %d, 768] -> %s)" % (frames, "ClipEncoder, CLS out" if kind != "stage1_dense" else "Linear projector"),
                               decode="merged (serve.DecodeServer: 32-row pools, prefills four to a pass)")
 
         def run1(n):
@@ -611,17 +639,8 @@ def main():
 
     extra = {}
     if extras:
-        server32 = {"s": None}
-
         def leg(name, nq, fp8, fp8p=False, eos=False, merged=True):
             stages.server = server if merged else None
-            if merged and fp8 and server is not None and args.pool_rows > 32:
-                # the FP8 weight copies are wired into the <= 32-row decode kernel only: these legs decode through 32-row pools
-                if server32["s"] is None:
-                    from revisionllm_amd import serve
-                    server32["s"] = serve.DecodeServer(model, rows=32, smax=server.Smax, gmax=max(16, G), pools=args.pools, gang=args.pools > 1, slot=110)
-                    inter.servers.append(server32["s"])
-                stages.server = server32["s"]
             work["sets"] = input_sets(nq)
             eng.set_option("fp8_decode", int(fp8))
             eng.set_option("fp8_prefill", int(fp8p))
@@ -630,7 +649,7 @@ def main():
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
                            "ms_per_step": t / args.steps * 1e3, "recursions_per_step": nq,
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
-                           "decode_weights": "fp8 e4m3fn, per-row scale (32-row pools)" if fp8 else "bf16",
+                           "decode_weights": "fp8 e4m3fn, per-row scale (same pools and merged steps as the headline)" if fp8 else "bf16",
                            "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
             if not merged:
                 extra[name]["decode"] = "every step in flight runs its own decode passes (no DecodeServer): the round-1 pipeline"
@@ -742,11 +761,15 @@ def main():
                 entry = {"value": args.steps / t, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3, "config": cfg1,
                          "prefill_flops": 2.0 * S1 * 6.476e9 + 2.6e5 * S1 * S1 + 2.6e8}
                 if kind == "stage1_sparse":      # adapter alone: SURVEY 8d: 46.9 GFLOP per 1024-frame segment (MFMA-bound)
-                    x1 = ops.init_hash_(torch.empty(1, 1024, 768, dtype=torch.bfloat16, device=dev), "bench.s1.a", args.seed, synth.SQRT3)
-                    ms = event_time_ms(lambda: eng.clip_encoder(x1, qf[None], torch.ones(1, args.lq), "cls"), 10)
-                    entry["roofline"] = {"stage": "sparse adapter (ClipEncoder, 1 x 1024 frames, CLS out)", "bound": "mfma", "achieved": 46.9 / ms,
-                                         "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 46.9 / ms / MFMA_BF16_PEAK_TF, "avg_ms": ms,
-                                         "note": "ONE 1025-row sequence: 5-9 row tiles per GEMM on 256 CUs - a latency-bound chain of ~40 launches"}
+                    x1 = ops.init_hash_(torch.empty(32, 1024, 768, dtype=torch.bfloat16, device=dev), "bench.s1.a", args.seed, synth.SQRT3)
+                    q32 = qf[None].expand(32, -1, -1).contiguous()
+                    ms32 = event_time_ms(lambda: eng.clip_encoder(x1, q32, torch.ones(32, args.lq), "cls"), 5)
+                    ms1 = event_time_ms(lambda: eng.clip_encoder(x1[:1], qf[None], torch.ones(1, args.lq), "cls"), 10)
+                    entry["roofline"] = {"stage": "sparse adapter (ClipEncoder, 32 windows x 1024 frames in ONE call, CLS out): what the windows in flight run",
+                                         "bound": "mfma", "achieved": 32 * 46.9 / ms32, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                         "frac": 32 * 46.9 / ms32 / MFMA_BF16_PEAK_TF, "avg_ms": ms32,
+                                         "one_window_alone": {"achieved": 46.9 / ms1, "frac": 46.9 / ms1 / MFMA_BF16_PEAK_TF, "avg_ms": ms1,
+                                                              "note": "ONE 1025-row sequence: 5-9 row tiles per GEMM on 256 CUs - a latency-bound chain of ~40 launches"}}
                 extra["workload_" + kind] = entry
             except Exception as e:  # noqa: BLE001
                 extra["workload_" + kind] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -823,7 +846,9 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else
                                        f"queries x{world}: whole recursions dealt to the ranks (each rank = the 1-GPU pipeline on its own videos / queries), "
                                        "one RCCL all-gather of the per-call proposals at the end of the timed region" if by_query else
-                                       f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals in every recursion")},
+                                       f"{'one recursion sharded' if strong else 'segments'} x{world} + RCCL all-gather of CLS rows and proposals in every recursion")
+                                      + (f" [PLUMBING RUN: {world} ranks share {torch.cuda.device_count()} GPU(s), backend {backend}, stream-K GEMMs off - not a measurement]"
+                                         if shared_gpu else "")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,
                          "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"], "other": other},

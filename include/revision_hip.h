@@ -133,13 +133,14 @@ int rv_gemm(const rv_ctx* ctx /* optional: tunables */, const void* A, int64_t l
 /* One projection of a MERGED decode step (33 .. 128 rows; what rv_llm_decode_rows launches four times per block):
  * C[M,N] = act(X . Wp^T), X = M bf16 rows in the fragment-packed decode layout - element (r, k) at
  *     ((((k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7),   mbp = 4 (M <= 64), 5 (<= 80), 8 (<= 128)
- * row blocks (16 * mbp rows allocated) -, Wp fragment-packed as for rv_gemm, C row-major (ldc = N, or N / 2 with RV_ACT_SILU_MUL, which
- * writes bf16).  planes: workspace of rv_gemm_rows_ws_bytes() bytes; arrive: 2048 int32 arrival counters, ZERO before the first launch
+ * row blocks (16 * mbp rows allocated) -, Wp fragment-packed as for rv_gemm (w_scale == NULL) or, with w_scale f32 [N], the FP8
+ * (e4m3fn) bytes of rv_gemv_fp8's layout (opt-in fp8 LLM path: half the weight bytes, widened to bf16 in registers), C row-major
+ * (ldc = N, or N / 2 with RV_ACT_SILU_MUL, which writes bf16).  planes: workspace of rv_gemm_rows_ws_bytes() bytes; arrive: 2048 int32 arrival counters, ZERO before the first launch
  * and private to one stream (the split-K workgroups of a column group count up in them; they are never reset, so the caller never
  * cleans them either).  N % 64 == 0, K % 128 == 0, K >= 1024, N <= 32768. */
 size_t rv_gemm_rows_ws_bytes(void);
-int rv_gemm_rows(const void* Xp, const void* Wp, void* C, int32_t M, int32_t N, int32_t K, void* planes, int32_t* arrive, int act,
-                 int out_dtype, void* stream);
+int rv_gemm_rows(const void* Xp, const void* Wp, const float* w_scale, void* C, int32_t M, int32_t N, int32_t K, void* planes,
+                 int32_t* arrive, int act, int out_dtype, void* stream);
 /* y = LayerNorm(x) * w + b, eps 1e-5, biased variance (nn.LayerNorm, transformer.py:202-203).
  * x f32 [rows,d]; any of y_f32 / y_bf16 / y_pos_bf16 may be NULL; y_pos = bf16(y + pos[row % period]). */
 int rv_layernorm(const float* x, const float* w, const float* b, float* y_f32, void* y_bf16, void* y_pos_bf16,
@@ -210,7 +211,7 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  * rv_llm_prefill_pool: rv_llm_prefill_shared (P0 > 0) / rv_llm_forward prefill (P0 = 0) of B sequences whose cache rows are
  *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
  * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 128: up to 32 rows take the weight-streaming kernel,
- * 33 .. 128 the split-K kernel with LDS-shared activations; bf16 weights only above 32 rows), row r at its OWN position row_pos[r]
+ * 33 .. 128 the split-K kernel with LDS-shared activations; both stream the FP8 weight copies when bound and enabled), row r at its OWN position row_pos[r]
  *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified; an active row
  *   needs row_pos[r] < Smax (NOT checked: the positions live on the device).  h f32 [R, D]
  *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.

@@ -505,7 +505,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     // Decode steps (M <= 32 rows) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
     const bool fuse_norm = S == 1 && P0 == 0 && M <= 128 && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
-    const bool f8 = fuse_norm && M <= 32 && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only
+    const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only (any row count <= 128)
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
     const bool p8 = !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
@@ -553,6 +553,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             GemvNorm cq = (fuse_norm && l > l0) ? consume : GemvNorm{};
             cq.w_scale = L.sqkv;
             cq.x_packed = xp;
+            cq.planes = w.planes;
+            cq.arrive = w.arrive;
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv8, M, D, qr, &cq, nullptr, 0, st, 2));
         } else {
             GemvNorm first;       // layer 0 of a decode step: no norm to consume, but the operand layout still applies

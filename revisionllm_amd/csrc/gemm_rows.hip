@@ -22,6 +22,8 @@
 // per 7-row generate (112 rows: 8.7 ms, 0.54 ms).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "gemv_finish.h"
 
@@ -54,7 +56,25 @@ constexpr int RS_THREADS = (RS_W + 1) * 64;
 // TB/s (long K) where the sixteen waves of gemv_stream reach 5.8.
 // MB = 4 row blocks: 4 slabs of 16 KiB, two workgroups per CU;  MB = 5 (65 .. 80 rows: ten 7-row generates): 3 slabs of 20 KiB, two per CU;
 // MB = 8: 3 slabs of 32 KiB, one workgroup per CU
-template <int MB> struct RowsCfg { static constexpr int DW = 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2; };
+// WP = 2: FP8 (e4m3fn) weights in gemv_stream's fp8 fragment packing (gemm.hip: a lane's 16-byte load = its operand of two consecutive
+// 32-k blocks), widened to bf16 in registers right before the MFMA, per-output-row scales applied in the shared epilogue
+// (GemvNorm::w_scale).  A 128-k stage is then 2 loads of 1 KiB per consumer wave instead of 4: the ring is twice as many STAGES deep for
+// the same registers (and the same bytes in flight).
+template <int MB, int WP = 1> struct RowsCfg {
+    static constexpr int DW = WP == 2 ? 8 : 4, LPS = WP == 2 ? 2 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2;
+};
+typedef unsigned int rs_w8 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 rs_fp8x8(unsigned lo, unsigned hi) {     // = gemm.hip fp8x8_to_bf16x8 (exact: e4m3 has 3 mantissa bits)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    union { bf16x8 v; unsigned u[4]; } r;
+    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
+    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
+    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
+    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
+    return r.v;
+}
 
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
@@ -64,16 +84,16 @@ template <int MB> struct RowsCfg { static constexpr int DW = 4, DX = MB == 4 ? 4
 // wave copies the activation slabs into LDS (LDS-DMA, DX slabs deep, its own vmcnt).  vmcnt retires in order, so a wave that issued
 // both could not wait for a young slab without also waiting for every older weight load - the weight ring would be no deeper than
 // the slab ring.  One raw s_barrier per stage hands slab g to the consumers and the slot of slab g - 1 back to the producer.
-template <int MB, int VPW, int FIN>
+template <int MB, int VPW, int FIN, int WP = 1>
 __global__ __attribute__((amdgpu_flat_work_group_size(RS_THREADS, RS_THREADS), amdgpu_waves_per_eu(RowsCfg<MB>::WPE, RowsCfg<MB>::WPE))) void
 rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
             const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm, QkvRope qr) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     constexpr int S = 8 / VPW, LOG = VPW == 8 ? 3 : VPW == 4 ? 2 : VPW == 2 ? 1 : 0;
-    constexpr int DW = RowsCfg<MB>::DW, DX = RowsCfg<MB>::DX;
+    constexpr int DW = RowsCfg<MB, WP>::DW, DX = RowsCfg<MB, WP>::DX, LPS = RowsCfg<MB, WP>::LPS;
     constexpr int SLAB = MB * 4096;                   // bytes of one 128-k slab of MB row blocks
     constexpr int XL = MB * 4;                        // LDS-DMA fragments (1 KiB) per slab
-    static_assert((DX - 2) * XL <= 63 && (DW - 2) * 4 <= 63, "vmcnt is a 6-bit counter");
+    static_assert((DX - 2) * XL <= 63 && (DW - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = blockIdx.x / S, sp = blockIdx.x % S;
@@ -117,8 +137,8 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs issued past the end must not outlive the ring's reuse below
     } else {
         // ---------------- consumers: weight fragments of stage g in ring slot g % DW (static: the loop is unrolled by DW) ----------------
-        const bf16_t* wp = W + (int64_t)ntile * (K >> 5) * 512 + lane * 8;
-        bf16x8 wf[DW][4];
+        const bf16_t* wp = W + (int64_t)ntile * (K >> 5) * (WP == 2 ? 256 : 512) + lane * 8;   // (fp8: half the bytes per tile)
+        typename std::conditional<WP == 2, rs_w8, bf16x8>::type wf[DW][LPS];
         int li = 0, lc = 0;     // next stage to issue
         int ci = 0, cc = 0;     // stage being computed
 #define RS_ISSUE_W(slot)                                                                                                             \
@@ -128,8 +148,9 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             kb_ = sp * VPW + li + 8 * lc;                                                                                            \
             if (++lc == vcount(li)) { lc = 0; ++li; }                                                                                \
         }                                                                                                                            \
-        const bf16_t* ws_ = kb_ >= 0 ? wp + (int64_t)kb_ * 2048 : X + lane * 8;                                    \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) wf[slot][j_] = __builtin_nontemporal_load((const bf16x8*)(ws_ + j_ * 512)); \
+        const bf16_t* ws_ = kb_ >= 0 ? wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048) : X + lane * 8;                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < LPS; ++j_)                                                                          \
+            wf[slot][j_] = __builtin_nontemporal_load((const typename std::remove_reference<decltype(wf[0][0])>::type*)(ws_ + j_ * 512)); \
     } while (0)
 #pragma unroll
         for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
@@ -138,18 +159,22 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             for (int u = 0; u < DW; ++u) {
                 const int g = g0 + u;
                 if (g < T) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * 4) : "memory");   // the weights of stage g have landed
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * LPS) : "memory");   // the weights of stage g have landed
                     __builtin_amdgcn_s_barrier();                                        // ... and its slab (producer)
                     RS_ISSUE_W((u + DW - 1) % DW);
                     {
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 4; ++j) {
+                            bf16x8 wj;
+                            if constexpr (WP == 2) wj = rs_fp8x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
+                            else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
                                 const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
-                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], xf, acc[mb], 0, 0, 0);
+                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
                             }
+                        }
                     }
                     if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
                         if constexpr (VPW > 1) {
@@ -294,7 +319,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + fr];
         }
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemv_finish<NT, OUT_BF16, ACT, 1, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
+        gemv_finish<NT, OUT_BF16, ACT, WP, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
     }
 }
 
@@ -305,38 +330,47 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
     return s;
 }
 
-template <int MB, int VPW, int FIN>
+template <int MB, int VPW, int FIN, int WP>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    static bool attr = false;
-    const size_t lds = (size_t)RowsCfg<MB>::DX * MB * 4096;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
-            return RV_ERR_HIP;
-        }
-        attr = true;
+    const size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
+    // (the > 64 KiB opt-in is per device and cheap: set on every launch rather than remembered in a process-wide flag)
+    if (lds > 65536 && hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
+        return RV_ERR_HIP;
     }
-    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN>), dim3((unsigned)(N / 64 * (8 / VPW))), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C, ldc,
-                       M, N, K, nrm, qr);
+    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN, WP>), dim3((unsigned)(N / 64 * (8 / VPW))), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
+                       ldc, M, N, K, nrm, qr);
     return RV_OK;
 }
-template <int MB, int FIN>
+template <int MB, int FIN, int WP>
 int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                   const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     switch (S) {
-        case 1: return rows_launch<MB, 8, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        case 2: return rows_launch<MB, 4, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        case 4: return rows_launch<MB, 2, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        default: return rows_launch<MB, 1, FIN>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 1: return rows_launch<MB, 8, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 2: return rows_launch<MB, 4, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 4: return rows_launch<MB, 2, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        default: return rows_launch<MB, 1, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
     }
 }
-template <int FIN>
+template <int FIN, int WP>
 int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
                int K, const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    return MBp == 4 ? rows_by_split<4, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
-         : MBp == 5 ? rows_by_split<5, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
-                    : rows_by_split<8, FIN>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+    return MBp == 4 ? rows_by_split<4, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
+         : MBp == 5 ? rows_by_split<5, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
+                    : rows_by_split<8, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+}
+template <int WP>
+int rows_by_fin(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype,
+                int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st) {
+    const QkvRope q0{};
+    if (qr) return rows_by_mb<3, WP>(MBp, S, X, W, nullptr, nullptr, 0, nullptr, 0, M, N, K, nrm, *qr, st);
+    if (act == RV_ACT_SILU_MUL) return rows_by_mb<1, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    if (N >= 16384 && out_dtype == RV_F32) return rows_by_mb<2, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    if (N < 16384 && out_dtype == RV_BF16) return rows_by_mb<4, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    if (N < 16384) return rows_by_mb<0, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    rv_set_error("gemm_rows: bf16 output with N >= 16384 is not instantiated");
+    return RV_ERR_ARG;
 }
 
 }  // namespace
@@ -346,9 +380,10 @@ size_t gemm_rows_ws_bytes() { return (size_t)(2 * 32768 / 16) * 8 * 1024; }
 extern "C" size_t rv_gemm_rows_ws_bytes(void) { return gemm_rows_ws_bytes(); }
 
 // X: 33 .. 128 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
-// qr != nullptr: the fused q/k/v + RoPE epilogue.
+// qr != nullptr: the fused q/k/v + RoPE epilogue.  w_layout 1: bf16 fragment-packed W; 2: FP8 fragment-packed W + nrm.w_scale.
 int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
-              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr) {
+              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout) {
+    RV_CHECK_ARG(w_layout == 1 || (w_layout == 2 && nrm.w_scale), "gemm_rows: bf16 (1) or fp8 + per-row scales (2) fragment-packed weights");
     RV_CHECK_ARG(M > 32 && M <= 128 && nrm.x_packed == rv_xp_blocks(M) && nrm.planes && nrm.arrive,
                  "gemm_rows: 33 .. 128 fragment-packed rows, a plane workspace and arrival counters");
     RV_CHECK_ARG(N / 64 <= RV_ROWS_COUNTERS / 4, "gemm_rows: too many column groups");
@@ -357,14 +392,8 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_BF16, "gemm_rows: SILU_MUL writes bf16");
     const int MBp = nrm.x_packed, S = rows_splits(N, MBp);
     RV_CHECK_ARG((size_t)S * (N / 16) * MBp * 1024 <= gemm_rows_ws_bytes(), "gemm_rows: %d partial planes of N = %d do not fit the plane workspace", S, N);
-    const QkvRope q0{};
-    int rc;
-    if (qr) rc = rows_by_mb<3>(MBp, S, X, W, nullptr, nullptr, 0, nullptr, 0, M, N, K, nrm, *qr, st);
-    else if (act == RV_ACT_SILU_MUL) rc = rows_by_mb<1>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
-    else if (N >= 16384 && out_dtype == RV_F32) rc = rows_by_mb<2>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
-    else if (N < 16384 && out_dtype == RV_BF16) rc = rows_by_mb<4>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
-    else if (N < 16384) rc = rows_by_mb<0>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
-    else { rv_set_error("gemm_rows: bf16 output with N >= 16384 is not instantiated"); return RV_ERR_ARG; }
+    const int rc = w_layout == 2 ? rows_by_fin<2>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st)
+                                 : rows_by_fin<1>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st);
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_rows");
     return RV_OK;
@@ -372,13 +401,15 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
 
 // Building block (include/revision_hip.h): one projection of a merged decode step on 33 .. 128 fragment-packed rows, with the engine's
 // epilogue variants (act = RV_ACT_SILU_MUL + bf16 out: the gate/up launch).
-extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, void* C, int32_t M, int32_t N, int32_t K, void* planes, int32_t* arrive, int act,
-                            int out_dtype, void* stream) {
+extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, const float* w_scale, void* C, int32_t M, int32_t N, int32_t K, void* planes,
+                            int32_t* arrive, int act, int out_dtype, void* stream) {
     RV_CHECK_ARG(Xp && Wp && C && planes && arrive, "rv_gemm_rows: null argument");
     GemvNorm nrm;
+    nrm.w_scale = w_scale;
     nrm.x_packed = rv_xp_blocks(M);
     nrm.planes = (float*)planes;
     nrm.arrive = arrive;
     const int ldc = act == RV_ACT_SILU_MUL ? N / 2 : N;
-    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr);
+    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr,
+                     w_scale ? 2 : 1);
 }

@@ -131,7 +131,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
 int gemv_blocks(int act, int64_t N);
 int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
-              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr);   // gemm_rows.hip: 33 .. 128 fragment-packed rows
+              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 128 fragment-packed rows
 size_t gemm_rows_ws_bytes();   // partial planes of the 33 .. 128-row decode kernel (any LLM shape up to N = 32768)  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
 // A-resident kernel for short-K many-row problems (gemm_arows.hip): a workgroup keeps its block of A rows in LDS and walks N
 bool gemm_arows_supported(int w_layout, int act, int64_t M, int64_t N, int64_t K);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "rv_ctx_get_option": (C.c_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "rv_gemm_ws_bytes": (_sz, []),
     "rv_gemm_rows_ws_bytes": (_sz, []),
-    "rv_gemm_rows": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, C.c_int, C.c_int, _p]),
+    "rv_gemm_rows": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, C.c_int, C.c_int, _p]),
     "rv_gemm": (C.c_int, [_p, _p, _i64, _p, _i64, C.c_int, _p, _p, _i64, _p, _i64, C.c_int, C.c_int, _i64, _i64, _i64, _p, _sz, _p]),
     "rv_rmsnorm_quant_fp8": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f, _p]),
     "rv_quant_rows_fp8": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),

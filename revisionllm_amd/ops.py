@@ -82,11 +82,12 @@ def pack_rows(x):
 _ROWS_WS = {}
 
 
-def gemm_rows(x, wp, act=hip.RV_ACT_NONE, out_dtype=torch.float32, out=None, xp=None):
+def gemm_rows(x, wp, act=hip.RV_ACT_NONE, out_dtype=torch.float32, out=None, xp=None, w_scale=None, N=None):
     """One projection of a merged decode step on 33 .. 128 rows (rv_gemm_rows: the split-K kernel with LDS-shared activations).
-    x [M,K] bf16 row-major (packed here; or ``xp`` already packed), wp fragment-packed [N,K] -> row-major [M, N] (N / 2 with SILU_MUL)."""
+    x [M,K] bf16 row-major (packed here; or ``xp`` already packed), wp fragment-packed [N,K] -> row-major [M, N] (N / 2 with SILU_MUL).
+    ``w_scale`` f32 [N]: ``wp`` holds FP8 bytes (``pack_fragments_fp8``: uint8 [N*K]) instead of bf16 fragments."""
     M, K = x.shape
-    N = wp.shape[0]
+    N = (w_scale.shape[0] if w_scale is not None else wp.shape[0]) if N is None else N
     key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
     if key not in _ROWS_WS:
         _ROWS_WS[key] = (torch.zeros(hip.lib().rv_gemm_rows_ws_bytes(), dtype=torch.uint8, device=x.device),
@@ -97,7 +98,7 @@ def gemm_rows(x, wp, act=hip.RV_ACT_NONE, out_dtype=torch.float32, out=None, xp=
     n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
     if out is None:
         out = torch.empty(M, n_out, dtype=torch.bfloat16 if act == hip.RV_ACT_SILU_MUL else out_dtype, device=x.device)
-    hip.check(hip.lib().rv_gemm_rows(hip.ptr(xp), hip.ptr(wp), hip.ptr(out), M, N, K, hip.ptr(planes), hip.ptr(arrive), act, hip.dtype_code(out),
+    hip.check(hip.lib().rv_gemm_rows(hip.ptr(xp), hip.ptr(wp), hip.ptr(w_scale), hip.ptr(out), M, N, K, hip.ptr(planes), hip.ptr(arrive), act, hip.dtype_code(out),
                                      hip.stream()), "rv_gemm_rows")
     return out
 

@@ -110,7 +110,9 @@ def test_full_depth_scores_vs_reference(g8_run):
     # --- what is asserted ---
     assert np.isfinite(ours).all() and np.isfinite(st[:, :3]).all()
     assert e_cos.max() < 1e-3                                              # the north star's bound, element-wise, for the LLM-free score
-    assert agree[safe].all()                                               # wherever the reference's margin exceeds the error, same argmax
+    # (no discrete assertion here: on these random-init weights NO step's top-1 margin clears the bf16 error - ``steps_with_safe_margin``
+    #  is 0 - so "same argmax where the margin allows" would be vacuous.  Token ids, answers and window indices are asserted EXACT on the
+    #  well-conditioned fixture G8c: tests/test_gpu_full_depth_conditioned.py)
     # bf16 arithmetic through 32 random layers: no further from the fp32 reference than the reference's OWN bf16 path
     assert err.mean() <= 1.25 * err16.mean() and err.max() <= 1.5 * err16.max()
     assert np.median(e_max) <= 1.5 * np.median(b_max) + 1e-3 and np.median(e_mean) <= 1.5 * np.median(b_mean) + 1e-3

@@ -26,7 +26,8 @@ from helpers import SEED, T, feats
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENT_TOL = 1e-2          # element-wise relative bound on 1/max_entropy, 1/mean_entropy (north star: 1e-3, printed next to it)
+ENT_TOL = 5e-3          # element-wise relative bound on 1/max_entropy, 1/mean_entropy (measured: <= 2.5e-3; the reference's own bf16 leg:
+                        # 1.4e-3 .. 1.7e-2; north star: 1e-3, printed next to it)
 LAYER_TOL = 1e-2        # one block, bf16 activations: |out - oracle| max over the tensor / max |branch output of that block|
 
 
@@ -146,7 +147,7 @@ def test_conditioned_scores_tokens_and_windows_vs_reference(g8c):
     assert safe.sum() >= 0.9 * safe.size and mt.agree[safe].all()            # same argmax wherever the margin clears the error (most steps must)
     assert mt.e_max.max() <= ENT_TOL and mt.e_mean.max() <= ENT_TOL          # 1/max_entropy, 1/mean_entropy: every call
     assert mf.e_max.max() <= ENT_TOL and mf.e_mean.max() <= ENT_TOL          # ... free-running too
-    assert mt.err.mean() <= mt.err16.mean() and mt.err.max() <= 1.25 * mt.err16.max()      # no further out than the reference's own GPU arithmetic
+    assert mt.err.mean() <= 0.5 * mt.err16.mean() and mt.err.max() <= mt.err16.max()      # well inside the reference's own GPU arithmetic (measured: 0.18x / 0.21x)
     assert e_cos.max() < 1e-3
 
 
@@ -242,8 +243,8 @@ def test_conditioned_every_layer_teacher_forced(g8c):
     b = meta["batch"] // z
     feat = feats("g8.feat", (meta["W"], meta["T"], 768), bf16=True)[start:start + b][r.perms[0]].repeat_interleave(z, 0)
     qf = feats("g8.q", (meta["Lq"], 768), bf16=True)
-    wa = clip_weights(bf16=True)
-    wa32 = clip_weights(bf16=False)
+    wa = clip_weights(bf16=True, prefix="model.mm_projector.")
+    wa32 = clip_weights(bf16=False, prefix="model.mm_projector.")
     wa = {k: (v if v.dim() > 1 else wa32[k]) for k, v in wa.items()}
     rows = o_adapter.encode_images(feat[None], wa, (qf[None], torch.ones(1, meta["Lq"])), hierarchy=True)
     get = eng._synth_get(synth.llama_spec(eng.shape, cond=cond), SEED, "")
@@ -338,5 +339,54 @@ def test_conditioned_parity_detects_a_broken_layer(g8c, fault):
     print("\n[G8c fault %s] 1/max_entropy rel err %.3e (intact %.3e), 1/mean %.3e (intact %.3e), logit err / bf16-leg err %.2f (intact %.2f)"
           % (fault, mb.e_max.max(), ok.e_max.max(), mb.e_mean.max(), ok.e_mean.max(), mb.err.mean() / mb.err16.mean(), ok.err.mean() / ok.err16.mean()))
     assert ok.e_max.max() <= ENT_TOL and ok.e_mean.max() <= ENT_TOL
-    assert max(mb.e_max.max(), mb.e_mean.max()) > ENT_TOL                    # the entropy bound catches it
-    assert mb.err.mean() > mb.err16.mean()                                   # and so does the logit bound
+    assert max(mb.e_max.max(), mb.e_mean.max()) > ENT_TOL                    # the entropy bound catches it (measured: 2.1e-2 / 1.1e-2 vs 2.4e-3 intact)
+    assert mb.err.mean() > 2 * 0.5 * mb.err16.mean()                         # and so does the logit bound (asserted: <= 0.5 x the bf16 leg's)
+
+
+def test_conditioned_fp8_llm_path_through_the_headline_pipeline(g8c):
+    """BASELINE configs[4] in its stated precision: the fp8 MFMA LLM path (FP8 x FP8 prefill GEMMs, FP8 decode weights in the 70-row
+    split-K kernel) at 32 layers on the 100-window recursion, through the bench's pipeline (10 instances in flight, prefills four to a
+    pass, 70-row merged decode steps), teacher-forced on the reference's tokens.  There is no reference counterpart for e4m3
+    arithmetic, so these are PROPERTIES: every instance produces the same record; the scores stay within a quantisation-sized
+    distance of the fp32 reference (printed; an e4m3 step is 6-12 % of a weight); the bf16 path of the same engine is closer."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    r, g, meta = g8c, g8c.g, g8c.meta
+    m = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device="cuda:0")
+    m.get_model().initialize_vision_modules(_hier_args())
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=True, cond=synth.CONDITIONED, fp8_decode=True, fp8_prefill=True)
+    m.generation_config.eos_token_id = None
+    tok = synth.FakeTokenizer()
+
+    def run(copies=10, pool_rows=70):
+        st = parallel.HipStages(m, tok)
+        st.forced_tokens = T(g["tokens"]).t().contiguous()
+        server = serve.DecodeServer(m, rows=pool_rows, smax=192, gmax=16, pools=2, gang=True, prefill_batch=4)
+        st.server = server
+        streams = [torch.cuda.Stream("cuda:0") for _ in range(copies)]
+        torch.cuda.synchronize()
+        inter = sched.Interleaver(servers=[server])
+        kw = dict(batch=meta["batch"], perms=[r.perms], max_new_tokens=meta["G"])
+        tasks = [inter.add(sched.Task(lambda t: parallel.launch_queries_sharded_steps(st, tok, r.features, meta["W"], [(r.qf, r.qc, meta["sentence"])], turn=t, **kw),
+                                      streams[i], m.engine, i)) for i in range(copies)]
+        recs = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+        m.engine.slot = 0
+        assert server.rows_served >= server.steps_run * 7 * min(copies, pool_rows // 7) * 0.99
+        return recs
+    recs8 = run()
+    m.engine.set_option("fp8_decode", 0).set_option("fp8_prefill", 0)
+    recs16 = run()
+    e8 = np.stack([np.concatenate([_rel(rec["max_entropy"], g["inv_max"]), _rel(rec["mean_entropy"], g["inv_mean"])]) for rec in recs8])
+    e16 = np.stack([np.concatenate([_rel(rec["max_entropy"], g["inv_max"]), _rel(rec["mean_entropy"], g["inv_mean"])]) for rec in recs16])
+    print("\n[G8c fp8 LLM path, 70-row pipeline] rel err of 1/max_entropy | 1/mean_entropy per call: fp8", np.round(e8[0], 4).tolist(), "bf16", np.round(e16[0], 4).tolist())
+    with open(os.path.join(ROOT, "gpurun_out", "g8c_fp8_path.json"), "w") as f:
+        json.dump({"fp8_llm_path_rel_err": e8[0].tolist(), "bf16_rel_err": e16[0].tolist(), "instances": len(recs8)}, f, indent=1)
+    for rec in recs8:
+        assert np.isfinite(rec["max_entropy"]).all() and np.isfinite(rec["mean_entropy"]).all()
+        assert rec["answers"] == meta["answers"]                             # (teacher-forced tokens: the decode / parse plumbing)
+    # the instances rode in prefill passes of 4, 4 and 2 (different f32 summation orders in front of the e4m3 activation quantiser):
+    # within a quantisation step of each other
+    assert np.abs(e8 - e8[0]).max() < 0.2
+    assert np.median(e8) < 0.15 and e8.max() < 0.5                          # a quantisation-sized distance, not a different function
+    assert np.median(e16) < np.median(e8)                                   # the unquantised path of the same engine is closer

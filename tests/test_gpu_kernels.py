@@ -491,3 +491,29 @@ def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
     assert rel_err(y.float().cpu(), z.cpu()) < (1.5e-2 if act == hip.RV_ACT_SILU_MUL else 1e-4)     # bf16 output / f32 output of f32 sums
     # a second launch on the same (never cleaned) arrival counters gives the same bits
     assert torch.equal(y, ops.gemm_rows(x, wp, act=act, out_dtype=torch.float32))
+
+
+@pytest.mark.parametrize("M", [56, 70, 112])
+@pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 11008, 0), (32000, 4096, 0)])
+def test_gemm_rows_fp8_weights_vs_float64_and_the_16_row_kernel(dev, M, N, K, act):
+    """FP8 (e4m3fn, per-row scale) weights in the 33 .. 128-row decode kernel (opt-in fp8 LLM path, BASELINE configs[4]): against the
+    float64 product of the DEQUANTISED weights, and bit-identical per row to the <= 16-row FP8 kernel (rv_gemv_fp8) - the widening to
+    bf16 is exact and the summation order is the shared one."""
+    from revisionllm_amd import hip, ops
+    g = torch.Generator().manual_seed(M * 17 + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    w8, sc = ops.pack_fragments_fp8(w)
+    q, sc2 = ops.quantize_rows_fp8(w)
+    assert torch.equal(sc, sc2)
+    wd = q.double() * sc.double()[:, None]                                # what the kernel multiplies by (scales applied in the epilogue)
+    y = ops.gemm_rows(x, w8, act=act, out_dtype=torch.float32, w_scale=sc)
+    z = x.double() @ wd.t()
+    if act == hip.RV_ACT_SILU_MUL:
+        z3 = z.view(M, N // 32, 2, 16)
+        z = (torch.nn.functional.silu(z3[:, :, 0]) * z3[:, :, 1]).reshape(M, N // 2)
+    assert rel_err(y.float().cpu(), z.cpu()) < (1.5e-2 if act == hip.RV_ACT_SILU_MUL else 1e-4)
+    od = torch.bfloat16 if act == hip.RV_ACT_SILU_MUL else torch.float32
+    for r0 in (0, 16, M - 16):
+        lo = ops.gemv_fp8(x[r0:r0 + 16], w8, sc, out_dtype=od, act=act)
+        assert torch.equal(y[r0:r0 + 16], lo), r0

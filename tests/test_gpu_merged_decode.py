@@ -376,3 +376,61 @@ def test_a_failing_generate_fails_alone_and_gives_its_rows_back():
     for i in (0, 2, 3):
         assert torch.equal(results[i]["sequences"], want[i]["sequences"]) and torch.equal(results[i]["entropy"], want[i]["entropy"])
     assert all(p.pending == 0 and p.live == 0 for p in server.pools) and sum(n for _, n, _ in server.free) == 16
+
+
+@pytest.mark.parametrize("R", [70, 112])
+def test_fp8_decode_weights_in_wide_merged_steps_7b_layer(R):
+    """The fp8 LLM path of BASELINE configs[4] through the MERGED pipeline's kernels: one Vicuna-7B-shaped block + lm_head, R rows
+    (ten / sixteen 7-row generates) prefilled into one KV pool, then merged decode steps streaming the FP8 weight copies
+    (rv_llm_decode_rows above 32 rows: the split-K kernel) - against the CPU oracle running its decode steps on the same fake-quantised
+    weights (``oracle.llama.fp8_decode_weights``), and bit-identical per generate to the <= 16-row FP8 kernel."""
+    from oracle import llama
+    from revisionllm_amd import engine
+    from revisionllm_amd.utils import synth
+    shape = synth.LlamaShape(layers=1, vocab=2048)
+    eng = engine.Engine(shape, adapter_text=False, device="cuda:0")
+    eng.init_synthetic(seed=SEED, llm=True, clip=False, fp8_decode=True)
+    D, S, Smax, steps = 4096, 40, 64, 3
+    n = R // 7
+    g = torch.Generator().manual_seed(R)
+    hs = [torch.randn(7, S, D, generator=g).mul(0.02) for _ in range(n)]
+    toks = [[torch.randn(7, 1, D, generator=g).mul(0.02) for _ in range(steps)] for _ in range(n)]
+    pool, sm = eng.new_kv_pool(R, Smax)
+    for i in range(n):
+        eng.llm_prefill_pool(hs[i].cuda().view(7 * S, D).contiguous(), 7, 0, pool, R, 7 * i, Smax)
+    got = []
+    for s_ in range(steps):
+        hrow = torch.zeros(R, D, device="cuda:0")
+        p = torch.full((R,), -1, dtype=torch.int32, device="cuda:0")
+        for i in range(n):
+            hrow[7 * i:7 * i + 7] = toks[i][s_][:, 0].cuda()
+            p[7 * i:7 * i + 7] = S + s_
+        got.append(eng.llm_decode_rows(hrow, p, pool, Smax).clone())
+    # (a) the <= 16-row FP8 kernel on each generate's own cache: same bits
+    for i in (0, n - 1):
+        kv, _ = eng.new_kv(7, Smax, reuse=False)
+        eng.llm_forward(hs[i].cuda().clone(), 0, kv, Smax)
+        for s_ in range(steps):
+            want = eng.llm_forward(toks[i][s_].cuda().clone(), S + s_, kv, Smax)
+            assert torch.equal(got[s_][7 * i:7 * i + 7], want), (i, s_)
+    # (b) the oracle with the same fake-quantised decode weights (prefill on the bf16 weights), generates 0 and n - 1
+    w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), SEED).items()}
+    w = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    w8 = llama.fp8_decode_weights(w, cfg)
+    for i in (0, n - 1):
+        cache = llama.KVCache(cfg.layers)
+        llama.forward(hs[i], w, cfg, cache=cache, last_only=True)
+        for s_ in range(steps):
+            want = llama.forward(toks[i][s_], w8, cfg, cache=cache)[:, -1]
+            want16 = None
+            assert rel_err(got[s_][7 * i:7 * i + 7].cpu(), want) < 2e-2, (i, s_)
+    # it really is the quantised weights that ran: switching the copies off changes the logits
+    eng.set_option("fp8_decode", 0)
+    hrow = torch.zeros(R, D, device="cuda:0")
+    p = torch.full((R,), S + steps, dtype=torch.int32, device="cuda:0")
+    a16 = eng.llm_decode_rows(hrow + 0.01, p, pool, Smax).clone()
+    eng.set_option("fp8_decode", 1)
+    p2 = torch.full((R,), S + steps, dtype=torch.int32, device="cuda:0")
+    a8 = eng.llm_decode_rows(hrow + 0.01, p2, pool, Smax)
+    assert not torch.equal(a16, a8)

@@ -21,7 +21,7 @@ for N in (4096, 12288, 22016):
         i = [0]
 
         def run():
-            rc = f(hip.ptr(x), hip.ptr(ws[i[0] % nw]), hip.ptr(c), M, N, K, hip.ptr(planes), hip.ptr(arrive), hip.RV_ACT_NONE, hip.RV_F32, hip.stream())
+            rc = f(hip.ptr(x), hip.ptr(ws[i[0] % nw]), None, hip.ptr(c), M, N, K, hip.ptr(planes), hip.ptr(arrive), hip.RV_ACT_NONE, hip.RV_F32, hip.stream())
             assert rc == 0, hip.last_error()
             i[0] += 1
         for _ in range(4):
