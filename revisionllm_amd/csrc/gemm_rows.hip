@@ -20,8 +20,17 @@
 // flight (8 consumer waves x 5 stages x 4 KiB = 160 KiB per CU, all the registers the accumulator stack leaves; gemv_stream at <= 16
 // rows keeps 256 KiB in flight and streams at 5.8 TB/s); a 63-row step 6.5 ms vs 4.1 ms for 28 rows on gemv_stream, i.e. 0.72 vs 1.02 ms
 // per 7-row generate (112 rows: 8.7 ms, 0.54 ms).
+//
+// Round 3, measured and NOT kept: (a) FP8 weights (WP = 2, kept as the opt-in fp8 path) halve the bytes of a launch and leave its time
+// where it was (70 rows, isolated step: gate/up 67.4 -> 62.7 us, qkv 51.8 -> 49.8, o / down 23.2 -> 24.4): the launch is not bound by
+// weight bytes at these row counts.  (b) A PERSISTENT grid (2 workgroups per CU walking their (column group, split) items as one
+// stream of stages, weight and slab rings running on across item boundaries, the item's hand-over / finish inside the stream): same
+// results, and the same time as one workgroup per item (70-row step 7.23 vs 7.30 ms; both behind this kernel's 6.84 ms because the
+// finish must then stay small enough to keep the ring's 64 VGPRs live: pair-by-pair plane loads) - the cold start and tail of a
+// 16-stage workgroup are not what bounds the launch either.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.h"
@@ -334,10 +343,17 @@ template <int MB, int VPW, int FIN, int WP>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     const size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
-    // (the > 64 KiB opt-in is per device and cheap: set on every launch rather than remembered in a process-wide flag)
-    if (lds > 65536 && hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
-        return RV_ERR_HIP;
+    // the > 64 KiB opt-in is a per-DEVICE attribute of the function: remembered per device (bit d of the mask), not per process
+    static std::atomic<uint64_t> opted{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (lds > 65536 && !(opted.load(std::memory_order_relaxed) & bit)) {
+        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
+            return RV_ERR_HIP;
+        }
+        opted.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN, WP>), dim3((unsigned)(N / 64 * (8 / VPW))), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
                        ldc, M, N, K, nrm, qr);

@@ -8,7 +8,8 @@ north star's quantities can be held tight at the depth the headline runs at:
   * ``1/max_entropy``, ``1/mean_entropy``: element-wise relative error asserted (``ENT_TOL``) and printed next to 1e-3,
   * raw logits at the reference's top-64: no further from the fp32 reference than the reference's own bf16 leg,
   * every one of the 32 blocks on its own, fed the fp32 chain's input (teacher forcing), prefill and one decode step,
-  * a deliberately broken layer (q rows of ONE block bound without the RoPE pair interleave; a cache row read one off) is DETECTED.
+  * a deliberately broken layer (q rows of ONE block bound without the RoPE pair interleave; a cache row read one off) is DETECTED
+    (the asserted logit bound fails by 5x or more; the RoPE fault also breaks the entropy bound).
 
 Reference lines: vtimellm_llama.py:38-90 (forward), eval_nlq_retrieval_e2e2.py:337-386 (recursion), :356-359 (1/max, 1/mean),
 funs_get_feature_X.py:120-146 (entropy statistics).
@@ -174,9 +175,6 @@ def test_conditioned_batched_recursion_equals_reference(g8c):
                            mode="batched", max_new_tokens=meta["G"], uniforms=u)
     print("\n[G8c batched recursion] 1/max rel err", _rel(rec["max_entropy"], g["inv_max"]).tolist(), "1/mean", _rel(rec["mean_entropy"], g["inv_mean"]).tolist())
     _records_equal_reference(rec, g, meta)
-    ref = stage2.run_query(r.model, synth.FakeTokenizer(), r.features, r.qf, r.qc, meta["sentence"], batch=meta["batch"], perms=r.perms,
-                           mode="reference", max_new_tokens=meta["G"], uniforms=u)
-    _records_equal_reference(ref, g, meta)
 
 
 @pytest.mark.parametrize("copies,pool_rows", [(4, 32), (8, 56), (10, 70)])
@@ -325,7 +323,8 @@ def test_conditioned_parity_detects_a_broken_layer(g8c, fault):
         # shift block 9's K planes of the prefilled positions by one position inside the cache after the prefill: done through the
         # after_prefill hook of generate (the cache is [L, B, H, Smax, 128])
         def shift():
-            (key, kv), = [(k_, t) for k_, t in eng._ws.items() if isinstance(k_, tuple) and k_[0] == "kv" and k_[1] == eng.slot and k_[2] == 1]
+            want = (r.ids.shape[1] - 1 + meta["batch"] + meta["G"] + 31) // 32 * 32       # the cache generate() just prefilled: S + max_new_tokens, rounded
+            (key, kv), = [(k_, t) for k_, t in eng._ws.items() if isinstance(k_, tuple) and k_[0] == "kv" and k_[1] == eng.slot and k_[2] == 1 and k_[3] == want]
             L, H, Smax = eng.shape.layers, eng.shape.heads, key[3]
             kc = kv[:kv.numel() // 2].view(L, 1, H, Smax, 128)
             kc[9, :, :, 1:Smax] = kc[9, :, :, 0:Smax - 1].clone()
@@ -338,9 +337,13 @@ def test_conditioned_parity_detects_a_broken_layer(g8c, fault):
     ok = _metrics(_run_calls(r.model, g, meta, r.features, r.qf, r.ids, r.perms, free=False, calls=calls), g)
     print("\n[G8c fault %s] 1/max_entropy rel err %.3e (intact %.3e), 1/mean %.3e (intact %.3e), logit err / bf16-leg err %.2f (intact %.2f)"
           % (fault, mb.e_max.max(), ok.e_max.max(), mb.e_mean.max(), ok.e_mean.max(), mb.err.mean() / mb.err16.mean(), ok.err.mean() / ok.err16.mean()))
-    assert ok.e_max.max() <= ENT_TOL and ok.e_mean.max() <= ENT_TOL
-    assert max(mb.e_max.max(), mb.e_mean.max()) > ENT_TOL                    # the entropy bound catches it (measured: 2.1e-2 / 1.1e-2 vs 2.4e-3 intact)
-    assert mb.err.mean() > 2 * 0.5 * mb.err16.mean()                         # and so does the logit bound (asserted: <= 0.5 x the bf16 leg's)
+    assert ok.e_max.max() <= ENT_TOL and ok.e_mean.max() <= ENT_TOL and ok.err.mean() <= 0.5 * ok.err16.mean()
+    # the logit bound of the parity test (<= 0.5 x the bf16 leg's mean error; intact: 0.2 x) is left far behind by either fault
+    # (measured: 4.0 x / 2.6 x); the wrong RoPE partners of a whole block also break the entropy bound (2e-2), a K cache read one
+    # position off in one block moves the entropies by 3.5e-3 only - it is the logit bound that catches that one
+    assert mb.err.mean() > 4 * 0.5 * mb.err16.mean()
+    if fault == "rope_pairing_layer17":
+        assert max(mb.e_max.max(), mb.e_mean.max()) > 2 * ENT_TOL
 
 
 def test_conditioned_fp8_llm_path_through_the_headline_pipeline(g8c):

@@ -6,9 +6,10 @@ import torch
 from revisionllm_amd import engine
 from revisionllm_amd.utils import synth
 
-rows = [int(a) for a in sys.argv[1:]] or [7, 14, 16, 21, 28, 32]
+fp8 = "--fp8" in sys.argv
+rows = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [7, 14, 16, 21, 28, 32]
 eng = engine.Engine(synth.LlamaShape(), adapter_text=False, device="cuda:0")
-eng.init_synthetic(seed=0, llm=True, clip=False)
+eng.init_synthetic(seed=0, llm=True, clip=False, fp8_decode=fp8)
 D, V = eng.shape.hidden, eng.shape.vocab
 Smax = 256
 wbytes = sum(t.numel() * t.element_size() for t in eng._llm_tensors()) if hasattr(eng, "_llm_tensors") else 13.2e9
@@ -29,4 +30,4 @@ for R in rows:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print(f"rows {R:2d}: {ms:.3f} ms/step  {wbytes / ms / 1e9:.2f} TB/s  {ms / R * 1e3:.1f} us/row", flush=True)
+    print(f"{'fp8 ' if fp8 else ''}rows {R:2d}: {ms:.3f} ms/step  {wbytes / ms / 1e9:.2f} TB/s  {ms / R * 1e3:.1f} us/row", flush=True)
