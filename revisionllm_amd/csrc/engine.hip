@@ -272,6 +272,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "fp8_prefill") return &o.fp8_prefill;
     if (k == "sample_variant") return &o.sample_variant;
     if (k == "gemm_arows") return &o.gemm_arows;
+    if (k == "rows_fill") return &o.rows_fill;
     return nullptr;
 }
 }  // namespace

@@ -335,7 +335,8 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the smallest power of two that fills the CUs, <= 8
     const int64_t cg = N / 64;
     int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs)
-    while (s < 8 && cg * s < 240) s *= 2;
+    const int fill = rv_cur_opts().rows_fill;   // workgroups a launch should at least have (tunable; 2 per CU are resident with <= 5 row blocks)
+    while (s < 8 && cg * s < fill) s *= 2;
     return s;
 }
 

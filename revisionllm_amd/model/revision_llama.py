@@ -82,8 +82,6 @@ class _Inner:
             self.clip_adapter_feature = "cls"
         self.hierarchy = bool(getattr(a, "hierarchy", False))
         self.pretrain_clip_adapter = getattr(a, "pretrain_clip_adapter", None)
-        if self.clip_adapter_feature == "alternate":
-            raise NotImplementedError("clip_adapter_feature='alternate' needs iteration_step (training-time only)")
         eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text if self.clip_adapter else None)
         if state_dict is None:
             path = self.pretrain_clip_adapter if self.clip_adapter else getattr(a, "pretrain_mm_mlp_adapter", None)
@@ -97,6 +95,14 @@ class _Inner:
         self.mm_projector = _Projector(self)
         if self.cross_attn_variant:
             self.cross_attn = self.mm_projector
+        if self.clip_adapter_feature == "alternate":
+            # vtimellm_arch.py:72-73: nn.LayerNorm(hidden) applied to the adapter output (:146-147); a fresh LayerNorm is the
+            # identity affine - ``load_alternate_layer_norm`` binds trained values ("model.alternate_layer_norm.{weight,bias}")
+            self.load_alternate_layer_norm(torch.ones(self.config.hidden_size), torch.zeros(self.config.hidden_size))
+
+    def load_alternate_layer_norm(self, weight, bias):
+        dev = self.engine.device
+        self.alternate_layer_norm = (weight.to(device=dev, dtype=torch.float32).contiguous(), bias.to(device=dev, dtype=torch.float32).contiguous())
 
 
 class ReVisionLlamaForCausalLM:
@@ -158,11 +164,31 @@ class ReVisionLlamaForCausalLM:
         return self
 
     # ---- adapter dispatch (vtimellm_arch.py:102-147) ---------------------------------------------
-    def encode_images(self, images, query_feats):
+    def encode_images(self, images, query_feats, iteration_step=None):
         """-> (video_rows f32 [R,D], rows_per_sample).  hierarchy: [b,v,t,d] -> v rows per sample;
-        ClipEncoder: [b,t,d] -> 1 (cls) / t (temporal) rows; Linear: [b,t,d] -> t rows."""
+        ClipEncoder: [b,t,d] -> 1 (cls) / t (temporal) rows; Linear: [b,t,d] -> t rows.
+        ``clip_adapter_feature='alternate'`` (transformer.py:134-138, vtimellm_arch.py:112-123,146-147): ``iteration_step`` even ->
+        the CLS row(s), odd -> the T temporal rows of [b,t,d] features; then ``alternate_layer_norm`` over the hidden dim."""
         m = self.model
         eng = self.engine
+        if m.clip_adapter and m.clip_adapter_feature == "alternate":
+            if iteration_step is None:   # the reference evaluates ``iteration_step % 2`` (transformer.py:135)
+                raise TypeError("unsupported operand type(s) for %: 'NoneType' and 'int' (clip_adapter_feature='alternate' needs iteration_step)")
+            qf, qm = query_feats[0], query_feats[1]
+            if int(iteration_step) % 2 == 0:
+                if m.hierarchy:
+                    b, v, t, d = images.shape
+                    y, rps = eng.clip_encoder(images.reshape(b * v, t, d), qf, qm, "cls"), v
+                else:
+                    y, rps = eng.clip_encoder(images, qf, qm, "cls"), 1
+            else:
+                if images.dim() != 3:
+                    raise ValueError("clip_adapter_feature='alternate' at an odd iteration_step projects the temporal rows of [b,t,d] features "
+                                     "(vtimellm_arch.py:112-113)")
+                y = eng.clip_encoder(images, qf, qm, "all")[:, 1:].reshape(-1, self.shape.hidden)
+                rps = images.shape[1]
+            w, b_ = m.alternate_layer_norm
+            return ops.layernorm(y.contiguous(), w, b_, want=("f32",))[0], rps
         if isinstance(images, (list, tuple)):
             images = torch.cat(list(images), dim=0)
         if not m.clip_adapter:
@@ -226,7 +252,7 @@ class ReVisionLlamaForCausalLM:
                        max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
                        return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
                        attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
-                       share_prefix=True, eos_lookahead=1, server=None, **kwargs):
+                       share_prefix=True, eos_lookahead=1, server=None, iteration_step=None, **kwargs):
         """``generate`` as a generator: enqueues device work and YIELDS a ``torch.cuda.Event`` whenever the host has to learn
         something from the device before it may enqueue more - which only happens with an EOS id configured: the "all rows
         finished" flag of step s is copied to pinned host memory asynchronously and looked at only after step s + ``eos_lookahead``
@@ -243,6 +269,7 @@ class ReVisionLlamaForCausalLM:
         ``server`` (a ``serve.DecodeServer``: prefill into its KV pool, then let ITS merged steps decode this generate's rows
         together with the other generates in flight - same tokens / entropies, one pass over the weights per step for all of
         them; only under ``sched.Interleaver(servers=[server])``; falls back to the loop below when it does not apply).
+        ``iteration_step``: the reference's ``forward`` kwarg for ``clip_adapter_feature='alternate'`` (vtimellm_llama.py:55).
         ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
         """
         if num_beams != 1:
@@ -262,7 +289,7 @@ class ReVisionLlamaForCausalLM:
             if images is None:
                 video_rows, rows_per_sample = None, 0
             else:
-                video_rows, rows_per_sample = self.encode_images(images, query_feats)
+                video_rows, rows_per_sample = self.encode_images(images, query_feats, iteration_step)
         # host inputs go up once, before the loop, through pinned non-blocking copies: a pageable upload inside the loop
         # would make the host wait for the whole queue at every step and the launch queue would run dry behind it
         if uniforms is not None:

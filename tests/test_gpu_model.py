@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats, rel_err
+from helpers import SEED, T, clip_weights, feats, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -627,3 +627,39 @@ def test_clip_extractor_vit_l14_shapes():
     for j, n in enumerate((5, 12, 77)):
         assert rel_err(tf[j].cpu(), hid[j, 1:n - 1]) < 2e-2
         assert rel_err(eot[j].cpu(), pool[j]) < 2e-2
+
+
+@pytest.mark.parametrize("hierarchy", [False, True])
+def test_alternate_adapter_feature_with_iteration_step(hierarchy):
+    """``clip_adapter_feature='alternate'`` (transformer.py:134-138, vtimellm_arch.py:112-123,146-147): ``iteration_step`` even -> the
+    CLS row(s), odd -> the temporal rows of [b,t,d] features, then ``alternate_layer_norm`` (LayerNorm over the hidden dim) - the
+    adapter rows against the oracle (pinned by the reference's own outputs for both parities: golden G3), and a generate that runs
+    on them; without an iteration_step the reference's ``None % 2`` TypeError."""
+    from oracle import adapter
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = ReVisionLlamaForCausalLM(shape, device="cuda:0")
+    m.get_model().initialize_vision_modules(_args(clip_adapter_feature="alternate", hierarchy=hierarchy))
+    m.engine.init_synthetic(seed=SEED)
+    m.generation_config.eos_token_id = None
+    g = torch.Generator().manual_seed(5)
+    ln_w, ln_b = 1 + 0.1 * torch.randn(shape.hidden, generator=g), 0.1 * torch.randn(shape.hidden, generator=g)
+    m.get_model().load_alternate_layer_norm(ln_w, ln_b)
+    w = clip_weights(hidden=shape.hidden, bf16=True, prefix="model.mm_projector.")
+    w32 = clip_weights(hidden=shape.hidden, bf16=False, prefix="model.mm_projector.")
+    w = {k: (v if v.dim() > 1 else w32[k]) for k, v in w.items()}
+    q = (feats("alt.q", (2, 6, 768), bf16=True), torch.ones(2, 6))
+    flat = feats("alt.x", (2, 24, 768), bf16=True)                     # [b, t, d]
+    hier = feats("alt.xh", (2, 5, 24, 768), bf16=True)                 # [b, v, t, d]
+    for it in (0, 1, 2, 3):
+        images = hier if (hierarchy and it % 2 == 0) else flat
+        rows, rps = m.encode_images(images, q, it)
+        want = adapter.encode_images(images, w, q, feature="alternate", hierarchy=hierarchy, iteration_step=it)
+        want = torch.nn.functional.layer_norm(want, (shape.hidden,), ln_w, ln_b)
+        assert rps == want.shape[1] and rel_err(rows.cpu().view_as(want), want) < 2e-2, (it, rps)
+    with pytest.raises(TypeError):
+        m.encode_images(flat, q)
+    ids = T(synth.synthetic_prompt_ids(40, 20, 1, vocab=shape.vocab))[None].repeat(2, 1)
+    out = m.generate(ids, images=flat, query_feats=q, iteration_step=1, do_sample=False, max_new_tokens=3, return_dict_in_generate=True)
+    assert out["sequences"].shape == (2, 43)
