@@ -110,11 +110,13 @@ def test_full_depth_scores_vs_reference(g8_run):
     # --- what is asserted ---
     assert np.isfinite(ours).all() and np.isfinite(st[:, :3]).all()
     assert e_cos.max() < 1e-3                                              # the north star's bound, element-wise, for the LLM-free score
-    # (no discrete assertion here: on these random-init weights NO step's top-1 margin clears the bf16 error - ``steps_with_safe_margin``
-    #  is 0 - so "same argmax where the margin allows" would be vacuous.  Token ids, answers and window indices are asserted EXACT on the
-    #  well-conditioned fixture G8c: tests/test_gpu_full_depth_conditioned.py)
+    # wherever the reference's top-1 margin clears twice the largest logit error, the same argmax - and that must be MOST steps (measured:
+    # 37 of 56 safe, all agree; 53 of 56 agree overall).  Round 2's G8 had NO safe step: its golden generator left the adapter's
+    # Dropout(0.1) in training mode (the reference builds the adapter after .eval(), builder.py:42), so the "reference" video rows carried
+    # random noise that no implementation could match.  Token ids / answers / windows EXACT: the well-conditioned fixture G8c.
+    assert safe.sum() >= 0.5 * safe.size and agree[safe].all() and agree.mean() >= 0.85
     # bf16 arithmetic through 32 random layers: no further from the fp32 reference than the reference's OWN bf16 path
-    assert err.mean() <= 1.25 * err16.mean() and err.max() <= 1.5 * err16.max()
+    assert err.mean() <= 0.5 * err16.mean() and err.max() <= err16.max()            # measured: 0.28 x / 0.26 x
     assert np.median(e_max) <= 1.5 * np.median(b_max) + 1e-3 and np.median(e_mean) <= 1.5 * np.median(b_mean) + 1e-3
 
 
