@@ -167,7 +167,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
             assert rc == 0, hip.last_error()
             state["i"] += 1
         split = 2 if mbp >= 5 else 1      # (rows_splits in gemm_rows.hip)
-        kname = f"rows_kernel<{mbp},{8 // split},1>"
+        kname = f"rows_kernel<{mbp},{8 // split},1,1>"
         gthreads = (2 * s.inter // 64) * split * 320
     ms = event_time_ms(gemv, 64, warm=4)
     legs["decode_gateup_gemv"] = dict(kernel=kname, bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes,
