@@ -19,6 +19,7 @@
 // once per XCD): the algorithmic bytes.
 // Rows are dealt evenly: rows_per_wg = ceil(M / (#CU * rounds)); the last 16-row fragment of a block is partly padding
 // (M = 25600 on 256 CUs: 100 rows in 7 fragments, 89 % useful MFMA work).
+#include <atomic>
 #include "kernels.h"
 
 namespace {
@@ -252,14 +253,18 @@ ArPlan plan_for(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
+// (the dynamic-LDS opt-in is a per-DEVICE attribute of the function: remembered per device, bit d of the mask)
 template <typename Kern>
-int set_lds(Kern k, size_t bytes, size_t& have) {
-    if (bytes > have) {
+int set_lds(Kern k, std::atomic<uint64_t>& have) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(have.load(std::memory_order_relaxed) & bit)) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AR_LDS_MAX) != hipSuccess) {
             rv_set_error("gemm_arows: cannot reserve %d bytes of LDS", AR_LDS_MAX);
             return RV_ERR_HIP;
         }
-        have = AR_LDS_MAX;
+        have.fetch_or(bit, std::memory_order_relaxed);
     }
     return RV_OK;
 }
@@ -267,8 +272,8 @@ int set_lds(Kern k, size_t bytes, size_t& have) {
 template <int OUT_BF16, int ACT, int MF, int NW>
 int launch(const ArPlan& p, const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C,
            int64_t ldc, int M, int N, int K, hipStream_t st) {
-    static size_t have = 0;
-    if (int rc = set_lds(gemm_arows_kernel<OUT_BF16, ACT, MF, NW>, p.lds, have)) return rc;
+    static std::atomic<uint64_t> have{0};
+    if (int rc = set_lds(gemm_arows_kernel<OUT_BF16, ACT, MF, NW>, have)) return rc;
     hipLaunchKernelGGL((gemm_arows_kernel<OUT_BF16, ACT, MF, NW>), dim3(p.grid), dim3(512), p.lds, st, A, lda, Wp, bias, res, ldr, C, ldc, M,
                        N, K, p.rows_per_wg, rv_cur_opts().gemm_arows >> 4);
     return RV_OK;

@@ -615,14 +615,18 @@ int pp_num_cus() {
     return (want > 0 && want <= n) ? want : n;
 }
 
+// The > 64 KiB dynamic-LDS opt-in is a per-DEVICE attribute of the function: remembered per device (bit d of the mask), not per process.
 template <typename Kern>
-int reserve_lds(Kern k, bool& done) {
-    if (!done) {
+int reserve_lds(Kern k, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) {
             rv_set_error("gemm_pp: cannot reserve %d bytes of LDS", PP_LDS);
             return RV_ERR_HIP;
         }
-        done = true;
+        done.fetch_or(bit, std::memory_order_relaxed);
     }
     return RV_OK;
 }
@@ -630,7 +634,7 @@ int reserve_lds(Kern k, bool& done) {
 template <int OUT_BF16, int ACT, int NF>
 int launch(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
            int M, int N, int K, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_set{0};
     if (int rc = reserve_lds(gemm_pp<OUT_BF16, ACT, NF>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64);
     hipLaunchKernelGGL((gemm_pp<OUT_BF16, ACT, NF>), dim3(tiles_m * tiles_n), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N,
@@ -649,7 +653,7 @@ int pp_teams(int64_t M) {
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
               int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr, PpScale sc = PpScale{nullptr, nullptr}) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_set{0};
     if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64), nk = K / PBK;
     const int G = pp_num_cus() & ~7, per_x = G >> 3;

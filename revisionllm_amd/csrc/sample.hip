@@ -725,7 +725,7 @@ extern "C" int rv_topk_pool(const void* video, int dtype, const float* text, int
     RV_CHECK_ARG(k >= 1 && k <= 64 && k <= T, "rv_topk_pool: k=%d must be in [1, min(64, T=%d)]", k, T);
     RV_CHECK_ARG(Nt <= 65535, "rv_topk_pool: at most 65535 texts per launch");
     const size_t sm = (size_t)(d + T) * sizeof(float);
-    RV_CHECK_ARG(sm <= 64 * 1024, "rv_topk_pool: d + T too large for LDS");
+    RV_CHECK_ARG(sm + 64 * sizeof(int) <= 64 * 1024, "rv_topk_pool: d + T too large for LDS (dynamic %zu B + 256 B static)", sm);
     if (dtype == RV_BF16)
         hipLaunchKernelGGL(topk_pool_kernel<bf16_t>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const bf16_t*)video, text, T, d, Nt, k, out, out_idx);
     else
