@@ -823,7 +823,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
         // of the prefill), output-tiled when the tile count fills the CUs; everything else stays on the 128x128 ring kernel
         void* sk_ws = (ws && ws_bytes >= gemm_pp_ws_bytes() && gemm_pp_sk_supported(w_layout, M, N, K)) ? ws : nullptr;
         const int v = rv_cur_opts().gemm_tile_variant;
-        if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0) || gemm_pp_dp_profitable(M, N, K))))
+        if (v == 4 || v == 5 || (v == 2 && ((sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0) || gemm_pp_dp_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0)))
             return gemm_pp_launch(A, lda, W, bias, residual, ldr, C, ldc, out_dtype, act, M, N, K,
                                   (v == 5 || (v == 2 && sk_ws && gemm_pp_sk_plan(M, N, K, act == RV_ACT_SILU_MUL) != 0)) ? sk_ws : nullptr, st);
     }

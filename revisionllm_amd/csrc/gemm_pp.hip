@@ -722,11 +722,20 @@ bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K) { return gemm_pp_sk_
 
 // Output-tiled ping-pong pays for long K (the prologue / epilogue of a 256x256 tile is ~3 us) when the tiles fill the
 // CUs: 1.2 vs 0.86 PFLOP/s at 4096^3; short-K adapter GEMMs (K = 768) and ragged tile counts stay on the ring kernel.
-bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K) {
-    const int64_t tiles = cdiv(M, PBM) * (N / PBN), cus = pp_num_cus();
-    const int64_t rounds = cdiv(tiles, cus);
-    return K >= 2048 && tiles >= cus && tiles * 100 >= rounds * cus * 85;
+// -> 4 (256-column tiles), 3 (192-column tiles: N = 768 of the adapter's FFN-2 over 100 x 257 rows gives 101 x 4 = 404 tiles = 79 % of two
+// rounds where 256-column tiles give 303 = 59 %), 0 (ring kernel).
+int gemm_pp_dp_plan(int64_t M, int64_t N, int64_t K, bool gated) {
+    const int64_t cus = pp_num_cus();
+    if (K < 2048) return 0;
+    const int64_t t4 = cdiv(M, PBM) * (N / PBN), r4 = cdiv(t4, cus);
+    if (t4 >= cus && t4 * 100 >= r4 * cus * 85) return 4;
+    if (!gated && N % 192 == 0) {
+        const int64_t t3 = cdiv(M, PBM) * (N / 192), r3 = cdiv(t3, cus);
+        if (t3 >= cus && t3 * 100 >= r3 * cus * 75) return 3;
+    }
+    return 0;
 }
+bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K) { return gemm_pp_dp_plan(M, N, K, false) == 4; }
 
 int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st) {
@@ -736,6 +745,16 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
     const bool sk = ws && gemm_pp_sk_supported(1, M, N, K);
     const bool nf3 = sk && act != RV_ACT_SILU_MUL && gemm_pp_sk_plan(M, N, K, false) == 3;
     int rc;
+    if (!sk && gemm_pp_dp_plan(M, N, K, act == RV_ACT_SILU_MUL) == 3) {     // output-tiled with 192-column tiles
+        if (ob && act == RV_ACT_NONE) rc = launch<1, RV_ACT_NONE, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st);
+        else if (ob && act == RV_ACT_RELU) rc = launch<1, RV_ACT_RELU, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st);
+        else if (!ob && act == RV_ACT_NONE) rc = launch<0, RV_ACT_NONE, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st);
+        else if (!ob && act == RV_ACT_RELU) rc = launch<0, RV_ACT_RELU, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st);
+        else rc = launch<0, RV_ACT_QUICK_GELU, 3>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st);
+        if (rc) return rc;
+        RV_CHECK_LAUNCH("gemm_pp");
+        return RV_OK;
+    }
 #define PP(OB, AC)                                                                                                       \
     rc = sk ? launch_sk<OB, AC, 0, 4>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, ws, st, QkvRope{})      \
             : launch<OB, AC, 4>(a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)

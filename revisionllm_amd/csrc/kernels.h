@@ -144,6 +144,7 @@ bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K);
 int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated);   // 0 = no, 4 / 3 = persistent launch with 256- / 192-column panels
 bool gemm_pp_sk_profitable(int64_t M, int64_t N, int64_t K);
 bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K);   // long K and a tile count that fills the CUs
+int gemm_pp_dp_plan(int64_t M, int64_t N, int64_t K, bool gated);   // output-tiled ping-pong: 4 / 3 (256- / 192-column tiles) or 0
 size_t gemm_pp_ws_bytes();
 // FP8 x FP8 prefill GEMM (persistent stream-K form only; see gemm_pp.hip): A8 bytes [M,K] + row scales, W8p + column scales
 bool gemm_pp_fp8_supported(int64_t M, int64_t N, int64_t K, bool gated, bool rope);
