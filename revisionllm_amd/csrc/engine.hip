@@ -273,6 +273,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "sample_variant") return &o.sample_variant;
     if (k == "gemm_arows") return &o.gemm_arows;
     if (k == "rows_fill") return &o.rows_fill;
+    if (k == "rows_spread") return &o.rows_spread;
     return nullptr;
 }
 }  // namespace

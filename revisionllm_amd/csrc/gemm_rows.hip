@@ -343,20 +343,28 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
 template <int MB, int VPW, int FIN, int WP>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    const size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
+    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
+    // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
+    // occupies 128 of the 256 CUs (PMC: SQ_BUSY_CU_CYCLES = 0.50 of the launch).  A launch with no more workgroups than `rows_spread`
+    // asks for more LDS than two workgroups can share, so each gets a CU of its own.
+    const unsigned grid = (unsigned)(N / 64 * (8 / VPW));
+    constexpr size_t alone = 81 * 1024;
+    const bool spread = MB <= 5 && (int)grid <= rv_cur_opts().rows_spread;
+    if (spread && lds < alone) lds = alone;
     // the > 64 KiB opt-in is a per-DEVICE attribute of the function: remembered per device (bit d of the mask), not per process
     static std::atomic<uint64_t> opted{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (lds > 65536 && !(opted.load(std::memory_order_relaxed) & bit)) {
-        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(MB <= 5 && lds < alone ? alone : lds)) != hipSuccess) {
             rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
             return RV_ERR_HIP;
         }
         opted.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN, WP>), dim3((unsigned)(N / 64 * (8 / VPW))), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
+    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN, WP>), dim3(grid), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
                        ldc, M, N, K, nrm, qr);
     return RV_OK;
 }
