@@ -380,3 +380,14 @@ def test_scheduler_isolates_task_errors_and_reports_a_stall():
     with pytest.raises(RuntimeError, match="stalled"):
         inter.finish(s)
     assert closed == [True] and not inter.tasks         # the generator was closed (its finally ran)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """``bench.py --gpus N`` under a launcher: the number of ranks the launcher started must be N (round 2: --gpus was never read and a
+    1-rank run could be labelled with any N).  Checked before anything touches the GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2 rank(s)" in (r.stderr + r.stdout)
