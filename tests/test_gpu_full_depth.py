@@ -203,7 +203,7 @@ def test_7b_layer_vs_reference_g6(golden):
     want = g["logits"]
     err = np.abs(got - want).max() / np.abs(want).max()
     print(f"\n[G6 7B-shaped layer vs reference] logits max err / max|logit| = {err:.3e}; tokens {seq[0, -3:].tolist()}")
-    assert err < 3e-2                                                      # bf16 weights + activations against fp32 weights
+    assert err < 2e-2                                                      # bf16 weights + activations against fp32 weights
     margin = np.sort(want, -1)[..., -1] - np.sort(want, -1)[..., -2]
     for s_ in range(3):
         if margin[s_, 0] > 2 * np.abs(got[s_] - want[s_]).max():

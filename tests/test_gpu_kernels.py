@@ -2,7 +2,7 @@
 seeded inputs.  Both sides see identical (bf16-representable) weights and inputs, so differences come only
 from bf16 activation rounding between kernels and fp32 accumulation order.  Tolerances are stated per test:
   f32 outputs of a single kernel ........ 2e-5 relative (max-norm)
-  bf16 outputs / chained bf16 kernels ... 1.5e-2 relative (bf16 eps = 3.9e-3)
+  bf16 outputs / chained bf16 kernels ... 8e-3 relative (bf16 eps = 3.9e-3; measured <= 3.8e-3), full adapter / logits 1e-2
 """
 import math
 
@@ -15,7 +15,7 @@ from helpers import SEED, T, clip_weights, feats, linear_weights, llama_weights,
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 2e-5
-BF16_TOL = 1.5e-2
+BF16_TOL = 8e-3        # (measured <= 3.8e-3: one bf16 rounding of the output + bf16 inputs)
 
 
 @pytest.fixture(scope="module")
@@ -348,10 +348,10 @@ def test_clip_encoder(dev, text, Tn):
     qf = txt.repeat_interleave(N // Nq, 0)
     qm = mask.repeat_interleave(N // Nq, 0)
     ref = adapter.clip_encoder(x, w, qf if text else None, qm if text else None, text, "cls", True)[:, 0]
-    assert rel_err(y.cpu(), ref) < 2e-2
+    assert rel_err(y.cpu(), ref) < 1e-2
     yall = eng.clip_encoder(x, txt, mask, "all")
     refall = adapter.clip_encoder(x, w, qf if text else None, qm if text else None, text, "all", False)
-    assert rel_err(yall.cpu(), refall) < 2e-2
+    assert rel_err(yall.cpu(), refall) < 1e-2
     assert rel_err(yall[:, 0].cpu(), y.cpu()) < 1e-6
 
 
@@ -385,14 +385,14 @@ def test_llm_prefill_and_decode(dev):
     h = eng.splice_embed(ids.int(), None)
     assert rel_err(h.cpu(), emb) < 1e-6
     logits = eng.llm_forward(h, 0, kv, Smax)
-    assert rel_err(logits.cpu(), ref) < 2e-2
+    assert rel_err(logits.cpu(), ref) < 1.2e-2
     for step in range(3):
         nxt = ref.argmax(-1)
         e1 = w["model.embed_tokens.weight"][nxt][:, None]
         ref = llama.forward(e1, w, cfg, cache=cache)[:, -1]
         h1 = eng.splice_embed(nxt.int()[:, None], None)
         logits = eng.llm_forward(h1, S + step, kv, Smax)
-        assert rel_err(logits.cpu(), ref) < 2e-2, step
+        assert rel_err(logits.cpu(), ref) < 1.2e-2, step
 
 
 def test_sample_and_scores(dev):

@@ -65,7 +65,7 @@ def test_generate_vs_reference_golden_and_oracle(golden, tag):
                      output_logits=True, output_scores=True, forced_tokens=forced)
     got = torch.stack(out["logits"]).cpu()
     ref = T(g[f"{tag}_greedy_logits"])
-    assert rel_err(got, ref) < 6e-2                      # vs the reference's own fp32 outputs
+    assert rel_err(got, ref) < 2e-2                      # vs the reference's own fp32 outputs
     assert (out["sequences"].cpu() == seq).all()         # prompt echoed incl. the -200 sentinel, forced continuation
     assert len(out["scores"]) == 6 and out["scores"][0].shape == (B, shape.vocab)
     # vs the oracle on identical weights (inputs rounded to bf16 on both sides)
@@ -76,7 +76,7 @@ def test_generate_vs_reference_golden_and_oracle(golden, tag):
     o = sampling.generate(ids, fb, qb, w, wa, cfg, adapter_kw=dict(clip_adapter=clip, hierarchy=clip), max_new_tokens=6,
                           eos_token_id=-1, forced_tokens=forced)
     want = torch.stack(o["logits"])
-    assert rel_err(got, want) < 3e-2
+    assert rel_err(got, want) < 1.2e-2
     # free-running greedy tokens agree with the oracle wherever its top-2 margin exceeds the logit tolerance
     top2 = want.topk(2, -1).values
     safe = (top2[..., 0] - top2[..., 1]) > 2 * 3e-2 * want.abs().max()
@@ -111,14 +111,14 @@ def test_fp8_decode_weights_vs_oracle_with_the_same_quantisation():
     ok = dict(adapter_kw=dict(clip_adapter=True, hierarchy=True), max_new_tokens=5, eos_token_id=-1, forced_tokens=forced)
     want8 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, w_llm_decode=llama.fp8_decode_weights(w, cfg), **ok)["logits"])
     want16 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, **ok)["logits"])
-    assert rel_err(got, want8) < 3e-2
+    assert rel_err(got, want8) < 1.2e-2
     assert rel_err(got[1:], want8[1:]) < rel_err(got[1:], want16[1:])          # it really is the quantised weights that ran
     try:
         m.engine.set_option("fp8_decode", 0)
         off = torch.stack(m.generate(ids, **kw)["logits"]).cpu()
     finally:
         m.engine.set_option("fp8_decode", 1)
-    assert torch.equal(off[0], got[0]) and rel_err(off, want16) < 3e-2
+    assert torch.equal(off[0], got[0]) and rel_err(off, want16) < 1.2e-2
 
 
 def _entropy(logits):
@@ -147,7 +147,7 @@ def test_sampling_scores_and_entropy_vs_oracle():
     out = m.generate(ids, images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=5, output_scores=True,
                      return_dict_in_generate=True, uniforms=u, forced_tokens=forced, output_logits=True)
     got_raw, want_raw = torch.stack(out["logits"]).cpu(), torch.stack(o["logits"])
-    assert rel_err(got_raw, want_raw) < 3e-2
+    assert rel_err(got_raw, want_raw) < 1.2e-2
     got_sc, want_sc = torch.stack(out["scores"]).cpu(), torch.stack(o["scores"])
     # supports may differ only for candidates whose scaled score sits within tolerance of the nucleus cut
     agree = (torch.isfinite(got_sc) == torch.isfinite(want_sc)).float().mean()
@@ -221,7 +221,7 @@ def test_kv_cache_growth_matches_oracle():
     w, wa = _oracle_weights(shape, True)
     o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), max_new_tokens=G, eos_token_id=-1,
                           forced_tokens=out["sequences"][:, ids.shape[1]:].t().cpu())
-    assert rel_err(torch.stack(out["logits"][-3:]).cpu(), torch.stack(o["logits"][-3:])) < 3e-2
+    assert rel_err(torch.stack(out["logits"][-3:]).cpu(), torch.stack(o["logits"][-3:])) < 1.2e-2
 
 
 def test_stage2_batched_equals_reference_mode():
@@ -304,7 +304,7 @@ def test_load_pretrained_model_with_lora_checkpoint(tmp_path, monkeypatch):
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), max_new_tokens=3, eos_token_id=-1,
                           forced_tokens=out["sequences"][:, ids.shape[1]:].t().cpu())
-    assert rel_err(torch.stack(out["logits"]).cpu(), torch.stack(o["logits"])) < 3e-2
+    assert rel_err(torch.stack(out["logits"]).cpu(), torch.stack(o["logits"])) < 1.2e-2
 
 
 def test_stage1_driver_runs():
@@ -368,7 +368,7 @@ def test_sparse_adapter_1024_frames():
     txt = feats("ce1024.txt", (1, 16, 768), bf16=True)
     y = eng.clip_encoder(x, txt, torch.ones(1, 16), "cls")
     ref = adapter.clip_encoder(x, w, txt, torch.ones(1, 16), True, "cls", False)[:, 0]
-    assert rel_err(y.cpu(), ref) < 2e-2
+    assert rel_err(y.cpu(), ref) < 1e-2
 
 
 @pytest.fixture(scope="module")
