@@ -30,7 +30,7 @@ def llm_7b():
     from revisionllm_amd.utils import synth
     hier = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device="cuda:0")
     hier.get_model().initialize_vision_modules(_args())
-    hier.engine.init_synthetic(seed=5, llm=True, clip=True, linear=True)
+    hier.engine.init_synthetic(seed=5, llm=True, clip=True, linear=True, cond=synth.CONDITIONED)     # well-conditioned weights: tight bounds below
     dense = ReVisionLlamaForCausalLM(synth.VICUNA_7B, engine=hier.engine)
     dense.get_model().initialize_vision_modules(_args(clip_adapter=False, clip_adapter_text=False, hierarchy=False))
     sparse = ReVisionLlamaForCausalLM(synth.VICUNA_7B, engine=hier.engine)
@@ -154,10 +154,13 @@ def test_stage2_long_33_at_7b(llm_7b):
     assert len(a["score_cos"]) == len(b["score_cos"]) and np.allclose(a["score_cos"], b["score_cos"], rtol=1e-5, atol=1e-6)
     assert np.isfinite(b["max_entropy"]).all() and np.isfinite(b["mean_entropy"]).all()
     same = [x == y for x, y in zip(a["answers"], b["answers"])]
-    assert sum(same) >= 5          # free-running tokens on a random-init model: near-ties may flip a call; most calls agree
+    print("\n[stage2_long_33 batched vs reference mode] answers equal", sum(same), "/ 9; 1/max_entropy rel diff",
+          [round(abs(x - y) / abs(x), 5) for x, y in zip(a["max_entropy"], b["max_entropy"])])
+    assert sum(same) >= 6          # free-running with a uniform of 0.5 at every step (no safety margin to the CDF boundaries): measured 7 of 9
     for i, ok in enumerate(same):
-        if ok:                     # identical token sequence -> the step entropies differ only by bf16 noise
-            assert abs(a["max_entropy"][i] - b["max_entropy"][i]) <= 0.5 * abs(a["max_entropy"][i])
+        if ok:                     # identical token sequence -> the step entropies differ only by the f32 summation order of the larger GEMMs
+            assert abs(a["max_entropy"][i] - b["max_entropy"][i]) <= 1e-2 * abs(a["max_entropy"][i])
+            assert abs(a["mean_entropy"][i] - b["mean_entropy"][i]) <= 1e-2 * abs(a["mean_entropy"][i])
 
 
 # ---------------------------------------------------------------- EOS-terminated decode -----------------------------------------------
