@@ -10,7 +10,7 @@ Every step in flight works on its OWN video, query and window permutations (hash
 flight), so the prefills batched into one GEMM pass and the rows of a merged decode step are all different.
 N ranks (``--gpus N`` without a launcher: this process starts ``torch.distributed.run`` with N ranks as a child and relays rank 0's line):
 ``--scaling queries`` (default; what "whole node" means here): whole recursions are dealt to the ranks - every rank runs the 1-GPU
-pipeline on its own queries, no data-path collective, ONE RCCL all-gather of the per-call proposals at the end of the timed region
+pipeline on its own queries (``parallel.LOCAL``), no data-path collective, ONE RCCL all-gather of the per-call proposals at the end of the timed region
 (the reference itself shards by query: e2e2.py:221-222).  ``--scaling segments``: a 100*N-window video per step, windows
 block-partitioned, CLS rows and proposals exchanged by RCCL all-gathers inside every recursion (per-GPU work fixed).
 ``--scaling strong``: ONE 100-window recursion per step sharded over the N ranks (100/N windows each, the 7 calls dealt over the
@@ -419,11 +419,9 @@ def main():
     W = (33 if args.workload == "stage2_long_33" else args.windows) * (1 if (strong or by_query) else world)
     lo, hi = (0, W) if by_query else parallel.shard_bounds(W, rank, world)
     Wl, Tn = hi - lo, args.frames
-    # queries mode: the recursion's own "world" is this rank alone (a one-rank group: the sharded driver then issues no collective)
-    own_group = None
-    if by_query:
-        groups = [dist.new_group([r]) for r in range(world)]      # (new_group is collective: every rank creates every group)
-        own_group = groups[rank]
+    # queries mode: the recursion's own "world" is this rank alone (parallel.LOCAL: the sharded driver then issues no collective and no
+    # sub-communicator exists)
+    own_group = parallel.LOCAL if by_query else None
     plan = stage2.plan_groups(W, batch)
     torch.manual_seed(args.seed + (rank if by_query else 0))      # the device-side sampling draws (torch.rand in generate)
 

@@ -18,6 +18,11 @@ from .eval import stage2
 from .ops import h2d as ops_h2d
 
 
+#: ``group=LOCAL``: this rank runs the recursion on its own - a world of one whatever process group exists (bench.py --scaling queries:
+#: whole recursions per rank).  No sub-communicator is created and no collective is issued.
+LOCAL = object()
+
+
 def shard_bounds(n, rank, world):
     """Contiguous block partition of ``n`` items: rank r owns [lo, hi); sizes differ by at most one."""
     base, rem = divmod(n, world)
@@ -166,8 +171,9 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
     device -> pinned-host copies of the proposals are enqueued here, so a driver can launch the next pass before it collects
     this one.  Stages without ``generate_async`` (CPU stand-ins) and an EOS-terminated generate (which synchronises per step)
     do their waiting here.  Records (``collect_queries``) are identical to running the recursions one by one."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    alone = group is LOCAL or not dist.is_initialized()
+    world = 1 if alone else dist.get_world_size(group)
+    rank = 0 if alone else dist.get_rank(group)
     lo, hi = shard_bounds(W, rank, world)
     feats_of = features_local if isinstance(features_local, (list, tuple)) else [features_local] * len(queries)
     assert len(feats_of) == len(queries) and all(f.shape[0] == hi - lo for f in feats_of), f"rank {rank} must hold windows [{lo},{hi})"

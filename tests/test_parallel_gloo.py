@@ -303,8 +303,7 @@ def _run_rank_queries(rank, n, group, gang=3):
 def _worker_queries(rank, world, port, q, n):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    groups = [dist.new_group([r]) for r in range(world)]
-    recs, sizes = _run_rank_queries(rank, n, groups[rank])
+    recs, sizes = _run_rank_queries(rank, n, parallel.LOCAL)
     mine = torch.tensor([r["max_entropy"] + r["mean_entropy"] for r in recs], dtype=torch.float32)
     everyone = parallel._all_gather_cat(mine, None)                      # the ONE exchange of the mode: every rank ends with all proposals
     q.put((rank, [r["answers"] for r in recs], everyone.tolist(), sizes))
@@ -313,7 +312,7 @@ def _worker_queries(rank, world, port, q, n):
 
 
 def test_world2_queries_mode_whole_recursions_per_rank():
-    """bench.py --scaling queries on 2 ranks: every rank runs WHOLE recursions on its own inputs (a one-rank group: no collective in
+    """bench.py --scaling queries on 2 ranks: every rank runs WHOLE recursions on its own inputs (``parallel.LOCAL``: no collective in
     the data path) through a gang-stepping server, 5 in flight; one final all-gather hands every rank all proposals.  Equal to the
     same recursions run in one process."""
     n = 5
