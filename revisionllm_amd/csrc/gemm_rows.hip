@@ -28,6 +28,16 @@
 // results, and the same time as one workgroup per item (70-row step 7.23 vs 7.30 ms; both behind this kernel's 6.84 ms because the
 // finish must then stay small enough to keep the ring's 64 VGPRs live: pair-by-pair plane loads) - the cold start and tail of a
 // 16-stage workgroup are not what bounds the launch either.
+// (c) What the RS_PROBE builds say (tools/rows_probe.sh, 70 rows, back-to-back launches, gate/up shape N = 22016, K = 4096: 53.1 us):
+// every weight load L1 / L2-hot 37.1 us; no per-stage barriers 54.1; no MFMAs 53.7; no slabs staged 52.2; hot weights + no barriers + no slabs
+// 34.0.  And the K sweep (tools/rows_time.py): launch time = FIXED + weights at 5.4 TB/s marginal, with FIXED = 19.9 us (gate/up: 688
+// workgroups = two rounds of the 512 resident slots), 14.4 us (QKV: 384 workgroups), 7 - 9 us (o / down: 256).  So: the streaming itself
+// runs at what HBM gives; a ROUND of workgroups costs ~10 us whatever it streams (first weights cold, planes out + acknowledged, the
+// arrival counter's round trip, the last arriver's plane loads and epilogue), and gate/up pays it twice because an item (column group,
+// split) must be whole virtual k-waves of the shared summation tree and 688 items do not deal out over 512 slots.  What would remove the second
+// round: a persistent grid with FINER items (S = 4: 1376 items of 8 stages, <= 3 per workgroup) whose hand-overs are DEFERRED (planes stored
+// without waiting; one acknowledgement, the counters and the finishes once at the end of the workgroup's life) - estimated 53 -> 38 us for
+// gate/up, nothing for the other three launches (their items already fit one round): ~7 % of a decode step.  Not built.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -35,6 +45,15 @@
 
 #include "kernels.h"
 #include "gemv_finish.h"
+
+// Timing probes (tools/rows_probe.sh builds one library per value; results are garbage, only the time means something):
+//   RS_PROBE & 1   every weight load re-reads the same 8 KiB (L1 / L2 hot): no HBM latency or bandwidth in the consumers' loop
+//   RS_PROBE & 2   no per-stage barrier: consumers and producer run free (slabs may be stale)
+//   RS_PROBE & 4   no MFMAs (the accumulators get one add per stage so that the loads stay live)
+//   RS_PROBE & 8   the producer stages no slabs at all
+#ifndef RS_PROBE
+#define RS_PROBE 0
+#endif
 
 namespace {
 
@@ -137,11 +156,12 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
             for (int i = 0; i < XL; ++i) glds16(xs + i * 512, dst + i * 1024);
         };
-        for (int d = 0; d < DX - 1; ++d) issue(d);
+        if constexpr (!(RS_PROBE & 8))
+            for (int d = 0; d < DX - 1; ++d) issue(d);
         for (int g = 0; g < T; ++g) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DX - 2) * XL) : "memory");   // slab g has landed
-            __builtin_amdgcn_s_barrier();                                          // consumers: slab g is yours, slot of slab g - 1 is mine
-            issue(g + DX - 1);
+            if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();           // consumers: slab g is yours, slot of slab g - 1 is mine
+            if constexpr (!(RS_PROBE & 8)) issue(g + DX - 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs issued past the end must not outlive the ring's reuse below
     } else {
@@ -157,7 +177,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             kb_ = sp * VPW + li + 8 * lc;                                                                                            \
             if (++lc == vcount(li)) { lc = 0; ++li; }                                                                                \
         }                                                                                                                            \
-        const bf16_t* ws_ = kb_ >= 0 ? wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048) : X + lane * 8;                                    \
+        const bf16_t* ws_ = kb_ >= 0 ? ((RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048)) : X + lane * 8; \
         _Pragma("unroll") for (int j_ = 0; j_ < LPS; ++j_)                                                                          \
             wf[slot][j_] = __builtin_nontemporal_load((const typename std::remove_reference<decltype(wf[0][0])>::type*)(ws_ + j_ * 512)); \
     } while (0)
@@ -169,7 +189,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
                 const int g = g0 + u;
                 if (g < T) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * LPS) : "memory");   // the weights of stage g have landed
-                    __builtin_amdgcn_s_barrier();                                        // ... and its slab (producer)
+                    if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();         // ... and its slab (producer)
                     RS_ISSUE_W((u + DW - 1) % DW);
                     {
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
@@ -181,7 +201,11 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
                                 const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
-                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
+                                if constexpr (RS_PROBE & 4) {
+                                    if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
+                                } else {
+                                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
+                                }
                             }
                         }
                     }
@@ -334,7 +358,8 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 
 int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the smallest power of two that fills the CUs, <= 8
     const int64_t cg = N / 64;
-    int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs)
+    int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs:
+                                           //  measured with the 68 B of spills it takes, 70-row step 6.85 -> 7.05 ms)
     const int fill = rv_cur_opts().rows_fill;   // workgroups a launch should at least have (tunable; 2 per CU are resident with <= 5 row blocks)
     while (s < 8 && cg * s < fill) s *= 2;
     return s;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Build probe variants of the library (gemm_rows.hip with -DRS_PROBE=n, everything else from the regular objects) HERE, then time them on the GPU box:
+#   bash tools/rows_probe.sh build 1 2 3 4 5 8      (build container)
+#   gpurun -- 'bash tools/rows_probe.sh run 1 2 3 4 5 8'
+set -e
+cd "$(dirname "$0")/.."
+C=revisionllm_amd/csrc
+mode=$1; shift
+if [ "$mode" = build ]; then
+  python -c "from revisionllm_amd import build; build.build_library()"
+  for p in "$@"; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -Wno-unused-function -Wno-pass-failed -DRS_PROBE=$p -c $C/gemm_rows.hip -o $C/build/gemm_rows_p$p.o &
+  done
+  wait
+  for p in "$@"; do
+    objs=$(ls $C/build/*.o | grep -v "gemm_rows" | grep -v "gemm_sk.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o revisionllm_amd/librevision_hip_p$p.so $objs $C/build/gemm_rows_p$p.o
+  done
+  ls -la revisionllm_amd/librevision_hip_p*.so
+else
+  export PYTHONPATH=.
+  echo "== regular"; python tools/rows_time.py 70 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
+  for p in "$@"; do
+    echo "== RS_PROBE=$p"; REVISION_HIP_LIB=$PWD/revisionllm_amd/librevision_hip_p$p.so python tools/rows_time.py 70 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
+  done
+fi
