@@ -77,6 +77,9 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        "<name>.s8" next to every LLM projection and lm_head); 0: always decode on the bf16 weights
  *   "fp8_prefill"        1 (default): prefill passes run their QKV / o / gate-up / down GEMMs as FP8 x FP8 when the "<name>.f8p"
  *                        copies of every layer are bound and the shape has a persistent plan; 0: always the bf16 weights
+ *   "rows_persistent"    1 (default): a 33 .. 128-row decode projection with more (column group, split) items than workgroups fit the chip at once
+ *                        runs as a persistent grid whose workgroups stream several items back to back and hand their partial sums over once, at
+ *                        the end; 0: one workgroup per item (the round-2 launch).  Same results.
  *   "rows_spread"        the 33 .. 128-row decode projections: a launch with at most this many workgroups asks for a CU per workgroup
  *                        (more LDS than two can share) instead of being packed two to a CU (0 = never)
  *   "rows_fill"          (default 240) the 33 .. 128-row decode projections split K (2 / 4 / 8 ways) until a launch has at least this many

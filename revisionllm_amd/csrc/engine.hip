@@ -274,6 +274,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "gemm_arows") return &o.gemm_arows;
     if (k == "rows_fill") return &o.rows_fill;
     if (k == "rows_spread") return &o.rows_spread;
+    if (k == "rows_persistent") return &o.rows_persistent;
     return nullptr;
 }
 }  // namespace

@@ -356,23 +356,326 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     }
 }
 
+// PERSISTENT launches (round 3).  A work item = (64-column group cg, split sp) = T stages.  When a launch has more items than workgroups fit the
+// chip at once (gate/up at 65 .. 80 rows: 688 items on 512 slots) the old one-workgroup-per-item launch ran TWO rounds and each round paid the
+// fixed ~10 us of a workgroup's life (cold first weights; planes out and acknowledged; the arrival counter's round trip; the last arriver's plane
+// loads and epilogue).  Now such a launch is a grid of resident workgroups that walk items it, it + G, ... (G a multiple of S: the split sp never
+// changes) as ONE stream of stages - the weight ring and the slab ring run on across item boundaries - and DEFER the hand-over: at the end of an
+// item the consumers only store its partial planes (no wait) and clear their accumulators; the acknowledgement, the arrival counters of all the
+// workgroup's items and the finishes of the groups it completed come once, behind the stream.  Finer items (S = 4: 1376 items of 8 stages, <= 3 per
+// workgroup) then balance the stream lengths.  An item occupies T rounded up to the ring depth stage SLOTS (pad slots load an L2-hot dummy and
+// compute nothing), so the ring slot of a stage is a compile-time constant.  grid == items is the old launch.  Same sums, same finish: same bits.
+constexpr int RS_MAXIT = 8;   // items per workgroup at most
+// (A separate kernel: folded into rows_kernel, the item bookkeeping cost the 5-row-block S = 2 variant 8 spilled VGPRs per stage.)
+template <int MB, int VPW, int FIN, int WP = 1>
+__global__ __attribute__((amdgpu_flat_work_group_size(RS_THREADS, RS_THREADS), amdgpu_waves_per_eu(RowsCfg<MB>::WPE, RowsCfg<MB>::WPE))) void
+rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
+            const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm, QkvRope qr) {
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    constexpr int S = 8 / VPW, LOG = VPW == 8 ? 3 : VPW == 4 ? 2 : VPW == 2 ? 1 : 0;
+    constexpr int DW = RowsCfg<MB, WP>::DW, DX = RowsCfg<MB, WP>::DX, LPS = RowsCfg<MB, WP>::LPS;
+    constexpr int SLAB = MB * 4096;                   // bytes of one 128-k slab of MB row blocks
+    constexpr int XL = MB * 4;                        // LDS-DMA fragments (1 KiB) per slab
+    static_assert((DX - 2) * XL <= 63 && (DW - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nitems = (N >> 6) * S, G = (int)gridDim.x;   // (host: G % S == 0 or G == nitems, so this workgroup's split never changes)
+    const int sp = blockIdx.x % S;
+    const int nkb = K >> 7;
+    const int n_it = (nitems - (int)blockIdx.x + G - 1) / G;    // items of this workgroup: blockIdx.x + n * G   (host: <= RS_MAXIT; S == 1: 1)
+    // stage sequence of ONE item: virtual waves v = sp * VPW + i, i = 0 .. VPW - 1, one after the other; virtual wave v owns k-blocks
+    // v, v + 8, ... (cnt(v) of them): T stages, Tp slots.  Both roles run exactly n_it * Tp slots (+ slots issued past the end as L2-hot dummies).
+    auto vcount = [&](int i) -> int { return (nkb - (sp * VPW + i) + 7) >> 3; };
+    int T = 0;
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) T += vcount(i);
+    const int Tp = (T + DW - 1) / DW * DW;
+    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 32 MiB: 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
+
+    f32x4 acc[MB], stk[LOG ? LOG : 1][MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave == RS_W) {
+        // ---------------- producer: slab of slot g -> LDS slot g % DX (the same k-block sequence for every item: sp is fixed) ----------------
+        int pi = 0, pc = 0, pp = 0, pn = 0;     // next slab to issue: (virtual wave, k-block in it, slot in the item, item)
+        auto issue = [&](int g) {
+            int kb = -1;
+            if (pn < n_it) {
+                if (pp < T) {
+                    kb = sp * VPW + pi + 8 * pc;
+                    if (++pc == vcount(pi)) { pc = 0; ++pi; }
+                }
+                if (++pp == Tp) { pp = 0; pi = 0; ++pn; }
+            }
+            const bf16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
+            char* dst = rs_smem + (g % DX) * SLAB;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) glds16(xs + i * 512, dst + i * 1024);
+        };
+        if constexpr (!(RS_PROBE & 8))
+            for (int d = 0; d < DX - 1; ++d) issue(d);
+        const int TT = n_it * Tp;
+        for (int g = 0; g < TT; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DX - 2) * XL) : "memory");   // slab g has landed
+            if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();           // consumers: slab g is yours, slot of slab g - 1 is mine
+            if constexpr (!(RS_PROBE & 8)) issue(g + DX - 1);
+        }
+    } else {
+        // ---------------- consumers: weight fragments of slot g in ring slot g % DW = (slot in the item) % DW: a compile-time constant ----------------
+        const int64_t tile_stride = (int64_t)(K >> 5) * (WP == 2 ? 256 : 512);     // elements of one 16-column tile (fp8: half the bytes)
+        const int64_t item_stride = (int64_t)(G / S) * RS_W * tile_stride;         // the next item of this workgroup: column group + G / S
+        const bf16_t* wp = W + ((int)blockIdx.x / S * RS_W + wave) * tile_stride + lane * 8;     // this wave's tile of the item being ISSUED
+        typename std::conditional<WP == 2, rs_w8, bf16x8>::type wf[DW][LPS];
+        int li = 0, lc = 0, lp = 0, ln = 0;     // next slot to issue: (virtual wave, k-block in it, slot in the item, item)
+#define RS_ISSUE_W(slot)                                                                                                             \
+    do {                                                                                                                             \
+        const bf16_t* ws_ = X + lane * 8;                                                                                            \
+        if (ln < n_it) {                                                                                                             \
+            if (lp < T) {                                                                                                            \
+                const int kb_ = sp * VPW + li + 8 * lc;                                                                              \
+                ws_ = (RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048);                 \
+                if (++lc == vcount(li)) { lc = 0; ++li; }                                                                            \
+            }                                                                                                                        \
+            if (++lp == Tp) { lp = 0; li = 0; ++ln; wp += item_stride; }                                                             \
+        }                                                                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < LPS; ++j_)                                                                          \
+            wf[slot][j_] = __builtin_nontemporal_load((const typename std::remove_reference<decltype(wf[0][0])>::type*)(ws_ + j_ * 512)); \
+    } while (0)
+#pragma unroll
+        for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
+        int g = 0;
+        for (int n = 0; n < n_it; ++n) {
+            int ci = 0, cc = 0;             // stage being computed: (virtual wave, k-block in it)
+            for (int s0 = 0; s0 < Tp; s0 += DW) {
+#pragma unroll
+                for (int u = 0; u < DW; ++u, ++g) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * LPS) : "memory");   // the weights of slot g have landed
+                    if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();         // ... and its slab (producer)
+                    RS_ISSUE_W((u + DW - 1) % DW);
+                    if (s0 + u < T) {
+                        const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bf16x8 wj;
+                            if constexpr (WP == 2) wj = rs_fp8x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
+                            else wj = wf[u][j];
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) {
+                                const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
+                                if constexpr (RS_PROBE & 4) {
+                                    if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
+                                } else {
+                                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
+                                }
+                            }
+                        }
+                        if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
+                            if constexpr (VPW > 1) {
+                                bool placed = false;
+#pragma unroll
+                                for (int b = 0; b < LOG; ++b) {
+                                    if (placed) continue;
+                                    if ((ci >> b) & 1) {
+#pragma unroll
+                                        for (int mb = 0; mb < MB; ++mb) acc[mb] = stk[b][mb] + acc[mb];
+                                    } else {
+#pragma unroll
+                                        for (int mb = 0; mb < MB; ++mb) stk[b][mb] = acc[mb];
+                                        placed = true;
+                                    }
+                                }
+                                if (placed) {
+#pragma unroll
+                                    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                }
+                            }
+                            cc = 0;
+                            ++ci;
+                        }
+                    }
+                }
+            }
+            if constexpr (S > 1) {          // the item's partial sums: planes out, NOT waited for; the stream goes on
+                const unsigned ntile = (unsigned)(((int)blockIdx.x + n * G) / S * RS_W + wave);
+                const unsigned off = sp * plane + (ntile * MB * 64 + lane) * 16;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    st_sc1(pr, off + mb * 1024, acc[mb]);
+                    acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#undef RS_ISSUE_W
+    }
+    // ---------------- behind the stream: acknowledge, count arrivals, finish what this workgroup completed ----------------
+    char* xch = rs_smem + 16384;      // S == 1: the waves' sums change hands through LDS (behind the sums-of-squares area), no plane round trip
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through; the trailing LDS-DMA / weight padding loads are done
+    __syncthreads();                                   // everyone is through with the slab ring
+    if constexpr (S == 1) {
+        if (wave < RS_W) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) *(f32x4*)(xch + ((wave * MB + mb) * 64 + lane) * 16) = acc[mb];
+        }
+        __syncthreads();
+    }
+    // The LAST of the S workgroups of a column group to arrive finishes it.  Arrival counter: one per (column group, log2 S), never reset - a
+    // launch adds exactly S to it (launches of one stream are ordered and every engine slot owns its workspace), so the last arrival of this
+    // launch is the one that reads S - 1 (mod S).  Nobody WAITS for anybody: a workgroup that spun for the others could deadlock against the
+    // stream-K prefill GEMMs of another stream, whose workgroups spin for each other too.
+    __shared__ int is_last[RS_MAXIT];
+    if constexpr (S > 1) {
+        if (tid < n_it) {
+            unsigned* cnt = (unsigned*)nrm.arrive + (LOG * (RV_ROWS_COUNTERS / 4) + ((int)blockIdx.x + tid * G) / S);     // (LOG of VPW: 0 .. 2 here)
+            is_last[tid] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % S == S - 1;
+        }
+        __syncthreads();
+        bool any = false;
+        for (int n = 0; n < n_it; ++n) any = any || is_last[n];
+        if (!any) return;
+    }
+    constexpr int NT = (FIN == 1 || FIN == 2) ? 2 : 1;
+    constexpr int OUT_BF16 = (FIN == 1 || FIN == 4) ? 1 : 0;
+    constexpr int ACT = FIN == 1 ? RV_ACT_SILU_MUL : RV_ACT_NONE;
+    constexpr int ROPE = FIN == 3 ? 1 : 0;
+    constexpr int BPG = RS_W / NT;                      // blocks (of NT tiles) per column group
+    constexpr int PAIRS = BPG * MB;                     // (block, row block) pairs of the group; pair p = block * MB + mb
+    constexpr int PPW = (PAIRS + RS_W - 1) / RS_W;      // pairs per consumer wave: p = wave + RS_W * i  ->  mb = p % MB
+    const int fr = lane & 15, kg = lane >> 4;
+    const int nblk = N / (16 * NT);
+    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
+    //     blocks at a time (registers)
+    float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now (once for all the groups this workgroup finishes)
+    if (nrm.in_sumsq) {
+        constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
+#pragma unroll
+        for (int m0 = 0; m0 < MB; m0 += 2) {
+            float pj[2][VT][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    const int vt = tid + v * RS_THREADS;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int b = (vt >> 4) + 32 * j;
+                        pj[i][v][j] = (m0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    const int vt = tid + v * RS_THREADS;
+                    if (vt >= 512 || m0 + i >= MB) continue;
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += pj[i][v][j];
+                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
+                    ssq[(m0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
+                }
+        }
+        __syncthreads();
+    }
+    if (wave >= RS_W) return;
+    for (int n = 0; n < n_it; ++n) {
+        if constexpr (S > 1) {
+            if (!is_last[n]) continue;
+        }
+        const int cg = ((int)blockIdx.x + n * G) / S;
+        // (1) the partial planes of this wave's pairs: agent-coherent loads, all in flight at once (one memory latency, not PPW of them)
+        f32x4 pl[PPW][NT][S];
+        if (wave < RS_W) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int p = wave + RS_W * i < PAIRS ? wave + RS_W * i : PAIRS - 1;      // (ragged last pass: a valid pair, not used)
+                const int blk = cg * BPG + p / MB, mb = p % MB;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (S == 1) {
+                        pl[i][t][0] = *(const f32x4*)(xch + (((p / MB * NT + t) * MB + mb) * 64 + lane) * 16);
+                    } else {
+                        const unsigned q = (((unsigned)(blk * NT + t) * MB + mb) * 64 + lane) * 16;
+#pragma unroll
+                        for (int w = 0; w < S; ++w) pl[i][t][w] = ld_sc1(pr, q + w * plane);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + RS_W * i;
+            if (p >= PAIRS) break;
+            const int blk = cg * BPG + p / MB, mb = p % MB;
+            f32x4 sres[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (S == 8) sres[t] = gemv_tree8(pl[i][t]);
+                else if constexpr (S == 4) sres[t] = (pl[i][t][0] + pl[i][t][1]) + (pl[i][t][2] + pl[i][t][3]);
+                else if constexpr (S == 2) sres[t] = pl[i][t][0] + pl[i][t][1];
+                else sres[t] = pl[i][t][0];
+            }
+            float tot = 0.f;
+            if (nrm.in_sumsq) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + fr];
+            }
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemv_finish<NT, OUT_BF16, ACT, WP, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
+        }
+    }
+}
+
+int rows_num_cus(int dev) {     // CUs of the device (cached per device id)
+    static std::atomic<int> cus[64];
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+// workgroups resident at once: two per CU up to 5 row blocks (60 KiB of LDS, 168 VGPRs), one with 8
+int rows_slots(int MBp) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (rows_num_cus(dev) & ~7) * (MBp <= 5 ? 2 : 1);
+}
+
 int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the smallest power of two that fills the CUs, <= 8
     const int64_t cg = N / 64;
     int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs:
                                            //  measured with the 68 B of spills it takes, 70-row step 6.85 -> 7.05 ms)
     const int fill = rv_cur_opts().rows_fill;   // workgroups a launch should at least have (tunable; 2 per CU are resident with <= 5 row blocks)
     while (s < 8 && cg * s < fill) s *= 2;
+    // More items than resident workgroups: the launch becomes a persistent grid (rows_launch); finer items then balance the streams.
+    // Cost = the longest stream in virtual k-waves; a finer split must shorten it by >= 20 % to pay for its extra planes.
+    if (rv_cur_opts().rows_persistent) {
+        const int64_t slots = rows_slots(MBp);
+        auto longest = [&](int s_) { return (cg * s_ + slots - 1) / slots * (8 / s_); };
+        if (cg * s > slots)
+            for (int s2 = s * 2; s2 <= 8; s2 *= 2)
+                if (longest(s2) * 5 <= longest(s) * 4) s = s2;
+    }
     return s;
 }
 
-template <int MB, int VPW, int FIN, int WP>
+#define RS_KERNEL (PERS ? rows_kernel_p<MB, VPW, FIN, WP> : rows_kernel<MB, VPW, FIN, WP>)
+template <int MB, int VPW, int FIN, int WP, int PERS>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
     // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
     // occupies 128 of the 256 CUs (PMC: SQ_BUSY_CU_CYCLES = 0.50 of the launch).  A launch with no more workgroups than `rows_spread`
     // asks for more LDS than two workgroups can share, so each gets a CU of its own.
-    const unsigned grid = (unsigned)(N / 64 * (8 / VPW));
+    const unsigned items = (unsigned)(N / 64 * (8 / VPW));
+    unsigned grid = items;
+    if constexpr (PERS) {
+        const unsigned slots = (unsigned)rows_slots(MB);
+        if (slots >= 8 && slots < items) grid = slots;       // a multiple of 8, hence of S: a workgroup's split never changes
+    }
+    RV_CHECK_ARG(items <= (unsigned)RS_MAXIT * grid, "gemm_rows: %u items for %u workgroups", items, grid);
     constexpr size_t alone = 81 * 1024;
     const bool spread = MB <= 5 && (int)grid <= rv_cur_opts().rows_spread;
     if (spread && lds < alone) lds = alone;
@@ -382,26 +685,33 @@ int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (lds > 65536 && !(opted.load(std::memory_order_relaxed) & bit)) {
-        if (hipFuncSetAttribute((const void*)rows_kernel<MB, VPW, FIN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)RS_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(MB <= 5 && lds < alone ? alone : lds)) != hipSuccess) {
             rv_set_error("gemm_rows: cannot reserve %zu bytes of LDS", lds);
             return RV_ERR_HIP;
         }
         opted.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((rows_kernel<MB, VPW, FIN, WP>), dim3(grid), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
+    hipLaunchKernelGGL((RS_KERNEL), dim3(grid), dim3(RS_THREADS), lds, st, X, W, nrm.planes, bias, res, ldr, C,
                        ldc, M, N, K, nrm, qr);
     return RV_OK;
 }
+#undef RS_KERNEL
 template <int MB, int FIN, int WP>
 int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                   const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
+    // more items than resident workgroups (and a real split): the persistent grid with deferred hand-overs
+    // (5 row blocks: only the S = 4 instantiation of the persistent kernel is spill-free - S = 2 needs 8 more VGPRs than three waves per SIMD have)
+    const bool pers = S > 1 && rv_cur_opts().rows_persistent && (int64_t)(N / 64) * S > rows_slots(MB) && (MB != 5 || S == 4);
+#define RS_LAUNCH(VPW_) (pers ? rows_launch<MB, VPW_, FIN, WP, 1>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st) \
+                              : rows_launch<MB, VPW_, FIN, WP, 0>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st))
     switch (S) {
-        case 1: return rows_launch<MB, 8, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        case 2: return rows_launch<MB, 4, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        case 4: return rows_launch<MB, 2, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
-        default: return rows_launch<MB, 1, FIN, WP>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 1: return rows_launch<MB, 8, FIN, WP, 0>(X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+        case 2: return RS_LAUNCH(4);
+        case 4: return RS_LAUNCH(2);
+        default: return RS_LAUNCH(1);
     }
+#undef RS_LAUNCH
 }
 template <int FIN, int WP>
 int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,

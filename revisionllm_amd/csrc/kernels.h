@@ -12,6 +12,7 @@ struct RvOpts {
     int fp8_prefill = 1;        // use bound ".f8p" prefill weight copies
     int sample_variant = 1;     // 1 compacted-candidate top-k fast path, 0 general selection (identical outputs)
     int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
+    int rows_persistent = 1;    // 33 .. 128-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
     int rows_spread = 0;        // 33 .. 128-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
     int rows_fill = 240;        // 33 .. 128-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
 };

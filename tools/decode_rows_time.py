@@ -13,6 +13,8 @@ eng.init_synthetic(seed=0, llm=True, clip=False, fp8_decode=fp8)
 for a in sys.argv:
     if a.startswith("--fill="):
         eng.set_option("rows_fill", int(a.split("=")[1]))
+    if a == "--one-item-per-workgroup":
+        eng.set_option("rows_persistent", 0)
     if a.startswith("--spread="):
         eng.set_option("rows_spread", int(a.split("=")[1]))
 D, V = eng.shape.hidden, eng.shape.vocab
