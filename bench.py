@@ -82,12 +82,13 @@ def parse():
                    help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
                         "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
     p.add_argument("--pool-rows", type=int, default=70,
-                   help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 128: the split-K kernel with LDS-shared activations)")
+                   help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 144: the split-K kernel with LDS-shared activations)")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
     p.add_argument("--fp8-prefill", action="store_true",
                    help="extra measurement (NOT the headline): prefill GEMMs run FP8 x FP8 (activations quantised per row on the fly)")
+    p.add_argument("--gemm-waves", type=int, default=0, choices=(0, 4, 8), help="waves per workgroup of the persistent prefill GEMMs (0 = the library default; see include/revision_hip.h)")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--gemm-variant", type=int, default=2, help="rv_ctx_set_option gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--settle", type=int, default=16,
@@ -155,7 +156,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         gthreads = (2 * s.inter // 32) * (256 if dec_rows > 16 else 512)
     else:
         f = hip.lib().rv_gemm_rows
-        mbp = 4 if dec_rows <= 64 else 5 if dec_rows <= 80 else 8
+        mbp = ops.xp_blocks(dec_rows)
         xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(torch.bfloat16)          # fragment-packed rows (any values: timing)
         outs = torch.empty(mbp * 16 * s.inter, dtype=torch.bfloat16, device=dev)
         planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
@@ -166,9 +167,13 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
                    hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
-        split = 2 if mbp >= 5 else 1      # (rows_splits in gemm_rows.hip)
-        kname = f"rows_kernel<{mbp},{8 // split},1,1>"
-        gthreads = (2 * s.inter // 64) * split * 320
+        # what rows_splits / rows_by_split (gemm_rows.hip) pick for this shape (344 column groups): 4 row blocks: one workgroup per group;
+        # 5: 4 splits = 1376 items on a persistent grid of 2 workgroups per CU; 8 / 9: 2 splits = 688 items, one workgroup per CU
+        cgs, slots = 2 * s.inter // 64, (cus & ~7) * (2 if mbp <= 5 else 1)
+        split = 1 if mbp == 4 else 4 if mbp == 5 else 2
+        pers = split > 1 and cgs * split > slots
+        kname = f"rows_kernel{'_p' if pers else ''}<{mbp},{8 // split},1,1>"
+        gthreads = (slots if pers else cgs * split) * 320
     ms = event_time_ms(gemv, 64, warm=4)
     legs["decode_gateup_gemv"] = dict(kernel=kname, bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic=nbytes,
                                       rows=dec_rows, grid_threads=gthreads, timing="64 back-to-back launches of this kernel alone (layers rotated); "
@@ -402,6 +407,8 @@ def main():
     eng.set_option("fp8_decode", 1 if args.fp8_decode else 0)
     eng.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
     eng.set_option("gemm_cus", args.gemm_cus)
+    if args.gemm_waves:
+        eng.set_option("gemm_waves", args.gemm_waves)
     shared_gpu = world > max(torch.cuda.device_count(), 1)
     if shared_gpu:
         # plumbing run (several ranks on ONE GPU, e.g. REVISION_DIST_BACKEND=gloo on a 1-GPU box): the persistent stream-K prefill GEMMs
@@ -716,24 +723,24 @@ def main():
         small_leg("prefill_only_G1", prefill_only,
                   "G = 1: adapter + prefill + the first sampled token only, no KV-cached decode step (SURVEY 8d: separates the phases); same pipeline, "
                   "same steps in flight")
-        # steady state with wider gangs: 112-row pools (16 recursions per merged step on the 8-row-block split-K kernel), 32 steps in flight,
-        # 64 timed steps after 32 warm-up steps - what the pipeline sustains when the fill / drain of a 20-step run no longer matters
+        # steady state with wider gangs: 140-row pools (20 recursions per merged step on the 9-row-block split-K kernel), 40 steps in flight,
+        # 80 timed steps after 40 warm-up steps - what the pipeline sustains when the fill / drain of a 20-step run no longer matters
         if server is not None and args.pools > 1 and world == 1:
             old_streams = streams
             try:
                 from revisionllm_amd import serve
                 work["sets"] = input_sets(1)
-                wide = serve.DecodeServer(model, rows=112, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130)
+                wide = serve.DecodeServer(model, rows=140, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130)
                 inter.servers.append(wide)
                 stages.server = wide
-                streams = [torch.cuda.Stream(dev) for _ in range(32)]
-                work["depth"] = 32
-                t, _ = timed(run, steps=64, warm=32)
-                extra["steady_state_112_row_pools"] = {"value": W * 64 / t, "unit": "segments/s", "ms_per_step": t / 64 * 1e3, "steps": 64, "warmup": 32,
-                                                       "steps_in_flight": 32, "rows_per_merged_step": wide.rows_served / max(1, wide.steps_run),
+                streams = [torch.cuda.Stream(dev) for _ in range(40)]
+                work["depth"] = 40
+                t, _ = timed(run, steps=80, warm=40)
+                extra["steady_state_140_row_pools"] = {"value": W * 80 / t, "unit": "segments/s", "ms_per_step": t / 80 * 1e3, "steps": 80, "warmup": 40,
+                                                       "steps_in_flight": 40, "rows_per_merged_step": wide.rows_served / max(1, wide.steps_run),
                                                        "note": "same workload and kernels; longer run, wider gangs (NOT the headline: the headline keeps the contract's K / W)"}
             except Exception as e:  # noqa: BLE001
-                extra["steady_state_112_row_pools"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                extra["steady_state_140_row_pools"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 try:
                     torch.cuda.synchronize()
                 except Exception:  # noqa: BLE001
@@ -793,7 +800,7 @@ def main():
         pf_groups = 1
         if server is not None and server.prefill_batch > 1 and server.pf_batches:
             pf_groups = max(server.pf_hist, key=server.pf_hist.get)       # the pass size that served most steps of this run: 1, 2, 4 or 8 prefills
-        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(128, gang * n_calls_rank), prefill_groups=pf_groups)
+        legs = roofline_legs(model, n_calls_rank, M_prefill, dec_rows=min(144, gang * n_calls_rank), prefill_groups=pf_groups)
         # dominant = the larger share of a recursion: 32 prefill launches shared by `pf_groups` recursions, or 32 x G decode launches
         # shared by `gang` recursions
         dom = max((legs[k] for k in ("prefill_gateup_gemm", "decode_gateup_gemv")),

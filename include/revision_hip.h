@@ -77,12 +77,16 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        "<name>.s8" next to every LLM projection and lm_head); 0: always decode on the bf16 weights
  *   "fp8_prefill"        1 (default): prefill passes run their QKV / o / gate-up / down GEMMs as FP8 x FP8 when the "<name>.f8p"
  *                        copies of every layer are bound and the shape has a persistent plan; 0: always the bf16 weights
- *   "rows_persistent"    1 (default): a 33 .. 128-row decode projection with more (column group, split) items than workgroups fit the chip at once
+ *   "gemm_waves"         8 (default) / 4: waves of a persistent prefill GEMM workgroup (bf16 operands, 256-column panels): 8 = two waves per SIMD
+ *                        in ping-pong (128 x 64 outputs each); 4 = one wave per SIMD owning 128 x 128 outputs (accumulators in the AGPR half of
+ *                        the register file; 128 instead of 192 KiB of LDS fragment reads per k-tile).  Bit-identical results; measured level
+ *                        with 8 up to ~4000 rows (0 .. -2.5 %) and ahead for more rows (8192^3: +30 %).  FP8 x FP8 and 192-column forms: always 8.
+ *   "rows_persistent"    1 (default): a 33 .. 144-row decode projection with more (column group, split) items than workgroups fit the chip at once
  *                        runs as a persistent grid whose workgroups stream several items back to back and hand their partial sums over once, at
  *                        the end; 0: one workgroup per item (the round-2 launch).  Same results.
- *   "rows_spread"        the 33 .. 128-row decode projections: a launch with at most this many workgroups asks for a CU per workgroup
+ *   "rows_spread"        the 33 .. 144-row decode projections: a launch with at most this many workgroups asks for a CU per workgroup
  *                        (more LDS than two can share) instead of being packed two to a CU (0 = never)
- *   "rows_fill"          (default 240) the 33 .. 128-row decode projections split K (2 / 4 / 8 ways) until a launch has at least this many
+ *   "rows_fill"          (default 240) the 33 .. 144-row decode projections split K (2 / 4 / 8 ways) until a launch has at least this many
  *                        workgroups; measurement knob (same results whatever the split: the summation tree is fixed)
  *   "sample_variant"     1 (default) = top-k selection through the compacted-candidate fast path when the row qualifies (V >= 1024,
  *                        no tie across the k-th place); 0 = always the general 16-round selection.  Identical outputs.
@@ -137,9 +141,9 @@ int rv_gemm_fp8(const rv_ctx* ctx /* optional: tunables */, const void* A8, int6
 int rv_gemm(const rv_ctx* ctx /* optional: tunables */, const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias, const float* residual,
             int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws,
             size_t ws_bytes, void* stream);
-/* One projection of a MERGED decode step (33 .. 128 rows; what rv_llm_decode_rows launches four times per block):
+/* One projection of a MERGED decode step (33 .. 144 rows; what rv_llm_decode_rows launches four times per block):
  * C[M,N] = act(X . Wp^T), X = M bf16 rows in the fragment-packed decode layout - element (r, k) at
- *     ((((k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7),   mbp = 4 (M <= 64), 5 (<= 80), 8 (<= 128)
+ *     ((((k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7),   mbp = 4 (M <= 64), 5 (<= 80), 8 (<= 128), 9 (<= 144)
  * row blocks (16 * mbp rows allocated) -, Wp fragment-packed as for rv_gemm (w_scale == NULL) or, with w_scale f32 [N], the FP8
  * (e4m3fn) bytes of rv_gemv_fp8's layout (opt-in fp8 LLM path: half the weight bytes, widened to bf16 in registers), C row-major
  * (ldc = N, or N / 2 with RV_ACT_SILU_MUL, which writes bf16).  planes: workspace of rv_gemm_rows_ws_bytes() bytes; arrive: 2048 int32 arrival counters, ZERO before the first launch
@@ -198,7 +202,7 @@ int rv_llm_forward(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, vo
 /* Blocks [layer_begin, layer_end) of the decoder stack over h f32 [B,S,D], in place: the residual stream behind block
  * layer_end - 1, no final norm, no lm_head (rv_llm_forward = rv_llm_layers(0, L) + model.norm + lm_head on the last position).
  * Same kernels, cache layout and workspace as rv_llm_forward: S > 1 prefill rows at positions 0..S-1 (pos0 = 0), S == 1 one
- * KV-cached decode step at pos0 (B <= 128; above 32 rows the split-K decode kernel); only the cache planes of those blocks are
+ * KV-cached decode step at pos0 (B <= 144; above 32 rows the split-K decode kernel); only the cache planes of those blocks are
  * touched.  This is what the per-layer parity tests drive: block l is fed the REFERENCE's input of block l
  * (transformers LlamaDecoderLayer.forward as called from vtimellm_llama.py:79-90) and compared with the reference's output. */
 int rv_llm_layers(rv_ctx* ctx, float* h, int32_t B, int32_t S, int32_t pos0, void* kv, int32_t Smax, int32_t layer_begin,
@@ -217,8 +221,8 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  * steps can be merged into one pass over the weights (a decode step streams all 13 GB whatever the number of rows).
  * rv_llm_prefill_pool: rv_llm_prefill_shared (P0 > 0) / rv_llm_forward prefill (P0 = 0) of B sequences whose cache rows are
  *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
- * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 128: up to 32 rows take the weight-streaming kernel,
- * 33 .. 128 the split-K kernel with LDS-shared activations; both stream the FP8 weight copies when bound and enabled), row r at its OWN position row_pos[r]
+ * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 144: up to 32 rows take the weight-streaming kernel,
+ * 33 .. 144 the split-K kernel with LDS-shared activations; both stream the FP8 weight copies when bound and enabled), row r at its OWN position row_pos[r]
  *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified; an active row
  *   needs row_pos[r] < Smax (NOT checked: the positions live on the device).  h f32 [R, D]
  *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.

@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "librevision_hip.so")
-SOURCES = ["error.hip", "init.hip", "gemm.hip", "gemm_pp.hip", "gemm_arows.hip", "gemm_rows.hip", "rowops.hip", "attention.hip", "sample.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", "gemv_finish.h", os.path.join("..", "..", "include", "revision_hip.h")]
+SOURCES = ["error.hip", "init.hip", "gemm.hip", "gemm_pp.hip", "gemm_arows.hip", "gemm_rows.hip", "gemm_rows_p1.hip", "gemm_rows_p2.hip", "gemm_rows_p3.hip", "rowops.hip", "attention.hip", "sample.hip", "engine.hip"]
+HEADERS = ["common.h", "kernels.h", "gemv_finish.h", "gemm_rows.hip", os.path.join("..", "..", "include", "revision_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 
@@ -47,7 +47,7 @@ def build_library(force=False, verbose=False):
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

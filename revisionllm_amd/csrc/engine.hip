@@ -275,6 +275,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "rows_fill") return &o.rows_fill;
     if (k == "rows_spread") return &o.rows_spread;
     if (k == "rows_persistent") return &o.rows_persistent;
+    if (k == "gemm_waves") return &o.gemm_waves;
     return nullptr;
 }
 }  // namespace
@@ -285,6 +286,7 @@ extern "C" int rv_ctx_set_option(rv_ctx* c, const char* key, int64_t value) {
     RV_CHECK_ARG(slot, "rv_ctx_set_option: unknown option '%s'", key);
     const std::string k(key);
     if (k == "gemm_tile_variant") RV_CHECK_ARG(value >= 0 && value <= 6, "rv_ctx_set_option: gemm_tile_variant must be in [0, 6]");
+    if (k == "gemm_waves") RV_CHECK_ARG(value == 4 || value == 8, "rv_ctx_set_option: gemm_waves must be 4 or 8");
     if (k == "gemm_cus") RV_CHECK_ARG(value >= 0 && value % 8 == 0, "rv_ctx_set_option: gemm_cus must be a non-negative multiple of 8");
     *slot = (int)value;
     return RV_OK;
@@ -438,7 +440,7 @@ namespace {
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
     float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
-    float* planes;   // split-K partial planes of the 33 .. 128-row decode kernel
+    float* planes;   // split-K partial planes of the 33 .. 144-row decode kernel
     int* arrive;     // ... and its arrival counters: at a FIXED offset (right behind sk) whatever the carve's row count, zero from the allocation on
     uint8_t* x8;     // FP8 prefill: the quantised GEMM operand [M, max(D, F)] ...
     float* sa;       // ... and its row scales [M]
@@ -453,14 +455,14 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.sk_bytes = gemm_pp_ws_bytes();
     w.sk = k.take(w.sk_bytes);
     w.arrive = (int*)k.take((size_t)RV_ROWS_COUNTERS * 4);
-    const int64_t Mp = M <= 128 ? 16 * rv_xp_blocks(M) : M;   // the fragment-packed decode layout spans whole row blocks
+    const int64_t Mp = M <= RV_ROWS_MAX ? 16 * rv_xp_blocks(M) : M;   // the fragment-packed decode layout spans whole row blocks
     w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2);
     w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
     w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2);
     w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2);
     w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
-    w.ss = (float*)k.take((size_t)8 * (D / 16) * 16 * 4);   // [<= 8 row blocks][D/16 workgroups][16]
+    w.ss = (float*)k.take((size_t)RV_XP_MAX_BLOCKS * (D / 16) * 16 * 4);   // [<= 9 row blocks][D/16 workgroups][16]
     w.planes = (float*)k.take(gemm_rows_ws_bytes());
     w.x8 = (uint8_t*)k.take((size_t)M * (F > D ? F : D));
     w.sa = (float*)k.take((size_t)M * 4);
@@ -507,8 +509,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     else RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
     // Decode steps (M <= 32 rows) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
-    const bool fuse_norm = S == 1 && P0 == 0 && M <= 128 && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
-    const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only (any row count <= 128)
+    const bool fuse_norm = S == 1 && P0 == 0 && M <= RV_ROWS_MAX && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
+    const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only (any row count <= 144)
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
     const bool p8 = !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
@@ -722,7 +724,7 @@ extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t*
                                   size_t ws_bytes, void* stream) {
     RV_CHECK_ARG(c && h && row_pos && kv && logits && ws, "rv_llm_decode_rows: null argument");
     RvOptScope scope(&c->opt);
-    RV_CHECK_ARG(R > 0 && R <= 128, "rv_llm_decode_rows: 1 .. 128 rows per step (got %d)", R);
+    RV_CHECK_ARG(R > 0 && R <= RV_ROWS_MAX, "rv_llm_decode_rows: 1 .. %d rows per step (got %d)", RV_ROWS_MAX, R);
     RV_CHECK_ARG(Smax % 32 == 0, "rv_llm_decode_rows: Smax=%d must be a multiple of 32", Smax);
     return llm_forward_impl(c, h, R, 1, 0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), R, 0, row_pos);
 }

@@ -800,7 +800,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     const bool gemv = (M <= 32) && (K % 128 == 0) && (N % 16 == 0);   // 17 .. 32 rows: two MFMA column blocks per weight fragment
-    if (norm && norm->planes && M > 32 && M <= 128 && w_layout >= 1)   // 33 .. 128 rows of a merged decode step: the split-K kernel (bf16 or fp8 W)
+    if (norm && norm->planes && M > 32 && M <= RV_ROWS_MAX && w_layout >= 1)   // 33 .. 144 rows of a merged decode step: the split-K kernel (bf16 or fp8 W)
         return gemm_rows(a, w, bias, residual, ldr, C, ldc, out_dtype, act, (int)M, (int)N, (int)K, st, *norm, nullptr, w_layout);
     RV_CHECK_ARG(!norm || gemv, "rv_gemm: RMSNorm fusion / fp8 weights are only available in the M <= 32 kernel");
     const GemvNorm nrm = norm ? *norm : GemvNorm{};
@@ -870,7 +870,7 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
         else
             hipLaunchKernelGGL((gemv_stream<1, 0, RV_ACT_NONE, 2, 1>), dim3((unsigned)(N / 16)), dim3(512), 0, st, a, lda, w, (int64_t)K, nullptr,
                                nullptr, (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, *norm, r);
-    } else if (M > 32 && M <= 128 && r.S == 1 && norm && norm->planes && w_layout >= 1) {
+    } else if (M > 32 && M <= RV_ROWS_MAX && r.S == 1 && norm && norm->planes && w_layout >= 1) {
         return gemm_rows(a, w, nullptr, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, (int)M, N, K, st, *norm, &r, w_layout);
     } else if (M <= 32 && (r.S == 1 || M <= 16)) {     // KV-cached decode rows (17 .. 32: several recursions' steps merged)
         if (M > 16)

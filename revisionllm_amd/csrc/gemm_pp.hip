@@ -279,6 +279,153 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
 
+// ---- the FOUR-wave form of the 256 x 256 x 64 tile (bf16 operands, 256-column panels) --------------------------------------------
+// One wave per SIMD, 2 (M) x 2 (N) waves of 128 x 128 outputs: 64 accumulator fragments = 256 registers, pinned to the AGPR half of the
+// unified file, plus two operand fragment sets (k32 halves, 2 x 64 VGPRs).  Per k-tile the workgroup then reads 128 KiB of fragments
+// from LDS (the eight-wave form above: 192 KiB) and there is no second wave on a SIMD to keep in lock-step: every wave interleaves its
+// own ds_reads and LDS-DMA issues between its MFMAs (two MFMAs, one memory instruction, pinned with sched_barrier).  Same LDS budget
+// and latency distances as above: two A stages (one tile ahead) + three W stages (two tiles ahead) = 160 KiB; ONE barrier per k-tile,
+// in the middle: behind it the first half's operands (k32 half 0 of the next tile) are read and the stages the tile has finished with
+// (its A stage and W stage: all of their fragments are in registers by then) are refilled.  The MFMAs are inline asm: the register
+// allocator, left to choose, trades accumulators and operand fragments between the two halves of the file inside the loop.
+// tools/micro/gemm4w.hip is the stand-alone probe this came from (4096^3 sustained: 98 us against 102 us for the eight-wave form).
+struct Pp4Src {
+    const char* A;
+    const char* W;
+    unsigned a[8];   // this wave's 8 pieces (8 rows x 128 B) of the A tile, k = 0
+    unsigned w[8];   // this wave's 8 pieces (fragment nfrag = wave * 4 + (i >> 1), k32 half i & 1) of the W tile
+};
+__device__ __forceinline__ void pp4_sources(Pp4Src& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int K,
+                                            int m0, int n0, int wave, int lane) {
+    s.A = (const char*)A;
+    s.W = (const char*)Wp;
+    const int kfr = K >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int g = m0 + (wave * 8 + i) * 8 + (lane >> 3);   // LDS slot (lane & 7) of the row holds global chunk slot ^ (row & 7)
+        g = g < M ? g : M - 1;
+        s.a[i] = (unsigned)(((int64_t)g * lda + (((lane & 7) ^ (lane >> 3)) * 8)) * 2);
+        const int nb = (n0 >> 4) + wave * 4 + (i >> 1);
+        s.w[i] = (unsigned)(((((int64_t)nb * kfr + (i & 1)) * 64 + lane) * 8) * 2);
+    }
+}
+constexpr int PP4_TILE = 256 * 64 * 2;   // bytes of one operand tile: stages A0 A1 W0 W1 W2
+template <int DUMMY = 0>
+__device__ __forceinline__ void pp4_mainloop(f32x4 (&acc)[8][8], const Pp4Src& src, int kt0, int nks, char* smem, int wave, int lane) {
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+    const int a_rd = (wr * 128 + fr) * 128;
+    const int a_c[2] = {((kg ^ (fr & 7)) << 4), (((4 + kg) ^ (fr & 7)) << 4)};
+    const int w_rd = wc * 16384 + lane * 16;
+    bf16x8 fa[2][8], fw[2][8];
+#define P4_A_STAGE(c) (smem + ((c) & 1) * PP4_TILE)
+#define P4_W_STAGE(ws) (smem + (2 + (ws)) * PP4_TILE)
+#define P4_ISSUE_A(KT, ST, i) glds16(src.A + (int64_t)(KT) * 128 + src.a[i], (ST) + (wave * 8 + (i)) * 1024)
+#define P4_ISSUE_W(KT, ST, i) glds16(src.W + (int64_t)(KT) * 2048 + src.w[i], (ST) + (wave * 8 + (i)) * 1024)
+#define P4_READ_A(B, ST, KS, f) fa[B][f] = *(const bf16x8*)((ST) + a_rd + (f) * 2048 + a_c[KS])
+#define P4_READ_W(B, ST, KS, j) fw[B][j] = *(const bf16x8*)((ST) + w_rd + (j) * 2048 + (KS) * 1024)
+#define P4_MFMA1(B, j, f) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][f]) : "v"(fw[B][j]), "v"(fa[B][f]));
+#define P4_MFMA2(B, j, f) P4_MFMA1(B, j, f) P4_MFMA1(B, j, (f) + 1)
+#define P4_PIN __builtin_amdgcn_sched_barrier(0);
+    const int last = kt0 + nks - 1;
+    auto kclamp = [&](int k) { return k < last ? k : last; };   // past the range: the last tile again, into a stage nobody reads
+    // prologue: A(0), W(0), W(1), A(1), W(2) in that order (a wave's loads retire in order; see the counted wait below)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P4_ISSUE_A(kt0, P4_A_STAGE(0), i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P4_ISSUE_W(kt0, P4_W_STAGE(0), i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P4_ISSUE_W(kclamp(kt0 + 1), P4_W_STAGE(1), i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P4_ISSUE_A(kclamp(kt0 + 1), P4_A_STAGE(1), i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P4_ISSUE_W(kclamp(kt0 + 2), P4_W_STAGE(2), i);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { P4_READ_A(0, P4_A_STAGE(0), 0, f); P4_READ_W(0, P4_W_STAGE(0), 0, f); }
+    int ws = 0;
+    for (int c = 0; c < nks; ++c) {
+        char* a_cur = P4_A_STAGE(c);
+        char* a_nxt = P4_A_STAGE(c + 1);
+        char* w_cur = P4_W_STAGE(ws);
+        const int ws1 = ws == 2 ? 0 : ws + 1;
+        char* w_nxt = P4_W_STAGE(ws1);
+        const int ka = kclamp(kt0 + c + 2), kw = kclamp(kt0 + c + 3);
+        P4_PIN
+        // first half: MFMAs on (c, k32 half 0) while the fragments of (c, half 1) arrive
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            P4_MFMA2(0, j, 0) P4_PIN
+            P4_READ_A(1, a_cur, 1, j); P4_MFMA2(0, j, 2) P4_PIN
+            P4_READ_W(1, w_cur, 1, j); P4_MFMA2(0, j, 4) P4_PIN
+            P4_MFMA2(0, j, 6) P4_PIN
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // A(c + 1), W(c + 1) landed; W(c + 2) may stay in flight
+        __builtin_amdgcn_s_barrier();
+        P4_PIN
+        // second half: MFMAs on (c, half 1); fragments of (c + 1, half 0) arrive; A(c + 2) -> this tile's A stage, W(c + 3) -> its W stage
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            P4_MFMA2(1, j, 0) P4_PIN
+            if (j < 4) { P4_READ_A(0, a_nxt, 0, 2 * j); P4_ISSUE_A(ka, a_cur, 2 * j); } else { P4_READ_W(0, w_nxt, 0, 2 * (j - 4)); P4_ISSUE_W(kw, w_cur, 2 * (j - 4)); }
+            P4_MFMA2(1, j, 2) P4_PIN
+            if (j < 4) { P4_READ_A(0, a_nxt, 0, 2 * j + 1); } else { P4_READ_W(0, w_nxt, 0, 2 * (j - 4) + 1); }
+            P4_MFMA2(1, j, 4) P4_PIN
+            if (j < 4) { P4_ISSUE_A(ka, a_cur, 2 * j + 1); } else { P4_ISSUE_W(kw, w_cur, 2 * (j - 4) + 1); }
+            P4_MFMA2(1, j, 6) P4_PIN
+        }
+        ws = ws1;
+    }
+    // drain: the clamped loads of the last tiles and the fragment reads behind the last barrier target LDS the next user rewrites;
+    // the MFMA results are read by ordinary VALU code from here on (the compiler does not see the asm as an MFMA: cover the hazard)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#undef P4_A_STAGE
+#undef P4_W_STAGE
+#undef P4_ISSUE_A
+#undef P4_ISSUE_W
+#undef P4_READ_A
+#undef P4_READ_W
+#undef P4_MFMA1
+#undef P4_MFMA2
+#undef P4_PIN
+}
+
+// One row's NFR fragments (columns slab0 + ni * 16 + kg * 4 .. + 3 of head `head` in section `sec`; slab0 = offset of the wave's slab in the head).
+template <int NFR>
+__device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const QkvRope& qr, const QkvRow& row, int sec, int head, int slab0, int kg) {
+    const int p0 = slab0 + kg * 4;
+    if (sec == 2) {
+        for (int bb = row.b0; bb < row.b1; ++bb) {
+            bf16_t* dst = (bf16_t*)qr.vtc + (((int64_t)bb * qr.H + head) * 128 + p0) * qr.Smax + row.pos;
+#pragma unroll
+            for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(int64_t)(ni * 16 + e) * qr.Smax] = f32_to_bf16(v[ni][e]);
+        }
+        return;
+    }
+    u32x2 o[NFR];
+#pragma unroll
+    for (int ni = 0; ni < NFR; ++ni) {
+        const f32x4 t = *(const f32x4*)(row.cs + (p0 + ni * 16));   // pairs (p >> 1) of p = p0 + ni * 16: (c0, s0, c1, s1) at cs + (p >> 1) * 2
+        const float a0 = __fmaf_rn(v[ni][0], t[0], -__fmul_rn(v[ni][1], t[1])), b0 = __fmaf_rn(v[ni][1], t[0], __fmul_rn(v[ni][0], t[1]));
+        const float a1 = __fmaf_rn(v[ni][2], t[2], -__fmul_rn(v[ni][3], t[3])), b1 = __fmaf_rn(v[ni][3], t[2], __fmul_rn(v[ni][2], t[3]));
+        o[ni] = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+    }
+    if (sec == 0) {
+        bf16_t* dst = (bf16_t*)qr.q16 + (int64_t)row.mrow * (qr.H * 128) + head * 128 + p0;
+#pragma unroll
+        for (int ni = 0; ni < NFR; ++ni) *(u32x2*)(dst + ni * 16) = o[ni];
+    } else {
+        for (int bb = row.b0; bb < row.b1; ++bb) {
+            bf16_t* dst = (bf16_t*)qr.kc + (((int64_t)bb * qr.H + head) * qr.Smax + row.pos) * 128 + p0;
+#pragma unroll
+            for (int ni = 0; ni < NFR; ++ni) *(u32x2*)(dst + ni * 16) = o[ni];
+        }
+    }
+}
 // Epilogue: lane owns row m = .. + fr, columns n = .. + kg * 4 .. + 3 of every 16 x 16 fragment.
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const float* __restrict__ bias, const float* res, int64_t ldr,
@@ -295,7 +442,17 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
         f32x4 acc[NF][1];   // this row block's fragments, dequantised for FP8 operands ([.][0] keeps the indexing below)
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) acc[ni][0] = F8 ? pp_scaled(sc, m, n0 + wc * WN + ni * 16 + kg * 4, acc_in[ni][mi]) : acc_in[ni][mi];
-        if constexpr (ROPE) {
+        if constexpr (ROPE && NF == 4) {   // 64-column slab: one head of one section (see pp_rope_row_store)
+            const int D = qr.H * 128, nb = n0 + wc * WN;
+            const int sec = __builtin_amdgcn_readfirstlane(nb / D), hd0 = nb - sec * D;
+            const QkvRow row = qkv_rope_row(qr, m);
+            if (row.b1 > row.b0) {
+                f32x4 v[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) v[ni] = acc[ni][0];
+                pp_rope_row_store<4>(v, qr, row, sec, hd0 >> 7, hd0 & 127, kg);
+            }
+        } else if constexpr (ROPE) {
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) qkv_rope_store(qr, m, n0 + wc * WN + ni * 16 + kg * 4, acc[ni][0]);
         } else if (ACT == RV_ACT_SILU_MUL) {
@@ -314,6 +471,66 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
             for (int ni = 0; ni < NF; ++ni) {
                 const int n = n0 + wc * WN + ni * 16 + kg * 4;
                 f32x4 v = acc[ni][0];
+                if (bias) v += *(const f32x4*)(bias + n);
+                if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
+                }
+                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
+            }
+        }
+    }
+}
+
+// Whole-panel epilogue of the four-wave form: wave = (wr, wc) owns rows wr * 128 .. + 127, columns wc * 128 .. + 127; acc[nj][mi].
+// The fused QKV form: a wave's 128 (64 in the eight-wave form) columns lie in ONE head of ONE section (q, k or v: D and the slab start are
+// multiples of the slab width, which divides 128), so section and head are decided once per panel (uniform) and the row (group, sequence,
+// position, table row: two integer divisions) once per row block instead of once per fragment.  Values and addresses are those of
+// qkv_rope_store (kernels.h) - with its per-fragment section tests inlined 64 times the register allocator gave up on keeping the
+// four-wave form's accumulators in place.
+template <int OUT_BF16, int ACT, int ROPE>
+__device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                             int64_t ldc, int M, int m0, int n0, int wave, int lane, const QkvRope& qr) {
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+    if constexpr (ROPE) {
+        const int D = qr.H * 128, nb = n0 + wc * 128;
+        const int sec = __builtin_amdgcn_readfirstlane(nb / D), hd0 = nb - sec * D, head = hd0 >> 7;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wr * 128 + mi * 16 + fr;
+            if (m >= M) continue;
+            const QkvRow row = qkv_rope_row(qr, m);
+            if (row.b1 <= row.b0) continue;
+            f32x4 v[8];
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) v[ni] = acc[ni][mi];
+            pp_rope_row_store<8>(v, qr, row, sec, head, 0, kg);
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wr * 128 + mi * 16 + fr;
+        if (m >= M) continue;
+        if (ACT == RV_ACT_SILU_MUL) {
+#pragma unroll
+            for (int ni = 0; ni < 8; ni += 2) {
+                const int n = n0 + wc * 128 + ni * 16;
+                const int no = (n >> 1) + kg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const int n = n0 + wc * 128 + ni * 16 + kg * 4;
+                f32x4 v = acc[ni][mi];
                 if (bias) v += *(const f32x4*)(bias + n);
                 if (ACT == RV_ACT_RELU || ACT == RV_ACT_QUICK_GELU) {
 #pragma unroll
@@ -395,14 +612,15 @@ __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
 }
 
 // Epilogue of one reduction unit = the fragment pair (ni = 2 nip, 2 nip + 1) x mi of wave w's sub-tile.
-template <int OUT_BF16, int ACT, int ROPE, int F8 = 0>
+// (W4: the four-wave form - wave w = (w >> 1, w & 1) owns 128 x 128 outputs, four fragment pairs per row block)
+template <int OUT_BF16, int ACT, int ROPE, int F8 = 0, int W4 = 0>
 __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int mi, int nip, const float* __restrict__ bias,
                                                  const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int m0, int n0, int lane,
                                                  const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr}) {
     const int fr = lane & 15, kg = lane >> 4;
-    const int m = m0 + (w >> 2) * 128 + mi * 16 + fr;
+    const int m = m0 + (W4 ? (w >> 1) : (w >> 2)) * 128 + mi * 16 + fr;
     if (m >= M) return;
-    const int nf = n0 + (w & 3) * 64 + nip * 32;   // first column of fragment ni = 2 nip
+    const int nf = n0 + (W4 ? (w & 1) * 128 : (w & 3) * 64) + nip * 32;   // first column of fragment ni = 2 nip
     if constexpr (F8) {
         v0 = pp_scaled(sc, m, nf + kg * 4, v0);
         v1 = pp_scaled(sc, m, nf + 16 + kg * 4, v1);
@@ -436,15 +654,16 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
 
 // Reduce + store this workgroup's share of a shared panel: units x = j, j + c, ... of the 128 (wave, mi, ni-pair) units,
 // dealt to the 8 waves.  C participants are read per pass (ids[base .. base + C), absent ones masked); C = c for c <= 4.
-template <int C, int OUT_BF16, int ACT, int ROPE, int F8 = 0>
+template <int C, int OUT_BF16, int ACT, int ROPE, int F8 = 0, int W4 = 0>
 __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, int c, int j, int wave, int lane,
                                                 const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv, int64_t ldc,
                                                 int M, int m0, int n0, const QkvRope& qr, const PpScale& sc = PpScale{nullptr, nullptr},
                                                 float poison = 0.f) {
     // poison: 0 normally; NaN when a participant never published its partial tile (bounded wait expired): the share is then
     // stored as NaN instead of a silently incomplete sum
-    constexpr int UPW = C <= 4 ? (128 + 8 * C - 1) / (8 * C) : 1;   // units per wave and pass
-    const int per_pass = 8 * UPW;
+    constexpr int NW = W4 ? 4 : 8;                                  // waves of the workgroup
+    constexpr int UPW = C <= 4 ? (128 + NW * C - 1) / (NW * C) : 1;   // units per wave and pass
+    const int per_pass = NW * UPW;
     for (int q0 = 0; j + q0 * c < 128; q0 += per_pass) {
         f32x4 s[UPW][2];
 #pragma unroll
@@ -457,8 +676,10 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
                 const __amdgpu_buffer_rsrc_t r = pp_slot_rsrc(partial, __builtin_amdgcn_readfirstlane(ids[have ? base + i : 0]));
 #pragma unroll
                 for (int u = 0; u < UPW; ++u) {
-                    const int x = j + (q0 + wave + 8 * u) * c;
-                    const unsigned off = (have && x < 128) ? (unsigned)((((x >> 4) * 32 + (x & 1) * 16 + ((x >> 1) & 7)) * 64 + lane) * 16) : PP_OOB;
+                    const int x = j + (q0 + wave + NW * u) * c;
+                    // unit x -> (wave, mi, fragment pair): the published order is fragment (wave, ni, mi) at ((wave * F + ni * 8 + mi) * 64 + lane) * 16, F = 32 / 64
+                    const unsigned fragx = W4 ? (unsigned)((x >> 5) * 64 + (x & 3) * 16 + ((x >> 2) & 7)) : (unsigned)((x >> 4) * 32 + (x & 1) * 16 + ((x >> 1) & 7));
+                    const unsigned off = (have && x < 128) ? (fragx * 64 + lane) * 16 : PP_OOB;
                     v[u][i][0] = ld_sc1(r, off);
                     v[u][i][1] = ld_sc1(r, off == PP_OOB ? PP_OOB : off + 8 * 1024);
                 }
@@ -473,18 +694,22 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
         }
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
-            const int x = j + (q0 + wave + 8 * u) * c;
-            if (x < 128) pp_epilogue_unit<OUT_BF16, ACT, ROPE, F8>(s[u][0], s[u][1], x >> 4, (x >> 1) & 7, x & 1, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr, sc);
+            const int x = j + (q0 + wave + NW * u) * c;
+            if (x < 128) {
+                if constexpr (W4) pp_epilogue_unit<OUT_BF16, ACT, ROPE, F8, 1>(s[u][0], s[u][1], x >> 5, (x >> 2) & 7, x & 3, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr, sc);
+                else pp_epilogue_unit<OUT_BF16, ACT, ROPE, F8>(s[u][0], s[u][1], x >> 4, (x >> 1) & 7, x & 1, bias, res, ldr, Cv, ldc, M, m0, n0, lane, qr, sc);
+            }
         }
     }
 }
 
-template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
-__global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
-                                                  const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
-                                                  int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
-                                                  int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr,
-                                                  PpScale sc, int PG, int tiles_n) {
+template <int OUT_BF16, int ACT, int ROPE, int NF, int F8, int W4>
+__device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+                                           const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                           int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
+                                           int total_units, f32x4* partial, int* flags, int* status, int epoch, const QkvRope& qr,
+                                           const PpScale& sc, int PG, int tiles_n) {
+    static_assert(!W4 || (NF == 4 && !F8), "the four-wave form: bf16 operands, 256-column panels");
     // PG > 1 (many-row problems: batched prefills): a team is tiles_m x PG workgroups - the m-tiles of PG ADJACENT panels walk the same
     // k-range together, so an activation k-slice is fetched once per PG panels too (with one panel per team the 33 MB activation panel
     // of a 4020-row pass is re-read for every panel: 2.5 GB of fabric traffic per gate/up launch, 20 % of its time).  The unit space,
@@ -528,17 +753,25 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
         int m0 = m0_wg;
         asm volatile("" : "+s"(m0));
-        PpSrc src;
-        pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
-        f32x4 acc[NF][8];
+        constexpr int NFW = W4 ? 8 : NF;   // fragments per wave along N
+        f32x4 acc[NFW][8];
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
+        for (int i = 0; i < NFW; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pp_mainloop<NF, F8>(acc, src, ks0, nks, smem, wave, lane);
+        if constexpr (W4) {
+            Pp4Src src;
+            pp4_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+            pp4_mainloop(acc, src, ks0, nks, smem, wave, lane);
+        } else {
+            PpSrc src;
+            pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+            pp_mainloop<NF, F8>(acc, src, ks0, nks, smem, wave, lane);
+        }
 
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
-            pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
+            if constexpr (W4) pp4_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
+            else pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
             continue;
         }
         if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
@@ -546,9 +779,9 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
             const int ps = ks0 == 0 ? 1 : 0, id = (team * TS + tsl) * 2 + ps;
             shared_panel[ps] = sk_panel;
             const __amdgpu_buffer_rsrc_t pr = pp_slot_rsrc(partial, id);
-            const unsigned off = (wave * 32 * 64 + lane) * 16;
+            const unsigned off = (wave * (NFW * 8) * 64 + lane) * 16;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NFW; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) st_sc1(pr, off + (ni * 8 + mi) * 1024, acc[ni][mi]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -593,11 +826,30 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
         __syncthreads();
         const float poison = ids[1024] ? __int_as_float(0x7fc00000) : 0.f;   // a missing partial poisons this share (never a silent partial sum)
         const int m0 = m0_wg, n0 = ((dp_panels + panel) * PG + pgi) * PBN;
-        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
-        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
-        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
-        else pp_reduce_share<8, OUT_BF16, ACT, ROPE, F8>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
+        else pp_reduce_share<8, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
     }
+}
+
+template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
+__global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+                                                  const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
+                                                  int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
+                                                  int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr,
+                                                  PpScale sc, int PG, int tiles_n) {
+    pp_sk_body<OUT_BF16, ACT, ROPE, NF, F8, 0>(A, lda, Wp, bias, res, ldr, Cv, ldc, M, N, K, tiles_m, TS, nk, dp_panels, total_units, partial, flags,
+                                               status, epoch, qr, sc, PG, tiles_n);
+}
+// the four-wave form (pp4_mainloop): one wave per SIMD, all 512 registers of the unified file
+template <int OUT_BF16, int ACT, int ROPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pp4_sk(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, const float* __restrict__ bias, const float* res, int64_t ldr,
+    void* Cv, int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels, int total_units, f32x4* partial, int* flags,
+    int* status, int epoch, QkvRope qr, PpScale sc, int PG, int tiles_n) {
+    pp_sk_body<OUT_BF16, ACT, ROPE, 4, 0, 1>(A, lda, Wp, bias, res, ldr, Cv, ldc, M, N, K, tiles_m, TS, nk, dp_panels, total_units, partial, flags,
+                                             status, epoch, qr, sc, PG, tiles_n);
 }
 
 int pp_device_cus() {
@@ -653,8 +905,12 @@ int pp_teams(int64_t M) {
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
               int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr, PpScale sc = PpScale{nullptr, nullptr}) {
-    static std::atomic<uint64_t> attr_set{0};
-    if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>, attr_set)) return rc;
+    static std::atomic<uint64_t> attr_set{0}, attr_set4{0};
+    constexpr bool can4 = NF == 4 && !F8;
+    const bool w4 = can4 && rv_cur_opts().gemm_waves == 4;
+    if (w4) {
+        if constexpr (can4) if (int rc = reserve_lds(gemm_pp4_sk<OUT_BF16, ACT, ROPE>, attr_set4)) return rc;
+    } else if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>, attr_set)) return rc;
     const int tiles_m = (int)cdiv(M, PBM), tiles_n = N / (NF * 64), nk = K / PBK;
     const int G = pp_num_cus() & ~7, per_x = G >> 3;
     // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle.  From 8 m-tiles on (batched prefills) with
@@ -672,6 +928,13 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     int* flags = (int*)ws;
     int* status = flags + PP_HDR / 4 - 1;
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
+    if constexpr (can4) {
+        if (w4) {
+            hipLaunchKernelGGL((gemm_pp4_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(256), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K, tiles_m, TS,
+                               nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG, tiles_n);
+            return RV_OK;
+        }
+    }
     hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
                        tiles_m, TS, nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG, tiles_n);
     return RV_OK;

@@ -1,4 +1,4 @@
-// Decode projections with 33 .. 128 rows: several pools' worth of generates merged into ONE pass over the weights.
+// Decode projections with 33 .. 144 rows: several pools' worth of generates merged into ONE pass over the weights.
 //
 // The <= 32-row kernel (gemv_stream, gemm.hip) re-reads the activations once per workgroup from L2; with MB = 4 / 8 row blocks
 // that is 4 - 8x the weight bytes.  Here the 4 consumer waves of a workgroup own different 16-column tiles (64 columns per
@@ -54,6 +54,9 @@
 #ifndef RS_PROBE
 #define RS_PROBE 0
 #endif
+#ifndef RS_PART
+#define RS_PART 0
+#endif
 
 namespace {
 
@@ -83,7 +86,7 @@ constexpr int RS_THREADS = (RS_W + 1) * 64;
 // weight fragment instead of five - 5-8 % faster): the eight consumer waves of a CU simply stream their weights at 3.4 (K = 4096) .. 4.6
 // TB/s (long K) where the sixteen waves of gemv_stream reach 5.8.
 // MB = 4 row blocks: 4 slabs of 16 KiB, two workgroups per CU;  MB = 5 (65 .. 80 rows: ten 7-row generates): 3 slabs of 20 KiB, two per CU;
-// MB = 8: 3 slabs of 32 KiB, one workgroup per CU
+// MB = 8 / 9 (81 .. 128 / 129 .. 144 rows: twenty 7-row generates): 3 slabs of 32 / 36 KiB, one workgroup per CU
 // WP = 2: FP8 (e4m3fn) weights in gemv_stream's fp8 fragment packing (gemm.hip: a lane's 16-byte load = its operand of two consecutive
 // 32-k blocks), widened to bf16 in registers right before the MFMA, per-output-row scales applied in the shared epilogue
 // (GemvNorm::w_scale).  A 128-k stage is then 2 loads of 1 KiB per consumer wave instead of 4: the ring is twice as many STAGES deep for
@@ -237,7 +240,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
         }
 #undef RS_ISSUE_W
     }
-    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 32 MiB: 32-bit offsets)
+    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 36 MiB: 32-bit offsets)
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
     char* xch = rs_smem + 16384;      // S == 1: the waves' sums change hands through LDS (behind the sums-of-squares area), no plane round trip
     if constexpr (S == 1) {
@@ -390,7 +393,7 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
 #pragma unroll
     for (int i = 0; i < VPW; ++i) T += vcount(i);
     const int Tp = (T + DW - 1) / DW * DW;
-    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 32 MiB: 32-bit offsets)
+    const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 36 MiB: 32-bit offsets)
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
 
     f32x4 acc[MB], stk[LOG ? LOG : 1][MB];
@@ -716,9 +719,13 @@ int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, co
 template <int FIN, int WP>
 int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
                int K, const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
+#if RS_PART & 2
+    return MBp == 8 ? rows_by_split<8, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
+                    : rows_by_split<9, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+#else
     return MBp == 4 ? rows_by_split<4, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
-         : MBp == 5 ? rows_by_split<5, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
-                    : rows_by_split<8, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+                    : rows_by_split<5, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st);
+#endif
 }
 template <int WP>
 int rows_by_fin(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype,
@@ -735,31 +742,48 @@ int rows_by_fin(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* b
 
 }  // namespace
 
+// This file is compiled four times (build.py; gemm_rows_p1 / _p2 / _p3.hip include it with RS_PART set): bit 0 = FP8 weights, bit 1 = the
+// 8 / 9 row-block instantiations.  Part 0 (this file itself) also holds the entry points.
+#define RS_PART_FN_(n) gemm_rows_part##n
+#define RS_PART_FN(n) RS_PART_FN_(n)
+int RS_PART_FN(RS_PART)(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+                        int out_dtype, int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st) {
+    return rows_by_fin<(RS_PART & 1) ? 2 : 1>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st);
+}
+
+#if RS_PART == 0
+#define RS_PART_DECL(n)                                                                                                                      \
+    int gemm_rows_part##n(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, \
+                          int out_dtype, int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st)
+RS_PART_DECL(1);
+RS_PART_DECL(2);
+RS_PART_DECL(3);
+
 // S * (N / 16) tiles * MB KiB with S = rows_splits(N, MB): S * N < 2 * 240 * 128 wherever the CU fill asks for S > 2; N <= 32768, S = 2 otherwise
-size_t gemm_rows_ws_bytes() { return (size_t)(2 * 32768 / 16) * 8 * 1024; }
+size_t gemm_rows_ws_bytes() { return (size_t)(2 * 32768 / 16) * RV_XP_MAX_BLOCKS * 1024; }
 extern "C" size_t rv_gemm_rows_ws_bytes(void) { return gemm_rows_ws_bytes(); }
 
-// X: 33 .. 128 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
+// X: 33 .. 144 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
 // qr != nullptr: the fused q/k/v + RoPE epilogue.  w_layout 1: bf16 fragment-packed W; 2: FP8 fragment-packed W + nrm.w_scale.
 int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
               int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout) {
     RV_CHECK_ARG(w_layout == 1 || (w_layout == 2 && nrm.w_scale), "gemm_rows: bf16 (1) or fp8 + per-row scales (2) fragment-packed weights");
-    RV_CHECK_ARG(M > 32 && M <= 128 && nrm.x_packed == rv_xp_blocks(M) && nrm.planes && nrm.arrive,
-                 "gemm_rows: 33 .. 128 fragment-packed rows, a plane workspace and arrival counters");
+    RV_CHECK_ARG(M > 32 && M <= RV_ROWS_MAX && nrm.x_packed == rv_xp_blocks(M) && nrm.planes && nrm.arrive,
+                 "gemm_rows: 33 .. 144 fragment-packed rows, a plane workspace and arrival counters");
     RV_CHECK_ARG(N / 64 <= RV_ROWS_COUNTERS / 4, "gemm_rows: too many column groups");
     RV_CHECK_ARG(N % 64 == 0 && K % 128 == 0 && K >= 1024 && N <= 32768, "gemm_rows: N %% 64, K %% 128, K >= 1024, N <= 32768");
     RV_CHECK_ARG(act == RV_ACT_NONE || act == RV_ACT_SILU_MUL, "gemm_rows: no activation or SILU_MUL");
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_BF16, "gemm_rows: SILU_MUL writes bf16");
     const int MBp = nrm.x_packed, S = rows_splits(N, MBp);
     RV_CHECK_ARG((size_t)S * (N / 16) * MBp * 1024 <= gemm_rows_ws_bytes(), "gemm_rows: %d partial planes of N = %d do not fit the plane workspace", S, N);
-    const int rc = w_layout == 2 ? rows_by_fin<2>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st)
-                                 : rows_by_fin<1>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st);
+    auto* part = MBp >= 8 ? (w_layout == 2 ? gemm_rows_part3 : gemm_rows_part2) : (w_layout == 2 ? gemm_rows_part1 : gemm_rows_part0);
+    const int rc = part(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st);
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_rows");
     return RV_OK;
 }
 
-// Building block (include/revision_hip.h): one projection of a merged decode step on 33 .. 128 fragment-packed rows, with the engine's
+// Building block (include/revision_hip.h): one projection of a merged decode step on 33 .. 144 fragment-packed rows, with the engine's
 // epilogue variants (act = RV_ACT_SILU_MUL + bf16 out: the gate/up launch).
 extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, const float* w_scale, void* C, int32_t M, int32_t N, int32_t K, void* planes,
                             int32_t* arrive, int act, int out_dtype, void* stream) {
@@ -773,3 +797,4 @@ extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, const float* w_scale
     return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr,
                      w_scale ? 2 : 1);
 }
+#endif   // RS_PART == 0

@@ -12,6 +12,7 @@ struct RvOpts {
     int fp8_prefill = 1;        // use bound ".f8p" prefill weight copies
     int sample_variant = 1;     // 1 compacted-candidate top-k fast path, 0 general selection (identical outputs)
     int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
+    int gemm_waves = 8;         // persistent 256 x 256 x 64 prefill GEMMs (bf16, 256-column panels): 4 = one wave per SIMD with 128 x 128 outputs each, 8 = the two-wave-per-SIMD ping-pong form
     int rows_persistent = 1;    // 33 .. 128-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
     int rows_spread = 0;        // 33 .. 128-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
     int rows_fill = 240;        // 33 .. 128-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
@@ -38,21 +39,23 @@ struct GemvNorm {
     const float* w_next = nullptr;    // [N] norm weight of the consumer
     float* out_sumsq = nullptr;       // [gridDim.x][16]
     const float* w_scale = nullptr;   // fp8 weights (w_layout 2): per-output-row dequantisation scale [N]
-    // Fragment-packed decode activations (<= 128 rows): element (row r, k) of a [rows, K] bf16 operand lives at
+    // Fragment-packed decode activations (<= 144 rows): element (row r, k) of a [rows, K] bf16 operand lives at
     // rv_xp_index(r, k, mbp), i.e. every 16-row x 32-k MFMA operand fragment is one contiguous 1 KiB block, the mbp row blocks
-    // (2: <= 32 rows, 4: <= 64, 5: <= 80, 8: <= 128) of a k-fragment adjacent - a 128-k slab of all rows is one contiguous 4 * mbp KiB run.
+    // (2: <= 32 rows, 4: <= 64, 5: <= 80, 8: <= 128, 9: <= 144) of a k-fragment adjacent - a 128-k slab of all rows is one contiguous 4 * mbp KiB run.
     // A wave then fetches its x operand of a k-step with ONE contiguous load per fragment instead of 16 row segments of 64 B -
     // with 17 .. 32 rows the row-major x loads cost the address units more than the weight stream itself.
     int x_packed = 0;                 // 0: X is row-major; 2 / 4 / 8: X is fragment-packed with that many row blocks (lda ignored)
     int out_packed = 0;               // same for xw_out and a bf16 C (ldc ignored for bf16 C)
-    float* planes = nullptr;          // 33 .. 128 rows (split-K kernel): workspace for the partial planes, gemm_rows_ws_bytes() bytes
+    float* planes = nullptr;          // 33 .. 144 rows (split-K kernel): workspace for the partial planes, gemm_rows_ws_bytes() bytes
     int* arrive = nullptr;            // ... and its arrival counters: RV_ROWS_COUNTERS ints, zero before the first launch
 };
 __host__ __device__ __forceinline__ int64_t rv_xp_index(int r, int k, int mbp) {
     return ((((int64_t)(k >> 5) * mbp + (r >> 4)) * 64 + (r & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
 }
 constexpr int RV_ROWS_COUNTERS = 2048;
-__host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows <= 32 ? 2 : rows <= 64 ? 4 : rows <= 80 ? 5 : 8; }
+constexpr int RV_ROWS_MAX = 144;       // rows of one merged decode step (9 row blocks: twenty 7-row generates)
+constexpr int RV_XP_MAX_BLOCKS = 9;
+__host__ __device__ __forceinline__ int rv_xp_blocks(int64_t rows) { return rows <= 32 ? 2 : rows <= 64 ? 4 : rows <= 80 ? 5 : rows <= 128 ? 8 : 9; }
 
 // Fused QKV epilogue: the fused q/k/v projection writes its results straight into their final homes - RoPE-rotated Q
 // (bf16 [M,D]), RoPE-rotated K into the cache and V into the transposed cache - instead of an f32 [M,3D] buffer that two
@@ -120,6 +123,31 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
             for (int r = 0; r < 4; ++r) dst[(int64_t)r * q.Smax] = f32_to_bf16(v[r]);
         }
     }
+}
+// The ROW part of the epilogue (group, sequence, position, prefix broadcast range, table row) decoded once for all the column groups a
+// lane owns in that row (the four-wave prefill GEMM, gemm_pp.hip pp4_rope_rows: 8 groups per row).  Values and store addresses are
+// exactly those of qkv_rope_store.
+struct QkvRow {
+    int mrow, pos, b0, b1;     // row of q16; position; cache rows [b0, b1) that receive K / V (the shared prefix goes to all B of its group)
+    const float* cs;           // (cos, sin) pairs of the position
+};
+static __device__ __forceinline__ QkvRow qkv_rope_row(const QkvRope& q, int m) {
+    QkvRow r;
+    r.mrow = m;
+    int goff = 0, b;
+    bool prefix = false;
+    int mt = m;
+    if (q.G > 1) { const int gi = m / q.Mg; mt = m - gi * q.Mg; goff = q.grow[gi]; }
+    if (q.row_pos) { b = mt; r.pos = q.row_pos[mt]; r.cs = q.cs + (int64_t)mt * 128; }
+    else {
+        if (mt < q.P0) { b = 0; r.pos = mt; prefix = true; }
+        else { const int rr = mt - q.P0; b = rr / q.S; r.pos = q.pos0 + (rr - b * q.S); }
+        r.cs = q.cs + (int64_t)(r.pos - q.cs_pos0) * 128;
+    }
+    r.b0 = (prefix ? 0 : b) + goff;
+    r.b1 = (prefix ? q.B : b + 1) + goff;
+    if (q.row_pos && r.pos < 0) r.b1 = r.b0 - 1;   // inactive row: nothing is stored (b1 < b0; Q is skipped through pos < 0)
+    return r;
 }
 static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {
     qkv_rope_store(q, m, n, v, qkv_rope_coeffs(q, m, n));

@@ -66,11 +66,11 @@ def gemm(a, w, bias=None, residual=None, out_dtype=torch.bfloat16, act=hip.RV_AC
 
 def xp_blocks(rows):
     """Row blocks of the fragment-packed decode layout (csrc/kernels.h rv_xp_blocks)."""
-    return 2 if rows <= 32 else 4 if rows <= 64 else 5 if rows <= 80 else 8
+    return 2 if rows <= 32 else 4 if rows <= 64 else 5 if rows <= 80 else 8 if rows <= 128 else 9
 
 
 def pack_rows(x):
-    """[M,K] bf16 (M <= 128, K % 32 == 0) -> the fragment-packed decode layout [16 * mbp * K] (csrc/kernels.h rv_xp_index): every
+    """[M,K] bf16 (M <= 144, K % 32 == 0) -> the fragment-packed decode layout [16 * mbp * K] (csrc/kernels.h rv_xp_index): every
     16-row x 32-k operand fragment one contiguous 1 KiB block, the mbp row blocks of a k-fragment adjacent; rows past M are zero."""
     M, K = x.shape
     mbp = xp_blocks(M)
@@ -83,7 +83,7 @@ _ROWS_WS = {}
 
 
 def gemm_rows(x, wp, act=hip.RV_ACT_NONE, out_dtype=torch.float32, out=None, xp=None, w_scale=None, N=None):
-    """One projection of a merged decode step on 33 .. 128 rows (rv_gemm_rows: the split-K kernel with LDS-shared activations).
+    """One projection of a merged decode step on 33 .. 144 rows (rv_gemm_rows: the split-K kernel with LDS-shared activations).
     x [M,K] bf16 row-major (packed here; or ``xp`` already packed), wp fragment-packed [N,K] -> row-major [M, N] (N / 2 with SILU_MUL).
     ``w_scale`` f32 [N]: ``wp`` holds FP8 bytes (``pack_fragments_fp8``: uint8 [N*K]) instead of bf16 fragments."""
     M, K = x.shape

@@ -50,7 +50,7 @@ class DecodePool:
 
     def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, gang=False):
         eng = model.engine
-        assert 1 <= rows <= 128      # <= 32: the weight-streaming kernel; 33 .. 128: the split-K kernel with LDS-shared activations
+        assert 1 <= rows <= 144      # <= 32: the weight-streaming kernel; 33 .. 144: the split-K kernel with LDS-shared activations
         self.model, self.eng, self.R, self.G, self.max_ahead, self.slot = model, eng, rows, gmax, max_ahead, slot
         dev = eng.device
         self.kv, self.Smax = eng.new_kv_pool(rows, smax)

@@ -139,6 +139,39 @@ def test_gemm_a_resident_kernel_is_bit_identical_to_the_ring_kernel(dev, M, N, K
     assert torch.equal(ops.gemm(big[:, :K], wp, bias=bias, residual=r, out_dtype=od, act=act, w_packed=True, stream_k=False), rows)
 
 
+@pytest.mark.parametrize("M,N,K,act,out,res", [
+    (1005, 4096, 4096, 0, "f32", True),        # o projection of one recursion's prefill: pure split-k stream-K
+    (1005, 22016, 4096, 2, "bf16", False),     # gate/up: whole panels + a stream-K tail, gated epilogue
+    (4020, 22016, 4096, 2, "bf16", False),     # four prefills to a pass: teams of two panels
+    (4020, 4096, 11008, 0, "f32", True),       # down projection
+    (2010, 12288, 4096, 0, "bf16", False),
+    (700, 4096, 11008, 0, "f32", False),       # ragged last row tile
+])
+def test_four_wave_persistent_gemm_is_bit_identical_to_the_eight_wave_form(dev, M, N, K, act, out, res):
+    """Option gemm_waves = 4 (one wave per SIMD owning 128 x 128 outputs, accumulators in AGPRs; gemm_pp.hip pp4_mainloop) sums every
+    output in the same k order with the same MFMA as the eight-wave ping-pong form, whole panels and stream-K shares alike: results are
+    BIT-identical; and correct against float64 on a sample of rows."""
+    from revisionllm_amd import hip, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(torch.bfloat16).to(dev)
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    r = torch.randn(M, n_out, generator=g).to(dev) if res else None
+    od = torch.bfloat16 if out == "bf16" else torch.float32
+    wp = ops.pack_fragments(w)
+    y8 = ops.gemm(a, wp, residual=r, out_dtype=od, act=act, w_packed=True, ctx=hip.Options(gemm_waves=8))
+    y4 = ops.gemm(a, wp, residual=r, out_dtype=od, act=act, w_packed=True, ctx=hip.Options(gemm_waves=4))
+    assert torch.equal(y8, y4)
+    sel = torch.arange(0, M, max(1, M // 61), device=dev)
+    z = a[sel].double() @ w.double().t()
+    if act == hip.RV_ACT_SILU_MUL:                                   # gate / up rows interleaved in 16-row groups (ops.pack_fragments input order)
+        z = z.view(len(sel), N // 32, 2, 16)
+        z = (torch.nn.functional.silu(z[:, :, 0]) * z[:, :, 1]).reshape(len(sel), N // 2)
+    if res:
+        z = z + r[sel].double()
+    assert rel_err(y4[sel].float().cpu(), z.cpu()) < (BF16_TOL if out == "bf16" else F32_TOL * 5)
+
+
 @pytest.mark.parametrize("M,N,K", [(9, 1024, 256), (771, 4096, 1024), (1000, 1024, 4096)])
 def test_gemm_quick_gelu_epilogue(dev, M, N, K):
     """bias + QuickGELU (x * sigmoid(1.702 x), the CLIP MLP activation) fused into the GEMM epilogue: every kernel family."""
@@ -471,7 +504,7 @@ def test_topk_cosine(dev):
     assert rel_err(y.cpu(), scores.stage1_cosine(feat[0, 5:19], q, topk_pool=False)) < 1e-4
 
 
-@pytest.mark.parametrize("M", [33, 56, 70, 112, 128])
+@pytest.mark.parametrize("M", [33, 56, 70, 112, 128, 129, 140, 144])
 @pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 4096, 0), (4096, 11008, 0), (12288, 4096, 0), (32000, 4096, 0)])
 def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
     """The decode projection kernel of the HEADLINE (33 .. 128 fragment-packed rows, split-K with LDS-shared activations,
@@ -493,7 +526,7 @@ def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
     assert torch.equal(y, ops.gemm_rows(x, wp, act=act, out_dtype=torch.float32))
 
 
-@pytest.mark.parametrize("M", [56, 70, 112])
+@pytest.mark.parametrize("M", [56, 70, 112, 140])
 @pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 11008, 0), (32000, 4096, 0)])
 def test_gemm_rows_fp8_weights_vs_float64_and_the_16_row_kernel(dev, M, N, K, act):
     """FP8 (e4m3fn, per-row scale) weights in the 33 .. 128-row decode kernel (opt-in fp8 LLM path, BASELINE configs[4]): against the

@@ -109,9 +109,9 @@ def test_merged_decode_rows_equal_separate_generates():
     assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
 
 
-@pytest.mark.parametrize("n_groups,R", [(6, 48), (9, 64), (10, 70), (11, 80), (16, 112), (18, 128)])
-def test_wide_pools_33_to_128_rows_equal_separate_generates(n_groups, R):
-    """Merged decode steps with 33 .. 128 rows (the split-K kernel: activations shared through LDS, 1 - 8 workgroups per column group,
+@pytest.mark.parametrize("n_groups,R", [(6, 48), (9, 64), (10, 70), (11, 80), (16, 112), (18, 128), (19, 133), (20, 140), (20, 144)])
+def test_wide_pools_33_to_144_rows_equal_separate_generates(n_groups, R):
+    """Merged decode steps with 33 .. 144 rows (the split-K kernel: activations shared through LDS, 1 - 8 workgroups per column group,
     partial planes folded as subtrees of the 8-way tree): every group's logits at every step BIT-identical to the same group decoded
     on its own cache by the <= 16-row kernel; groups at different positions, the last one leaving after two steps."""
     eng = _engine()
@@ -378,7 +378,7 @@ def test_a_failing_generate_fails_alone_and_gives_its_rows_back():
     assert all(p.pending == 0 and p.live == 0 for p in server.pools) and sum(n for _, n, _ in server.free) == 16
 
 
-@pytest.mark.parametrize("R", [70, 112])
+@pytest.mark.parametrize("R", [70, 112, 140])
 def test_fp8_decode_weights_in_wide_merged_steps_7b_layer(R):
     """The fp8 LLM path of BASELINE configs[4] through the MERGED pipeline's kernels: one Vicuna-7B-shaped block + lm_head, R rows
     (ten / sixteen 7-row generates) prefilled into one KV pool, then merged decode steps streaming the FP8 weight copies

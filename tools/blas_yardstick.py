@@ -1,0 +1,62 @@
+"""Yardstick only (never on the product path): what torch.matmul (hipBLASLt / rocBLAS) reaches on the prefill GEMM shapes, next to
+rv_gemm on the same shapes.  Usage: python tools/blas_yardstick.py"""
+import torch
+
+import os
+
+from revisionllm_amd import hip, ops
+
+dev = torch.device("cuda:0")
+OPT = hip.Options(gemm_waves=int(os.environ["WAVES"])) if os.environ.get("WAVES") else None   # WAVES=4 / 8: the rv_gemm form
+shapes = [(4020, 22016, 4096), (4020, 4096, 4096), (4020, 4096, 11008), (4020, 12288, 4096), (2010, 22016, 4096), (4096, 4096, 4096), (8192, 8192, 8192)]
+
+
+def timeit(fn, n=20, warm=5, min_ms=300.0):
+    """Sustained rate: warm up for min_ms / 2, then time at least min_ms of back-to-back launches (the clock ramps over milliseconds)."""
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(4):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    one = max(a.elapsed_time(b) / 4, 1e-3)
+    n = max(n, int(min_ms / one))
+    warm = max(warm, n // 2)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+for M, N, K in shapes:
+    copies = 6                                   # rotate weights: the 256 MB infinity cache must not serve them
+    x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    ws = [(torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16) for _ in range(copies)]
+    i = [0]
+
+    def blas():
+        torch.matmul(x, ws[i[0] % copies].t())
+        i[0] += 1
+    t_blas = timeit(blas)
+    wps = [ops.pack_fragments(w) for w in ws]
+    line = f"M={M:5d} N={N:5d} K={K:5d}  torch.matmul {t_blas * 1e3:7.1f} us  {2.0 * M * N * K / t_blas / 1e9:7.1f} TF/s"
+    if wps is not None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+
+        def mine():
+            ops.gemm(x, wps[i[0] % copies], out=out, w_packed=True, ctx=OPT)
+            i[0] += 1
+        try:
+            t = timeit(mine)
+            line += f"   rv_gemm {t * 1e3:7.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TF/s"
+        except Exception as e:  # noqa: BLE001
+            line += f"   rv_gemm failed: {e}"
+    print(line, flush=True)
