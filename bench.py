@@ -81,8 +81,9 @@ def parse():
     p.add_argument("--prefill-batch", type=int, default=4,
                    help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
                         "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
-    p.add_argument("--pool-rows", type=int, default=70,
-                   help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 144: the split-K kernel with LDS-shared activations)")
+    p.add_argument("--pool-rows", type=int, default=0,
+                   help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 144: the split-K kernel with LDS-shared activations); "
+                        "0 = one gang for all the steps in flight: rows of a recursion (7) x min(streams, steps, 20) = 140 rows at --steps 20")
     p.add_argument("--eos", action="store_true", help="configure a real EOS id (2): the decode loop polls a lagging device-side stop flag")
     p.add_argument("--fp8-decode", action="store_true",
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
@@ -464,6 +465,9 @@ def main():
     server = None
     if args.merge_decode:
         from revisionllm_amd import serve
+        if not args.pool_rows:      # one merged decode pass for everything in flight: the weights stream once per step for all of it
+            rows_rec = len(stage2.plan_groups(W, batch)) * args.queries
+            args.pool_rows = rows_rec * max(1, min(args.streams, args.steps, 144 // rows_rec))
         server = serve.DecodeServer(model, rows=args.pool_rows, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1,
                                     prefill_batch=args.prefill_batch)
         stages.server = server
@@ -827,6 +831,20 @@ def main():
                                                           "frac": nb / row["avg_us"] / 1e3 / HBM_PEAK_GBS,
                                                           "source": f"profiles/{fname} (rocprofv3 kernel trace of isolated {legs['decode_gateup_gemv']['rows']}-row steps)"}
                 break
+        # the dominant kernel inside a batched prefill pass (other kernels between its launches: the clock is not pinned at the power cap
+        # by one kernel), from the committed rocprofv3 summary of tools/prefill_prof.sh - next to the live back-to-back figure above
+        pf = committed_profile("r3_prefill_pass.json")
+        if pf is not None and pf.get("rows") == dom.get("rows"):
+            row = next((r_ for r_ in pf.get("kernels", []) if r_["kernel"].replace(" ", "") == dom["kernel"].replace(" ", "")), None)
+            if row is not None:
+                fl = dom["algorithmic"]
+                roof_in_situ = {"avg_launch_ms": row["avg_us"] / 1e3, "achieved": fl / row["avg_us"] / 1e6, "unit": "TFLOP/s",
+                                "frac": fl / row["avg_us"] / 1e6 / MFMA_BF16_PEAK_TF,
+                                "source": "profiles/r3_prefill_pass.json (rocprofv3 kernel trace of batched prefill passes at this row count)"}
+            else:
+                roof_in_situ = None
+        else:
+            roof_in_situ = None
         out = {
             "metric": METRIC,
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -856,7 +874,9 @@ def main():
                                          if shared_gpu else "")},
             "roofline": {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
                          "unit": dom["unit"], "frac": dom["achieved"] / dom["peak"], "traffic": traffic,
-                         "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"], "other": other},
+                         "avg_launch_ms": dom["ms"], "algorithmic_per_launch": dom["algorithmic"],
+                         "timing": "64 back-to-back launches of this kernel alone, HIP events on the launch stream (sustained: the socket power limit sets the clock)",
+                         **({"in_situ": roof_in_situ} if roof_in_situ else {}), "other": other},
         }
         if rec is not None:
             out["answers_sample"] = rec["answers"][:2] if not os.environ.get("REVISION_BENCH_ALL_ANSWERS") else rec["answers"]

@@ -35,9 +35,15 @@
 // runs at what HBM gives; a ROUND of workgroups costs ~10 us whatever it streams (first weights cold, planes out + acknowledged, the
 // arrival counter's round trip, the last arriver's plane loads and epilogue), and gate/up pays it twice because an item (column group,
 // split) must be whole virtual k-waves of the shared summation tree and 688 items do not deal out over 512 slots.  What would remove the second
-// round: a persistent grid with FINER items (S = 4: 1376 items of 8 stages, <= 3 per workgroup) whose hand-overs are DEFERRED (planes stored
-// without waiting; one acknowledgement, the counters and the finishes once at the end of the workgroup's life) - estimated 53 -> 38 us for
-// gate/up, nothing for the other three launches (their items already fit one round): ~7 % of a decode step.  Not built.
+// round: a persistent grid whose hand-overs are DEFERRED (planes stored without waiting; one acknowledgement, the counters and the finishes
+// once at the end of the workgroup's life).
+// (d) BUILT as rows_kernel_p (below; option rows_persistent, on by default): a launch with more (column group, split) items than resident
+// workgroups runs as a grid of exactly the resident workgroups, item i + k * grid going to workgroup i; rows_splits picks a finer split
+// when it shortens the longest stream by >= 20 %.  Measured (isolated steps, us per launch inside the step): 112 rows (one workgroup per
+// CU: 688 / 384 items on 256 slots) gate/up 91.0 -> 67.0, QKV 81.4 -> 70.6, step 9.82 -> 8.62 ms; 70 rows (two per CU) gate/up with
+// S = 4: 67.6 -> 65.1, step 6.92 -> 6.81 ms - not the 15 us the model above promised: 1376 planes of 20 KiB out and in again are
+// 56 MB of extra traffic next to 180 MB of weights (PMC: 241 MB per launch), which eats most of the second round's fixed cost.
+// 129 .. 144 rows (MB = 9: twenty 7-row generates in one step): 10.07 ms per step = 0.50 ms per generate (70 rows: 0.68, 112: 0.54).
 #include <hip/hip_runtime.h>
 
 #include <atomic>

@@ -78,6 +78,7 @@ class Engine:
         self._keep = {}      # name -> tensor (keeps device memory alive while bound)
         self._ws = {}        # workspace cache
         self.slot = 0        # workspace / KV-pool namespace: one per in-flight call stream (weights are shared, read-only)
+        self.slots_in_flight = set()   # slots whose generate (decoding alone) has started and not finished: see model.generate_steps
         self.gate = gate if gate is not None else PersistGate.for_device(self.device)
         self.has_llm = self.has_clip = self.has_linear = False
 

@@ -314,9 +314,20 @@ class ReVisionLlamaForCausalLM:
             finally:
                 if not job.finished:        # an exception here or in a task this one was pumped from, or the task was cancelled
                     server.abandon(job)
-        return (yield from self._generate_alone(eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
-                                                max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, output_scores, output_logits,
-                                                eos, pad, eos_lookahead))
+        # A generate that decodes alone owns its engine slot's KV cache and workspace from its prefill to its last step.  Under a cooperative
+        # scheduler (it yields at the EOS flag polls) a second generate started on the SAME slot meanwhile would be handed the same recycled
+        # cache and overwrite it: refuse loudly - every call in flight needs its own slot (sched.Task(..., slot=i); engine.slot).
+        slot = eng.slot
+        if slot in eng.slots_in_flight:
+            raise RuntimeError(f"engine slot {slot} already has a generate in flight: give every call in flight its own workspace slot "
+                               "(sched.Task(..., slot=i) / engine.slot) - two generates on one slot share one recycled KV cache")
+        eng.slots_in_flight.add(slot)
+        try:
+            return (yield from self._generate_alone(eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
+                                                    max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, output_scores, output_logits,
+                                                    eos, pad, eos_lookahead))
+        finally:
+            eng.slots_in_flight.discard(slot)
 
     def _generate_in_pool(self, server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
                           max_new_tokens, uniforms, forced_tokens, return_dict_in_generate):

@@ -209,8 +209,11 @@ def test_eos_lagging_flag_equals_per_step_sync():
 
 
 def test_eos_generates_interleave_on_two_streams():
-    """Two EOS-terminated recursions in flight on two HIP streams under the cooperative scheduler (each task yields at its
-    stop-flag polls, the other's launches are enqueued meanwhile) give exactly the records of running them one after the other."""
+    """Three EOS-terminated recursions in flight on two HIP streams under the cooperative scheduler (each task yields at its
+    stop-flag polls, the others' launches are enqueued meanwhile; each has its own engine slot) give exactly the records of running
+    them one after the other.  (Until round 3 recursions 0 and 2 shared slot 0: whenever recursion 0 was still waiting for a flag when
+    recursion 2 started - a slow host, about one cold run in five - they shared one recycled KV cache and the records differed.
+    ``generate`` now refuses a second generate on a slot that has one in flight: test_second_generate_on_a_busy_slot_is_refused.)"""
     from revisionllm_amd import parallel, sched
     from revisionllm_amd.eval import stage2
     from revisionllm_amd.utils import synth
@@ -228,12 +231,39 @@ def test_eos_generates_interleave_on_two_streams():
     kw = dict(batch=batch, perms=[perms], uniforms=uni, max_new_tokens=6)
     seq = [parallel.run_queries_sharded(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], **kw)[0] for i in range(3)]
     streams = [torch.cuda.Stream("cuda:0"), torch.cuda.Stream("cuda:0")]
-    torch.cuda.synchronize()
-    inter = sched.Interleaver()
-    tasks = [inter.add(sched.Task(parallel.launch_queries_sharded_steps(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], **kw),
-                                  streams[i % 2], m.engine, i % 2)) for i in range(3)]
-    par = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
-    m.engine.slot = 0
-    for a, b in zip(seq, par):
-        assert a["answers"] == b["answers"] and a["max_entropy"] == b["max_entropy"] and a["mean_entropy"] == b["mean_entropy"]
-        assert a["score_cos"] == b["score_cos"]
+
+    def in_flight():
+        torch.cuda.synchronize()
+        inter = sched.Interleaver()
+        tasks = [inter.add(sched.Task(parallel.launch_queries_sharded_steps(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], **kw),
+                                      streams[i % 2], m.engine, i)) for i in range(3)]   # a slot (workspace, KV cache) per recursion in flight; two streams
+        try:
+            return [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+        finally:
+            m.engine.slot = 0
+    from helpers import assert_in_flight_equals_sequential
+    assert_in_flight_equals_sequential(seq, in_flight, "eos_two_streams")
+
+
+def test_second_generate_on_a_busy_slot_is_refused():
+    """A generate that has yielded (EOS flag poll) still owns its slot's KV cache: starting another one on the same slot raises instead
+    of silently sharing the cache."""
+    m = _tiny_model()
+    m.generation_config.eos_token_id = 2
+    ids = torch.randint(3, 200, (2, 24))
+    feat = feats("busy.feat", (2, 6, 16, 768), bf16=True)
+    q = (feats("busy.q", (2, 5, 768), bf16=True), torch.ones(2, 5))
+    kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=8, return_dict_in_generate=True)
+    first = m.generate_steps(ids, **kw)
+    ev = next(first)                       # runs the prefill and the first steps, then asks for a flag
+    assert ev is not None and m.engine.slot in m.engine.slots_in_flight
+    with pytest.raises(RuntimeError, match="already has a generate in flight"):
+        next(m.generate_steps(ids, **kw))
+    m.engine.slot = 1                      # another slot is fine
+    try:
+        from revisionllm_amd import sched
+        other = sched.drive(m.generate_steps(ids, **kw))
+    finally:
+        m.engine.slot = 0
+    out = sched.drive(first)
+    assert torch.equal(out["sequences"], other["sequences"]) and not m.engine.slots_in_flight

@@ -177,10 +177,10 @@ def test_conditioned_batched_recursion_equals_reference(g8c):
     _records_equal_reference(rec, g, meta)
 
 
-@pytest.mark.parametrize("copies,pool_rows", [(4, 32), (8, 56), (10, 70)])
+@pytest.mark.parametrize("copies,pool_rows", [(4, 32), (8, 56), (10, 70), (20, 140)])
 def test_conditioned_headline_pipeline_equals_reference(g8c, copies, pool_rows):
     """The pipeline the bench runs, free-running at 32 layers: ``copies`` instances of the G8c recursion in flight on their own HIP
-    streams, prefills up to four to a pass (~4000-row GEMMs), decode steps merged into 28- / 56- / 70-row passes of gang-filled KV pools.
+    streams, prefills up to four to a pass (~4000-row GEMMs), decode steps merged into 28- / 56- / 70- / 140-row passes of gang-filled KV pools (140 rows = the bench's default: all twenty steps in flight in one pass).
     EVERY instance must reproduce the reference's record."""
     from revisionllm_amd import parallel, sched, serve
     from revisionllm_amd.utils import synth

@@ -454,28 +454,13 @@ def test_recursions_in_flight_on_two_streams_match_sequential(model_7b):
             torch.cuda.synchronize()
             pend = []
             for i in range(3):
-                m.engine.slot = i % 2
+                m.engine.slot = i           # a slot (workspace, KV cache) per recursion in flight; two streams
                 with torch.cuda.stream(streams[i % 2]):
                     pend.append(parallel.launch_query_sharded(st, tok, feat, 100, qfs[i], qcs, f"query {i}", **kw))
             return [parallel.collect_query(p) for p in pend]
 
-        def differences(par):
-            return [(i, k) for i, (a, b) in enumerate(zip(seq, par)) for k in ("answers", "max_entropy", "mean_entropy", "score_cos") if a[k] != b[k]]
-        par = in_flight()
-        diff = differences(par)
-        if diff:
-            # Seen ONCE in ~60 runs of this test (inside a full-suite run; never alone): say exactly what differed, then tell a one-off
-            # from a reproducible fault - a second mismatch fails the test, a single one is reported as a warning with the fields.
-            import json
-            import os
-            import warnings
-            detail = [dict(query=i, field=k, sequential=str(seq[i][k])[:400], in_flight=str(par[i][k])[:400]) for i, k in diff]
-            os.makedirs("gpurun_out", exist_ok=True)
-            with open("gpurun_out/two_streams_mismatch.json", "w") as f:
-                json.dump(detail, f, indent=1)
-            again = differences(in_flight())
-            assert not again, f"recursions in flight differ from the sequential run twice in a row: {diff} then {again}: {detail}"
-            warnings.warn(f"recursions in flight differed from the sequential run ONCE (not on the retry): {detail}")
+        from helpers import assert_in_flight_equals_sequential
+        assert_in_flight_equals_sequential(seq, in_flight, "two_streams_7b")
     finally:
         m.engine.slot = 0
         m.generation_config.eos_token_id = eos

@@ -14,14 +14,14 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA
 python3 tools/pmc_summary.py gpurun_out/r3_stats gpurun_out/r3_fetch gpurun_out/r3_write gpurun_out/r3 gpurun_out/r3_sq gpurun_out/r3_grbm
 for d in r3_fetch r3_write r3_sq r3_grbm; do find gpurun_out/$d -name '*.csv' -size +4M -delete; done
 # isolated merged decode steps
-( cd /tmp; bash $GRAFT_REPO_ROOT/tools/decode_rows_prof.sh 14 28 56 70 112; bash $GRAFT_REPO_ROOT/tools/decode_rows_prof.sh 70 112 fp8 ) > gpurun_out/r3_decode_prof.log 2>&1
-python3 tools/decode_rows_time.py 7 14 28 56 70 112 > gpurun_out/r3_decode_ms.log 2>&1
-python3 tools/decode_rows_time.py 56 70 112 --fp8 >> gpurun_out/r3_decode_ms.log 2>&1
-python3 tools/decode_rows_summary.py 14 28 56 70 112 70f8 112f8
+( cd /tmp; bash $GRAFT_REPO_ROOT/tools/decode_rows_prof.sh 14 28 56 70 112 140; bash $GRAFT_REPO_ROOT/tools/decode_rows_prof.sh 70 112 140 fp8 ) > gpurun_out/r3_decode_prof.log 2>&1
+python3 tools/decode_rows_time.py 7 14 28 56 70 112 140 > gpurun_out/r3_decode_ms.log 2>&1
+python3 tools/decode_rows_time.py 56 70 112 140 --fp8 >> gpurun_out/r3_decode_ms.log 2>&1
+python3 tools/decode_rows_summary.py 14 28 56 70 112 140 70f8 112f8 140f8
 # clocks / power: one sample per second next to (a) the 4096^3 ping-pong GEMM on random data, (b) the decode gate/up weight stream, (c) the bench
 sample() { for i in $(seq 1 $2); do echo "== $1 t=$i"; rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power" ; sleep 1; done; }
 ( python3 tools/clock_probe.py gemm_random 10 > gpurun_out/r3_clk_gemm.out 2>&1 & sleep 3; sample gemm 6; wait ) > gpurun_out/r3_clocks.log 2>&1
 ( python3 tools/clock_probe.py gemv 10 > gpurun_out/r3_clk_gemv.out 2>&1 & sleep 3; sample gemv 6; wait ) >> gpurun_out/r3_clocks.log 2>&1
-( python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/r3_clk_bench.out 2>&1 & sleep 40; sample bench 6; wait ) >> gpurun_out/r3_clocks.log 2>&1
+( python3 bench.py --steps 4000 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/r3_clk_bench.out 2>&1 & sleep 40; sample bench 6; wait ) >> gpurun_out/r3_clocks.log 2>&1
 ls -la gpurun_out/r3_*.json gpurun_out/r3_*.csv 2>/dev/null
 tail -2 gpurun_out/r3_sq.log
