@@ -275,6 +275,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "rows_fill") return &o.rows_fill;
     if (k == "rows_spread") return &o.rows_spread;
     if (k == "rows_persistent") return &o.rows_persistent;
+    if (k == "rows_single") return &o.rows_single;
     if (k == "gemm_waves") return &o.gemm_waves;
     return nullptr;
 }

@@ -44,6 +44,9 @@
 // S = 4: 67.6 -> 65.1, step 6.92 -> 6.81 ms - not the 15 us the model above promised: 1376 planes of 20 KiB out and in again are
 // 56 MB of extra traffic next to 180 MB of weights (PMC: 241 MB per launch), which eats most of the second round's fixed cost.
 // 129 .. 144 rows (MB = 9: twenty 7-row generates in one step): 10.07 ms per step = 0.50 ms per generate (70 rows: 0.68, 112: 0.54).
+// (e) rows_single (8 / 9 row blocks): the fused QKV projection (192 column groups) runs UNSPLIT on 192 of the 256 CUs - 84 -> 64 us per launch at
+// 140 rows, step 10.06 -> 9.47 ms: at one workgroup per CU the four consumer waves each read the WHOLE slab (4 x 36 KiB per stage = 1150 LDS
+// cycles), so a launch is bound by LDS reads per stage rather than by how many CUs stream - fewer, longer workgroups without planes win.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -657,6 +660,10 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
     int s = MBp >= 5 ? 2 : 1;              // (5 / 8 row blocks x all 8 virtual waves in one workgroup: 4 accumulator sets do not fit the VGPRs:
                                            //  measured with the 68 B of spills it takes, 70-row step 6.85 -> 7.05 ms)
     const int fill = rv_cur_opts().rows_fill;   // workgroups a launch should at least have (tunable; 2 per CU are resident with <= 5 row blocks)
+    // 8 / 9 row blocks (one workgroup per CU, 256 registers per wave: all 8 virtual waves fit): a launch whose column groups alone fill
+    // >= 3/4 of the CUs runs UNSPLIT - no partial planes, no hand-over, every workgroup finishes its own columns (the QKV projection:
+    // 192 groups on 256 CUs)
+    if (MBp >= 8 && rv_cur_opts().rows_single && cg <= rows_slots(MBp) && cg * 4 >= (int64_t)rows_slots(MBp) * 3) return 1;
     while (s < 8 && cg * s < fill) s *= 2;
     // More items than resident workgroups: the launch becomes a persistent grid (rows_launch); finer items then balance the streams.
     // Cost = the longest stream in virtual k-waves; a finer split must shorten it by >= 20 % to pay for its extra planes.

@@ -15,6 +15,8 @@ for a in sys.argv:
         eng.set_option("rows_fill", int(a.split("=")[1]))
     if a == "--one-item-per-workgroup":
         eng.set_option("rows_persistent", 0)
+    if a == "--single":
+        eng.set_option("rows_single", 1)
     if a.startswith("--spread="):
         eng.set_option("rows_spread", int(a.split("=")[1]))
 D, V = eng.shape.hidden, eng.shape.vocab
