@@ -315,31 +315,35 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now
     if (nrm.in_sumsq) {
         constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
+        // the partials of CH row blocks in flight at once, then their sums: with the unsplit form (VPW = 8: no partial planes held in
+        // registers here) all of them - ONE memory round trip in the tail of the workgroup instead of MB / 2 dependent ones
+        constexpr int CH = VPW == 8 ? MB : 2;
 #pragma unroll
-        for (int m0 = 0; m0 < MB; m0 += 2) {
-            float pj[2][VT][8];
+        for (int c0 = 0; c0 < MB; c0 += CH) {
+            float pj[CH][VT][8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CH; ++i)
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     const int vt = tid + v * RS_THREADS;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int b = (vt >> 4) + 32 * j;
-                        pj[i][v][j] = (m0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
+                        pj[i][v][j] = (c0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((c0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
                     }
                 }
+            __builtin_amdgcn_sched_barrier(0);   // (keep a chunk's loads together)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CH; ++i)
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     const int vt = tid + v * RS_THREADS;
-                    if (vt >= 512 || m0 + i >= MB) continue;
+                    if (vt >= 512 || c0 + i >= MB) continue;
                     float a = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a += pj[i][v][j];
-                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
-                    ssq[(m0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
+                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((c0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
+                    ssq[(c0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
                 }
         }
         __syncthreads();
@@ -561,33 +565,34 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
     float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now (once for all the groups this workgroup finishes)
     if (nrm.in_sumsq) {
         constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
+        // every partial of every row block in flight at once (the accumulators are in LDS by now: the registers are free), then the sums:
+        // one memory round trip in the tail of the workgroup instead of one per pair of row blocks (MB / 2 of them, dependent through
+        // the in-order vmcnt)
+        float pj[MB][VT][8];
 #pragma unroll
-        for (int m0 = 0; m0 < MB; m0 += 2) {
-            float pj[2][VT][8];
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int v = 0; v < VT; ++v) {
+                const int vt = tid + v * RS_THREADS;
 #pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    const int vt = tid + v * RS_THREADS;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int b = (vt >> 4) + 32 * j;
-                        pj[i][v][j] = (m0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int b = (vt >> 4) + 32 * j;
+                    pj[mb][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
                 }
+            }
+        __builtin_amdgcn_sched_barrier(0);       // (keep the loads together: the sums below must not be interleaved pairwise again)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    const int vt = tid + v * RS_THREADS;
-                    if (vt >= 512 || m0 + i >= MB) continue;
-                    float a = 0.f;
+            for (int v = 0; v < VT; ++v) {
+                const int vt = tid + v * RS_THREADS;
+                if (vt >= 512) continue;
+                float a = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a += pj[i][v][j];
-                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((m0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
-                    ssq[(m0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
-                }
-        }
+                for (int j = 0; j < 8; ++j) a += pj[mb][v][j];
+                for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)];
+                ssq[mb * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
+            }
         __syncthreads();
     }
     if (wave >= RS_W) return;

@@ -21,8 +21,9 @@ if [ "$mode" = build ]; then
   ls -la revisionllm_amd/librevision_hip_p*.so
 else
   export PYTHONPATH=.
-  echo "== regular"; python tools/rows_time.py 70 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
+  M=${ROWS:-70}
+  echo "== regular"; python tools/rows_time.py $M 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
   for p in "$@"; do
-    echo "== RS_PROBE=$p"; REVISION_HIP_LIB=$PWD/revisionllm_amd/librevision_hip_p$p.so python tools/rows_time.py 70 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
+    echo "== RS_PROBE=$p"; REVISION_HIP_LIB=$PWD/revisionllm_amd/librevision_hip_p$p.so python tools/rows_time.py $M 2>&1 | grep -E "N=22016 K= 4096|N= 4096 K= 4096|N=12288 K= 4096"
   done
 fi

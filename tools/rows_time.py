@@ -9,8 +9,9 @@ lib = hip.lib()
 f = lib.rv_gemm_rows
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 63
-mbp = 2 if M <= 32 else 4 if M <= 64 else 5 if M <= 80 else 8
-planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
+from revisionllm_amd import ops
+mbp = ops.xp_blocks(M)
+planes = torch.zeros(lib.rv_gemm_rows_ws_bytes(), dtype=torch.uint8, device=dev)
 arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
 for N in (4096, 12288, 22016):
     for K in (1024, 2048, 4096, 8192, 16384):
