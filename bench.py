@@ -141,7 +141,7 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     # (2) decode gate/up weight-streaming projection: reads W [22016,4096] bf16 once  (HBM-bound); rotate layers so the
     #     256 MB infinity cache cannot serve the weights.  rows = what a merged decode step of the timed region carries (gang policy:
     #     a full pool of generates): <= 16 rows: the 512-thread kernel, 17 .. 32: two MFMA column blocks per weight fragment on
-    #     256-thread workgroups, 33 .. 128: the split-K kernel with LDS-shared activations (gemm_rows.hip, fragment-packed rows)
+    #     256-thread workgroups, 33 .. 144: the split-K kernel with LDS-shared activations (gemm_rows.hip, fragment-packed rows)
     dec_rows = dec_rows or n_calls
     ws = [eng.weight(f"llm.L{i}.wgu") for i in range(s.layers)]
     state = {"i": 0}

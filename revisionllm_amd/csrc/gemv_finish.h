@@ -1,4 +1,4 @@
-// Shared tail of the decode projection kernels (gemv_stream: <= 32 rows; gemm_rows: 33 .. 128 rows): the summation tree over the 8
+// Shared tail of the decode projection kernels (gemv_stream: <= 32 rows; gemm_rows: 33 .. 144 rows): the summation tree over the 8
 // virtual k-waves and the epilogue of one wave.  Kept in one place because the two kernel families must produce bit-identical rows.
 #pragma once
 #include "kernels.h"
@@ -8,7 +8,7 @@ namespace {
 __device__ __forceinline__ float gemv_silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // The 8 virtual k-waves' partial sums of an output element are added as a balanced tree.  Every kernel of the decode family
-// (gemv_stream with 8 or 4 physical waves, the split-K kernel for 33 .. 128 rows whose workgroups carry 1, 2 or 4 adjacent virtual
+// (gemv_stream with 8 or 4 physical waves, the split-K kernel for 33 .. 144 rows whose workgroups carry 1, 2 or 4 adjacent virtual
 // waves) produces exactly this tree, so a row's result does not depend on which of them served it.
 __device__ __forceinline__ f32x4 gemv_tree8(const f32x4 (&p)[8]) {
     return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));

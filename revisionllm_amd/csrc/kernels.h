@@ -14,9 +14,9 @@ struct RvOpts {
     int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
     int gemm_waves = 8;         // persistent 256 x 256 x 64 prefill GEMMs (bf16, 256-column panels): 4 = one wave per SIMD with 128 x 128 outputs each, 8 = the two-wave-per-SIMD ping-pong form
     int rows_single = 1;        // 81 .. 144-row decode kernel: a launch whose column groups fill >= 3/4 of the CUs runs without a K split
-    int rows_persistent = 1;    // 33 .. 128-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
-    int rows_spread = 0;        // 33 .. 128-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
-    int rows_fill = 240;        // 33 .. 128-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
+    int rows_persistent = 1;    // 33 .. 144-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
+    int rows_spread = 0;        // 33 .. 144-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
+    int rows_fill = 240;        // 33 .. 144-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
 };
 extern const RvOpts g_default_opts;   // the production defaults every context starts from (rv_ctx_create)
 const RvOpts& rv_cur_opts();
@@ -163,8 +163,8 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
 int gemv_blocks(int act, int64_t N);
 int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
-              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 128 fragment-packed rows
-size_t gemm_rows_ws_bytes();   // partial planes of the 33 .. 128-row decode kernel (any LLM shape up to N = 32768)  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
+              int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 144 fragment-packed rows
+size_t gemm_rows_ws_bytes();   // partial planes of the 33 .. 144-row decode kernel (any LLM shape up to N = 32768)  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
 // A-resident kernel for short-K many-row problems (gemm_arows.hip): a workgroup keeps its block of A rows in LDS and walks N
 bool gemm_arows_supported(int w_layout, int act, int64_t M, int64_t N, int64_t K);
 int gemm_arows_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,

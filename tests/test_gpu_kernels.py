@@ -507,7 +507,7 @@ def test_topk_cosine(dev):
 @pytest.mark.parametrize("M", [33, 56, 70, 112, 128, 129, 140, 144])
 @pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 4096, 0), (4096, 11008, 0), (12288, 4096, 0), (32000, 4096, 0)])
 def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
-    """The decode projection kernel of the HEADLINE (33 .. 128 fragment-packed rows, split-K with LDS-shared activations,
+    """The decode projection kernel of the HEADLINE (33 .. 144 fragment-packed rows, split-K with LDS-shared activations,
     csrc/gemm_rows.hip through rv_gemm_rows) directly against the float64 product of the same bf16 operands, for every projection
     shape of a Vicuna-7B block + lm_head, at the row counts the bench's pools run (56, 70, 112) and the edges (33, 128)."""
     from revisionllm_amd import hip, ops
@@ -529,7 +529,7 @@ def test_gemm_rows_split_k_decode_kernel_vs_float64(dev, M, N, K, act):
 @pytest.mark.parametrize("M", [56, 70, 112, 140])
 @pytest.mark.parametrize("N,K,act", [(22016, 4096, 2), (4096, 11008, 0), (32000, 4096, 0)])
 def test_gemm_rows_fp8_weights_vs_float64_and_the_16_row_kernel(dev, M, N, K, act):
-    """FP8 (e4m3fn, per-row scale) weights in the 33 .. 128-row decode kernel (opt-in fp8 LLM path, BASELINE configs[4]): against the
+    """FP8 (e4m3fn, per-row scale) weights in the 33 .. 144-row decode kernel (opt-in fp8 LLM path, BASELINE configs[4]): against the
     float64 product of the DEQUANTISED weights, and bit-identical per row to the <= 16-row FP8 kernel (rv_gemv_fp8) - the widening to
     bf16 is exact and the summation order is the shared one."""
     from revisionllm_amd import hip, ops

@@ -1,4 +1,4 @@
-"""Time the 33..128-row split-K decode kernel alone on synthetic operands: us per launch vs K and N (fit the fixed cost).
+"""Time the 33..144-row split-K decode kernel alone on synthetic operands: us per launch vs K and N (fit the fixed cost).
 python tools/rows_time.py [M]"""
 import ctypes
 import sys
