@@ -193,7 +193,8 @@ int rv_clip_encoder(rv_ctx* ctx, const void* x, const void* txt, const uint8_t* 
 /* Embedding gather + video-row splice (vtimellm_arch.py:149-238). map i32 [rows]: v >= 0 -> token id
  * (row of llm.embed), v < 0 -> video row -(v+1) of video_rows f32 [*,D].  h f32 [rows,D]. */
 int rv_splice_embed(rv_ctx* ctx, const int32_t* map, const float* video_rows, float* h, int64_t rows, void* stream);
-/* KV cache for B rows, Smax positions: K [L,B,H,Smax,dh] and V^T [L,B,H,dh,Smax], bf16. */
+/* KV cache for B rows, Smax positions (a multiple of 32): K [L,B,H,Smax,dh] and V^T [L,B,H,Smax/8,dh,8], bf16 - V transposed in blocks of 8
+ * positions: element (d, pos) of one (row, head) at ((pos >> 3) * dh + d) * 8 + (pos & 7).  Opaque to callers that only hand it back. */
 size_t rv_kv_bytes(const rv_ctx* ctx, int32_t B, int32_t Smax);
 size_t rv_llm_ws_bytes(const rv_ctx* ctx, int32_t B, int32_t S);
 /* 32x Llama block over h f32 [B,S,D] (clobbered), positions pos0..pos0+S-1, causal, appends to the cache;

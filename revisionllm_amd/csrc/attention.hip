@@ -39,7 +39,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     for (int c = 0; c < NC; ++c) qf[c] = *(const bf16x8*)(qp + c * 32);
 
     const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
-    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * 8;
+    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
     const int krow = (fr >> 2) * 8 + (fr & 3);   // key of score-tile row fr within the 32-key block (+ 4 for tile 1)
     const uint8_t* pad = PAD ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
 
@@ -63,7 +63,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         }
         bf16x8 vf[ND];
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + k0);
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -217,7 +217,7 @@ static int attn_check(const AttnArgs& a) {
     RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
     RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 8 == 0 && a.vt_hs % 8 == 0 && a.vt_bs % 8 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
-    RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
+    RV_CHECK_ARG(a.vt_ks != 8 || a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     return RV_OK;
 }
 
@@ -239,7 +239,7 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");
     RV_CHECK_ARG(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.k_hs % 8 == 0 && a.vt_ds % 8 == 0 && a.vt_hs % 8 == 0 && a.vt_bs % 8 == 0 && a.o_rs % 4 == 0,
                  "attention: stride alignment");
-    RV_CHECK_ARG(a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
+    RV_CHECK_ARG(a.vt_ks != 8 || a.vt_ds >= ((a.Lk + 31) / 32) * 32, "attention: V^T rows must be padded to a multiple of 32 keys");
     const bool split = a.Lq <= 16 && !a.no_split;
     const int tiles = (int)cdiv(a.Lq, split ? 16 : 64);
     const dim3 grid(attn_grid(tiles, a.H * a.B));

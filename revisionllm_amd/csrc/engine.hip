@@ -570,6 +570,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > l0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
+        auto blocked_vt = [&](AttnArgs& x) { x.vt_ds = 8; x.vt_ks = (int64_t)dh * 8; };   // the V^T cache is blocked by 8 positions (rv_vt_index)
         if (P0 > 0 && P0 > 16 && S > 16 && dh == 128) {
             // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch) - for all G groups of a batched prefill
             AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
@@ -577,6 +578,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             AttnArgs am{w.q16 + (int64_t)P0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
                         (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
                         S, pos0 + S, 1, pos0, 1, scale};
+            blocked_vt(ap);
+            blocked_vt(am);
             AttnGroups gr;
             gr.G = G;
             for (int gi = 0; gi < G; ++gi) {
@@ -590,6 +593,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                 const int64_t qo = (int64_t)gi * Mg * D, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
                 AttnArgs ap{w.q16 + qo, D, (int64_t)P0 * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
                             (int64_t)dh * Smax, Smax, w.a16 + qo, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+                blocked_vt(ap);
                 RV_TRY(k_attention(ap, st));
             }
         }
@@ -609,6 +613,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                            (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
                 a.row_pos = row_pos;
                 a.out_packed = xp;
+                blocked_vt(a);
                 RV_TRY(k_attention(a, st));
             }
             if (p8_o) {

@@ -398,11 +398,11 @@ __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const Q
     const int p0 = slab0 + kg * 4;
     if (sec == 2) {
         for (int bb = row.b0; bb < row.b1; ++bb) {
-            bf16_t* dst = (bf16_t*)qr.vtc + (((int64_t)bb * qr.H + head) * 128 + p0) * qr.Smax + row.pos;
+            bf16_t* dst = (bf16_t*)qr.vtc + ((int64_t)bb * qr.H + head) * 128 * qr.Smax + rv_vt_index(p0, row.pos);
 #pragma unroll
             for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(int64_t)(ni * 16 + e) * qr.Smax] = f32_to_bf16(v[ni][e]);
+                for (int e = 0; e < 4; ++e) dst[(ni * 16 + e) * 8] = f32_to_bf16(v[ni][e]);
         }
         return;
     }

@@ -285,6 +285,12 @@ class Engine:
                 self._ws[key] = t
         return t, Smax
 
+    @staticmethod
+    def vt_logical(vt, *lead, head_dim=128, Smax=None):
+        """The V^T half of a KV cache as a LOGICAL [*lead, head_dim, Smax] tensor (a copy).  On the device V^T is blocked by 8 positions:
+        element (d, pos) of one (row, head) lives at ((pos >> 3) * head_dim + d) * 8 + (pos & 7) (csrc/kernels.h rv_vt_index)."""
+        return vt.view(*lead, Smax // 8, head_dim, 8).movedim(-3, -2).reshape(*lead, head_dim, Smax)
+
     def _persist_begin(self):
         self.gate.begin(torch.cuda.current_stream(self.device))
 

@@ -478,9 +478,10 @@ class ReVisionLlamaForCausalLM:
         new, new_smax = self.engine.new_kv(B, new_smax)
         half_old, half_new = kv.numel() // 2, new.numel() // 2
         k_old = kv[:half_old].view(s.layers, B, s.heads, Smax, s.head_dim)
-        v_old = kv[half_old:].view(s.layers, B, s.heads, s.head_dim, Smax)
+        # V^T is blocked by 8 positions ([.., Smax / 8, head_dim, 8], csrc/kernels.h rv_vt_index): a longer cache has more blocks behind the old ones
+        v_old = kv[half_old:].view(s.layers, B, s.heads, Smax // 8, s.head_dim, 8)
         new[:half_new].view(s.layers, B, s.heads, new_smax, s.head_dim)[:, :, :, :Smax] = k_old
-        new[half_new:].view(s.layers, B, s.heads, s.head_dim, new_smax)[..., :Smax] = v_old
+        new[half_new:].view(s.layers, B, s.heads, new_smax // 8, s.head_dim, 8)[:, :, :, :Smax // 8] = v_old
         return new, new_smax
 
 

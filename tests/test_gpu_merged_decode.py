@@ -98,12 +98,12 @@ def test_merged_decode_rows_equal_separate_generates():
     L = 2
     halfp = pool.numel() // 2
     kp = pool[:halfp].view(L, R, H, Smax, 128)
-    vp = pool[halfp:].view(L, R, H, 128, Smax)
+    vp = eng.vt_logical(pool[halfp:], L, R, H, Smax=Smax)          # (blocked by 8 positions on the device)
     for gi, ((B, S), r0) in enumerate(zip(groups, row0)):
         n = S + (2 if gi == 2 else steps)
         half = ref_kv[gi].numel() // 2
         kr = ref_kv[gi][:half].view(L, B, H, Smax, 128)
-        vr = ref_kv[gi][half:].view(L, B, H, 128, Smax)
+        vr = eng.vt_logical(ref_kv[gi][half:], L, B, H, Smax=Smax)
         assert torch.equal(kp[:, r0:r0 + B, :, :n], kr[:, :, :, :n]) and torch.equal(vp[:, r0:r0 + B, :, :, :n], vr[..., :n])
     assert (kp[:, 14:17, :, 142:] == 0).all()                 # the stopped group's rows were not written after it went inactive
     assert (kp[:, 17:] == 0).all() and (vp[:, 17:] == 0).all()    # unused rows never touched
@@ -166,7 +166,7 @@ def test_batched_prefill_groups_match_separate_prefills(G, P0):
         assert rel_err(bat[gi * B:(gi + 1) * B].cpu(), sep[gi].cpu()) < 1e-2, gi       # (bf16 activations: a different f32 summation order moves roundings)
     half = pool_a.numel() // 2
     ka, kb = pool_a[:half].view(L, R, H, Smax, 128).float(), pool_b[:half].view(L, R, H, Smax, 128).float()
-    va, vb = pool_a[half:].view(L, R, H, 128, Smax).float(), pool_b[half:].view(L, R, H, 128, Smax).float()
+    va, vb = eng.vt_logical(pool_a[half:], L, R, H, Smax=Smax).float(), eng.vt_logical(pool_b[half:], L, R, H, Smax=Smax).float()
     n = P0 + S
     assert rel_err(kb[:, :, :, :n].cpu(), ka[:, :, :, :n].cpu()) < 1e-2 and rel_err(vb[..., :n].cpu(), va[..., :n].cpu()) < 1e-2
     assert (kb[:, :3] == 0).all() and (kb[:, 3 + 7 * G:] == 0).all() and (kb[:, :, :, n:] == 0).all()      # nothing outside the groups' rows / positions

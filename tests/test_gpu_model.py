@@ -483,7 +483,7 @@ def test_persistent_qkv_rope_epilogue_is_bit_exact():
             kv, Smax = eng.new_kv(B, S + 8, reuse=False)
             logits = eng.llm_prefill_shared(h0.clone(), B, P0, kv, Smax)
             per = B * 32 * Smax * 128
-            out[v] = (kv[:per].view(B, 32, Smax, 128)[:, :, :S].clone(), kv[per:2 * per].view(B, 32, 128, Smax)[..., :S].clone(), logits)
+            out[v] = (kv[:per].view(B, 32, Smax, 128)[:, :, :S].clone(), eng.vt_logical(kv[per:2 * per], B, 32, Smax=Smax)[..., :S].clone(), logits)
     finally:
         eng.set_option("gemm_tile_variant", 2)
     assert torch.equal(out[6][0], out[2][0]) and torch.equal(out[6][1], out[2][1])
@@ -505,7 +505,7 @@ def test_batched_prefill_qkv_epilogue_forms_agree_bit_for_bit():
     per = R * 32 * Smax * 128
 
     def caches(pool):
-        return pool[:per].view(R, 32, Smax, 128)[:, :, :P0 + S].clone(), pool[per:2 * per].view(R, 32, 128, Smax)[..., :P0 + S].clone()
+        return pool[:per].view(R, 32, Smax, 128)[:, :, :P0 + S].clone(), eng.vt_logical(pool[per:2 * per], R, 32, Smax=Smax)[..., :P0 + S].clone()
     got = {}
     try:
         for waves in (8, 4):
