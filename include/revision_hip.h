@@ -227,8 +227,9 @@ int rv_llm_prefill_shared(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t 
  *   kv_row0 .. kv_row0 + B - 1 of the pool; results bit-identical to the same prefill into a cache of its own.
  * rv_llm_decode_rows: ONE KV-cached decode step of the pool's R = kv_rows rows (R <= 144: up to 32 rows take the weight-streaming kernel,
  * 33 .. 144 the split-K kernel with LDS-shared activations; both stream the FP8 weight copies when bound and enabled), row r at its OWN position row_pos[r]
- *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified; an active row
- *   needs row_pos[r] < Smax (NOT checked: the positions live on the device).  h f32 [R, D]
+ *   (device int32 [R]); row_pos[r] < 0 = inactive row: nothing is appended to its cache, its logits are unspecified; a row with
+ *   row_pos[r] >= Smax (past the pool's capacity) is treated like an inactive one on the device - nothing is stored, no other row's
+ *   cache is touched, its logits are unspecified (the positions live on the device: no error can be returned).  h f32 [R, D]
  *   (clobbered), logits f32 [R, V].  A row's result equals what rv_llm_forward(S = 1, pos0 = row_pos[r]) gives for it in any batch.
  *   Workspace: rv_llm_ws_bytes(ctx, R, 1). */
 int rv_llm_prefill_pool(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows, int32_t kv_row0, int32_t Smax,

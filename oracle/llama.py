@@ -79,30 +79,48 @@ class KVCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None, act_quant=None):
+#: The places where the build's bf16 path rounds an f32 value to bf16 (error-budget instrumentation, tests/test_gpu_error_budget.py):
+#: ``rnd`` = a set of these names makes the fp32 oracle round at exactly those places and nowhere else, so that each one's share of the
+#: build's distance from the fp32 reference can be measured on its own.  Not part of the restated algorithm: the default is none.
+ROUNDING_POINTS = ("norm_out", "q", "k_cache", "v_cache", "p", "attn_out", "mlp_act", "lm_in")
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None, act_quant=None, rnd=()):
     """One Llama block: x + Wo(softmax(QK^T/sqrt(dh) + mask) V); then + W_down(silu(W_gate n) * W_up n).
-    ``act_quant`` (build-defined, opt-in FP8 prefill mirror): applied to the input rows of the four projections."""
+    ``act_quant`` (build-defined, opt-in FP8 prefill mirror): applied to the input rows of the four projections.
+    ``rnd``: names of ``ROUNDING_POINTS`` at which a bf16 rounding is emulated (error budget; default: none)."""
     aq = act_quant if act_quant is not None else (lambda t: t)
+    r = (lambda name, t: _bf16(t) if name in rnd else t)
     p = f"model.layers.{i}."
     B, S, D = h.shape
     H, dh = cfg.heads, cfg.head_dim
-    n = aq(rmsnorm(h, w[p + "input_layernorm.weight"], cfg.eps))
+    n = r("norm_out", aq(rmsnorm(h, w[p + "input_layernorm.weight"], cfg.eps)))
     q = F.linear(n, w[p + "self_attn.q_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     k = F.linear(n, w[p + "self_attn.k_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     v = F.linear(n, w[p + "self_attn.v_proj.weight"]).view(B, S, H, dh).transpose(1, 2)
     q, k = apply_rope(q, k, cos, sin)
+    q, k, v = r("q", q), r("k_cache", k), r("v_cache", v)
     if cache is not None:
         k, v = cache.append(i, k, v)
     s = (q @ k.transpose(2, 3)) * (1.0 / math.sqrt(dh))
     if attn_bias is not None:
         s = s + attn_bias
-    pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
-    o = (pr @ v).transpose(1, 2).reshape(B, S, D)
-    h = h + F.linear(aq(o), w[p + "self_attn.o_proj.weight"])
-    n = aq(rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.eps))
+    if "p" in rnd:      # the build's kernel: exp(s - max) rounded to bf16 in front of P.V, the row sum kept in f32, one division at the end
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = (_bf16(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = pr @ v
+    o = o.transpose(1, 2).reshape(B, S, D)
+    h = h + F.linear(r("attn_out", aq(o)), w[p + "self_attn.o_proj.weight"])
+    n = r("norm_out", aq(rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.eps)))
     g = F.linear(n, w[p + "mlp.gate_proj.weight"])
     u = F.linear(n, w[p + "mlp.up_proj.weight"])
-    return h + F.linear(aq(F.silu(g) * u), w[p + "mlp.down_proj.weight"])
+    return h + F.linear(r("mlp_act", aq(F.silu(g) * u)), w[p + "mlp.down_proj.weight"])
 
 
 def _bias_from_mask(attention_mask, q_len, past_len, dtype):
@@ -118,7 +136,7 @@ def _bias_from_mask(attention_mask, q_len, past_len, dtype):
 
 
 def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=None, cache: KVCache = None,
-            last_only=False, n_layers=None, act_quant=None):
+            last_only=False, n_layers=None, act_quant=None, rnd=()):
     """``LlamaForCausalLM.forward(inputs_embeds=...)`` -> logits [B,S,V] (or [B,1,V] if last_only).
 
     attention_mask [B, past+S] (1 = real token); position_ids [B,S]; cache is updated in place.
@@ -134,10 +152,12 @@ def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=N
     bias = _bias_from_mask(attention_mask, S, past, inputs_embeds.dtype)
     h = inputs_embeds
     for i in range(cfg.layers if n_layers is None else n_layers):
-        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache, act_quant)
+        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache, act_quant, rnd)
     if last_only:
         h = h[:, -1:]
     h = rmsnorm(h, w["model.norm.weight"], cfg.eps)
+    if "lm_in" in rnd:
+        h = _bf16(h)
     return F.linear(h, w["lm_head.weight"])
 
 

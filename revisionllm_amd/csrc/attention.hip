@@ -30,7 +30,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     const int kb_ = b / a.kv_div;
     // per-row key count (merged decode steps): everything below uses Lk / q_pos0 of THIS batch row
     const int Lk = a.row_pos ? a.row_pos[b] + 1 : a.Lk;
-    if (Lk <= 0) return;
+    if (Lk <= 0 || (a.row_pos && Lk > a.Lk)) return;   // inactive row; a row past the pool's capacity (a.Lk = Smax) is treated like one
     const int q_pos0 = a.row_pos ? Lk - a.Lq : a.q_pos0;
 
     const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;

@@ -251,7 +251,11 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     }
     const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 36 MiB: 32-bit offsets)
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
-    char* xch = rs_smem + 16384;      // S == 1: the waves' sums change hands through LDS (behind the sums-of-squares area), no plane round trip
+    // S == 1: the waves' sums change hands through LDS, no plane round trip.  The exchange area lies BEHIND the sums-of-squares area
+    // ssq [MB][32][16] f32 = MB * 2 KiB (18 KiB at 9 row blocks: a fixed 16 KiB offset let ssq[8] overlap the sums of tile 0)
+    constexpr int XCH_OFF = MB * 2048 > 16384 ? MB * 2048 : 16384;
+    static_assert(XCH_OFF + RS_W * MB * 1024 <= DX * MB * 4096, "the exchange area must fit the slab ring");
+    char* xch = rs_smem + XCH_OFF;
     if constexpr (S == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the trailing LDS-DMA padding stages are done)
         __syncthreads();                                   // everyone is through with the slab ring
@@ -526,7 +530,11 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
 #undef RS_ISSUE_W
     }
     // ---------------- behind the stream: acknowledge, count arrivals, finish what this workgroup completed ----------------
-    char* xch = rs_smem + 16384;      // S == 1: the waves' sums change hands through LDS (behind the sums-of-squares area), no plane round trip
+    // S == 1: the waves' sums change hands through LDS, no plane round trip.  The exchange area lies BEHIND the sums-of-squares area
+    // ssq [MB][32][16] f32 = MB * 2 KiB (18 KiB at 9 row blocks: a fixed 16 KiB offset let ssq[8] overlap the sums of tile 0)
+    constexpr int XCH_OFF = MB * 2048 > 16384 ? MB * 2048 : 16384;
+    static_assert(XCH_OFF + RS_W * MB * 1024 <= DX * MB * 4096, "the exchange area must fit the slab ring");
+    char* xch = rs_smem + XCH_OFF;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes are written through; the trailing LDS-DMA / weight padding loads are done
     __syncthreads();                                   // everyone is through with the slab ring
     if constexpr (S == 1) {

@@ -105,7 +105,7 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
     bool prefix = false;
     const int mrow = m;      // row of q16 (the batch-wide row)
     if (q.G > 1) { const int gi = m / q.Mg; m -= gi * q.Mg; goff = q.grow[gi]; }
-    if (q.row_pos) { b = m; pos = q.row_pos[m]; if (pos < 0) return; }
+    if (q.row_pos) { b = m; pos = q.row_pos[m]; if (pos < 0 || pos >= q.Smax) return; }   // inactive, or past the pool's capacity (would land in another row's blocks of the blocked V^T cache): nothing is stored
     else if (m < q.P0) { b = 0; pos = m; prefix = true; }
     else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
     if (sec < 2) {
@@ -152,7 +152,7 @@ static __device__ __forceinline__ QkvRow qkv_rope_row(const QkvRope& q, int m) {
     }
     r.b0 = (prefix ? 0 : b) + goff;
     r.b1 = (prefix ? q.B : b + 1) + goff;
-    if (q.row_pos && r.pos < 0) r.b1 = r.b0 - 1;   // inactive row: nothing is stored (b1 < b0; Q is skipped through pos < 0)
+    if (q.row_pos && (r.pos < 0 || r.pos >= q.Smax)) r.b1 = r.b0 - 1;   // inactive row: nothing is stored (b1 < b0; Q is skipped through pos < 0)
     return r;
 }
 static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v) {

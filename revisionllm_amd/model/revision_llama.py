@@ -174,7 +174,16 @@ class ReVisionLlamaForCausalLM:
         if m.clip_adapter and m.clip_adapter_feature == "alternate":
             if iteration_step is None:   # the reference evaluates ``iteration_step % 2`` (transformer.py:135)
                 raise TypeError("unsupported operand type(s) for %: 'NoneType' and 'int' (clip_adapter_feature='alternate' needs iteration_step)")
+            if isinstance(images, (list, tuple)):
+                # the reference sends list inputs to ``mm_projector(concat_images)`` without query features (vtimellm_arch.py:102-108),
+                # which a ClipEncoder's forward rejects: same outcome here, said in words
+                raise TypeError("clip_adapter_feature='alternate': a list of feature tensors is not a valid input of the ClipEncoder adapter "
+                                "(the reference's list branch calls mm_projector without query features, vtimellm_arch.py:102-108)")
+            if query_feats is None:      # the reference subscripts it unconditionally (vtimellm_arch.py:113-122)
+                raise TypeError("'NoneType' object is not subscriptable (clip_adapter_feature='alternate' needs query_feats=(feats, mask))")
             qf, qm = query_feats[0], query_feats[1]
+            # hierarchy models at an ODD step: the reference forwards ``images`` as they are to the encoder (vtimellm_arch.py:112-113), which
+            # only accepts [b,t,d] - a [b,v,t,d] tensor fails there in ``src.permute(1, 0, 2)`` and is refused below for the same reason
             if int(iteration_step) % 2 == 0:
                 if m.hierarchy:
                     b, v, t, d = images.shape

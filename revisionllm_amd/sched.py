@@ -5,9 +5,12 @@ the host must learn something from the device before enqueuing more (the EOS fla
 one generator to the end, blocking on each event; ``Interleaver`` keeps several of them in flight - each bound to its own HIP
 stream and engine workspace slot - and resumes whichever one's event has completed, so one recursion waiting for its flag
 never keeps the others' launches off the device.  No threads: everything is enqueued from the calling thread."""
+import logging
 import time
 
 import torch
+
+log = logging.getLogger(__name__)
 
 #: yielded by a step generator that cannot continue yet for a reason other than a device event (e.g. it must issue a collective
 #: after an earlier-launched task has issued its own, so that every rank issues them in the same order): "resume me later"
@@ -64,6 +67,8 @@ class Task:
                 self.done, self.result, self.waiting = True, stop.value, None
             except Exception as e:  # noqa: BLE001 - whoever pumped this task is not the one to hear about it (``finish`` of THIS task is)
                 self.done, self.error, self.waiting = True, e, None
+                # heard at once, whoever ends up calling ``finish`` (or never does: ``Interleaver.close`` raises what is left)
+                log.warning("sched: task on slot %s raised %s: %s (stored; re-raised by Interleaver.finish / close)", self.slot, type(e).__name__, e)
         return True
 
     def cancel(self):
@@ -134,7 +139,8 @@ class Interleaver:
                             if stalled > 1000:
                                 self.tasks.remove(task)
                                 task.cancel()
-                                raise RuntimeError("sched.Interleaver: no task, server or device event can make progress (scheduler stalled)")
+                                raise RuntimeError("sched.Interleaver: no task, server or device event can make progress (scheduler stalled); "
+                                                   + self.describe())
                             time.sleep(1e-3)
                         continue
             stalled = 0
@@ -142,3 +148,34 @@ class Interleaver:
         if task.error is not None:
             raise task.error
         return task.result
+
+    def describe(self):
+        """Who is blocked on what (for the stall message and logs)."""
+        ts = ", ".join(f"slot {t.slot}: {'done' if t.done else 'waiting for an event' if t.waiting is not None else 'asked to be resumed later'}"
+                       f"{' [error: %r]' % (t.error,) if t.error is not None else ''}" for t in self.tasks) or "none"
+        sv = ", ".join(f"{type(s).__name__}(jobs {len(getattr(s, 'jobs', ()))}, queued prefills {len(getattr(s, 'pf_queue', ()))})" for s in self.servers) or "none"
+        return f"tasks: {ts}; servers: {sv}"
+
+    def close(self):
+        """End of the driver's work: tasks that were added and never finished are cancelled, and an error one of them stored is raised
+        here instead of being lost (the first one; the others are logged when they happen)."""
+        left, self.tasks = self.tasks, []
+        first = None
+        for t in left:
+            if t.error is not None and first is None:
+                first = t.error
+            t.cancel()
+        if first is not None:
+            raise first
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        else:               # already unwinding: cancel quietly, the original exception wins
+            for t in self.tasks:
+                t.cancel()
+            self.tasks = []
+        return False

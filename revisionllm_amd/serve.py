@@ -93,7 +93,7 @@ class DecodePool:
         return max((f[1] for f in self.free), default=0)
 
     def _release(self, job, event):
-        self.free.append((job.r0, job.B, (event,)))
+        self.free.append((job.r0, job.B, tuple(event) if isinstance(event, (tuple, list)) else (event,)))
         self.free.sort(key=lambda f: f[0])
         merged = []
         for r0, n, evs in self.free:         # coalesce neighbours; whoever takes the merged range waits for all their events
@@ -107,7 +107,7 @@ class DecodePool:
     def fits(self, S, max_new_tokens, B=1):
         return S + max_new_tokens <= self.Smax and max_new_tokens <= self.G and B <= self.R
 
-    def abandon(self, job):
+    def abandon(self, job, extra_streams=()):
         """A generate gives up its rows before its results are out (its task raised, or was cancelled): the rows go inactive and
         back to the free list, the pool's counts drop - a sealed gang pool must not wait for a generate that will never join or finish."""
         if job.finished or getattr(job, "abandoned", False):
@@ -121,9 +121,16 @@ class DecodePool:
         else:
             self.pending -= 1
         self.live -= 1
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        self._release(job, ev)
+        # Whoever takes the rows next must wait for EVERYTHING that may still write them: the pool's merged steps (decode stream) and,
+        # for a generate that has not joined yet, its prefill - running on the stream ``abandon`` is called under (the task's stream:
+        # ``generate_steps`` calls this from its ``finally``) or, for a batched ticket, on the server's prefill stream.
+        evs = []
+        for st in (self.stream, torch.cuda.current_stream(self.eng.device)) + tuple(extra_streams):
+            if st is not None and all(st is not s_ for s_, _ in evs):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append((st, ev))
+        self._release(job, tuple(e for _, e in evs))
 
     # ---- joining -------------------------------------------------------------------------------------------------------------
     def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None):
@@ -376,7 +383,7 @@ class DecodeServer:
     def abandon(self, job):
         """Release the rows of a generate that will not complete (``generate_steps`` calls this from its ``finally``)."""
         self.pf_queue = [t for t in self.pf_queue if t.job is not job]
-        job.pool.abandon(job)
+        job.pool.abandon(job, extra_streams=(self.pf_stream,) if self.pf_stream is not None else ())
 
     # ---- batched prefills ------------------------------------------------------------------------------------------------------
     def submit_prefill(self, job, h, B, P0):

@@ -27,8 +27,9 @@ from helpers import SEED, T, feats
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENT_TOL = 5e-3          # element-wise relative bound on 1/max_entropy, 1/mean_entropy (measured: <= 2.5e-3; the reference's own bf16 leg:
-                        # 1.4e-3 .. 1.7e-2; north star: 1e-3, printed next to it)
+ENT_TOL = 3e-3          # DEFAULT (bf16) mode: element-wise relative bound on 1/max_entropy, 1/mean_entropy (measured: <= 2.4e-3; the reference's
+                        # own bf16 leg: 1.4e-3 .. 1.7e-2).  The north star's 1e-3 is asserted in the parity precision mode (PARITY_TOL below)
+PARITY_TOL = 1e-3       # Engine option precision = parity: the north star's tolerance on the same quantities
 LAYER_TOL = 1e-2        # one block, bf16 activations: |out - oracle| max over the tensor / max |branch output of that block|
 
 
@@ -393,3 +394,54 @@ def test_conditioned_fp8_llm_path_through_the_headline_pipeline(g8c):
     assert np.abs(e8 - e8[0]).max() < 0.2
     assert np.median(e8) < 0.15 and e8.max() < 0.5                          # a quantisation-sized distance, not a different function
     assert np.median(e16) < np.median(e8)                                   # the unquantised path of the same engine is closer
+
+
+@pytest.fixture(scope="module")
+def fp8_model():
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    m = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device="cuda:0")
+    m.get_model().initialize_vision_modules(_hier_args())
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=True, cond=synth.CONDITIONED, fp8_decode=True, fp8_prefill=True)
+    m.generation_config.eos_token_id = None
+    return m
+
+
+@pytest.mark.parametrize("copies,pool_rows", [(10, 70), (20, 140)])
+def test_conditioned_fp8_llm_path_free_running_proposals(g8c, fp8_model, copies, pool_rows):
+    """BASELINE configs[4] judged the way SURVEY section 7 says an fp8 path is judged - on PROPOSALS: the fp8 MFMA LLM path (FP8 x FP8
+    prefill GEMMs, FP8 decode weights) FREE-RUNNING on the reference's recorded uniforms through the bench's pipeline (10 instances /
+    70-row gang, 20 instances / the 140-row gang of the bench's fp8 legs).  Every instance's decoded answers, parsed windows (``frames``),
+    hit flags (``iou``), group starts and zooms must equal the fp32 reference's record; the entropy scores are printed (quantisation-sized
+    distance, bounded in the teacher-forced property test above)."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    r, g, meta = g8c, g8c.g, g8c.meta
+    m = fp8_model
+    m.engine.set_option("fp8_decode", 1).set_option("fp8_prefill", 1)
+    tok = synth.FakeTokenizer()
+    st = parallel.HipStages(m, tok)
+    u = T(g["uniforms"]).t().contiguous()                                   # [G, calls]
+    server = serve.DecodeServer(m, rows=pool_rows, smax=192, gmax=16, pools=2, gang=True, prefill_batch=4)
+    st.server = server
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(copies)]
+    torch.cuda.synchronize()
+    inter = sched.Interleaver(servers=[server])
+    kw = dict(batch=meta["batch"], perms=[r.perms], max_new_tokens=meta["G"], uniforms=u)
+    tasks = [inter.add(sched.Task(lambda t: parallel.launch_queries_sharded_steps(st, tok, r.features, meta["W"], [(r.qf, r.qc, meta["sentence"])], turn=t, **kw),
+                                  streams[i], m.engine, i)) for i in range(copies)]
+    recs = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+    m.engine.slot = 0
+    assert server.rows_served >= server.steps_run * 7 * min(copies, pool_rows // 7) * 0.99
+    worst = 0.0
+    for rec in recs:
+        assert rec["answers"] == meta["answers"]                                                     # free-running tokens decode to the reference's answers
+        info = stage2.log_record(rec, meta["gt"], meta["batch"])
+        assert {str(k): list(v) for k, v in info["frames"].items()} == meta["frames"] and info["iou"] == meta["iou"]
+        assert rec["starts"] == g["starts"].tolist() and rec["hierarchy_zooms"] == g["zooms"].tolist()
+        worst = max(worst, float(_rel(rec["max_entropy"], g["inv_max"]).max()), float(_rel(rec["mean_entropy"], g["inv_mean"]).max()))
+    print("\n[G8c fp8 LLM path FREE-RUNNING] copies", copies, "pool rows", pool_rows, ": answers / frames / iou equal the reference's in every instance; "
+          "worst rel err of the entropy scores %.3e" % worst)
+    with open(os.path.join(ROOT, "gpurun_out", f"g8c_fp8_free_{pool_rows}.json"), "w") as f:
+        json.dump({"copies": copies, "pool_rows": pool_rows, "answers_equal": True, "frames_iou_equal": True, "worst_entropy_score_rel_err": worst}, f, indent=1)
