@@ -89,6 +89,9 @@ def parse():
                    help="extra measurement (NOT the headline): decode steps stream FP8 (e4m3fn, per-row scale) weight copies - half the bytes")
     p.add_argument("--fp8-prefill", action="store_true",
                    help="extra measurement (NOT the headline): prefill GEMMs run FP8 x FP8 (activations quantised per row on the fly)")
+    p.add_argument("--parity", action="store_true",
+                   help="extra measurement (NOT the headline): the PARITY precision (engine option precision = 1: split-bf16 GEMM operands against "
+                        "K-duplicated weights; the mode whose scores meet the north star's 1e-3 against the fp32 reference)")
     p.add_argument("--gemm-waves", type=int, default=0, choices=(0, 4, 8), help="waves per workgroup of the persistent prefill GEMMs (0 = the library default; see include/revision_hip.h)")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
     p.add_argument("--gemm-variant", type=int, default=2, help="rv_ctx_set_option gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
@@ -404,7 +407,9 @@ def main():
     # for the headline.
     extras = (world == 1 and headline and not args.no_extras and not args.fp8_decode and not args.fp8_prefill and args.queries == 1
               and not args.eos)
-    eng.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras)
+    eng.init_synthetic(seed=args.seed, llm=True, clip=True, fp8_decode=args.fp8_decode or extras, fp8_prefill=args.fp8_prefill or extras,
+                       parity=extras or args.parity)
+    eng.set_option("precision", 1 if args.parity else 0)
     eng.set_option("fp8_decode", 1 if args.fp8_decode else 0)
     eng.set_option("fp8_prefill", 1 if args.fp8_prefill else 0)
     eng.set_option("gemm_cus", args.gemm_cus)
@@ -436,16 +441,17 @@ def main():
     def hashed(shape, dtype, name):
         return ops.init_hash_(torch.empty(*shape, dtype=dtype, device=dev), name, args.seed, synth.SQRT3)
 
-    def input_set(k, nq=1, W_=None, Wl_=None, batch_=None):
+    def input_set(k, nq=1, W_=None, Wl_=None, batch_=None, per_rank=None):
         """The inputs of step k: ``nq`` recursions, each over its OWN video (this rank's windows of it), with its own query tokens,
         query CLS feature, sentence (same word count: the prompts keep one geometry, the token ids differ) and window permutations.
         Queries / permutations are identical on all ranks when a recursion is sharded over them (segments / strong), per-rank in
         queries mode; k = 0 of rank 0 reproduces the round-2 bench's single input."""
         W_, Wl_, batch_ = W_ or W, Wl_ or Wl, batch_ or batch
-        qtag = f".r{rank}" if by_query else ""
+        per_rank = by_query if per_rank is None else per_rank      # queries / permutations per rank (queries mode) or identical on all ranks
+        qtag = f".r{rank}" if per_rank else ""
         tag = "" if k == 0 else f".s{k}"
         plan_ = stage2.plan_groups(W_, batch_)
-        g = torch.Generator().manual_seed(args.seed * 100003 + k * 17 + (rank * 7919 if by_query else 0))
+        g = torch.Generator().manual_seed(args.seed * 100003 + k * 17 + (rank * 7919 if per_rank else 0))
         feats_ = [hashed((Wl_, Tn, 768), torch.bfloat16, f"bench.feat{i if nq > 1 else ''}{'' if W_ == W else W_}.r{rank}{tag}") for i in range(nq)]
         sent = SENTENCE if k == 0 else SENTENCE.replace("kitchen", f"kitchen{k}").replace("newspaper", f"newspaper{k}")
         qs = [(hashed((args.lq, 768), torch.bfloat16, f"bench.q{i if nq > 1 else ''}{qtag}{tag}"),
@@ -472,7 +478,7 @@ def main():
                                     prefill_batch=args.prefill_batch)
         stages.server = server
 
-    work = {"sets": input_sets(args.queries), "W": W, "batch": batch, "G": G}
+    work = {"sets": input_sets(args.queries), "W": W, "batch": batch, "G": G, "group": own_group, "by_query": by_query}
     streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
     counter = {"i": 0}
     inter = sched.Interleaver(servers=[server] if server is not None else ())
@@ -480,7 +486,7 @@ def main():
     def launch():
         """Start one step as a scheduler task bound to the next HIP stream / workspace slot."""
         s_ = work["sets"][counter["i"] % len(work["sets"])]
-        kw = dict(batch=work["batch"], perms=s_["perms"], max_new_tokens=work["G"], group=own_group)
+        kw = dict(batch=work["batch"], perms=s_["perms"], max_new_tokens=work["G"], group=work["group"])
         def g(task):
             return parallel.launch_queries_sharded_steps(stages, tok, s_["feats"], work["W"], s_["qs"], turn=task, **kw)
         if streams is None:
@@ -504,7 +510,7 @@ def main():
 
         def take():
             r = collect(pending.pop(0))
-            if by_query:
+            if work["by_query"]:
                 scores.append(r["max_entropy"] + r["mean_entropy"])
             return r
         for _ in range(n):
@@ -513,7 +519,7 @@ def main():
                 rec = take()
         while pending:
             rec = take()
-        if by_query and scores:
+        if work["by_query"] and scores:
             # the ONE exchange of this mode: the per-call proposals (1/max_entropy, 1/mean_entropy of every call of every recursion this
             # rank ran) all-gathered over RCCL, ordered against the persistent prefill GEMMs like every collective of the path
             mine = torch.tensor(scores, dtype=torch.float32, device=dev)
@@ -648,11 +654,12 @@ def main():
 
     extra = {}
     if extras:
-        def leg(name, nq, fp8, fp8p=False, eos=False, merged=True):
+        def leg(name, nq, fp8, fp8p=False, eos=False, merged=True, par=False):
             stages.server = server if merged else None
             work["sets"] = input_sets(nq)
             eng.set_option("fp8_decode", int(fp8))
             eng.set_option("fp8_prefill", int(fp8p))
+            eng.set_option("precision", int(par))
             model.generation_config.eos_token_id = 2 if eos else None
             t, _ = timed(run)
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
@@ -660,19 +667,25 @@ def main():
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
                            "decode_weights": "fp8 e4m3fn, per-row scale (same pools and merged steps as the headline)" if fp8 else "bf16",
                            "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
+            if par:
+                extra[name].update(decode_weights="bf16", prefill_gemms="bf16 x 2: split operands [hi | lo] against K-duplicated weights",
+                                   precision="PARITY (rv_ctx_set_option precision = 1): every GEMM operand and Q carry 16 mantissa bits; the mode in which "
+                                             "1/max_entropy, 1/mean_entropy meet 1e-3 against the fp32 reference (tests/test_gpu_full_depth_conditioned.py); "
+                                             "unfused decode steps through the generic kernels")
             if not merged:
                 extra[name]["decode"] = "every step in flight runs its own decode passes (no DecodeServer): the round-1 pipeline"
             if eos:
                 extra[name]["eos"] = ("EOS id 2 configured (random-init weights practically never emit it, so all G steps still run): the cost shown is "
                                       "that of the device-side stop flags (one tiny reduction + pinned D2H copy per generate and step, looked at when "
                                       "the copy has landed: never a host wait)")
-        for name, nq, fp8, fp8p, eos, merged in (("eos_enabled", 1, False, False, True, True), ("separate_decode_passes", 1, False, False, False, False),
-                                                 ("fp8_decode_weights", 1, True, False, False, True),
-                                                 ("fp8_llm_path", 1, True, True, False, True), ("two_videos_per_step", 2, False, False, False, True),
-                                                 ("two_videos_per_step_fp8_decode_weights", 2, True, False, False, True),
-                                                 ("two_videos_per_step_fp8_llm_path", 2, True, True, False, True)):
+        for name, nq, fp8, fp8p, eos, merged, par in (("eos_enabled", 1, False, False, True, True, False), ("separate_decode_passes", 1, False, False, False, False, False),
+                                                      ("fp8_decode_weights", 1, True, False, False, True, False),
+                                                      ("fp8_llm_path", 1, True, True, False, True, False), ("two_videos_per_step", 2, False, False, False, True, False),
+                                                      ("two_videos_per_step_fp8_decode_weights", 2, True, False, False, True, False),
+                                                      ("two_videos_per_step_fp8_llm_path", 2, True, True, False, True, False),
+                                                      ("parity_precision", 1, False, False, False, True, True)):
             try:
-                leg(name, nq, fp8, fp8p, eos, merged)
+                leg(name, nq, fp8, fp8p, eos, merged, par)
             except Exception as e:  # noqa: BLE001 - an extra leg must never cost the headline line
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 try:
@@ -681,6 +694,7 @@ def main():
                     pass
         eng.set_option("fp8_decode", 0)
         eng.set_option("fp8_prefill", 0)
+        eng.set_option("precision", 0)
         model.generation_config.eos_token_id = None
         stages.server = server
         work["sets"] = input_sets(1)
@@ -786,6 +800,66 @@ def main():
                     torch.cuda.synchronize()
                 except Exception:  # noqa: BLE001
                     pass
+
+    rccl_seen = None
+    if world > 1 and headline and not args.no_extras and not args.workload.startswith("stage1"):
+        # The one multi-GPU run the driver makes must also measure the split the north star's 60 % target is about: after the headline
+        # (whatever --scaling asked for) the OTHER modes are timed on the same ranks - ``segments`` (a 100 * N-window video per step, windows
+        # block-partitioned, all-gather #1 of the CLS rows and #2 of the proposals inside every recursion) and ``strong`` (ONE 100-window
+        # recursion sharded over the ranks) - and reported under extra_measurements next to the ratio to the headline.
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                                   # ranks the communicator really reaches (read back from the collective)
+        rccl_seen = {"backend": dist.get_backend(), "world_size_of_the_group": dist.get_world_size(), "ranks_counted_by_an_all_reduce": int(one.item())}
+        head_mode = "queries" if by_query else ("strong" if strong else "segments")
+        saved = dict(work)
+        for mode in ("queries", "segments", "strong"):
+            if mode == head_mode:
+                continue
+            try:
+                pq = mode == "queries"
+                Wm = args.windows * (1 if mode in ("strong", "queries") else world)
+                lo_m, hi_m = (0, Wm) if pq else parallel.shard_bounds(Wm, rank, world)
+                key = ("mode", mode)
+                if key not in sets_cache:
+                    sets_cache[key] = [input_set(k, 1, W_=Wm, Wl_=hi_m - lo_m, batch_=batch, per_rank=pq) for k in range(n_sets)]
+                work.update(sets=sets_cache[key], W=Wm, batch=batch, group=parallel.LOCAL if pq else None, by_query=pq)
+                stages._seq_next = 0                           # the rotating call deal restarts identically on every rank
+                if server is not None:
+                    # KV pools sized for what THIS rank decodes in this mode: whole recursions (7 rows each), or its share of the calls dealt
+                    # over the ranks (7 calls over 8 ranks: 0 or 1 row per recursion in flight) - a gang must be able to fill up
+                    from revisionllm_amd import serve
+                    nc_m = len(stage2.plan_groups(Wm, batch))
+                    in_flight = max(1, min(args.streams, args.steps))
+                    b_max = nc_m if pq else -(-nc_m // world)
+                    rows_m = b_max * max(1, min(in_flight, 144 // b_max)) if pq else min(144, max(b_max, in_flight * nc_m // world))
+                    srv = serve.DecodeServer(model, rows=rows_m, smax=server.Smax, gmax=max(16, G), pools=args.pools, gang=args.pools > 1,
+                                             prefill_batch=args.prefill_batch, slot=180 + 20 * ("queries", "segments", "strong").index(mode))
+                    inter.servers.append(srv)
+                    stages.server = srv
+                t, _ = timed(run)
+                if server is not None:
+                    inter.servers.remove(srv)
+                    stages.server = server
+                v = Wm * args.steps * (world if pq else 1) / t
+                extra["scaling_" + mode] = {"value": v, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3, "n_gpus": world,
+                                            "kv_pool_rows_per_rank": rows_m if server is not None else None,
+                                            "windows_per_step_all_ranks": Wm * (world if pq else 1), "ratio_to_the_headline_mode": v / value,
+                                            "headline_mode": head_mode,
+                                            "what": {"queries": "whole recursions per rank, one final all-gather (no data-path collective)",
+                                                     "segments": "a 100 * N-window video per step, windows block-partitioned over the ranks, RCCL all-gather of the CLS rows "
+                                                                 "and of the proposals inside every recursion (weak scaling of the segment-parallel split)",
+                                                     "strong": "ONE 100-window recursion per step sharded over the ranks, the 7 calls dealt with a rotating start "
+                                                               "(strong scaling: ratio = efficiency against N x the per-GPU rate)"}[mode]}
+            except Exception as e:  # noqa: BLE001 - an extra leg must never cost the headline line
+                extra["scaling_" + mode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+        work.clear()
+        work.update(saved)
+        if rccl_seen is not None:
+            extra["rccl_ranks_seen"] = rccl_seen
 
     if rank == 0:
         ids1, _ = _prompt_ids("<video>\n" + stage2.QUERY_TEMPLATE.format(SENTENCE), tok, 1)

@@ -93,6 +93,15 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        workgroups; measurement knob (same results whatever the split: the summation tree is fixed)
  *   "sample_variant"     1 (default) = top-k selection through the compacted-candidate fast path when the row qualifies (V >= 1024,
  *                        no tie across the k-th place); 0 = always the general 16-round selection.  Identical outputs.
+ *   "lm_head_split"      1 (default) = the lm_head input is the split pair [hi | lo] (bf16(x), bf16(x - hi)) over the K-duplicated lm_head whenever
+ *                        "llm.lm_head.p2" is bound (its bf16 rounding alone owns two thirds of the bf16 path's distance from the fp32 reference on the
+ *                        entropy scores, profiles/r4_error_budget.json); 0 = bf16 lm_head input.  Not used with the FP8 decode weights.
+ *   "precision"          0 (default) = bf16 GEMM operands; 1 = PARITY precision of the LLM forward (every rv_llm_* entry point): every GEMM
+ *                        operand (the outputs of the two RMSNorms, the attention output, silu(gate) * up, the lm_head input) is the split pair
+ *                        [hi | lo] = (bf16(x), bf16(x - hi)) - 16 mantissa bits - multiplied with K-duplicated weight copies on the unchanged
+ *                        GEMM kernels; no norm fusion, no FP8.  Needs "llm.L{i}.{wqkv,wo,wgu,wdown}.p2" and "llm.lm_head.p2" bound
+ *                        (RV_ERR_UNBOUND otherwise).  What it is for: the reference's fp32 segment scores to the north star's 1e-3
+ *                        (vtimellm_llama.py:38-90 executed in fp32 on the CPU; funs_get_feature_X.py:120-146); ~2 x the prefill GEMM time.
  * Unknown keys / out-of-range values return RV_ERR_ARG. */
 int rv_ctx_set_option(rv_ctx* ctx, const char* key, int64_t value);
 int rv_ctx_get_option(const rv_ctx* ctx, const char* key, int64_t* value);
@@ -102,6 +111,8 @@ int rv_ctx_get_option(const rv_ctx* ctx, const char* key, int64_t* value);
  *   pair-interleaved: row 2j = dim j, row 2j+1 = dim j+64, so RoPE partners meet in one lane); llm.L{i}.wo [D,D];
  *   llm.L{i}.wgu [2F,D] bf16, gate/up interleaved in 16-row blocks; llm.L{i}.wdown [D,F];
  *   llm.L{i}.norm1 / norm2 [D] f32; llm.norm [D] f32; llm.lm_head [V,D] bf16;
+ *   optional, all or none: "<matrix>.p2" = the fragment packing of [W | W] ([N, 2K]: W duplicated along K) for every llm.L{i} matrix and
+ *   llm.lm_head - the weight side of the parity precision (option "precision");
  *   adp.cls_token / adp.cls_pos [768] f32; adp.{t2v,enc}.{l}.{w_in[2304,768],w_out,w1,w2} bf16,
  *   adp.{..}.{b_in,b_out,b1,b2,ln1_w,ln1_b,ln2_w,ln2_b} f32; adp.proj_w [D,768] bf16; adp.proj_b [D] f32;
  *   proj.w [D,768] bf16; proj.b [D] f32   (dense nn.Linear projector, vtimellm_arch.py:42)

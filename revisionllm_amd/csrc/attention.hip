@@ -19,7 +19,7 @@ namespace {
 // walk all keys serially), so this cuts it ~4x.
 // PAD: a key-padding mask is present (the text cross-attention of the adapter); without it the per-key byte loads and their
 // branches are compiled out.
-template <int DH, bool SPLIT, bool PAD>
+template <int DH, bool SPLIT, bool PAD, bool QS = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int b) {
     constexpr int NC = DH / 32, ND = DH / 16;
     const int lane = threadIdx.x & 63;
@@ -37,6 +37,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     bf16x8 qf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) qf[c] = *(const bf16x8*)(qp + c * 32);
+    bf16x8 ql[QS ? NC : 1];      // parity precision: the low halves of the query row (scores = K.(Qhi + Qlo))
+    if constexpr (QS) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ql[c] = *(const bf16x8*)(qp + a.q_lo + c * 32);
+    }
 
     const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
     const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
@@ -70,6 +75,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s[t], 0, 0, 0);
+            if constexpr (QS) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], ql[c], s[t], 0, 0, 0);
+            }
         }
         float mx = -INFINITY;
         // interior block (wave-uniform): every key exists and is visible to all 16 rows - no per-element masking
@@ -158,6 +167,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
             }
             if (a.out_packed) *(uint32_t*)((bf16_t*)a.out + rv_xp_index(b, h * DH + dc + j, a.out_packed)) = pack_bf16x2(v0 * inv, v1 * inv);   // (Lq = 1)
             else *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
+            if (a.out_lo) *(uint32_t*)(op + a.out_lo + j) = pack_bf16x2_lo(v0 * inv, v1 * inv);
         }
         return;
     }
@@ -167,6 +177,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
         *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+    if (a.out_lo) {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+            *(u32x2*)(op + a.out_lo + dt * 16) = u32x2{pack_bf16x2_lo(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2_lo(o[dt][2] * inv, o[dt][3] * inv)};
+    }
 }
 
 // 1-D grid, XCD-aware: workgroup id lands on XCD id % 8 (private L2), so the query tiles of one (batch, head) - which read
@@ -182,17 +197,18 @@ __device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, i
 }
 __host__ inline unsigned attn_grid(int tiles, int pairs) { return (unsigned)(tiles * ((pairs + 7) / 8) * 8); }
 
-template <int DH, bool SPLIT>
+template <int DH, bool SPLIT, bool QS = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
     int bx, h, b;
     if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;
-    if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b);
+    if constexpr (QS) attn_body<DH, SPLIT, false, true>(a, bx, h, b);      // (the LLM has no key padding: checked by the launcher)
+    else if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b);
     else attn_body<DH, SPLIT, false>(a, bx, h, b);
 }
 
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
 // themselves, the per-call rows attend to prefix + own keys): blockIdx.z < a.B -> problem a, else problem b.
-template <int DH>
+template <int DH, bool QS = false>
 __global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles, AttnGroups gr) {
     int bx, h, z;
     const int per = a.B + b.B;
@@ -202,12 +218,12 @@ __global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, 
     AttnArgs& p = z < a.B ? a : b;
     if (gr.G > 1) {      // (uniform per workgroup)
         p.q = (const bf16_t*)p.q + gr.q_off[g];
-        p.out = (bf16_t*)p.out + gr.q_off[g];
+        p.out = (bf16_t*)p.out + gr.o_off[g];
         p.k = (const bf16_t*)p.k + gr.kv_off[g];
         p.vt = (const bf16_t*)p.vt + gr.kv_off[g];
     }
-    if (z < a.B) attn_body<DH, false, false>(p, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
-    else attn_body<DH, false, false>(p, bx, h, z - a.B);
+    if (z < a.B) attn_body<DH, false, false, QS>(p, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
+    else attn_body<DH, false, false, QS>(p, bx, h, z - a.B);
 }
 
 }  // namespace
@@ -229,7 +245,9 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const
     const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
     const AttnGroups gr = groups ? *groups : AttnGroups{};
     RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention pair: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
-    hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    RV_CHECK_ARG((a.q_lo != 0) == (b.q_lo != 0), "attention pair: both problems or neither carry split queries");
+    if (a.q_lo) hipLaunchKernelGGL((attn_kernel_pair<128, true>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    else hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     RV_CHECK_LAUNCH("attention pair");
     return RV_OK;
 }
@@ -243,6 +261,13 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
     const bool split = a.Lq <= 16 && !a.no_split;
     const int tiles = (int)cdiv(a.Lq, split ? 16 : 64);
     const dim3 grid(attn_grid(tiles, a.H * a.B));
+    if (a.q_lo) {      // parity precision: split queries (the LLM's 128-wide heads, no key padding)
+        RV_CHECK_ARG(a.dh == 128 && !a.key_pad, "attention: split queries are instantiated for 128-wide heads without key padding");
+        if (split) hipLaunchKernelGGL((attn_kernel<128, true, true>), grid, dim3(256), 0, st, a, tiles);
+        else hipLaunchKernelGGL((attn_kernel<128, false, true>), grid, dim3(256), 0, st, a, tiles);
+        RV_CHECK_LAUNCH("attention");
+        return RV_OK;
+    }
     if (a.dh == 64 && !split)
         hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 64)

@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// split-bf16 operands (parity precision): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) carries 16 mantissa bits
+__device__ __forceinline__ float bf16_residual(float x) { return x - bf16_to_f32(f32_to_bf16(x)); }
+__device__ __forceinline__ uint32_t pack_bf16x2_lo(float a, float b) { return pack_bf16x2(bf16_residual(a), bf16_residual(b)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

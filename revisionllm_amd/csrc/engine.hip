@@ -27,6 +27,9 @@ struct LlmLayer {
     // optional FP8 copies for the prefill GEMMs ("<name>.f8p": the byte matrix in the bf16 fragment packing of its 16-bit
     // words; same quantisation and ".s8" scales as the decode copies); all or none
     const uint8_t *wqkv8p = nullptr, *wo8p = nullptr, *wgu8p = nullptr, *wdown8p = nullptr;
+    // optional K-DUPLICATED copies ("<name>.p2" = [W | W] along K, fragment-packed) for the parity precision: a GEMM over the split
+    // operand [hi | lo] (K doubled) against [W | W] is W.hi + W.lo in one launch of the unchanged kernels; all or none
+    const bf16_t *wqkv2 = nullptr, *wo2 = nullptr, *wgu2 = nullptr, *wdown2 = nullptr;
 };
 
 struct rv_ctx {
@@ -44,6 +47,8 @@ struct rv_ctx {
     const float* slm_head = nullptr;
     bool fp8_decode = false;
     bool fp8_prefill = false;   // ".f8p" copies bound for every layer projection
+    const bf16_t* lm_head2 = nullptr;
+    bool parity = false;        // ".p2" copies bound for every projection + lm_head (the parity precision can be switched on)
     bool options_only = false;  // created without a model configuration: carries tunables for the building-block entry points
     RvOpts opt;                 // per-context tunables (rv_ctx_set_option)
 };
@@ -170,6 +175,22 @@ int resolve_llm(rv_ctx* c) {
             FIND(p + "wdown.s8", RV_F32, D, L.sdown);
         }
     }
+    // parity precision: used when the K-duplicated copies of ALL projections are bound (and the context's precision option asks for it)
+    // (the lm_head copy alone is bound by default: the lm_head input is a split pair in EVERY precision - the error budget names its bf16
+    //  rounding as the owner of two thirds of the default path's distance from the fp32 reference, and it costs one doubled-K launch per step)
+    c->lm_head2 = nullptr;
+    if (c->w.count("llm.lm_head.p2") != 0) FIND("llm.lm_head.p2", RV_BF16, 2 * V * D, c->lm_head2);
+    c->parity = c->lm_head2 && c->w.count("llm.L0.wqkv.p2") != 0;
+    if (c->parity) {
+        for (int l = 0; l < g.layers; ++l) {
+            const std::string p = "llm.L" + std::to_string(l) + ".";
+            LlmLayer& L = c->layers[l];
+            FIND(p + "wqkv.p2", RV_BF16, 2 * 3 * D * D, L.wqkv2);
+            FIND(p + "wo.p2", RV_BF16, 2 * D * D, L.wo2);
+            FIND(p + "wgu.p2", RV_BF16, 2 * 2 * F * D, L.wgu2);
+            FIND(p + "wdown.p2", RV_BF16, 2 * D * F, L.wdown2);
+        }
+    }
     c->resolved_llm = true;
     return RV_OK;
 }
@@ -277,6 +298,8 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "rows_persistent") return &o.rows_persistent;
     if (k == "rows_single") return &o.rows_single;
     if (k == "gemm_waves") return &o.gemm_waves;
+    if (k == "precision") return &o.precision;
+    if (k == "lm_head_split") return &o.lm_head_split;
     return nullptr;
 }
 }  // namespace
@@ -289,6 +312,7 @@ extern "C" int rv_ctx_set_option(rv_ctx* c, const char* key, int64_t value) {
     if (k == "gemm_tile_variant") RV_CHECK_ARG(value >= 0 && value <= 6, "rv_ctx_set_option: gemm_tile_variant must be in [0, 6]");
     if (k == "gemm_waves") RV_CHECK_ARG(value == 4 || value == 8, "rv_ctx_set_option: gemm_waves must be 4 or 8");
     if (k == "gemm_cus") RV_CHECK_ARG(value >= 0 && value % 8 == 0, "rv_ctx_set_option: gemm_cus must be a non-negative multiple of 8");
+    if (k == "precision") RV_CHECK_ARG(value == 0 || value == 1, "rv_ctx_set_option: precision must be 0 (bf16 operands) or 1 (parity: split operands)");
     *slot = (int)value;
     return RV_OK;
 }
@@ -438,8 +462,11 @@ extern "C" size_t rv_kv_bytes(const rv_ctx* c, int32_t B, int32_t Smax) {
 }
 
 namespace {
+// the parity precision applies when its weight copies are bound AND the context asks for it
+inline bool llm_parity(const rv_ctx* c) { return c->opt.precision == 1 && c->w.count("llm.L0.wqkv.p2") != 0 && c->w.count("llm.lm_head.p2") != 0; }
 struct LlmWs {
     bf16_t *xn16, *q16, *a16, *act16, *xl16;
+    float* g32;      // parity precision: the gated MLP activation silu(gate) * up in f32 [M, F] (split into act16 [M, 2F] afterwards)
     float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
     float* planes;   // split-K partial planes of the 33 .. 144-row decode kernel
     int* arrive;     // ... and its arrival counters: at a FIXED offset (right behind sk) whatever the carve's row count, zero from the allocation on
@@ -457,11 +484,13 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.sk = k.take(w.sk_bytes);
     w.arrive = (int*)k.take((size_t)RV_ROWS_COUNTERS * 4);
     const int64_t Mp = M <= RV_ROWS_MAX ? 16 * rv_xp_blocks(M) : M;   // the fragment-packed decode layout spans whole row blocks
-    w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2);
-    w.q16 = (bf16_t*)k.take((size_t)M * D * 2);
-    w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2);
-    w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2);
-    w.xl16 = (bf16_t*)k.take((size_t)M * D * 2);  // >= one row per sequence
+    const size_t par = llm_parity(c) ? 2 : 1;                         // split operands [hi | lo]: every bf16 GEMM input is twice as wide
+    w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2 * par);
+    w.q16 = (bf16_t*)k.take((size_t)M * D * 2 * par);
+    w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2 * par);
+    w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2 * par);
+    w.xl16 = (bf16_t*)k.take((size_t)Mp * D * 2 * 2);  // >= one row per sequence, as the split pair [hi | lo] (whole row blocks in the packed decode layout)
+    w.g32 = (float*)k.take(par == 2 ? (size_t)M * (F > 3 * D ? F : 3 * D) * 4 : 0);   // f32 q/k/v [M, 3D], then silu(gate) * up [M, F]
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.ss = (float*)k.take((size_t)RV_XP_MAX_BLOCKS * (D / 16) * 16 * 4);   // [<= 9 row blocks][D/16 workgroups][16]
     w.planes = (float*)k.take(gemm_rows_ws_bytes());
@@ -510,11 +539,18 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     else RV_TRY(k_rope_table(w.cs, pos0 + S - tab0, tab0, dh, g.rope_theta, st));
     // Decode steps (M <= 32 rows) fuse every RMSNorm but the first into the projections around it (GemvNorm, kernels.h):
     // o-proj / down-proj emit the pre-scaled activation + per-workgroup sums of squares, qkv / gate-up / lm_head apply r[b].
-    const bool fuse_norm = S == 1 && P0 == 0 && M <= RV_ROWS_MAX && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
+    // Parity precision: every GEMM operand is the split pair [hi | lo] (16 mantissa bits) against
+    // K-duplicated weights, on the unchanged GEMM kernels; no norm fusion, no FP8.  What stays bf16: Q, the K / V caches, P in front of P.V.
+    const bool par = llm_parity(c);
+    if (c->opt.precision == 1 && !par) {
+        rv_set_error("rv_llm_forward: precision = 1 (parity) needs the K-duplicated weight copies (\"<name>.p2\") bound");
+        return RV_ERR_UNBOUND;
+    }
+    const bool fuse_norm = !par && S == 1 && P0 == 0 && M <= RV_ROWS_MAX && D % 128 == 0 && F % 128 == 0 && (M <= 32 || (D % 64 == 0 && F % 32 == 0 && V % 64 == 0));
     const bool f8 = fuse_norm && c->fp8_decode && c->opt.fp8_decode;   // FP8 weight copies: KV-cached decode steps only (any row count <= 144)
     // FP8 x FP8 prefill: every GEMM with a persistent plan at this M takes quantised activations (per-row scales) and the ".f8p"
     // weights; the others (and lm_head) stay on the bf16 weights
-    const bool p8 = !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
+    const bool p8 = !par && !fuse_norm && M > 32 && c->fp8_prefill && c->opt.fp8_prefill && w.sk_bytes >= 8192;
     const bool p8_qkv = p8 && gemm_pp_fp8_supported(M, 3 * D, D, false, true), p8_o = p8 && gemm_pp_fp8_supported(M, D, D, false, false);
     const bool p8_gu = p8 && gemm_pp_fp8_supported(M, 2 * F, D, true, false), p8_down = p8 && gemm_pp_fp8_supported(M, D, F, false, false);
     auto norm_quant = [&](const float* nw) -> int {   // RMSNorm(h) -> FP8 rows + scales (fused for d = 4096)
@@ -540,7 +576,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         const LlmLayer& L = c->layers[l];
         bf16_t* kc = kbase + l * per_layer;
         bf16_t* vtc = vbase + l * per_layer;
-        if (p8_qkv) RV_TRY(norm_quant(L.norm1));
+        if (par) RV_TRY(k_rmsnorm_split(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
+        else if (p8_qkv) RV_TRY(norm_quant(L.norm1));
         else if (!fuse_norm || l == l0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st, xp));
         // fused q/k/v projection: RoPE-rotated Q -> q16, rotated K and V^T -> this layer's cache (no f32 qkv round trip)
         QkvRope qr;
@@ -553,7 +590,12 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         qr.G = G;
         qr.Mg = (int)Mg;
         for (int gi = 1; gi < G; ++gi) qr.grow[gi] = grow[gi] - grow[0];
-        if (p8_qkv) {
+        if (par) {   // f32 q/k/v, then RoPE + Q as a split pair + cache append in their own kernel (the fused epilogues keep their bf16 Q)
+            qr.q_ld = (int)(2 * D);
+            qr.q_lo = (int)D;
+            RV_TRY(rv_gemm_impl(w.xn16, 2 * D, L.wqkv2, 2 * D, 1, nullptr, nullptr, 0, w.g32, 3 * D, RV_F32, RV_ACT_NONE, M, 3 * D, 2 * D, w.sk, w.sk_bytes, st, nullptr));
+            RV_TRY(k_qkv_rope_split(w.g32, 3 * D, qr, M, D, st));
+        } else if (p8_qkv) {
             RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wqkv8p, L.sqkv, nullptr, 0, nullptr, 0, RV_F32, RV_ACT_NONE, M, 3 * D, D, &qr, w.sk, st));
         } else if (f8) {   // decode with FP8 weights: the scales ride in the norm descriptor
             GemvNorm cq = (fuse_norm && l > l0) ? consume : GemvNorm{};
@@ -570,30 +612,37 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             RV_TRY(gemm_qkv_rope(w.xn16, D, L.wqkv, M, D, qr, fuse_norm ? (l > l0 ? &consume : &first) : nullptr, w.sk, w.sk_bytes, st));
         }
         bool prefix_done = false;
+        const int64_t od = par ? 2 * D : D, olo = par ? D : 0;   // attention output rows (and query rows): [hi | lo] in the parity precision
+        const int64_t qd = od, qlo = olo;
         auto blocked_vt = [&](AttnArgs& x) { x.vt_ds = 8; x.vt_ks = (int64_t)dh * 8; };   // the V^T cache is blocked by 8 positions (rv_vt_index)
         if (P0 > 0 && P0 > 16 && S > 16 && dh == 128) {
             // prefix rows + per-call rows in ONE launch (the prefix problem alone is a ~9 us launch) - for all G groups of a batched prefill
-            AttnArgs ap{w.q16, D, (int64_t)P0 * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
-                        (int64_t)dh * Smax, Smax, w.a16, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
-            AttnArgs am{w.q16 + (int64_t)P0 * D, D, (int64_t)S * D, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
-                        (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * D, D, (int64_t)S * D, nullptr, B, H, dh,
+            AttnArgs ap{w.q16, qd, (int64_t)P0 * qd, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                        (int64_t)dh * Smax, Smax, w.a16, od, (int64_t)P0 * od, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+            AttnArgs am{w.q16 + (int64_t)P0 * qd, qd, (int64_t)S * qd, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc,
+                        (int64_t)H * dh * Smax, (int64_t)dh * Smax, Smax, w.a16 + (int64_t)P0 * od, od, (int64_t)S * od, nullptr, B, H, dh,
                         S, pos0 + S, 1, pos0, 1, scale};
             blocked_vt(ap);
             blocked_vt(am);
+            ap.out_lo = am.out_lo = olo;
+            ap.q_lo = am.q_lo = qlo;
             AttnGroups gr;
             gr.G = G;
             for (int gi = 0; gi < G; ++gi) {
-                gr.q_off[gi] = (int64_t)gi * Mg * D;
+                gr.q_off[gi] = (int64_t)gi * Mg * qd;
+                gr.o_off[gi] = (int64_t)gi * Mg * od;
                 gr.kv_off[gi] = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
             }
             RV_TRY(k_attention_pair(ap, am, st, &gr));
             prefix_done = true;
         } else {
             for (int gi = 0; gi < G && P0 > 0; ++gi) {
-                const int64_t qo = (int64_t)gi * Mg * D, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
-                AttnArgs ap{w.q16 + qo, D, (int64_t)P0 * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
-                            (int64_t)dh * Smax, Smax, w.a16 + qo, D, (int64_t)P0 * D, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
+                const int64_t qo = (int64_t)gi * Mg * qd, co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
+                AttnArgs ap{w.q16 + qo, qd, (int64_t)P0 * qd, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
+                            (int64_t)dh * Smax, Smax, w.a16 + (int64_t)gi * Mg * od, od, (int64_t)P0 * od, nullptr, 1, H, dh, P0, P0, 1, 0, 1, scale};
                 blocked_vt(ap);
+                ap.out_lo = olo;
+                ap.q_lo = qlo;
                 RV_TRY(k_attention(ap, st));
             }
         }
@@ -609,14 +658,18 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             for (int gi = 0; gi < G && !prefix_done; ++gi) {
                 const int64_t r0 = (int64_t)gi * Mg + P0;  // first row of the per-sequence part
                 const int64_t co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;
-                AttnArgs a{w.q16 + r0 * D, D, (int64_t)S * D, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
-                           (int64_t)dh * Smax, Smax, w.a16 + r0 * D, D, (int64_t)S * D, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
+                AttnArgs a{w.q16 + r0 * qd, qd, (int64_t)S * qd, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
+                           (int64_t)dh * Smax, Smax, w.a16 + r0 * od, od, (int64_t)S * od, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
                 a.row_pos = row_pos;
                 a.out_packed = xp;
+                a.out_lo = olo;
+                a.q_lo = qlo;
                 blocked_vt(a);
                 RV_TRY(k_attention(a, st));
             }
-            if (p8_o) {
+            if (par) {
+                RV_TRY(rv_gemm_impl(w.a16, 2 * D, L.wo2, 2 * D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, 2 * D, w.sk, w.sk_bytes, st, nullptr));
+            } else if (p8_o) {
                 RV_TRY(k_quant_rows_fp8(w.a16, D, w.x8, D, w.sa, M, (int)D, st));
                 RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wo8p, L.so, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, nullptr, w.sk, st));
             } else if (f8) {
@@ -627,6 +680,14 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                 RV_TRY(rv_gemm_impl(w.a16, D, L.wo, D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, D, w.sk, w.sk_bytes, st,
                                     fuse_norm ? &produce : nullptr));
             }
+        }
+        if (par) {
+            // norm -> [hi | lo]; gate/up with the gated activation kept in f32, split, down with the residual: all operands 16 bits wide
+            RV_TRY(k_rmsnorm_split(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
+            RV_TRY(rv_gemm_impl(w.xn16, 2 * D, L.wgu2, 2 * D, 1, nullptr, nullptr, 0, w.g32, F, RV_F32, RV_ACT_SILU_MUL, M, 2 * F, 2 * D, w.sk, w.sk_bytes, st, nullptr));
+            RV_TRY(k_split_bf16(w.g32, F, w.act16, M, (int)F, st));
+            RV_TRY(rv_gemm_impl(w.act16, 2 * F, L.wdown2, 2 * F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, 2 * F, w.sk, w.sk_bytes, st, nullptr));
+            continue;
         }
         if (p8_gu) RV_TRY(norm_quant(L.norm2));
         else if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
@@ -654,6 +715,27 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         }
     }
     if (!logits) return RV_OK;
+    if (c->lm_head2 && !(f8 && g.layers > 0) && c->opt.lm_head_split) {
+        // The lm_head input as a split pair [hi | lo] over the K-duplicated lm_head: its bf16 rounding alone moved 1/max_entropy by 1.6e-3 rms
+        // (profiles/r4_error_budget.json: two thirds of the default path's distance from the fp32 reference).  Decode steps: the final norm on
+        // the residual stream h (the last down-projection's fused norm outputs go unused), in the step's operand layout, through the same
+        // kernel families as every other decode projection (rows stay bit-identical whatever they are batched with).
+        if (fuse_norm) {
+            RV_TRY(k_rmsnorm_split(h, D, c->final_norm, w.xl16, M, (int)D, g.rms_eps, st, xp));
+            GemvNorm hn;
+            hn.x_packed = xp;
+            hn.planes = w.planes;
+            hn.arrive = w.arrive;
+            return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, 2 * D, w.sk, w.sk_bytes, st, &hn);
+        }
+        for (int gi = 0; gi < G; ++gi)
+            RV_TRY(k_rmsnorm_split(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * 2 * D, B, (int)D, g.rms_eps, st));
+        return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, (int64_t)G * B, V, 2 * D, w.sk, w.sk_bytes, st);
+    }
+    if (par) {
+        rv_set_error("rv_llm_forward: the parity precision needs the split lm_head (option lm_head_split = 1)");
+        return RV_ERR_ARG;
+    }
     if (f8 && g.layers > 0) {
         GemvNorm cl = consume;
         cl.w_scale = c->slm_head;

@@ -855,13 +855,14 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout) {
+                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout, int64_t Kdim) {
     RV_CHECK_ARG(A && Wp && r.cs && r.q16 && r.kc && r.vtc, "gemm_qkv_rope: null argument");
+    RV_CHECK_ARG(Kdim == 0 || (Kdim % 128 == 0 && !norm), "gemm_qkv_rope: an explicit reduction length needs K %% 128 == 0 and no norm fusion");
     RV_CHECK_ARG(D % 128 == 0 && D == (int64_t)r.H * 128 && M == (int64_t)r.G * ((int64_t)r.P0 + (int64_t)r.B * r.S) && (r.G == 1 || r.Mg == r.P0 + r.B * r.S),
                  "gemm_qkv_rope: bad geometry");
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)Wp;
-    const int N = (int)(3 * D), K = (int)D;
+    const int N = (int)(3 * D), K = (int)(Kdim ? Kdim : D);
     if (M <= 32 && w_layout == 2) {
         RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");
         if (M > 16)

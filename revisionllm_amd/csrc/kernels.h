@@ -17,6 +17,9 @@ struct RvOpts {
     int rows_persistent = 1;    // 33 .. 144-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
     int rows_spread = 0;        // 33 .. 144-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
     int rows_fill = 240;        // 33 .. 144-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
+    int lm_head_split = 1;      // LLM forward: the lm_head input is the split pair [hi | lo] over the K-duplicated lm_head whenever "llm.lm_head.p2" is bound (0: bf16 lm_head input, the round-3 arithmetic)
+    int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
+                                // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };
 extern const RvOpts g_default_opts;   // the production defaults every context starts from (rv_ctx_create)
 const RvOpts& rv_cur_opts();
@@ -83,6 +86,9 @@ struct QkvRope {
     // rows [g * Mg, (g + 1) * Mg) are group g's [P0 prefix ; B x S] block, its cache rows start grow[g] rows after kc / vtc's
     int G = 1, Mg = 0;
     int grow[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // parity precision only (read by qkv_rope_store_t<true>, i.e. by the stand-alone RoPE / append kernel - never by the fused GEMM
+    // epilogues): q16 rows are q_ld elements apart and also receive the LOW half bf16(q - bf16(q)) q_lo elements behind the high half
+    int q_ld = 0, q_lo = 0;
 };
 // Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
 // qkv_rope_coeffs fetches the (cos, sin) pairs the group needs (zeros for V columns); the decode kernel calls it BEFORE its
@@ -98,7 +104,8 @@ static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m,
     else { const int r = m - q.P0; const int b = r / q.S; pos = q.pos0 + (r - b * q.S); }
     return *(const f32x4*)(q.cs + ((int64_t)(pos - q.cs_pos0) * 64 + (p >> 1)) * 2);  // (c0, s0, c1, s1)
 }
-static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) {
+template <bool QSPLIT>
+static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) {
     const int D = q.H * 128;
     const int sec = n / D, hd = n - sec * D, head = hd >> 7, p = hd & 127;
     int b, pos, goff = 0;
@@ -115,7 +122,13 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
         const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
         const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
         if (sec == 0) {
-            *(u32x2*)((bf16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
+            if constexpr (QSPLIT) {
+                bf16_t* dst = (bf16_t*)q.q16 + (int64_t)mrow * q.q_ld + hd;
+                *(u32x2*)dst = o;
+                *(u32x2*)(dst + q.q_lo) = u32x2{pack_bf16x2_lo(a0, b0), pack_bf16x2_lo(a1, b1)};
+            } else {
+                *(u32x2*)((bf16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
+            }
         } else {
             const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
             for (int bb = b0_; bb < b1_; ++bb)
@@ -130,6 +143,7 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
         }
     }
 }
+static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, int n, f32x4 v, f32x4 t) { qkv_rope_store_t<false>(q, m, n, v, t); }
 // The ROW part of the epilogue (group, sequence, position, prefix broadcast range, table row) decoded once for all the column groups a
 // lane owns in that row (the four-wave prefill GEMM, gemm_pp.hip pp4_rope_rows: 8 groups per row).  Values and store addresses are
 // exactly those of qkv_rope_store.
@@ -160,7 +174,7 @@ static __device__ __forceinline__ void qkv_rope_store(const QkvRope& q, int m, i
 }
 
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
-                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout = 1);
+                  void* ws, size_t ws_bytes, hipStream_t st, int w_layout = 1, int64_t Kdim = 0);   // Kdim: reduction length (0: = D; 2 * D: split operands)
 
 // ws: optional zero-initialised stream-K workspace (>= gemm_pp_ws_bytes()); NULL -> output-tiled kernels only
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
@@ -197,6 +211,11 @@ int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* 
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st,
               int out_packed = 0);   // out_packed: 0, or the row blocks (2 / 4 / 8) of the fragment-packed decode layout y16 is written in (rv_xp_index)
+// parity precision (RvOpts::precision = 1): split-bf16 operands y [rows, 2 * d] = [hi | lo], hi = bf16(v), lo = bf16(v - hi)
+int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed = 0);   // out_packed: row blocks of the fragment-packed decode layout (K = 2 * d)
+int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hipStream_t st);   // f32 [rows, n] -> bf16 [rows, 2 * n]
+// f32 q/k/v [M, 3D] (row stride ld; q / k rows pair-interleaved like the fused epilogue's) -> RoPE, Q as the split pair (qr.q_ld, qr.q_lo), K / V^T cache append
+int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t M, int64_t D, hipStream_t st);
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
@@ -223,6 +242,10 @@ struct AttnArgs {
     // stride (elements) between consecutive GROUPS OF 8 KEYS of one V^T row: 8 = plain [dh, Lk] rows (vt_ds = the row stride); the Llama KV cache
     // is blocked (rv_vt_index): vt_ds = 8, vt_ks = dh * 8
     int64_t vt_ks = 8;
+    // parity precision: != 0 -> the output row also receives its LOW half, bf16(o - bf16(o)), out_lo elements behind the high half
+    int64_t out_lo = 0;
+    // parity precision: != 0 -> a query row carries its LOW half q_lo elements behind the high half; the scores are K.(Qhi + Qlo) (dh = 128 only)
+    int64_t q_lo = 0;
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
 // G copies of the problem pair in one launch (batched prefills): copy g reads q / writes out at + q_off[g] elements, its K / V^T at
@@ -230,6 +253,7 @@ int k_attention(const AttnArgs& a, hipStream_t st);
 struct AttnGroups {
     int G = 1;
     int64_t q_off[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t o_off[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};    // (= q_off unless the output rows are wider: parity precision)
     int64_t kv_off[RV_MAX_PREFILL_GROUPS] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const AttnGroups* groups = nullptr);   // two prefill problems (dh 128) in one launch

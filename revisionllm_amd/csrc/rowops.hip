@@ -93,6 +93,48 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     }
 }
 
+// ---- parity precision: RMSNorm whose output is the split pair [hi | lo] (row stride 2 * d), one wave per row, two passes;
+// and the plain split of an f32 matrix (the gated MLP activation computed in f32) ----
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* __restrict__ x, int64_t x_row_stride, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ y, int64_t rows, int d, float eps, int packed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_row_stride;
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float r = rsqrtf(wave_sum(s) / (float)d + eps);
+    bf16_t* yr = y + row * 2 * d;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
+        const float o0 = ww[0] * (v[0] * r), o1 = ww[1] * (v[1] * r), o2 = ww[2] * (v[2] * r), o3 = ww[3] * (v[3] * r);
+        *(u32x2*)(packed ? y + rv_xp_index((int)row, c, packed) : yr + c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+        *(u32x2*)(packed ? y + rv_xp_index((int)row, d + c, packed) : yr + d + c) = u32x2{pack_bf16x2_lo(o0, o1), pack_bf16x2_lo(o2, o3)};
+    }
+}
+// f32 q/k/v rows -> RoPE + Q (split pair) + K / V^T cache append: one thread per 4 consecutive columns, the store rules of the fused epilogue
+__global__ __launch_bounds__(256) void qkv_rope_split_kernel(const float* __restrict__ qkv, int64_t ld, QkvRope qr, int64_t M, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    const f32x4 v = *(const f32x4*)(qkv + (int64_t)m * ld + n);
+    qkv_rope_store_t<true>(qr, m, n, v, qkv_rope_coeffs(qr, m, n));
+}
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t rows, int n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= rows * n) return;
+    const int64_t row = i / n;
+    const int c = (int)(i - row * n);
+    const f32x4 v = *(const f32x4*)(x + row * ldx + c);
+    bf16_t* yr = y + row * 2 * n;
+    *(u32x2*)(yr + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)(yr + n + c) = u32x2{pack_bf16x2_lo(v[0], v[1]), pack_bf16x2_lo(v[2], v[3])};
+}
+
 // ---- per-row FP8 (e4m3fn, OCP) quantisation of bf16 activations for the FP8 prefill GEMMs: one wave per row;
 // scale = max|row| / 448 (1 for a zero row), q = RNE_e4m3(x * (1 / scale)): two IEEE f32 divisions per ROW (hipcc divides
 // correctly rounded by default) and one multiply per element, i.e. exactly torch's CPU `x.float() * (1.0 / scale)`.  rmsnorm_quant_kernel fuses the LlamaRMSNorm in front:
@@ -345,6 +387,31 @@ int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, i
     else
         hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
     RV_CHECK_LAUNCH("rmsnorm");
+    return RV_OK;
+}
+
+int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed) {
+    RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm_split: bad arguments");
+    RV_CHECK_ARG(!out_packed || (rows <= 16 * out_packed && d % 32 == 0), "rmsnorm_split: the packed decode layout holds <= 16 rows per block");
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
+    RV_CHECK_LAUNCH("rmsnorm_split");
+    return RV_OK;
+}
+
+int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t M, int64_t D, hipStream_t st) {
+    RV_CHECK_ARG(qkv32 && qr.cs && qr.q16 && qr.kc && qr.vtc && qr.q_ld >= 2 * D && qr.q_lo >= D && ld % 4 == 0 && D == (int64_t)qr.H * 128, "qkv_rope_split: bad arguments");
+    if (M == 0) return RV_OK;
+    hipLaunchKernelGGL(qkv_rope_split_kernel, dim3((unsigned)cdiv(M * (3 * D / 4), 256)), dim3(256), 0, st, qkv32, ld, qr, M, (int)(3 * D));
+    RV_CHECK_LAUNCH("qkv_rope_split");
+    return RV_OK;
+}
+
+int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hipStream_t st) {
+    RV_CHECK_ARG(x && y16 && n % 4 == 0 && ldx % 4 == 0, "split_bf16: bad arguments");
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdiv(rows * n / 4, 256)), dim3(256), 0, st, x, ldx, (bf16_t*)y16, rows, n);
+    RV_CHECK_LAUNCH("split_bf16");
     return RV_OK;
 }
 

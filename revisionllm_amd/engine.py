@@ -116,11 +116,14 @@ class Engine:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def _bind_matrix(self, name, w, fp8, fp8_prefill=False):
+    def _bind_matrix(self, name, w, fp8, fp8_prefill=False, parity=False):
         """Bind a row-major bf16 matrix fragment-packed; with ``fp8`` also its FP8 (e4m3fn, per-row scale) copy for the
         decode kernels (``<name>.f8`` uint8, ``<name>.s8`` f32 [rows]); with ``fp8_prefill`` the same quantised bytes in the
-        prefill GEMM's layout (``<name>.f8p``)."""
+        prefill GEMM's layout (``<name>.f8p``); with ``parity`` the K-duplicated copy ``<name>.p2`` = [W | W] the parity precision
+        multiplies split operands [hi | lo] with."""
         self.bind(name, ops.pack_fragments(w))
+        if parity:
+            self.bind(name + ".p2", ops.pack_fragments(torch.cat([w, w], dim=1).contiguous()))
         if fp8 or fp8_prefill:
             q, sc = ops.quantize_rows_fp8(w)
             self.bind(name + ".s8", sc)
@@ -129,29 +132,34 @@ class Engine:
             if fp8_prefill:
                 self.bind(name + ".f8p", ops.pack_fp8_prefill(q))
 
-    def load_llm(self, get, fp8_decode=False, fp8_prefill=False):
+    def load_llm(self, get, fp8_decode=False, fp8_prefill=False, parity=False):
         """``get(hf_name) -> tensor`` (any device / float dtype), HF Llama names.  Packs layer by layer.
         ``fp8_decode``: additionally keep an FP8 copy of every projection (+ lm_head) and stream THAT in KV-cached decode steps
         (opt-in "fp8 LLM path": half the decode weight bytes).  ``fp8_prefill``: additionally keep the layer projections in the
-        FP8 prefill layout; prefill passes then quantise their activations per row and run FP8 x FP8 MFMA GEMMs (lm_head stays bf16)."""
+        FP8 prefill layout; prefill passes then quantise their activations per row and run FP8 x FP8 MFMA GEMMs (lm_head stays bf16).
+        ``parity``: additionally keep K-duplicated copies of every projection and the lm_head (+ 2 x the weight bytes) so that
+        ``set_option("precision", 1)`` can switch the forward to split-bf16 operands (16 mantissa bits in every GEMM input: the
+        reference's fp32 scores to 1e-3, tests/test_gpu_full_depth_conditioned.py)."""
         s, dev = self.shape, self.device
+        self.parity = bool(parity)
         self.fp8_decode = bool(fp8_decode)
         self.fp8_prefill = bool(fp8_prefill)
         self.bind("llm.embed", _dev_bf16(get("model.embed_tokens.weight"), dev))
-        self._bind_matrix("llm.lm_head", _dev_bf16(get("lm_head.weight"), dev), fp8_decode)
+        # the lm_head's K-duplicated copy is bound in EVERY precision (+ 0.26 GB): the lm_head input is always a split pair (option lm_head_split)
+        self._bind_matrix("llm.lm_head", _dev_bf16(get("lm_head.weight"), dev), fp8_decode, parity=True)
         self.bind("llm.norm", _dev_f32(get("model.norm.weight"), dev))
         for i in range(s.layers):
             p = f"model.layers.{i}."
             q, k, v = (_dev_bf16(get(p + f"self_attn.{n}_proj.weight"), dev) for n in "qkv")
             q, k = pair_interleave_heads(q, s.heads), pair_interleave_heads(k, s.heads)
-            self._bind_matrix(f"llm.L{i}.wqkv", torch.cat([q, k, v], dim=0).contiguous(), fp8_decode, fp8_prefill)
+            self._bind_matrix(f"llm.L{i}.wqkv", torch.cat([q, k, v], dim=0).contiguous(), fp8_decode, fp8_prefill, parity)
             del q, k, v
-            self._bind_matrix(f"llm.L{i}.wo", _dev_bf16(get(p + "self_attn.o_proj.weight"), dev), fp8_decode, fp8_prefill)
+            self._bind_matrix(f"llm.L{i}.wo", _dev_bf16(get(p + "self_attn.o_proj.weight"), dev), fp8_decode, fp8_prefill, parity)
             g = _dev_bf16(get(p + "mlp.gate_proj.weight"), dev)
             u = _dev_bf16(get(p + "mlp.up_proj.weight"), dev)
-            self._bind_matrix(f"llm.L{i}.wgu", pack_gate_up(g, u), fp8_decode, fp8_prefill)
+            self._bind_matrix(f"llm.L{i}.wgu", pack_gate_up(g, u), fp8_decode, fp8_prefill, parity)
             del g, u
-            self._bind_matrix(f"llm.L{i}.wdown", _dev_bf16(get(p + "mlp.down_proj.weight"), dev), fp8_decode, fp8_prefill)
+            self._bind_matrix(f"llm.L{i}.wdown", _dev_bf16(get(p + "mlp.down_proj.weight"), dev), fp8_decode, fp8_prefill, parity)
             self.bind(f"llm.L{i}.norm1", _dev_f32(get(p + "input_layernorm.weight"), dev))
             self.bind(f"llm.L{i}.norm2", _dev_f32(get(p + "post_attention_layernorm.weight"), dev))
         self.has_llm = True
@@ -199,11 +207,11 @@ class Engine:
         return get
 
     def init_synthetic(self, seed=0, llm=True, clip=True, linear=False, llm_prefix="", clip_prefix="model.mm_projector.",
-                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False, cond=None):
+                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False, cond=None, parity=False):
         """Random-init weights of the reference's shapes, bit-identical to ``synth.build_numpy`` on the host.
         ``cond``: a ``synth.Conditioning`` (the well-conditioned LLM amplitudes of golden G8c); None = plain N(0, 0.02)."""
         if llm:
-            self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill)
+            self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill, parity=parity)
         if clip:
             self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text), seed,
                                                    clip_prefix))

@@ -35,8 +35,8 @@ def remap_projector_keys(weights, clip):
     out = {}
     for k, v in weights.items():
         if kw not in k:
-            if clip:
-                raise KeyError(f"unexpected adapter key {k}")
+            if clip:    # get_wc's else-branch indexes ``k.split('mm_projector.')[2]`` (vtimellm_arch.py:36): IndexError in the reference (golden G13)
+                raise IndexError(f"list index out of range (adapter checkpoint key '{k}' does not contain '{kw}.')")
             continue
         if not clip or f"{kw}.{kw}" not in k:
             out[k.split(kw + ".")[1]] = v
@@ -125,6 +125,7 @@ def load_pretrained_model(args, stage2=None, stage3=None, load_ckp=False):
     model = ReVisionLlamaForCausalLM(shape_from_config(cfg), max_sequence_length=cfg.get("max_sequence_length"))
     model.fp8_prefill = bool(getattr(args, "fp8_prefill", False))  # build-defined opt-in: FP8 x FP8 prefill GEMMs
     model.fp8_decode = bool(getattr(args, "fp8_decode", False))   # build-defined opt-in: FP8 copies of the LLM weights for decode steps
+    model.parity = bool(getattr(args, "parity", False))           # build-defined opt-in: K-duplicated copies for the parity precision (engine option precision = 1)
     gpath = os.path.join(model_base, "generation_config.json")
     if os.path.exists(gpath):
         with open(gpath) as f:
@@ -149,7 +150,9 @@ def finalize(model):
     """Pack the (merged) host state dict into HBM and drop the host copy."""
     sd = model._host_sd
     eng = model._ensure_engine()
-    eng.load_llm(lambda n: sd[n], fp8_decode=getattr(model, "fp8_decode", False), fp8_prefill=getattr(model, "fp8_prefill", False))
+    eng.load_llm(lambda n: sd[n], fp8_decode=getattr(model, "fp8_decode", False), fp8_prefill=getattr(model, "fp8_prefill", False), parity=getattr(model, "parity", False))
+    if getattr(model, "parity", False):
+        eng.set_option("precision", 1)
     root = "model.cross_attn." if getattr(model.get_model(), "cross_attn_variant", False) else "model.mm_projector."
     proj = {k[len(root):]: v for k, v in sd.items() if k.startswith(root)}
     if proj:

@@ -23,6 +23,14 @@ from .ops import h2d as ops_h2d
 LOCAL = object()
 
 
+def force_collectives():
+    """REVISION_FORCE_COLLECTIVES=1: issue the two exchanges of the segment-parallel recursion (and their gate bracketing) even in a
+    process group of ONE rank - the only way to put RCCL's kernels next to the persistent stream-K GEMMs on a single GPU
+    (tests/test_gpu_rccl_world1.py).  Read at call time; off by default: a world of one returns its local block without any collective."""
+    import os
+    return os.environ.get("REVISION_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+
+
 def shard_bounds(n, rank, world):
     """Contiguous block partition of ``n`` items: rank r owns [lo, hi); sizes differ by at most one."""
     base, rem = divmod(n, world)
@@ -54,7 +62,7 @@ def _all_gather_cat(padded, group):
 def allgather_rows(local, n_total, group=None):
     """All-gather a block-partitioned [n_local, ...] tensor into [n_total, ...] (blocks padded to equal size)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collectives():
         return local
     per = -(-n_total // world)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -145,7 +153,7 @@ def _gated(stages, world, fn):
     while a one-workgroup-per-CU stream-K GEMM of another stream waits in-kernel for ALL its workgroups would stall that GEMM
     (and, through the peer ranks waiting for this rank's contribution, the whole node) until the collective drains - so
     collectives and prefill GEMMs are serialised on the device by the same event chain.  Device-side waits only."""
-    gate = stages.gate() if (world > 1 and hasattr(stages, "gate")) else None
+    gate = stages.gate() if ((world > 1 or force_collectives()) and hasattr(stages, "gate")) else None
     if gate is not None:
         gate.begin()
     out = fn()
@@ -174,6 +182,7 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
     alone = group is LOCAL or not dist.is_initialized()
     world = 1 if alone else dist.get_world_size(group)
     rank = 0 if alone else dist.get_rank(group)
+    exchange = world > 1 or (not alone and force_collectives())      # (forced: a one-rank group still runs both all-gathers)
     lo, hi = shard_bounds(W, rank, world)
     feats_of = features_local if isinstance(features_local, (list, tuple)) else [features_local] * len(queries)
     assert len(feats_of) == len(queries) and all(f.shape[0] == hi - lo for f in feats_of), f"rank {rank} must hold windows [{lo},{hi})"
@@ -190,7 +199,7 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
     rows, prompts, cos_all = [], {}, []
     for qi, (qf, qc, sentence) in enumerate(queries):
         cls_local, cos_local = stages.encode(feats_of[qi], qf), stages.cosine(feats_of[qi], qc)
-        if world > 1:                                                # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
+        if exchange:                                                 # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
             cls_local, cos_local = _gated(stages, world, lambda: (allgather_rows(cls_local, W, group),
                                                                   allgather_rows(cos_local[:, None], W, group)[:, 0]))
         cos_all.append(cos_local)
@@ -218,7 +227,7 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
         if n:
             tw[:n, 0] = ops_h2d(torch.tensor(order, dtype=torch.int32), dev)
             tw[:n, 1], tw[:n, 2:], ew[:n] = nst.to(dev), tok.to(dev), ent.to(dev)
-        if world > 1:                                       # exchange 2: proposals (device side, no host round trip)
+        if exchange:                                        # exchange 2: proposals (device side, no host round trip)
             while turn is not None and not turn.finishing:
                 yield sched.RETRY
             tw, ew = _gated(stages, world, lambda: (_all_gather_cat(tw, group), _all_gather_cat(ew, group)))

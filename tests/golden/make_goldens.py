@@ -770,6 +770,92 @@ def g12_clip_tokenizer(M):
     print("wrote g12_clip_tokenizer.json", len(merges), "merges")
 
 
+def g13_loader(M):
+    """f-3: what the REFERENCE's own loader code ends up with for synthetic checkpoint files (tests/helpers.loader_fixture_files):
+    ``initialize_vision_modules`` (vtimellm_arch.py:12-73: get_wc :30-37, get_w :46-47, the cross_attn form :52-71) run on a tiny
+    reference model, and ``load_lora`` (builder.py:9-19: the prefix rule :13-15 + load_state_dict) run with ``PeftModel.from_pretrained``
+    replaced by a pass-through (peft is absent; the lines in front of it are the reference's).  Recorded per case: {module key: (shape,
+    checksum)} of every tensor the load CHANGED, the keys it left at their initial values, and load_state_dict's unexpected keys."""
+    import tempfile
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import helpers
+    L = M["llama"]
+    shape = synth.LlamaShape(hidden=helpers.LOADER_HIDDEN, inter=128, layers=1, heads=1, vocab=128)
+    tmp = tempfile.mkdtemp(prefix="g13_")
+    files = helpers.loader_fixture_files(tmp, SEED)
+
+    def fresh():
+        cfg = L.VTimeLLMConfig(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
+                               num_attention_heads=shape.heads, num_key_value_heads=shape.heads, vocab_size=shape.vocab,
+                               max_position_embeddings=2048, rms_norm_eps=shape.eps, rope_theta=shape.theta,
+                               pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")
+        return L.VTimeLLMLlamaForCausalLM(cfg).eval()
+
+    def changed(before, after):
+        ch = {k: v for k, v in after.items() if k not in before or not torch.equal(before[k], v)}
+        return helpers.sd_map(ch), sorted(k for k in after if k not in ch)
+
+    out = {}
+    # (A) clip_adapter + pretrain_clip_adapter, plain and peft-prefixed keys; (B) the chapters form: cross_attn + pretrain_clip_adapter
+    for case, fname, kw, attr in (("clip_adapter", "clip_adapter.bin", dict(), "mm_projector"),
+                                  ("clip_adapter_peft_keys", "clip_adapter_peft.bin", dict(), "mm_projector"),
+                                  ("cross_attn_pretrained", "clip_adapter.bin", dict(clip_adapter=False, cross_attn=True), "cross_attn")):
+        # the same module built WITHOUT the file gives the initial values (seeded: torch.manual_seed before each construction)
+        torch.manual_seed(0)
+        m0 = fresh()
+        m0.get_model().initialize_vision_modules(ns(pretrain_clip_adapter=None, **{**kw, **(dict(cross_attn=False, clip_adapter=True) if attr == "cross_attn" else {})}))
+        torch.manual_seed(0)
+        m1 = fresh()
+        m1.get_model().initialize_vision_modules(ns(pretrain_clip_adapter=files[fname], **kw))
+        mod = getattr(m1.get_model(), attr)
+        ref0 = m0.get_model().mm_projector.state_dict() if attr == "cross_attn" else getattr(m0.get_model(), attr).state_dict()
+        loaded, untouched = changed({k: v.clone() for k, v in ref0.items()} if attr != "cross_attn" else {}, mod.state_dict())
+        out[case] = {"module": attr, "file": fname, "loaded": loaded, "untouched": [] if attr == "cross_attn" else untouched,
+                     "mm_projector_type": type(m1.get_model().mm_projector).__name__}
+    # (C) Linear projector + pretrain_mm_mlp_adapter (get_w drops keys without the keyword)
+    torch.manual_seed(0)
+    m0 = fresh()
+    m0.get_model().initialize_vision_modules(ns(clip_adapter=False))
+    torch.manual_seed(0)
+    m1 = fresh()
+    m1.get_model().initialize_vision_modules(ns(clip_adapter=False, pretrain_mm_mlp_adapter=files["mm_projector.bin"]))
+    loaded, untouched = changed(m0.get_model().mm_projector.state_dict(), m1.get_model().mm_projector.state_dict())
+    out["linear_projector"] = {"module": "mm_projector", "file": "mm_projector.bin", "loaded": loaded, "untouched": untouched}
+    # a key WITHOUT the keyword in a ClipEncoder file: the exception class of get_wc
+    bad = os.path.join(tmp, "foreign.bin")
+    torch.save({"model.embed_tokens.weight": torch.zeros(2, 2)}, bad)
+    try:
+        fresh().get_model().initialize_vision_modules(ns(pretrain_clip_adapter=bad))
+        out["clip_adapter_foreign_key"] = {"raises": None}
+    except Exception as e:  # noqa: BLE001
+        out["clip_adapter_foreign_key"] = {"raises": type(e).__name__}
+    # (D) load_lora's prefix rule + load_state_dict, through the reference's own function
+    B = M["builder"]
+    import peft
+    peft.PeftModel = SimpleNamespace(from_pretrained=lambda model, path, is_trainable=False: model)
+    B.PeftModel = peft.PeftModel
+    for case in ("lora_peft", "lora_plain"):
+        torch.manual_seed(0)
+        m1 = fresh()
+        m1.get_model().initialize_vision_modules(ns())
+        before = {k: v.clone() for k, v in m1.state_dict().items()}
+        seen = {}
+        orig = m1.load_state_dict
+
+        def spy(sd, strict=True, _orig=orig, _seen=seen):
+            r = _orig(sd, strict=strict)
+            _seen["keys"], _seen["unexpected"], _seen["strict"] = sorted(sd), sorted(r.unexpected_keys), strict
+            return r
+        m1.load_state_dict = spy
+        B.load_lora(m1, os.path.dirname(files[case + "/non_lora_trainables.bin"]))
+        loaded, _ = changed(before, m1.state_dict())
+        out[case] = {"file": case + "/non_lora_trainables.bin", "keys_after_prefix_rule": seen["keys"], "unexpected_keys": seen["unexpected"],
+                     "strict": seen["strict"], "loaded": loaded}
+    with open(os.path.join(HERE, "g13_loader.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote g13_loader.json", {k: len(v.get("loaded", {})) for k, v in out.items()})
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -778,7 +864,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader)
     for k, fn in groups.items():
         if (only and k not in only) or (not only and k in ("g8", "g8c", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue

@@ -117,6 +117,7 @@ def install():
         ("inference", "revisionllm.inference"),
         ("e2e2", "revisionllm.eval.eval_nlq_retrieval_e2e2"),
         ("metric", "revisionllm.eval.metric_retrieval_forward"),
+        ("builder", "revisionllm.model.builder"),
     ]:
         try:
             mods[short] = importlib.import_module(name)

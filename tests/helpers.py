@@ -64,3 +64,48 @@ def assert_in_flight_equals_sequential(seq, in_flight, name, fields=("answers", 
         with open(f"gpurun_out/{name}_mismatch.json", "w") as f:
             json.dump(detail, f, indent=1)
         raise AssertionError(f"{name}: recursions in flight differ from the sequential run: {detail}")
+
+
+# ---- f-3: synthetic checkpoint files for the loader-parity fixture G13 (make_goldens.py g13 pushes the SAME files through the reference) ----
+LOADER_HIDDEN = 64      # hidden size of the tiny model the loader fixture uses (the ClipEncoder itself stays 768-d)
+
+
+def tensor_sha(t):
+    """Checksum of a tensor's values: sha256 over its float32 little-endian bytes (16 hex digits) - what G13 records per key."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(torch.as_tensor(t).detach().float().cpu().numpy()).tobytes()).hexdigest()[:16]
+
+
+def sd_map(sd):
+    return {k: [list(v.shape), tensor_sha(v)] for k, v in sd.items()}
+
+
+def loader_fixture_files(dirpath, seed=SEED):
+    """Write the synthetic adapter checkpoint files of fixture G13 (hash-seeded values; every tensor distinct) and return their paths:
+      clip_adapter.bin        a ClipEncoder saved by the trainer from the whole model's named_parameters (train.py:149-164): keys
+                              'model.mm_projector.<ClipEncoder key>' - among them 'model.mm_projector.mm_projector.weight'
+      clip_adapter_peft.bin   the same under a peft wrapper: 'base_model.model.model.mm_projector.<...>'
+      mm_projector.bin        a Linear projector ('model.mm_projector.weight' / '.bias') plus a foreign 'model.embed_tokens.weight'
+      lora_peft/non_lora_trainables.bin    keys 'base_model.model.model.mm_projector.<...>' + 'base_model.model.lm_head.weight'
+      lora_plain/non_lora_trainables.bin   keys 'model.mm_projector.<...>' (no wrapper prefix)"""
+    os.makedirs(dirpath, exist_ok=True)
+    enc = synth.build_numpy(synth.clip_encoder_spec(hidden=LOADER_HIDDEN, text=True), seed, prefix="g13.clip.")
+    enc = {k[len("g13.clip."):]: T(v) for k, v in enc.items()}
+    lin = {k[len("g13.lin."):]: T(v) for k, v in synth.build_numpy(synth.linear_projector_spec(hidden=LOADER_HIDDEN), seed, prefix="g13.lin.").items()}
+    enc2 = {k: T(synth.features("g13.nl." + k, tuple(v.shape), seed)) for k, v in enc.items()}       # different values: what stage 2 trained
+    paths = {}
+
+    def put(name, sd):
+        path = os.path.join(dirpath, name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(sd, path)
+        paths[name] = path
+    put("clip_adapter.bin", {"model.mm_projector." + k: v for k, v in enc.items()})
+    put("clip_adapter_peft.bin", {"base_model.model.model.mm_projector." + k: v for k, v in enc.items()})
+    put("mm_projector.bin", {"model.mm_projector.weight": lin["weight"], "model.mm_projector.bias": lin["bias"],
+                             "model.embed_tokens.weight": T(synth.features("g13.embed", (8, LOADER_HIDDEN), seed))})
+    head = T(synth.features("g13.head", (128, LOADER_HIDDEN), seed))
+    put("lora_peft/non_lora_trainables.bin", dict({"base_model.model.model.mm_projector." + k: v for k, v in enc2.items()},
+                                                  **{"base_model.model.lm_head.weight": head}))
+    put("lora_plain/non_lora_trainables.bin", {"model.mm_projector." + k: v for k, v in enc2.items()})
+    return paths

@@ -700,3 +700,43 @@ def test_alternate_adapter_feature_with_iteration_step(hierarchy):
     ids = T(synth.synthetic_prompt_ids(40, 20, 1, vocab=shape.vocab))[None].repeat(2, 1)
     out = m.generate(ids, images=flat, query_feats=q, iteration_step=1, do_sample=False, max_new_tokens=3, return_dict_in_generate=True)
     assert out["sequences"].shape == (2, 43)
+
+
+def test_parity_precision_closes_the_llm_gemm_operand_roundings():
+    """Engine option precision = 1 (split-bf16 GEMM operands against K-duplicated weights, rv_ctx_set_option "precision"): on the tiny
+    dense-projector model (its adapter is ONE GEMM of bf16-representable inputs: exact) the only roundings left between the HIP path and
+    the fp32 oracle are Q, the K / V caches and P.  Prefill + 5 KV-cached decode steps, batch 2, teacher-forced: the parity logits must
+    be several times closer to the oracle than the default path's, and the option must be refused without the weight copies."""
+    from oracle import llama, sampling
+    from revisionllm_amd import hip
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    args = _args(clip_adapter=False, clip_adapter_text=False, hierarchy=False)
+    m = ReVisionLlamaForCausalLM(shape, device="cuda:0")
+    m.get_model().initialize_vision_modules(args)
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=False, linear=True, parity=True)
+    m.generation_config.eos_token_id = None
+    ids = T(synth.synthetic_prompt_ids(24, 9, SEED, vocab=shape.vocab))[None].repeat(2, 1)
+    feat = feats("par.dense", (2, 24, 768), bf16=True)
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    w, wa = _oracle_weights(shape, False)
+    o = sampling.generate(ids, feat, None, w, wa, cfg, adapter_kw=dict(clip_adapter=False, hierarchy=False), max_new_tokens=6, eos_token_id=-1)
+    forced = o["sequences"][:, ids.shape[1]:].t()
+    want = torch.stack(o["logits"])
+    errs = {}
+    for prec in (0, 1):
+        m.engine.set_option("precision", prec)
+        out = m.generate(ids, images=feat, query_feats=None, do_sample=False, max_new_tokens=6, return_dict_in_generate=True, output_logits=True,
+                         forced_tokens=forced)
+        errs[prec] = rel_err(torch.stack(out["logits"]).cpu(), want)
+    m.engine.set_option("precision", 0)
+    print("\n[parity precision, tiny dense model] logits rel err vs the fp32 oracle: default %.3e, parity %.3e" % (errs[0], errs[1]))
+    assert errs[1] < 0.75 * errs[0]                          # (random N(0, 0.02) weights: the Q / K / V / P roundings left are a large share here; measured 0.6 x)
+    # without the K-duplicated copies the option is refused loudly (no silent fallback to bf16 operands)
+    m2 = _model(shape, args)
+    m2.engine.set_option("precision", 1)
+    with pytest.raises(hip.HipLibraryError, match="p2"):
+        m2.generate(ids, images=feat, query_feats=None, do_sample=False, max_new_tokens=2)
+    with pytest.raises(hip.HipLibraryError):
+        m2.engine.set_option("precision", 2)

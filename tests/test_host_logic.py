@@ -110,6 +110,40 @@ def test_loader_key_rules_and_lora_merge():
         builder.merge_lora({}, lora, 1, 1)
 
 
+def test_loader_key_rules_against_the_reference_loader(golden, tmp_path):
+    """f-3 pinned: the SAME synthetic checkpoint files that golden G13 pushed through the reference's own ``initialize_vision_modules``
+    (vtimellm_arch.py:12-73: get_wc / get_w / the cross_attn form) and ``load_lora`` (builder.py:9-19) go through the build's key rules;
+    the {key: (shape, checksum)} map of what gets loaded must be the reference's, key for key."""
+    from helpers import loader_fixture_files, sd_map
+    g = golden.json("g13_loader")
+    files = loader_fixture_files(str(tmp_path))
+    # (A) ClipEncoder files, plain and peft-prefixed keys; (B) the chapters form loads the same file into the ``cross_attn`` module
+    for case in ("clip_adapter", "clip_adapter_peft_keys", "cross_attn_pretrained"):
+        got = sd_map(builder.remap_projector_keys(torch.load(files[g[case]["file"]], map_location="cpu"), clip=True))
+        assert got == g[case]["loaded"], case
+        assert g[case]["untouched"] == []                                       # the reference left no tensor of the module at its initial value
+    assert g["cross_attn_pretrained"]["mm_projector_type"] == "Linear"          # (its mm_projector is a Linear whose output is discarded)
+    # (C) Linear projector: keys without the keyword are dropped
+    got = sd_map(builder.remap_projector_keys(torch.load(files["mm_projector.bin"], map_location="cpu"), clip=False))
+    assert got == g["linear_projector"]["loaded"]
+    # a foreign key in a ClipEncoder file: the reference's get_wc raises IndexError
+    assert g["clip_adapter_foreign_key"]["raises"] == "IndexError"
+    with pytest.raises(IndexError):
+        builder.remap_projector_keys({"model.embed_tokens.weight": torch.zeros(2, 2)}, clip=True)
+    # (D) load_lora's prefix rule: the keys handed to load_state_dict and the tensors that ended up in the model
+    for case in ("lora_peft", "lora_plain"):
+        out = builder.strip_trainable_prefixes(torch.load(files[g[case]["file"]], map_location="cpu"))
+        assert sorted(out) == g[case]["keys_after_prefix_rule"], case
+        assert g[case]["unexpected_keys"] == [] and g[case]["strict"] is False
+        assert sd_map(out) == g[case]["loaded"], case
+        # ... and through the build's directory-level entry point: the host state dict ends up holding exactly those tensors
+        sd, extra = builder.apply_lora_dir({}, os.path.dirname(files[g[case]["file"]]))
+        assert sd_map(sd) == g[case]["loaded"] and sorted(extra) == g[case]["keys_after_prefix_rule"]
+        # finalize() hands the adapter the keys behind 'model.mm_projector.': the reference module's own names
+        proj = {k[len("model.mm_projector."):] for k in sd if k.startswith("model.mm_projector.")}
+        assert proj == set(g["clip_adapter"]["loaded"])
+
+
 def test_abi_exports_every_declared_symbol():
     """include/revision_hip.h <-> the built library <-> the ctypes table must agree (loads on CPU, no compute)."""
     header = open(os.path.join(ROOT, "include", "revision_hip.h")).read()
