@@ -97,6 +97,8 @@ def parse():
     p.add_argument("--gemm-variant", type=int, default=2, help="rv_ctx_set_option gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--settle", type=int, default=16,
                    help="untimed steps run as part of the set-up, before the W warm-up steps (a fresh box starts at idle clocks; ~0.5 s)")
+    p.add_argument("--host-profile", action="store_true",
+                   help="measurement knob: cProfile the host side of the timed region and print the top entries to stderr (the line's value then includes the profiler's overhead)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the extra legs timed AFTER the headline")
@@ -537,10 +539,21 @@ def main():
         steps = args.steps if steps is None else steps
         fn_run(args.warmup if warm is None else warm)
         sync()
+        prof = None
+        if args.host_profile and rank == 0:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         rec = fn_run(steps)
+        t_host = time.perf_counter() - t0           # all launches made, records collected; the device may still be running
         sync()
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            sys.stderr.write(f"[host profile] {steps} steps: host loop {t_host * 1e3:.1f} ms, with the final device sync {dt * 1e3:.1f} ms\n")
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(22)
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -120,8 +120,12 @@ __device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* dst0, i
 
 template <int N_>
 __device__ __forceinline__ void wait_vm() {
-    static_assert(N_ >= 0 && N_ <= 8, "extend the table");
-    if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N_ >= 0 && N_ <= 12, "extend the table");
+    if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N_ == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if constexpr (N_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N_ == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N_ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -139,12 +143,18 @@ __device__ __forceinline__ void wait_vm() {
 // The activation panel is L2 / MALL resident (re-read by every team of the XCD) and stays one tile ahead; the weights come from
 // HBM exactly once and are issued TWO tiles ahead, which doubles the latency they may take (6 phases instead of 3: in the
 // recursion, where W is cold, the old distance showed as +20 % on the QKV projection against a MALL-warm benchmark loop).
-// Issue order inside tile c:  ph0 A-U0(c+1) | ph1 A-U3(c+1) | ph2 W-U1(c+2) | ph3 W-U2(c+2)  - the A units first, so that
-// waiting for them never forces the younger, slower W loads to land early (a wave's loads retire in order).  Waits (counted,
-// before the barrier that precedes the first read, as before):
-//   end of ph1: U3(c) landed          -> may stay in flight: U1, U2 (c+1), U0, U3 (c+1)        = 6 + n1 loads (0 if last tile)
-//   end of ph3: U0(c+1) landed (and with it the older U1, U2 (c+1))  -> U3(c+1) [+ U1, U2 (c+2)] = 2 [+ 2 + n1 loads]
-// WAR: a W stage is rewritten >= 1 tile after its last read, A unit U0 one tile, U3 four slots after its last read retired.
+// Round 4: the ACTIVATION units travel 1.5 tiles ahead too.  With 4020 rows (four prefills to a pass) the activation panel is 33 MB: it
+// lives in the infinity cache, not in L2, and every XCD re-reads it once per panel group; with U0(c+1) issued in phase 0 of tile c and
+// awaited at the end of its phase 3 (0.9 tiles = 1.2 us) those reads stalled the loop - the same launch with lda = 0 (A L2-hot,
+// tools/gemm_a_traffic_probe.py) ran 20 % faster (gate/up at 4020 rows: 684 vs 551 us back to back).  A unit's LDS is free as soon as
+// its fragments are in registers (U0: read in phase 0, U3: in phase 2), so the two A stages suffice for the longer distance:
+// Issue order inside tile c:  ph0 A-U3(c+1) | ph1 W-U1(c+2) | ph2 A-U0(c+2) | ph3 W-U2(c+2).  Waits (counted: a wave's loads retire in
+// order; before the barrier that precedes the first read of a unit; n1 / n2 = tile c+1 / c+2 exists, j = loads of unit U2):
+//   end of ph0: U2(c) landed     -> may stay in flight: U3(c), U1 U0 U2 (c+1), U3(c+1)          = n1 ? 8 + j : 2
+//   end of ph1: U3(c) landed     -> U1 U0 U2 (c+1), U3(c+1), U1(c+2)                            = n2 ? 8 + j : n1 ? 6 + j : 0
+//   end of ph3: U0(c+1) landed (and the older U1(c+1))  -> U2(c+1), U3(c+1), U1 U0 U2 (c+2)     = n2 ? 6 + 2j : 2 + j      (n1 only)
+// WAR: U3(c+1) overwrites U3(c-1), last read in phase 2 of tile c-1 (>= 3 slots earlier); U0(c+2) overwrites U0(c), read in phase 0 of
+// this tile by both groups (slots 0, 1; the issue is in slots 4, 5); a W stage is rewritten >= 1 tile after its last read.
 constexpr int PP_A_STAGE = 2 * UNIT, PP_W_BASE = 2 * PP_A_STAGE, PP_W_STAGE = 2 * UNIT;
 // F8: the operands are FP8 (e4m3fn) bytes addressed as if they were bf16 matrices of K / 2 columns - a 128-byte staged row is
 // then 128 k instead of 64 and a W piece holds, per lane, k = 16 kg .. + 15 of each 64-k half (the bf16 fragment packing of the
@@ -169,17 +179,18 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     const int w_rd = wc * 4096 + lane * 16;
     const int w_rd1 = NF == 4 ? w_rd : wc * 2048 + lane * 16;   // unit U2: pieces (wc * NJ1 + j) * 2 + ks
 
-    // prologue: all of tile 0, then the W units of tile 1
-    issue_unit<0, NF>(src, kt0 * PBK, smem, wave);
-    issue_unit<3, NF>(src, kt0 * PBK, smem + UNIT, wave);
+    // prologue: what tiles "-2" and "-1" of the steady state would have issued, in its order: U1 U0 U2 (0), U3(0), U1 U0 U2 (1)
     issue_unit<1, NF>(src, kt0 * PBK, smem + PP_W_BASE, wave);
+    issue_unit<0, NF>(src, kt0 * PBK, smem, wave);
     issue_unit<2, NF>(src, kt0 * PBK, smem + PP_W_BASE + UNIT, wave);
+    issue_unit<3, NF>(src, kt0 * PBK, smem + UNIT, wave);
     if (nks > 1) {
         issue_unit<1, NF>(src, (kt0 + 1) * PBK, smem + PP_W_BASE + PP_W_STAGE, wave);
+        issue_unit<0, NF>(src, (kt0 + 1) * PBK, smem + PP_A_STAGE, wave);
         issue_unit<2, NF>(src, (kt0 + 1) * PBK, smem + PP_W_BASE + PP_W_STAGE + UNIT, wave);
-        wait_vm<2 + NJ1>();                      // tile 0 landed
+        wait_vm<6 + 2 * NJ1>();                  // U1(0), U0(0) landed
     } else {
-        wait_vm<0>();
+        wait_vm<2 + NJ1>();
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
@@ -234,27 +245,27 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         // ---- phase 0: quadrant (m0, n0) ----
         PP_READ_W(b0, wcur, w_rd, 2)
         PP_READ_A(acur)
-        if constexpr (m1) issue_unit<0, NF>(src, k1, anxt, wave);
-        PP_SYNC_M((void)0)
+        if constexpr (m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
+        PP_SYNC_M(wait_vm<m1 ? 8 + NJ1 : 2>())                    // U2 of this tile
         PP_MFMA(b0, 0, 0, 2);
-        PP_SYNC_C((void)0)
+        PP_SYNC_C(wait_vm<m1 ? 8 + NJ1 : 2>())
         // ---- phase 1: quadrant (m0, n1) ----
         PP_READ_W(b1, wcur + UNIT, w_rd1, NJ1)
-        if constexpr (m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
-        PP_SYNC_M(wait_vm<m1 ? 6 + NJ1 : 0>())                    // U3 of this tile
+        if constexpr (m2) issue_unit<1, NF>(src, k2, wnn, wave);
+        PP_SYNC_M(wait_vm<m2 ? 8 + NJ1 : m1 ? 6 + NJ1 : 0>())     // U3 of this tile
         PP_MFMA(b1, 2, 0, NJ1);
-        PP_SYNC_C(wait_vm<m1 ? 6 + NJ1 : 0>())
+        PP_SYNC_C(wait_vm<m2 ? 8 + NJ1 : m1 ? 6 + NJ1 : 0>())
         // ---- phase 2: quadrant (m1, n1) ----
         PP_READ_A(acur + UNIT)
-        if constexpr (m2) issue_unit<1, NF>(src, k2, wnn, wave);
+        if constexpr (m2) issue_unit<0, NF>(src, k2, acur, wave);   // U0(c+2) into the slot U0(c) left in phase 0
         PP_SYNC_M((void)0)
         PP_MFMA(b1, 2, 4, NJ1);
         PP_SYNC_C((void)0)
         // ---- phase 3: quadrant (m1, n0) ----
         if constexpr (m2) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
-        PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 4 + NJ1 : 2>())  // U0 (and the older U1, U2) of the next tile
+        PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 : 2 + NJ1>())  // U0 (and the older U1) of the next tile
         PP_MFMA(b0, 0, 4, 2);
-        PP_SYNC_C(if constexpr (m1) wait_vm<m2 ? 4 + NJ1 : 2>())
+        PP_SYNC_C(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 : 2 + NJ1>())
     };
     auto run = [&](auto group_c) {
         int c = 0, ws = 0;

@@ -317,7 +317,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
     //     blocks at a time (registers)
     float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now
-    if (nrm.in_sumsq) {
+    if (nrm.in_sumsq && !(RS_PROBE & 16)) {
         constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
         // the partials of CH row blocks in flight at once, then their sums: with the unsplit form (VPW = 8: no partial planes held in
         // registers here) all of them - ONE memory round trip in the tail of the workgroup instead of MB / 2 dependent ones
@@ -571,7 +571,7 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
     // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
     //     blocks at a time (registers)
     float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now (once for all the groups this workgroup finishes)
-    if (nrm.in_sumsq) {
+    if (nrm.in_sumsq && !(RS_PROBE & 16)) {
         constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
         // every partial of every row block in flight at once (the accumulators are in LDS by now: the registers are free), then the sums:
         // one memory round trip in the tail of the workgroup instead of one per pair of row blocks (MB / 2 of them, dependent through

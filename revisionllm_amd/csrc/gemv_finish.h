@@ -3,6 +3,12 @@
 #pragma once
 #include "kernels.h"
 
+// Timing probes of the epilogue (tools/rows_probe.sh; results are garbage): RS_PROBE & 32: no fused-norm outputs (xw_out, out_sumsq);
+// & 64: the fused q/k/v epilogue stores nothing; & 128: no residual read.  (& 16, gemm_rows.hip: the consumers skip the sums of squares.)
+#ifndef RS_PROBE
+#define RS_PROBE 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ float gemv_silu(float x) { return x / (1.0f + __expf(-x)); }
@@ -37,6 +43,7 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
         for (int t = 0; t < NT; ++t) s[t] *= rr;
     }
     if constexpr (ROPE) {
+        if constexpr (RS_PROBE & 64) return;
         if (b < M) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -72,14 +79,14 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
-            if (res) v += one ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
+            if (res && !(RS_PROBE & 128)) v += one ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
             if (OUT_BF16) {
                 u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)((bf16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, n, nrm.out_packed) : (int64_t)b * ldc + n)) = p;
             } else {
                 *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
             }
-            if (nrm.out_sumsq) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
+            if (nrm.out_sumsq && !(RS_PROBE & 32)) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
                 const f32x4 wn = one ? wn_pre : *(const f32x4*)(nrm.w_next + n);
                 *(u32x2*)((bf16_t*)nrm.xw_out + (nrm.out_packed ? rv_xp_index(b, n, nrm.out_packed) : (int64_t)b * N + n)) =
                     u32x2{pack_bf16x2(v[0] * wn[0], v[1] * wn[1]), pack_bf16x2(v[2] * wn[2], v[3] * wn[3])};
@@ -88,7 +95,7 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
                 sq = __fmaf_rn(v[3], v[3], __fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], __fmaf_rn(v[0], v[0], sq))));
             }
         }
-        if (nrm.out_sumsq) {
+        if (nrm.out_sumsq && !(RS_PROBE & 32)) {
             sq += __shfl_xor(sq, 16, 64);
             sq += __shfl_xor(sq, 32, 64);
             if (kg == 0) nrm.out_sumsq[((int64_t)mb * nblk_grid + blk) * 16 + fr] = b < M ? sq : 0.f;

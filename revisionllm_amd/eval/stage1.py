@@ -58,26 +58,13 @@ def iou(outputs, gt, num_frames_clip, num_frames_video, scores, plus_baseline=Fa
     return clip_frames, ious, keep
 
 
-def run_query(model, tokenizer, features, query_feats, query_cls, sentence, timestamps, duration, batch=8, num_frames=250,
-              debug_window=125, score="mean_entropy", score_merge="multiply", normalize=True, topk_pool=False,
-              prompt="mad_grounding"):
-    """features [W,T,768] (device).  Returns (answers, info) with info = {'iou': [...], 'scores': [...]} (negative.py:337)."""
-    query = "<video>\n" + QUESTIONS[prompt].format(sentence)
-    answers, ent = [], []
-    for g in range(math.ceil(features.shape[0] / batch)):
-        feat = features[g * batch: min((g + 1) * batch, features.shape[0])]
-        qf = None
-        if query_feats is not None:
-            qf = pad_sequences_1d(query_feats[None].repeat(feat.shape[0], 1, 1), dtype=query_feats.dtype, device=query_feats.device)
-        ans, out = inference(model, feat, qf, query, tokenizer, return_list=True)
-        answers.extend(ans)
-        if "entropy" in score:
-            st = ops.entropy_stats(torch.stack(out["scores"], 1))
-            col = 0 if score == "max_entropy" else 2
-            ent.extend(float(e[col]) for e in st)
+def score_query(features, answers, ent, query_cls, timestamps, duration, num_frames=250, debug_window=125, score="mean_entropy",
+                score_merge="multiply", normalize=True, topk_pool=False, plus_baseline=False):
+    """Host epilogue of one query (negative.py:299-337): answers -> proposals + IoU, cosine score of every proposal, score merge.
+    ``ent``: one raw entropy statistic per window (max or mean over its decode steps; [] for --score cosine_sim)."""
     gt = (timestamps[0] / duration, timestamps[1] / duration)
     num_frames_video = int(duration * num_frames / debug_window)
-    frames, ious, ent = iou(answers, gt, num_frames, num_frames_video, ent)
+    frames, ious, ent = iou(answers, gt, num_frames, num_frames_video, ent, plus_baseline)
     cos = []
     for k, (a, b) in frames.items():
         prop = features[k][a:b + 1]
@@ -97,3 +84,69 @@ def run_query(model, tokenizer, features, query_feats, query_cls, sentence, time
     else:
         scores = cos
     return answers, {"iou": ious, "scores": scores}
+
+
+def run_query(model, tokenizer, features, query_feats, query_cls, sentence, timestamps, duration, batch=8, num_frames=250,
+              debug_window=125, score="mean_entropy", score_merge="multiply", normalize=True, topk_pool=False,
+              prompt="mad_grounding", plus_baseline=False):
+    """features [W,T,768] (device).  Returns (answers, info) with info = {'iou': [...], 'scores': [...]} (negative.py:337).
+    The reference's own loop: one ``inference()`` per batch of windows, entropy statistics from the returned scores."""
+    query = "<video>\n" + QUESTIONS[prompt].format(sentence)
+    answers, ent = [], []
+    for g in range(math.ceil(features.shape[0] / batch)):
+        feat = features[g * batch: min((g + 1) * batch, features.shape[0])]
+        qf = None
+        if query_feats is not None:
+            qf = pad_sequences_1d(query_feats[None].repeat(feat.shape[0], 1, 1), dtype=query_feats.dtype, device=query_feats.device)
+        ans, out = inference(model, feat, qf, query, tokenizer, return_list=True)
+        answers.extend(ans)
+        if "entropy" in score:
+            st = ops.entropy_stats(torch.stack(out["scores"], 1))
+            col = 0 if score == "max_entropy" else 2
+            ent.extend(float(e[col]) for e in st)
+    return score_query(features, answers, ent, query_cls, timestamps, duration, num_frames, debug_window, score, score_merge, normalize, topk_pool,
+                       plus_baseline)
+
+
+def launch_query_steps(model, tokenizer, features, query_feats, sentence, batch=8, score="mean_entropy", prompt="mad_grounding",
+                       max_new_tokens=64, server=None):
+    """The LLM part of ``run_query`` as a step generator (``revisionllm_amd.sched``): every batch of windows is one generate whose prefill
+    rides in the ``serve.DecodeServer``'s batched passes and whose rows decode in its merged steps (``--in_flight`` of the stage-1 driver;
+    the pipeline bench.py's stage-1 workloads time).  Nothing is waited for here beyond what ``generate_steps`` yields.
+    -> (device tokens [W, G], device step entropies [W, G], prompt ids, stop string): ``collect_query`` turns them into answers."""
+    from ..inference import _prompt_ids
+    query = "<video>\n" + QUESTIONS[prompt].format(sentence)
+    toks, ents = [], []
+    ids1, stop_str = _prompt_ids(query, tokenizer, 1)
+    for g in range(math.ceil(features.shape[0] / batch)):
+        feat = features[g * batch: min((g + 1) * batch, features.shape[0])]
+        qf = None
+        if query_feats is not None:
+            qf = pad_sequences_1d(query_feats[None].repeat(feat.shape[0], 1, 1), dtype=query_feats.dtype, device=query_feats.device)
+        out = yield from model.generate_steps(ids1.repeat(feat.shape[0], 1), images=feat, query_feats=qf, do_sample=True, temperature=0.05, num_beams=1,
+                                              max_new_tokens=max_new_tokens, return_dict_in_generate=True, server=server)
+        toks.append(out["sequences"][:, ids1.shape[1]:])
+        ents.append(out["entropy"])
+    width = max(t.shape[1] for t in toks)
+    pad = lambda t: torch.nn.functional.pad(t, (0, width - t.shape[1]))      # noqa: E731 - generates of one query may stop at different steps
+    return torch.cat([pad(t) for t in toks]), torch.cat([pad(e) for e in ents]), [int(t.shape[1]) for t in toks for _ in range(t.shape[0])], stop_str
+
+
+def collect_query(model, tokenizer, launched, score="mean_entropy"):
+    """Host side of ``launch_query_steps``: decode the answers (inference.py:61-70) and take the entropy statistic of every window over
+    ALL the steps its batch's generate ran - like the reference, whose ``get_entropy_statistics`` sees the batch's whole ``scores`` tuple
+    (negative.py:291-298): a row that finished early keeps contributing the steps it spent emitting the pad id.  -> (answers, ent)."""
+    tok, ent, produced, stop_str = launched
+    tok, ent = tok.cpu(), ent.cpu()
+    model.engine.check_handoff_status()
+    answers, stats = [], []
+    for j in range(tok.shape[0]):
+        g = produced[j]
+        text = tokenizer.batch_decode([tok[j, :g].tolist()], skip_special_tokens=True)[0].strip()
+        if text.endswith(stop_str):
+            text = text[:-len(stop_str)]
+        answers.append(text.strip())
+        if "entropy" in score:
+            e = ent[j, :g]
+            stats.append(float(e.max()) if score == "max_entropy" else float(e.mean()))
+    return answers, stats

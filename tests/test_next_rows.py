@@ -343,3 +343,55 @@ def test_eval_driver_resume_and_error_handling(tmp_path, monkeypatch):
     with open(log, "a") as f:
         f.write('{"video_id": "movieA", "task": "grou')
     assert drv.done_query_ids(log) == [f"q{i}" for i in range(5)]
+
+
+def test_stage1_driver_argument_surface_formats_and_windows(tmp_path):
+    """The stage-1 entry point's host logic (eval_nlq_negative.py:33-77 flags, :176-185 annotation formats, :222-247 window variants,
+    :115-125 record writer) - no device."""
+    from revisionllm_amd.eval import eval_nlq_negative as drv
+    from revisionllm_amd.eval import stage1
+    a = drv.parse_args([])
+    ref_flags = dict(task="grounding", debug_window=125, num_frames=250, mlp_adapter=False, ca_adapter=False, cross_attn=False, q_feat_dir=None,
+                     max_seq_length=2048, self_attn=None, ca_self_attn=None, sa_pos=1, neg_window=False, batch=1, split=0, total_split=1, topk_pool=True,
+                     adapter_input_dim=768, feature_fps=5, load_ckp=False, mad_prompt="mad_grounding", debug=False, clip_adapter=False,
+                     clip_adapter_text=False, vis_feat_storage="lmdb", score="mean_entropy", clip_adapter_feature="temporal", hierarchy=False,
+                     score_merge="multiply", normalize=True, skip_small_videos=True, baseline=False, plus_baseline=False, pretrain_mm_mlp_adapter=None,
+                     pretrain_clip_adapter=None, stage3=None)
+    for k, v in ref_flags.items():
+        assert getattr(a, k) == v, k
+    for k in ("clip_path", "model_base", "stage2", "data_path", "feat_folder", "log_path"):
+        assert hasattr(a, k)
+    # annotation formats: timestamps stay in seconds (no ground-truth-window conversion at stage 1)
+    with open(tmp_path / "mad.json", "w") as f:
+        json.dump({"q0": {"movie": "m", "sentence": "A.", "timestamps": [3.0, 9.0], "movie_duration": 400.0}}, f)
+    assert drv.load_items(str(tmp_path / "mad.json")) == [("q0", {"movie": "m", "sentence": "A.", "timestamps": [3.0, 9.0], "movie_duration": 400.0})]
+    with open(tmp_path / "a.jsonl", "w") as f:
+        f.write(json.dumps({"query_id": "z1", "timestamps": [0, 3], "duration": 500.0}) + "\n")
+    assert drv.load_items(str(tmp_path / "a.jsonl"))[0][0] == "z1"
+    with open(tmp_path / "v.json", "w") as f:
+        json.dump({"videos": [{"query": "a dog", "timestamps": [0, 3], "duration": 500.0}]}, f)
+    assert drv.load_items(str(tmp_path / "v.json"))[0][0] == "a dog"
+    # window variants, restated from negative.py:229-247 on index arrays
+    feats = np.arange(1900)
+    def ref_windows(features, baseline, plus_baseline, num_frames=32, debug_window=125, feature_fps=5.0):
+        if baseline:
+            features = features[np.linspace(0, features.shape[0] - 1, int(debug_window * feature_fps), dtype=np.int32)]
+        ctx_l = len(features)
+        clip_length = debug_window * feature_fps
+        num_window = math.ceil(ctx_l / (clip_length // 2)) - 1
+        out = []
+        for i in ([1] if baseline else list(range(num_window))):
+            start, end = max(i * clip_length // 2, 0), min(i * clip_length // 2 + clip_length, ctx_l - 1)
+            out.append(features[np.linspace(start, end, num_frames, dtype=np.int32)])
+        if plus_baseline:
+            out.append(features[np.linspace(0, features.shape[0] - 1, num_frames, dtype=np.int32)])
+        return np.array(out)
+    for baseline, plus in ((False, False), (True, False), (False, True), (True, True)):
+        args = drv.parse_args(["--num_frames", "32"] + (["--baseline", "True"] if baseline else []) + (["--plus_baseline", "True"] if plus else []))
+        got = feats[drv.window_features(feats, args)]
+        assert np.array_equal(got, ref_windows(feats, baseline, plus)), (baseline, plus)
+    assert drv.window_features(feats, drv.parse_args(["--num_frames", "32"])).shape[0] == stage1.cut_windows(1900, num_frames=32).shape[0] == 6
+    # record writer
+    drv.write_log(str(tmp_path / "log.txt"), "m", "grounding", "q0", ["From 1 to 2."], info={"iou": [0.5], "scores": [1.0]})
+    assert json.loads(open(tmp_path / "log.txt").read()) == {"video_id": "m", "task": "grounding", "query_id": "q0", "answer": ["From 1 to 2."],
+                                                              "info": {"iou": [0.5], "scores": [1.0]}}
