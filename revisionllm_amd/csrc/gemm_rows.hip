@@ -116,6 +116,60 @@ __device__ __forceinline__ bf16x8 rs_fp8x8(unsigned lo, unsigned hi) {     // = 
     return r.v;
 }
 
+// Round 4: the rows' sums of squares of a consumed fused RMSNorm.  Every workgroup needs all <= 144 rows' sums: MB x 256 per-block
+// partials of 16 rows each (36.8k floats at 9 row blocks).  Rounds 2 - 3 loaded them as 144 conditional four-byte loads per thread
+// (a branch and a 64-bit address computation each: ~1700 instructions per wave) in the TAIL of the workgroup - 8 us of every launch
+// that consumes a norm at 140 rows (probe without them: fused QKV 57.5 -> 49.2 us, gate/up 73.0 -> 65.9 us).  Now:
+//   * a thread owns CHAINS of (row block, q, quad of rows): its 8 partials q, q + 32, ... as 16-byte loads (four rows at once), added in
+//     the order gemv_stream's (q, row) threads add them (the finish then adds q = 0 .. 31): the rows stay bit-identical;
+//   * 8 / 9 row blocks (one workgroup per CU, 256 registers): the consumer waves do it at the HEAD of the workgroup, right behind the
+//     opening loads of the weight ring - the round trip hides under the first (cold, HBM) weights - into an LDS area of their own
+//     behind the slab ring; 4 / 5 row blocks (168 registers: the head form spilled): in the tail as before, into the freed ring;
+//   * every workgroup of an XCD starts at a different chain: all of them walking the same lines in the same order at the same moment
+//     queued up on one L2 channel after the other (2 - 3 us of the 8).
+constexpr bool rows_sumsq_at_head(int MB) { return MB >= 8; }
+template <int MB, int NTH, int PTB>       // NTH threads take part (tg = index among them); PTB chains per thread in flight at once
+__device__ __forceinline__ void rows_sumsq(const GemvNorm& nrm, float* ssq, int tg) {
+    if (!nrm.in_sumsq || (RS_PROBE & 16)) return;
+    constexpr int CHAINS = MB * 128;                       // (mb, q = 0 .. 31, row quad = 0 .. 3)
+    constexpr int PT = (CHAINS + NTH - 1) / NTH;
+    const int nblk = nrm.in_nblk;
+    const int off = (RS_PROBE & 2048) ? 0 : (int)((blockIdx.x >> 3) * 37u) % CHAINS;     // (workgroup b lands on XCD b % 8)
+#pragma unroll
+    for (int i0 = 0; i0 < PT; i0 += PTB) {
+        f32x4 pj[PTB][8];
+        int cc[PTB];
+#pragma unroll
+        for (int i = 0; i < PTB; ++i) {
+            const int idx = tg + (i0 + i) * NTH;
+            int c = idx + off;
+            c = c >= CHAINS ? c - CHAINS : c;
+            cc[i] = (i0 + i < PT && idx < CHAINS) ? c : -1;
+            const int mb = c >> 7, q = (c >> 2) & 31, rq = c & 3;
+            const float* src = nrm.in_sumsq + ((int64_t)(mb * nblk + q) * 16 + rq * 4);
+            // unconditional loads (a chain past the end re-reads a valid chain, a block past nblk re-reads block q: both are dropped by a
+            // select) - a branch per load was what made the old form slow
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool have = q + 32 * j < nblk;
+                const f32x4 v = *(const f32x4*)(src + (have ? j * 512 : 0));
+                pj[i][j] = have ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // (a batch's loads in flight at once: one round trip)
+#pragma unroll
+        for (int i = 0; i < PTB; ++i) {
+            if (cc[i] < 0) continue;
+            const int c = cc[i], mb = c >> 7, q = (c >> 2) & 31, rq = c & 3;
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += pj[i][j];
+            for (int b = q + 256; b < nblk; b += 32) a += *(const f32x4*)(nrm.in_sumsq + ((int64_t)(mb * nblk + b) * 16 + rq * 4));
+            *(f32x4*)(ssq + mb * 512 + q * 16 + rq * 4) = a;        // [mb][q][row]
+        }
+    }
+}
+
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
 //      3 = fused q/k/v + RoPE epilogue                        4 = bf16 out, one tile per block
@@ -195,6 +249,10 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     } while (0)
 #pragma unroll
         for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
+        if constexpr (rows_sumsq_at_head(MB)) {
+            rows_sumsq<MB, 256, 3>(nrm, (float*)(rs_smem + DX * SLAB), tid);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave's first stage barrier; read in the finish, many barriers later
+        }
         for (int g0 = 0; g0 < T; g0 += DW) {
 #pragma unroll
             for (int u = 0; u < DW; ++u) {
@@ -314,42 +372,11 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             }
         }
     }
-    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
-    //     blocks at a time (registers)
-    float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now
-    if (nrm.in_sumsq && !(RS_PROBE & 16)) {
-        constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
-        // the partials of CH row blocks in flight at once, then their sums: with the unsplit form (VPW = 8: no partial planes held in
-        // registers here) all of them - ONE memory round trip in the tail of the workgroup instead of MB / 2 dependent ones
-        constexpr int CH = VPW == 8 ? MB : 2;
-#pragma unroll
-        for (int c0 = 0; c0 < MB; c0 += CH) {
-            float pj[CH][VT][8];
-#pragma unroll
-            for (int i = 0; i < CH; ++i)
-#pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    const int vt = tid + v * RS_THREADS;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int b = (vt >> 4) + 32 * j;
-                        pj[i][v][j] = (c0 + i < MB && vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[((c0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);   // (keep a chunk's loads together)
-#pragma unroll
-            for (int i = 0; i < CH; ++i)
-#pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    const int vt = tid + v * RS_THREADS;
-                    if (vt >= 512 || c0 + i >= MB) continue;
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a += pj[i][v][j];
-                    for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[((c0 + i) * nrm.in_nblk + b) * 16 + (vt & 15)];
-                    ssq[(c0 + i) * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
-                }
-        }
+    // (2) the rows' sums of squares [MB][32][16]: added up at the head of the workgroup behind the slab ring (8 / 9 row blocks), or here
+    //     into the freed ring (4 / 5 row blocks)
+    float* ssq = (float*)(rs_smem + (rows_sumsq_at_head(MB) ? DX * SLAB : 0));
+    if constexpr (!rows_sumsq_at_head(MB)) {
+        rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
         __syncthreads();
     }
     if (wave >= RS_W) return;
@@ -465,6 +492,10 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
     } while (0)
 #pragma unroll
         for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
+        if constexpr (rows_sumsq_at_head(MB)) {
+            rows_sumsq<MB, 256, 3>(nrm, (float*)(rs_smem + DX * SLAB), tid);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave's first stage barrier; read in the finish, many barriers later
+        }
         int g = 0;
         for (int n = 0; n < n_it; ++n) {
             int ci = 0, cc = 0;             // stage being computed: (virtual wave, k-block in it)
@@ -568,39 +599,11 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
     constexpr int PPW = (PAIRS + RS_W - 1) / RS_W;      // pairs per consumer wave: p = wave + RS_W * i  ->  mb = p % MB
     const int fr = lane & 15, kg = lane >> 4;
     const int nblk = N / (16 * NT);
-    // (2) the rows' sums of squares in gemv_stream's order (thread (q, row) adds blocks q, q + 32, ...; then q = 0 .. 31), two row
-    //     blocks at a time (registers)
-    float* ssq = (float*)rs_smem;            // [MB][32][16]: the slab ring is free now (once for all the groups this workgroup finishes)
-    if (nrm.in_sumsq && !(RS_PROBE & 16)) {
-        constexpr int VT = (512 + RS_THREADS - 1) / RS_THREADS;     // gemv_stream's 512 (q, row) threads on this workgroup's
-        // every partial of every row block in flight at once (the accumulators are in LDS by now: the registers are free), then the sums:
-        // one memory round trip in the tail of the workgroup instead of one per pair of row blocks (MB / 2 of them, dependent through
-        // the in-order vmcnt)
-        float pj[MB][VT][8];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const int vt = tid + v * RS_THREADS;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int b = (vt >> 4) + 32 * j;
-                    pj[mb][v][j] = (vt < 512 && b < nrm.in_nblk) ? nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)] : 0.f;
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);       // (keep the loads together: the sums below must not be interleaved pairwise again)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const int vt = tid + v * RS_THREADS;
-                if (vt >= 512) continue;
-                float a = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a += pj[mb][v][j];
-                for (int b = (vt >> 4) + 256; b < nrm.in_nblk; b += 32) a += nrm.in_sumsq[(mb * nrm.in_nblk + b) * 16 + (vt & 15)];
-                ssq[mb * 512 + vt] = a;      // = [mb][vt >> 4][vt & 15]
-            }
+    // (2) the rows' sums of squares [MB][32][16]: added up at the head of the workgroup behind the slab ring (8 / 9 row blocks), or here
+    //     into the freed ring (4 / 5 row blocks)
+    float* ssq = (float*)(rs_smem + (rows_sumsq_at_head(MB) ? DX * SLAB : 0));
+    if constexpr (!rows_sumsq_at_head(MB)) {
+        rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
         __syncthreads();
     }
     if (wave >= RS_W) return;
@@ -694,7 +697,7 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
 template <int MB, int VPW, int FIN, int WP, int PERS>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096;
+    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * 2048 : 0);      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
     // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
     // occupies 128 of the 256 CUs (PMC: SQ_BUSY_CU_CYCLES = 0.50 of the launch).  A launch with no more workgroups than `rows_spread`
     // asks for more LDS than two workgroups can share, so each gets a CU of its own.

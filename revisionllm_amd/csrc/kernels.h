@@ -90,6 +90,12 @@ struct QkvRope {
     // epilogues): q16 rows are q_ld elements apart and also receive the LOW half bf16(q - bf16(q)) q_lo elements behind the high half
     int q_ld = 0, q_lo = 0;
 };
+// (timing probes of the wide decode kernel, tools/rows_probe.sh: RS_PROBE & 256 / 512 / 1024 = no V^T / K / Q stores; garbage results)
+#ifndef RS_PROBE
+#define RS_PROBE_K_ 0
+#else
+#define RS_PROBE_K_ RS_PROBE
+#endif
 // Fused QKV epilogue for one lane-owned group: v = 4 consecutive output columns n..n+3 of row m (see QkvRope).
 // qkv_rope_coeffs fetches the (cos, sin) pairs the group needs (zeros for V columns); the decode kernel calls it BEFORE its
 // weight stream so that the table's memory latency is not paid in the tail of every workgroup.
@@ -97,6 +103,7 @@ static __device__ __forceinline__ f32x4 qkv_rope_coeffs(const QkvRope& q, int m,
     const int D = q.H * 128;
     const int sec = n / D, p = (n - sec * D) & 127;
     if (sec >= 2) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr ((RS_PROBE_K_ & 4096) != 0) return f32x4{1.f, 0.f, 1.f, 0.f};   // (timing probe: no coefficient loads)
     if (q.row_pos) return *(const f32x4*)(q.cs + ((int64_t)m * 64 + (p >> 1)) * 2);   // per-row table
     if (q.G > 1) m -= (m / q.Mg) * q.Mg;
     int pos;
@@ -112,7 +119,7 @@ static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m,
     bool prefix = false;
     const int mrow = m;      // row of q16 (the batch-wide row)
     if (q.G > 1) { const int gi = m / q.Mg; m -= gi * q.Mg; goff = q.grow[gi]; }
-    if (q.row_pos) { b = m; pos = q.row_pos[m]; if (pos < 0 || pos >= q.Smax) return; }   // inactive, or past the pool's capacity (would land in another row's blocks of the blocked V^T cache): nothing is stored
+    if (q.row_pos) { b = m; pos = (RS_PROBE_K_ & 8192) ? 170 + (m & 7) : q.row_pos[m]; if (pos < 0 || pos >= q.Smax) return; }   // (& 8192, timing probe: no position load)   // inactive, or past the pool's capacity (would land in another row's blocks of the blocked V^T cache): nothing is stored
     else if (m < q.P0) { b = 0; pos = m; prefix = true; }
     else { const int r = m - q.P0; b = r / q.S; pos = q.pos0 + (r - b * q.S); }
     if (sec < 2) {
@@ -122,6 +129,7 @@ static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m,
         const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
         const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
         if (sec == 0) {
+            if constexpr ((RS_PROBE_K_ & 1024) != 0) return;
             if constexpr (QSPLIT) {
                 bf16_t* dst = (bf16_t*)q.q16 + (int64_t)mrow * q.q_ld + hd;
                 *(u32x2*)dst = o;
@@ -130,11 +138,13 @@ static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m,
                 *(u32x2*)((bf16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
             }
         } else {
+            if constexpr ((RS_PROBE_K_ & 512) != 0) return;
             const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
             for (int bb = b0_; bb < b1_; ++bb)
                 *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
         }
     } else {
+        if constexpr ((RS_PROBE_K_ & 256) != 0) return;
         const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
         for (int bb = b0_; bb < b1_; ++bb) {
             bf16_t* dst = (bf16_t*)q.vtc + ((int64_t)bb * q.H + head) * 128 * q.Smax + rv_vt_index(p, pos);
