@@ -170,6 +170,19 @@ __device__ __forceinline__ void rows_sumsq(const GemvNorm& nrm, float* ssq, int 
     }
 }
 
+// ... then ONE thread per row adds the 32 per-q sums (q = 0 .. 31, the order of gemv_stream's finish) into totl[MB * 16]: the finish of every
+// (tile, row block) pair reads one float instead of adding 32 LDS values again (36 pairs x 64 lanes did, with one wave per SIMD to hide nothing).
+template <int MB>
+__device__ __forceinline__ void rows_sumsq_total(const float* ssq, float* totl, int t) {
+    if (t < MB * 16) {
+        const int mb = t >> 4, row = t & 15;
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + row];
+        totl[t] = tot;
+    }
+}
+
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
 //      3 = fused q/k/v + RoPE epilogue                        4 = bf16 out, one tile per block
@@ -224,6 +237,9 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
         };
         if constexpr (!(RS_PROBE & 8))
             for (int d = 0; d < DX - 1; ++d) issue(d);
+        if constexpr (rows_sumsq_at_head(MB)) {
+            if (nrm.in_sumsq && !(RS_PROBE & 16)) __builtin_amdgcn_s_barrier();   // the consumers' head barrier (rows_sumsq)
+        }
         for (int g = 0; g < T; ++g) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DX - 2) * XL) : "memory");   // slab g has landed
             if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();           // consumers: slab g is yours, slot of slab g - 1 is mine
@@ -250,8 +266,14 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
 #pragma unroll
         for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
         if constexpr (rows_sumsq_at_head(MB)) {
-            rows_sumsq<MB, 256, 3>(nrm, (float*)(rs_smem + DX * SLAB), tid);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave's first stage barrier; read in the finish, many barriers later
+            if (nrm.in_sumsq && !(RS_PROBE & 16)) {
+                float* ssq_ = (float*)(rs_smem + DX * SLAB);
+                rows_sumsq<MB, 256, 3>(nrm, ssq_, tid);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // head barrier (the producer joins it): every (q, row) sum is in LDS
+                rows_sumsq_total<MB>(ssq_, ssq_ + MB * 512, tid);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // published by the stage barriers; read in the finish, many barriers later
+            }
         }
         for (int g0 = 0; g0 < T; g0 += DW) {
 #pragma unroll
@@ -376,9 +398,14 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     //     into the freed ring (4 / 5 row blocks)
     float* ssq = (float*)(rs_smem + (rows_sumsq_at_head(MB) ? DX * SLAB : 0));
     if constexpr (!rows_sumsq_at_head(MB)) {
-        rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
-        __syncthreads();
+        if (nrm.in_sumsq && !(RS_PROBE & 16)) {
+            rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
+            __syncthreads();
+            rows_sumsq_total<MB>(ssq, ssq + MB * 512, tid);
+            __syncthreads();
+        }
     }
+    const float* totl = ssq + MB * 512;
     if (wave >= RS_W) return;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -393,11 +420,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             else if constexpr (S == 2) sres[t] = pl[i][t][0] + pl[i][t][1];
             else sres[t] = pl[i][t][0];
         }
-        float tot = 0.f;
-        if (nrm.in_sumsq) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + fr];
-        }
+        const float tot = nrm.in_sumsq ? totl[mb * 16 + fr] : 0.f;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         gemv_finish<NT, OUT_BF16, ACT, WP, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
     }
@@ -463,6 +486,9 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
         };
         if constexpr (!(RS_PROBE & 8))
             for (int d = 0; d < DX - 1; ++d) issue(d);
+        if constexpr (rows_sumsq_at_head(MB)) {
+            if (nrm.in_sumsq && !(RS_PROBE & 16)) __builtin_amdgcn_s_barrier();   // the consumers' head barrier (rows_sumsq)
+        }
         const int TT = n_it * Tp;
         for (int g = 0; g < TT; ++g) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DX - 2) * XL) : "memory");   // slab g has landed
@@ -493,8 +519,14 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
 #pragma unroll
         for (int d = 0; d < DW - 1; ++d) RS_ISSUE_W(d);
         if constexpr (rows_sumsq_at_head(MB)) {
-            rows_sumsq<MB, 256, 3>(nrm, (float*)(rs_smem + DX * SLAB), tid);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave's first stage barrier; read in the finish, many barriers later
+            if (nrm.in_sumsq && !(RS_PROBE & 16)) {
+                float* ssq_ = (float*)(rs_smem + DX * SLAB);
+                rows_sumsq<MB, 256, 3>(nrm, ssq_, tid);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // head barrier (the producer joins it): every (q, row) sum is in LDS
+                rows_sumsq_total<MB>(ssq_, ssq_ + MB * 512, tid);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // published by the stage barriers; read in the finish, many barriers later
+            }
         }
         int g = 0;
         for (int n = 0; n < n_it; ++n) {
@@ -603,9 +635,14 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
     //     into the freed ring (4 / 5 row blocks)
     float* ssq = (float*)(rs_smem + (rows_sumsq_at_head(MB) ? DX * SLAB : 0));
     if constexpr (!rows_sumsq_at_head(MB)) {
-        rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
-        __syncthreads();
+        if (nrm.in_sumsq && !(RS_PROBE & 16)) {
+            rows_sumsq<MB, RS_THREADS, 2>(nrm, ssq, tid);
+            __syncthreads();
+            rows_sumsq_total<MB>(ssq, ssq + MB * 512, tid);
+            __syncthreads();
+        }
     }
+    const float* totl = ssq + MB * 512;
     if (wave >= RS_W) return;
     for (int n = 0; n < n_it; ++n) {
         if constexpr (S > 1) {
@@ -644,11 +681,7 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
                 else if constexpr (S == 2) sres[t] = pl[i][t][0] + pl[i][t][1];
                 else sres[t] = pl[i][t][0];
             }
-            float tot = 0.f;
-            if (nrm.in_sumsq) {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) tot += ssq[(mb * 32 + q) * 16 + fr];
-            }
+            const float tot = nrm.in_sumsq ? totl[mb * 16 + fr] : 0.f;
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
             gemv_finish<NT, OUT_BF16, ACT, WP, ROPE>(sres, mb, fr, kg, blk, nblk, M, N, bias, res, ldr, Cv, ldc, nrm, qr, tot, z, z, z, z, false);
         }
@@ -697,7 +730,7 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
 template <int MB, int VPW, int FIN, int WP, int PERS>
 int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * 2048 : 0);      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
+    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * (2048 + 64) : 0);      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
     // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
     // occupies 128 of the 256 CUs (PMC: SQ_BUSY_CU_CYCLES = 0.50 of the launch).  A launch with no more workgroups than `rows_spread`
     // asks for more LDS than two workgroups can share, so each gets a CU of its own.
