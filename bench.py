@@ -236,7 +236,7 @@ def pmc_traffic(kernel, grid_threads):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE; tools/pmc_summary.py).  None if no summary matches."""
     want = kernel.replace(" ", "")
-    for fname in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for fname in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         d = committed_profile(fname)
         if d is None:
             continue
@@ -338,7 +338,7 @@ def cpu_baseline(args, n_calls, P):
         return info
     t_rec = n_calls * t_call
     info.update(value=W / t_rec, extrapolated="x%d identical calls" % n_calls, repeats=1,
-                stage_seconds_per_call=stage_split(stage_log), full_run="profiles/r3_cpu_full.json (--cpu-full: all calls, 3 repeats, median)",
+                stage_seconds_per_call=stage_split(stage_log), full_run="profiles/r4_cpu_full.json (--cpu-full: all calls, 3 repeats, median)",
                 sample=f"torch-fp32 oracle: ONE full call of the recursion as the reference executes it (ClipEncoder on {W} segment rows x {Tn} frames, "
                        f"prefill S={P - 1 + W}, {G - 1} KV-cached decode steps, all 32 layers; driven through oracle.sampling.generate = the CPU "
                        f"restatement of inference()) timed once after a one-layer warm-up: {t_call:.1f} s; recursion = {n_calls} such calls "
@@ -901,13 +901,13 @@ def main():
                      **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {}),
                      **({"timing": v["timing"]} if "timing" in v else {}),
                      **({"prefills_per_launch": v["prefills_per_launch"]} if "prefills_per_launch" in v else {})} for k, v in legs.items()}
-        for fname in ("r3_pmc_mfma.json", "r2_pmc_mfma.json"):
+        for fname in ("r4_pmc_mfma.json", "r3_pmc_mfma.json", "r2_pmc_mfma.json"):
             pmc = committed_profile(fname)
             if pmc is not None:
                 other["prefill_gemm_pmc"] = dict(pmc.get("summary") or {}, source="profiles/" + fname)
                 break
         # the decode gate/up kernel INSIDE a decode step (rocprofv3 kernel trace of isolated steps, committed): the number to price it with
-        for fname in ("r3_decode_steps.json", "r2_decode_steps.json"):
+        for fname in ("r4_decode_steps.json", "r3_decode_steps.json", "r2_decode_steps.json"):
             prof = committed_profile(fname)
             ks = [] if prof is None else prof.get("rows", {}).get(str(legs["decode_gateup_gemv"]["rows"]), {}).get("kernels", [])
             want = legs["decode_gateup_gemv"]["kernel"].replace(" ", "")
@@ -920,14 +920,15 @@ def main():
                 break
         # the dominant kernel inside a batched prefill pass (other kernels between its launches: the clock is not pinned at the power cap
         # by one kernel), from the committed rocprofv3 summary of tools/prefill_prof.sh - next to the live back-to-back figure above
-        pf = committed_profile("r3_prefill_pass.json")
+        pf_name = "r4_prefill_pass.json" if committed_profile("r4_prefill_pass.json") is not None else "r3_prefill_pass.json"
+        pf = committed_profile(pf_name)
         if pf is not None and pf.get("rows") == dom.get("rows"):
             row = next((r_ for r_ in pf.get("kernels", []) if r_["kernel"].replace(" ", "") == dom["kernel"].replace(" ", "")), None)
             if row is not None:
                 fl = dom["algorithmic"]
                 roof_in_situ = {"avg_launch_ms": row["avg_us"] / 1e3, "achieved": fl / row["avg_us"] / 1e6, "unit": "TFLOP/s",
                                 "frac": fl / row["avg_us"] / 1e6 / MFMA_BF16_PEAK_TF,
-                                "source": "profiles/r3_prefill_pass.json (rocprofv3 kernel trace of batched prefill passes at this row count)"}
+                                "source": f"profiles/{pf_name} (rocprofv3 kernel trace of batched prefill passes at this row count)"}
             else:
                 roof_in_situ = None
         else:

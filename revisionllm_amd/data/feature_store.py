@@ -3,8 +3,8 @@
 On-disk formats follow the reference's writers / readers: per-movie ``<movie>.npy`` arrays [ctx_l, 768]
 (eval_nlq_retrieval_e2e2.py:246-247), or an LMDB whose values are ``np.savez_compressed`` blobs with key ``features``
 (or ``memory_global``) for videos and ``token_features`` / ``cls_features`` for queries (e2e2.py:187-192,238-255;
-writers data/feature_extraction/mad_clip_text_extractor.py:101-107).  LMDB is optional (not installed in this image);
-a directory of ``<key>.npz`` files with the same keys is accepted as a stand-in.
+writers data/feature_extraction/mad_clip_text_extractor.py:101-107).  The ``lmdb`` package is optional (not installed in this image):
+without it ``data/mdb_reader.py`` reads the environment's ``data.mdb`` itself; a directory of ``<key>.npz`` files with the same keys is accepted too.
 
 ``stage_windows`` is the step right before the hot path: gather the window frames on the host into a PINNED staging
 buffer and copy them to the GPU asynchronously on a side stream, so the H2D transfer of query i+1 overlaps the
@@ -40,9 +40,8 @@ class FeatureStore:
     def _open_lmdb(path):
         try:
             import lmdb
-        except ImportError as e:
-            raise ImportError("reading LMDB feature stores needs the 'lmdb' package; use vis_feat_storage='npy' or a "
-                              "directory of <key>.npz files") from e
+        except ImportError:      # the package is optional: the build's own reader of the data.mdb format does point lookups (data/mdb_reader.py)
+            from . import mdb_reader as lmdb
         env = lmdb.open(path, readonly=True, create=False, max_readers=4096 * 8, readahead=False)
         return env.begin(buffers=True)
 

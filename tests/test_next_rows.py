@@ -56,8 +56,8 @@ def test_f2_feature_store_formats(tmp_path):
     assert FeatureStore(str(tmp_path)).query("q7") == (None, None)
     try:
         import lmdb  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError, match="lmdb"):
+    except ImportError:      # without the package the build's own data.mdb reader is used: a directory without an environment is an OSError
+        with pytest.raises(OSError):
             FeatureStore(str(tmp_path), vis_feat_storage="lmdb")
 
 
@@ -131,6 +131,160 @@ def test_f2_lmdb_branch_with_the_reference_blob_format(tmp_path, monkeypatch):
     open(os.path.join(qdir, "data.mdb"), "wb").close()          # what marks a directory as an LMDB environment
     _write_stores(fake, vdir, qdir, feats)
     _check_stores(FeatureStore(vdir, q_feat_dir=qdir, vis_feat_storage="lmdb"), feats)
+
+
+def _write_mdb(path, items, psize=4096):
+    """Lay out an LMDB environment file (data format 1) from the PUBLISHED structures of lmdb.h / mdb.c - MDB_meta, MDB_page, MDB_node - the
+    way a single committed write transaction leaves it: meta pages 0 / 1, values too large for a leaf node in overflow runs (F_BIGDATA),
+    leaf pages filled in key order, branch levels above them until one root remains.  Test infrastructure for data/mdb_reader.py."""
+    import struct
+    os.makedirs(path, exist_ok=True)
+    items = sorted((bytes(k), bytes(v)) for k, v in items)
+    pages = {}                                   # pgno -> bytes (a run of pages for overflow values)
+    next_pg = [2]
+    nodemax = ((psize - 16) // 2) & ~1           # a node larger than this goes to overflow pages (mdb.c: me_nodemax)
+
+    def alloc(n=1):
+        p0 = next_pg[0]
+        next_pg[0] += n
+        return p0
+
+    def page(pgno, flags, nodes):
+        """nodes: [(lo, hi, flags, key, payload)] -> one page image; ptrs grow up from byte 16, nodes down from the end."""
+        buf = bytearray(psize)
+        upper = psize
+        ptrs = []
+        for lo, hi, fl, key, payload in nodes:
+            size = 8 + len(key) + len(payload)
+            size += size & 1
+            upper -= size
+            struct.pack_into("<HHHH", buf, upper, lo, hi, fl, len(key))
+            buf[upper + 8:upper + 8 + len(key)] = key
+            buf[upper + 8 + len(key):upper + 8 + len(key) + len(payload)] = payload
+            ptrs.append(upper)
+        lower = 16 + 2 * len(ptrs)
+        assert lower <= upper, "page overflow in the test writer"
+        struct.pack_into("<QHHHH", buf, 0, pgno, 0, flags, lower, upper)
+        for i, pt in enumerate(ptrs):
+            struct.pack_into("<H", buf, 16 + 2 * i, pt)
+        return bytes(buf)
+
+    def fits(nodes, extra):
+        used = 16 + sum(2 + ((8 + len(k) + len(pl) + 1) & ~1) for _, _, _, k, pl in nodes)
+        return used + 2 + ((extra + 1) & ~1) <= psize
+
+    n_over = 0
+    leaves, cur, first_keys = [], [], []
+    for k, v in items:
+        if 8 + len(k) + len(v) > nodemax:       # overflow run: header + the bytes, contiguous over ceil((16 + len) / psize) pages
+            n = -(-(16 + len(v)) // psize)
+            pg = alloc(n)
+            run = bytearray(n * psize)
+            struct.pack_into("<QHHI", run, 0, pg, 0, 0x04, n)
+            run[16:16 + len(v)] = v
+            pages[pg] = bytes(run)
+            n_over += n
+            node = (len(v) & 0xffff, len(v) >> 16, 0x01, k, struct.pack("<Q", pg))
+        else:
+            node = (len(v) & 0xffff, len(v) >> 16, 0, k, v)
+        if cur and not fits(cur, 8 + len(node[3]) + len(node[4])):
+            leaves.append(cur)
+            cur = []
+        cur.append(node)
+    if cur:
+        leaves.append(cur)
+    level = []
+    for nodes in leaves:
+        pg = alloc()
+        pages[pg] = page(pg, 0x02, nodes)
+        level.append((nodes[0][3], pg))
+    depth, n_branch = (1 if leaves else 0), 0
+    while len(level) > 1:
+        nxt, cur, cur_first = [], [], None
+        for i, (k, pg) in enumerate(level):
+            key = b"" if not cur else k                                          # node 0 of a branch page: the empty key
+            node = (pg & 0xffff, (pg >> 16) & 0xffff, (pg >> 32) & 0xffff, key, b"")
+            if cur and not fits(cur, 8 + len(key)):
+                bp = alloc()
+                pages[bp] = page(bp, 0x01, cur)
+                nxt.append((cur_first, bp))
+                n_branch += 1
+                cur = []
+                node = (node[0], node[1], node[2], b"", b"")
+            if not cur:
+                cur_first = k
+            cur.append(node)
+        bp = alloc()
+        pages[bp] = page(bp, 0x01, cur)
+        nxt.append((cur_first, bp))
+        n_branch += 1
+        level = nxt
+        depth += 1
+    root = level[0][1] if level else (1 << 64) - 1
+    last_pg = next_pg[0] - 1
+
+    def meta(pgno, txnid, with_db):
+        buf = bytearray(psize)
+        struct.pack_into("<QHHHH", buf, 0, pgno, 0, 0x08, 0, 0)
+        struct.pack_into("<IIQQ", buf, 16, 0xBEEFC0DE, 1, 0, 1 << 30)
+        struct.pack_into("<IHHQQQQQ", buf, 16 + 24, psize, 0, 0, 0, 0, 0, 0, (1 << 64) - 1)                      # FREE_DBI (md_pad = page size)
+        if with_db:
+            struct.pack_into("<IHHQQQQQ", buf, 16 + 24 + 48, 0, 0, depth, n_branch, len(leaves), n_over, len(items), root)
+        else:
+            struct.pack_into("<IHHQQQQQ", buf, 16 + 24 + 48, 0, 0, 0, 0, 0, 0, 0, (1 << 64) - 1)
+        struct.pack_into("<QQ", buf, 16 + 24 + 96, last_pg if with_db else 1, txnid)
+        return bytes(buf)
+    with open(os.path.join(path, "data.mdb"), "wb") as f:
+        f.write(meta(0, 0, False))               # the environment as created (txn 0: empty) ...
+        f.write(meta(1, 1, True))                # ... and after the one write transaction (txn 1 -> meta page 1)
+        pg = 2
+        while pg <= last_pg:
+            f.write(pages[pg])
+            pg += len(pages[pg]) // psize
+    return dict(depth=depth, leaves=len(leaves), branch=n_branch, overflow=n_over, last_pg=last_pg)
+
+
+def test_f2_mdb_reader_without_the_lmdb_package(tmp_path, monkeypatch):
+    """f-2 without the optional dependency: ``data/mdb_reader.py`` does the point lookups of the LMDB branch on a ``data.mdb`` laid out
+    from the published page / node / meta structures (test writer above): small values in leaf nodes, multi-megabyte feature blobs in
+    overflow runs, a three-level tree, missing keys; then ``FeatureStore`` end to end with ``import lmdb`` failing.
+    (No file written by liblmdb exists in this image: parity with liblmdb itself stays unpinned, as the module's header says.)"""
+    import builtins
+    from revisionllm_amd.data import mdb_reader
+    rs = np.random.RandomState(3)
+    # (1) a three-level tree of 20 000 short keys + a few larger values
+    items = [(b"key%05d" % i, b"v%d" % (i * 7)) for i in range(20000)] + [(b"big0", rs.bytes(5000)), (b"big1", rs.bytes(70000)), (b"a", b"")]
+    info = _write_mdb(str(tmp_path / "tree"), items, psize=1024)             # (small pages: a three-level tree from 20 000 keys)
+    assert info["depth"] >= 3 and info["overflow"] >= 5 + 69
+    env = mdb_reader.open(str(tmp_path / "tree"), readonly=True, create=False, max_readers=4096 * 8, readahead=False)
+    txn = env.begin(buffers=True)
+    assert env.stat()["entries"] == len(items) and env.stat()["depth"] == info["depth"]
+    want = dict(items)
+    for k in [b"key00000", b"key00001", b"key09999", b"key19999", b"key12345", b"big0", b"big1", b"a"] + [b"key%05d" % i for i in rs.randint(0, 20000, 300)]:
+        assert bytes(txn.get(k)) == want[k], k
+    for k in (b"", b"key", b"key20000", b"zzz", b"big2", b"key0000", b"key000000"):
+        assert txn.get(k) is None, k
+    with pytest.raises(mdb_reader.MdbError):
+        mdb_reader.open(str(tmp_path / "tree"), readonly=False)
+    # (2) the feature stores of the drivers, with the package absent: FeatureStore falls back to the reader
+    real_import = builtins.__import__
+
+    def no_lmdb(name, *a, **kw):
+        if name == "lmdb":
+            raise ImportError("No module named 'lmdb'")
+        return real_import(name, *a, **kw)
+    monkeypatch.setattr(builtins, "__import__", no_lmdb)
+    feats = rs.randn(300, 768).astype(np.float16)
+    vdir, qdir = str(tmp_path / "v"), str(tmp_path / "q")
+    _write_mdb(vdir, [(b"movieA", _dumps_npz({"features": feats.astype(np.float32)})), (b"movieB", _dumps_npz({"memory_global": feats[:10].astype(np.float32)}))])
+    _write_mdb(qdir, [(b"q7", _dumps_npz({"cls_features": feats[5].astype(np.float32), "token_features": feats[:5].astype(np.float32)}))])
+    _check_stores(FeatureStore(vdir, q_feat_dir=qdir, vis_feat_storage="lmdb"), feats)
+    # a file that is not an LMDB environment is refused with a clear error
+    os.makedirs(tmp_path / "junk")
+    with open(tmp_path / "junk" / "data.mdb", "wb") as f:
+        f.write(b"\0" * 16384)
+    with pytest.raises(mdb_reader.MdbError):
+        mdb_reader.open(str(tmp_path / "junk"))
 
 
 def test_f2_real_lmdb(tmp_path):
