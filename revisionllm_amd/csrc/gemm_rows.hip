@@ -183,6 +183,57 @@ __device__ __forceinline__ void rows_sumsq_total(const float* ssq, float* totl, 
     }
 }
 
+// The fused q/k/v finish of a MERGED decode step (rows at their own positions: qr.row_pos), written for this kernel: a (tile, row block)
+// pair's section / head / column offset are wave-uniform (no per-lane integer division), every pair's position, RoPE coefficients and FP8
+// scales are loaded BEFORE the first store (one round trip for the wave's <= 9 pairs), and a pair then costs a few dozen instructions - the
+// generic path (gemv_finish -> qkv_rope_store) spent ~390 per pair, and with one wave per SIMD that WAS the tail of the launch (round 4,
+// DESIGN section 8).  Same arithmetic, same stores: bit-identical caches and Q.
+template <int MB, int PPW, int PAIRS, int WP>
+__device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wave, int cg, int fr, int kg, int M, const GemvNorm& nrm, const QkvRope& qr,
+                                                const float* totl) {
+    const int D = qr.H * 128;
+    const int n0 = cg * 64;                               // the workgroup's 64 columns lie inside ONE head of ONE section
+    const int sec = n0 >= 2 * D ? 2 : n0 >= D ? 1 : 0;
+    const int hd0 = n0 - sec * D, head = hd0 >> 7;
+    int posv[PPW];
+    f32x4 cf[PPW], wsc[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + RS_W * i < PAIRS ? wave + RS_W * i : PAIRS - 1;
+        const int tile = p / MB, mb = p % MB, b = mb * 16 + fr;
+        const int pc = (hd0 & 127) + tile * 16 + kg * 4;  // column of the head (pair-interleaved order for q / k)
+        const int bc = b < M ? b : M - 1;
+        posv[i] = b < M ? qr.row_pos[bc] : -1;
+        cf[i] = sec < 2 ? *(const f32x4*)(qr.cs + ((int64_t)bc * 64 + (pc >> 1)) * 2) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (WP == 2) wsc[i] = *(const f32x4*)(nrm.w_scale + n0 + tile * 16 + kg * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + RS_W * i;
+        if (p >= PAIRS) break;
+        const int tile = p / MB, mb = p % MB, b = mb * 16 + fr;
+        const int pc = (hd0 & 127) + tile * 16 + kg * 4;
+        f32x4 v = sres[i];
+        if constexpr (WP == 2) v *= wsc[i];
+        if (nrm.in_sumsq) v *= rsqrtf(__fmaf_rn(totl[mb * 16 + fr], nrm.inv_d, nrm.eps));
+        const int pos = posv[i];
+        if (pos < 0 || pos >= qr.Smax) continue;          // inactive row, or past the pool's capacity: nothing is stored
+        if (sec < 2) {
+            const f32x4 t = cf[i];
+            const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
+            const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
+            const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+            if (sec == 0) *(u32x2*)((bf16_t*)qr.q16 + (int64_t)b * D + hd0 + tile * 16 + kg * 4) = o;
+            else *(u32x2*)((bf16_t*)qr.kc + (((int64_t)b * qr.H + head) * qr.Smax + pos) * 128 + pc) = o;
+        } else {
+            bf16_t* dst = (bf16_t*)qr.vtc + ((int64_t)b * qr.H + head) * 128 * qr.Smax + rv_vt_index(pc, pos);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r * 8] = f32_to_bf16(v[r]);
+        }
+    }
+}
+
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
 //      3 = fused q/k/v + RoPE epilogue                        4 = bf16 out, one tile per block
@@ -407,6 +458,20 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
     }
     const float* totl = ssq + MB * 512;
     if (wave >= RS_W) return;
+    if constexpr (ROPE) {
+        if (qr.row_pos && qr.G == 1 && !(RS_PROBE & 64)) {      // merged decode step: the finish written for it
+            f32x4 sv[PPW];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                if constexpr (S == 8) sv[i] = gemv_tree8(pl[i][0]);
+                else if constexpr (S == 4) sv[i] = (pl[i][0][0] + pl[i][0][1]) + (pl[i][0][2] + pl[i][0][3]);
+                else if constexpr (S == 2) sv[i] = pl[i][0][0] + pl[i][0][1];
+                else sv[i] = pl[i][0][0];
+            }
+            rows_qkv_finish<MB, PPW, PAIRS, WP>(sv, wave, cg, fr, kg, M, nrm, qr, totl);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int p = wave + RS_W * i;
@@ -668,6 +733,8 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
                 }
             }
         }
+        // (the q/k/v finish written for merged steps, rows_qkv_finish, is used by the one-item-per-workgroup kernel only: inside this item loop
+        //  its prefetch arrays cost the persistent instantiations 10 - 100 spilled registers, and no 7B launch with a RoPE epilogue is persistent)
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave + RS_W * i;
