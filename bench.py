@@ -194,7 +194,9 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     lg = torch.empty(R, s.vocab, dtype=torch.float32, device=dev)
     prev_slot, eng.slot = eng.slot, 170
     try:
-        ms = event_time_ms(lambda: eng.llm_decode_rows(hrow, pos, pool, smax, logits=lg), 12, warm=3)
+        # rows in groups of n_calls (the calls of one recursion) share the 32-position prompt prefix, as in the pipeline (serve.DecodePool.join)
+        share = (torch.tensor([(r_ // n_calls * n_calls) | (32 << 16) for r_ in range(R)], dtype=torch.int32, device=dev) if n_calls > 1 and R % n_calls == 0 else None)
+        ms = event_time_ms(lambda: eng.llm_decode_rows(hrow, pos, pool, smax, logits=lg, row_share=share), 12, warm=3)
     finally:
         eng.slot = prev_slot
     step_bytes = 6.607e9 * 2 + 2.0 * s.layers * (pos_at + 1) * s.hidden * 2 * R

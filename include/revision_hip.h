@@ -254,6 +254,15 @@ int rv_llm_prefill_pool_groups(rv_ctx* ctx, float* h, int32_t G, int32_t B, int3
                                const int32_t* kv_row0, int32_t Smax, float* logits, void* ws, size_t ws_bytes, void* stream);
 int rv_llm_decode_rows(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,
                        size_t ws_bytes, void* stream);
+/* rv_llm_decode_rows_shared: rv_llm_decode_rows + a hint about cache contents (round 4): row_share (device int32 [R], or NULL) holds, per
+ *   row r, sibling | len << 16: the first `len` cache positions of row r are BIT-IDENTICAL to those of row `sibling` (<= 143) - what the
+ *   shared-prefix prefill (rv_llm_prefill_pool with P0 > 0) leaves in the rows of one generate, whose prompts start with the same P0 tokens
+ *   (inference.py:36 repeats one prompt per batch row; the 7 calls of a stage-2 recursion share "system prompt + USER: <video>").  The decode
+ *   attention then reads the key blocks inside that prefix from the sibling's cache rows: the rows of one (generate, head) run on one XCD and hit
+ *   its L2 instead of fetching identical copies from HBM (15 % of the K / V bytes of a 140-row step).  The hint cannot change a result - the
+ *   bytes read are the same - only a wrong hint can; 0 (= row 0, length 0) means "nothing shared".  Smax <= 65535. */
+int rv_llm_decode_rows_shared(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, const int32_t* row_share, void* kv, int32_t Smax,
+                              float* logits, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- token selection + scores ----------------------------------------------------------- */
 /* HF warper chain temperature -> top-k -> top-p, inverse-CDF draw with caller uniforms (or argmax when

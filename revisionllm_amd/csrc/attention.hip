@@ -45,6 +45,16 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
 
     const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
     const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    // key blocks inside the prefix this row shares with a sibling row are read from the sibling's (bit-identical) cache rows: L2 hits
+    int share_len = 0;
+    int64_t share_k = 0, share_v = 0;       // element offsets from this row's bases to the sibling's
+    if (SPLIT && a.row_share) {
+        const int sv = a.row_share[b];
+        const int srow = sv & 0xffff;
+        share_len = sv >> 16;
+        share_k = (int64_t)(srow - kb_) * a.k_bs;
+        share_v = (int64_t)(srow - kb_) * a.vt_bs;
+    }
     const int krow = (fr >> 2) * 8 + (fr & 3);   // key of score-tile row fr within the 32-key block (+ 4 for tile 1)
     const uint8_t* pad = PAD ? a.key_pad + (int64_t)kb_ * a.Lk : nullptr;
 
@@ -59,16 +69,18 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         // issue every load of this key block up front (K rows and V^T rows are independent of the softmax), so the
         // block costs one memory round trip instead of two
         bf16x8 kf[2][NC];
+        const bool shared_blk = SPLIT && k0 + 32 <= share_len;      // (wave-uniform) the whole block lies inside the shared prefix
+        const int64_t sk = shared_blk ? share_k : 0, svo = shared_blk ? share_v : 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = min(k0 + krow + t * 4, Lk - 1);
-            const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
+            const bf16_t* kp = kbase + sk + (int64_t)key * a.k_rs;
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
         }
         bf16x8 vf[ND];
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + svo + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {

@@ -517,7 +517,7 @@ namespace {
 // is left holding the residual stream behind block l1 - 1 (rv_llm_layers).
 int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
                      size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr, int G = 1,
-                     const int* grow = nullptr, int l0 = 0, int l1 = -1) {
+                     const int* grow = nullptr, int l0 = 0, int l1 = -1, const int* row_share = nullptr) {
     RV_TRY(resolve_llm(c));
     const rv_config& g = c->cfg;
     if (G > 1) kv_row0 = grow[0];
@@ -661,6 +661,7 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                 AttnArgs a{w.q16 + r0 * qd, qd, (int64_t)S * qd, kc + co, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc + co, (int64_t)H * dh * Smax,
                            (int64_t)dh * Smax, Smax, w.a16 + r0 * od, od, (int64_t)S * od, nullptr, B, H, dh, S, row_pos ? Smax : pos0 + S, 1, pos0, 1, scale};
                 a.row_pos = row_pos;
+                a.row_share = row_pos ? row_share : nullptr;
                 a.out_packed = xp;
                 a.out_lo = olo;
                 a.q_lo = qlo;
@@ -815,4 +816,13 @@ extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t*
     RV_CHECK_ARG(R > 0 && R <= RV_ROWS_MAX, "rv_llm_decode_rows: 1 .. %d rows per step (got %d)", RV_ROWS_MAX, R);
     RV_CHECK_ARG(Smax % 32 == 0, "rv_llm_decode_rows: Smax=%d must be a multiple of 32", Smax);
     return llm_forward_impl(c, h, R, 1, 0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), R, 0, row_pos);
+}
+
+extern "C" int rv_llm_decode_rows_shared(rv_ctx* c, float* h, int32_t R, const int32_t* row_pos, const int32_t* row_share, void* kv, int32_t Smax,
+                                         float* logits, void* ws, size_t ws_bytes, void* stream) {
+    RV_CHECK_ARG(c && h && row_pos && kv && logits && ws, "rv_llm_decode_rows_shared: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(R > 0 && R <= RV_ROWS_MAX, "rv_llm_decode_rows_shared: 1 .. %d rows per step (got %d)", RV_ROWS_MAX, R);
+    RV_CHECK_ARG(Smax % 32 == 0 && Smax <= 65535, "rv_llm_decode_rows_shared: Smax=%d must be a multiple of 32 below 65536", Smax);
+    return llm_forward_impl(c, h, R, 1, 0, 0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), R, 0, row_pos, 1, nullptr, 0, -1, row_share);
 }

@@ -256,6 +256,11 @@ struct AttnArgs {
     int64_t out_lo = 0;
     // parity precision: != 0 -> a query row carries its LOW half q_lo elements behind the high half; the scores are K.(Qhi + Qlo) (dh = 128 only)
     int64_t q_lo = 0;
+    // merged decode steps (row_pos): row_share[b] = sibling | len << 16 - the first `len` cache positions of batch row b are bit-identical to
+    // those of row `sibling` (the shared prompt prefix of a generate's rows, written to every row's cache by the shared-prefix prefill), so
+    // the key blocks that lie inside them are READ from the sibling's cache: the rows of one (generate, head) run on one XCD and then hit
+    // its L2 instead of fetching 7 identical copies from HBM.  Results cannot change (same bytes); nullptr: every row reads its own cache.
+    const int* row_share = nullptr;
 };
 int k_attention(const AttnArgs& a, hipStream_t st);
 // G copies of the problem pair in one launch (batched prefills): copy g reads q / writes out at + q_off[g] elements, its K / V^T at

@@ -386,13 +386,20 @@ class Engine:
         self._persist_end()
         return logits
 
-    def llm_decode_rows(self, h, row_pos, kv, Smax, logits=None):
-        """One merged decode step: h f32 [R, D] (clobbered), row_pos int32 [R] on the device (< 0: inactive) -> logits f32 [R, V]."""
+    def llm_decode_rows(self, h, row_pos, kv, Smax, logits=None, row_share=None):
+        """One merged decode step: h f32 [R, D] (clobbered), row_pos int32 [R] on the device (< 0: inactive) -> logits f32 [R, V].
+        ``row_share`` int32 [R] on the device (optional): sibling | len << 16 per row - its first ``len`` cache positions are bit-identical to row
+        ``sibling``'s (the shared prompt prefix of a generate's rows); the decode attention then reads them from the sibling (L2 hits)."""
         R = h.shape[0]
         assert h.dtype == torch.float32 and h.is_contiguous() and row_pos.dtype == torch.int32 and row_pos.is_cuda
         if logits is None:
             logits = torch.empty(R, self.shape.vocab, dtype=torch.float32, device=self.device)
         ws = self._workspace("llm", self.lib.rv_llm_ws_bytes(self._ctx, R, 1))
+        if row_share is not None:
+            assert row_share.dtype == torch.int32 and row_share.is_cuda and row_share.numel() == R
+            hip.check(self.lib.rv_llm_decode_rows_shared(self._ctx, hip.ptr(h), R, hip.ptr(row_pos), hip.ptr(row_share), hip.ptr(kv), Smax, hip.ptr(logits),
+                                                         hip.ptr(ws), ws.numel(), hip.stream()), "rv_llm_decode_rows_shared")
+            return logits
         hip.check(self.lib.rv_llm_decode_rows(self._ctx, hip.ptr(h), R, hip.ptr(row_pos), hip.ptr(kv), Smax, hip.ptr(logits), hip.ptr(ws), ws.numel(),
                                               hip.stream()), "rv_llm_decode_rows")
         return logits

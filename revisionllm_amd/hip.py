@@ -72,6 +72,7 @@ SIGNATURES = {
     "rv_llm_prefill_pool": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "rv_llm_prefill_pool_groups": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_decode_rows": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p, _sz, _p]),
+    "rv_llm_decode_rows_shared": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i32, _p, _p, _sz, _p]),
     "rv_sample": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),
     "rv_entropy_stats": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "rv_topk_cosine": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _p, _p]),

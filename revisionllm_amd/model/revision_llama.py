@@ -374,7 +374,7 @@ class ReVisionLlamaForCausalLM:
                 server.prefill_tail = ready
         yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
         server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
-                    uniforms=uniforms if do_sample else None, forced=forced_tokens)
+                    uniforms=uniforms if do_sample else None, forced=forced_tokens, shared_prefix=p0)
         from .. import sched
         while not job.finished:
             yield sched.RETRY           # the scheduler pumps the server's merged steps

@@ -65,6 +65,8 @@ class DecodePool:
         self.entr_out = torch.zeros(rows, gmax + 1, dtype=torch.float32, device=dev)
         self.uni = torch.full((rows,), 0.5, dtype=torch.float32, device=dev)
         self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)      # EOS bookkeeping: 0 once a row has emitted the EOS id
+        self.share = torch.zeros(rows, dtype=torch.int32, device=dev)         # per row: sibling | shared prefix length << 16 (engine.llm_decode_rows)
+        self.share_prefix = True                                              # (measurement knob: False = every row reads its own prefix copy)
         self.stream = torch.cuda.Stream(dev)
         self.free = [(0, rows, ())]              # (first row, count, events after which the rows may be overwritten)
         self.jobs = []                           # joined, not finished
@@ -133,7 +135,7 @@ class DecodePool:
         self._release(job, tuple(e for _, e in evs))
 
     # ---- joining -------------------------------------------------------------------------------------------------------------
-    def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None):
+    def join(self, job, S, first_logits, ready_event, steps, sampling, uniforms=None, forced=None, shared_prefix=0):
         """The job's prefill has been enqueued (``ready_event`` recorded after it on the prefill's stream): hand its rows to the
         merged steps.  ``first_logits`` [B, V]: the prefill's last-position logits; ``uniforms`` / ``forced`` [steps, B] device tensors."""
         if self.sampling is None or not self.jobs:
@@ -148,6 +150,9 @@ class DecodePool:
             self.pos[r] = S
             self.stepidx[r] = 0
             self.unfinished[r] = 1
+            # the rows of this generate were prefilled with a shared prompt prefix of `shared_prefix` positions (bit-identical K / V in all of
+            # them): their decode attention reads it from the generate's first row
+            self.share[r] = (job.r0 | (int(shared_prefix) << 16)) if (shared_prefix > 0 and job.B > 1 and self.Smax <= 65535) else 0
         first_logits.record_stream(self.stream)
         job.joined = True
         self.pending -= 1
@@ -275,7 +280,7 @@ class DecodePool:
             self.jobs = still
             if self.jobs:
                 h = eng.splice_embed(tokens[:, None], None).view(self.R, -1)
-                eng.llm_decode_rows(h, self.pos, self.kv, self.Smax, logits=self.logits)
+                eng.llm_decode_rows(h, self.pos, self.kv, self.Smax, logits=self.logits, row_share=self.share if self.share_prefix else None)
                 self.pos += (self.pos >= 0).int()
             ev = torch.cuda.Event()
             ev.record(self.stream)

@@ -25,17 +25,19 @@ wbytes = sum(t.numel() * t.element_size() for t in eng._llm_tensors()) if hasatt
 for R in rows:
     kv, sm = eng.new_kv_pool(R, Smax)
     pos = torch.full((R,), 180, dtype=torch.int32, device="cuda:0")
+    # --share: rows in groups of 7 (the calls of one recursion) share a 32-position prompt prefix, read from the group's first row
+    share = torch.tensor([(r // 7 * 7) | (32 << 16) for r in range(R)], dtype=torch.int32, device="cuda:0") if "--share" in sys.argv else None
     h0 = torch.randn(R, D, device="cuda:0") * 0.02
     logits = torch.empty(R, V, device="cuda:0")
     for _ in range(3):
-        eng.llm_decode_rows(h0.clone(), pos, kv, sm, logits=logits)
+        eng.llm_decode_rows(h0.clone(), pos, kv, sm, logits=logits, row_share=share)
     torch.cuda.synchronize()
     n = 20
     hs = [h0.clone() for _ in range(n)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(n):
-        eng.llm_decode_rows(hs[i], pos, kv, sm, logits=logits)
+        eng.llm_decode_rows(hs[i], pos, kv, sm, logits=logits, row_share=share)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
