@@ -64,6 +64,7 @@ class DecodePool:
         self.ent_out = torch.zeros(rows, gmax + 1, dtype=torch.float32, device=dev)
         self.entr_out = torch.zeros(rows, gmax + 1, dtype=torch.float32, device=dev)
         self.uni = torch.full((rows,), 0.5, dtype=torch.float32, device=dev)
+        self.uni_all = torch.full((gmax + 1, rows), 0.5, dtype=torch.float32, device=dev)   # every joined generate's uniforms [step, row]: ONE gather per merged step
         self.unfinished = torch.ones(rows, dtype=torch.int32, device=dev)      # EOS bookkeeping: 0 once a row has emitted the EOS id
         self.share = torch.zeros(rows, dtype=torch.int32, device=dev)         # per row: sibling | shared prefix length << 16 (engine.llm_decode_rows)
         self.share_prefix = True                                              # (measurement knob: False = every row reads its own prefix copy)
@@ -150,6 +151,8 @@ class DecodePool:
             self.pos[r] = S
             self.stepidx[r] = 0
             self.unfinished[r] = 1
+            if uniforms is not None:        # one copy per generate instead of one per generate AND step (twenty tiny launches in front of every merged step)
+                self.uni_all[:min(steps, self.G), r] = uniforms[:min(steps, self.G)].to(torch.float32)
             # the rows of this generate were prefilled with a shared prompt prefix of `shared_prefix` positions (bit-identical K / V in all of
             # them): their decode attention reads it from the generate's first row
             self.share[r] = (job.r0 | (int(shared_prefix) << 16)) if (shared_prefix > 0 and job.B > 1 and self.Smax <= 65535) else 0
@@ -239,9 +242,8 @@ class DecodePool:
                 if not self.jobs:
                     eng.slot = prev_slot
                     return
-            for job in self.jobs:
-                if do_sample and job.uniforms is not None:
-                    self.uni[job.r0:job.r0 + job.B].copy_(job.uniforms[job.step])
+            if do_sample:                   # row r draws with uniform [its own step index, r]
+                self.uni = self.uni_all.gather(0, self.stepidx.clamp(max=self.G)[None])[0]
             o = ops.sample(self.logits, self.uni if do_sample else None, do_sample, temperature, top_k, top_p, ctx=eng)
             tokens = o["tokens"]
             for job in self.jobs:
