@@ -252,6 +252,15 @@ int rv_llm_prefill_pool(rv_ctx* ctx, float* h, int32_t B, int32_t P0, int32_t S,
  *   GEMMs (the stream-K split points depend on the row count). */
 int rv_llm_prefill_pool_groups(rv_ctx* ctx, float* h, int32_t G, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows,
                                const int32_t* kv_row0, int32_t Smax, float* logits, void* ws, size_t ws_bytes, void* stream);
+/* rv_llm_prefill_pool_groups_ragged (round 4): rv_llm_prefill_pool_groups for sequences of DIFFERENT lengths, right-padded to S rows each (the 9 calls
+ *   of a 33-window stage-2 recursion present 32 x 8 and 33 x 1 video tokens: one generate instead of two).  Under causal attention a valid row never sees
+ *   a later (pad) row, so the only thing that changes is WHICH row of a sequence feeds the lm_head: last_rows (DEVICE int32 [G * B]) holds, per
+ *   sequence, the index into h of its last valid row; logits row i comes from it.  The pad rows' K / V land at cache positions the first decode steps
+ *   overwrite before they are read (rv_llm_decode_rows appends at row_pos[r] = the sequence's own length, then attends to 0 .. row_pos[r]).
+ *   G = 1 is the single ragged prefill.  Everything else as rv_llm_prefill_pool_groups. */
+int rv_llm_prefill_pool_groups_ragged(rv_ctx* ctx, float* h, int32_t G, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows,
+                                      const int32_t* kv_row0, int32_t Smax, const int32_t* last_rows, float* logits, void* ws, size_t ws_bytes,
+                                      void* stream);
 int rv_llm_decode_rows(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,
                        size_t ws_bytes, void* stream);
 /* rv_llm_decode_rows_shared: rv_llm_decode_rows + a hint about cache contents (round 4): row_share (device int32 [R], or NULL) holds, per

@@ -517,7 +517,7 @@ namespace {
 // is left holding the residual stream behind block l1 - 1 (rv_llm_layers).
 int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* kv, int Smax, float* logits, void* ws,
                      size_t ws_bytes, hipStream_t st, int kv_rows = 0, int kv_row0 = 0, const int* row_pos = nullptr, int G = 1,
-                     const int* grow = nullptr, int l0 = 0, int l1 = -1, const int* row_share = nullptr) {
+                     const int* grow = nullptr, int l0 = 0, int l1 = -1, const int* row_share = nullptr, const int* last_rows = nullptr) {
     RV_TRY(resolve_llm(c));
     const rv_config& g = c->cfg;
     if (G > 1) kv_row0 = grow[0];
@@ -729,8 +729,11 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             hn.arrive = w.arrive;
             return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, 2 * D, w.sk, w.sk_bytes, st, &hn);
         }
-        for (int gi = 0; gi < G; ++gi)
-            RV_TRY(k_rmsnorm_split(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * 2 * D, B, (int)D, g.rms_eps, st));
+        if (last_rows)      // right-padded (ragged) sequences: row i of the head's input = input row last_rows[i], the last VALID position of sequence i
+            RV_TRY(k_rmsnorm_split(h, D, c->final_norm, w.xl16, (int64_t)G * B, (int)D, g.rms_eps, st, 0, last_rows));
+        else
+            for (int gi = 0; gi < G; ++gi)
+                RV_TRY(k_rmsnorm_split(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * 2 * D, B, (int)D, g.rms_eps, st));
         return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, (int64_t)G * B, V, 2 * D, w.sk, w.sk_bytes, st);
     }
     if (par) {
@@ -746,8 +749,11 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         return rv_gemm_impl(w.xn16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, B, V, D, w.sk, w.sk_bytes, st,
                             &consume);
     // final norm + lm_head on the last position of every sequence only
-    for (int gi = 0; gi < G; ++gi)
-        RV_TRY(k_rmsnorm(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * D, B, (int)D, g.rms_eps, st));
+    if (last_rows)
+        RV_TRY(k_rmsnorm(h, D, c->final_norm, w.xl16, (int64_t)G * B, (int)D, g.rms_eps, st, 0, last_rows));
+    else
+        for (int gi = 0; gi < G; ++gi)
+            RV_TRY(k_rmsnorm(h + (gi * Mg + P0 + S - 1) * D, (int64_t)S * D, c->final_norm, w.xl16 + (int64_t)gi * B * D, B, (int)D, g.rms_eps, st));
     return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, (int64_t)G * B, V, D, w.sk, w.sk_bytes, st);
 }
 }  // namespace
@@ -807,6 +813,19 @@ extern "C" int rv_llm_prefill_pool_groups(rv_ctx* c, float* h, int32_t G, int32_
                      kv_row0[gi] + B, kv_rows);
     RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_pool_groups: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
     return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), kv_rows, kv_row0[0], nullptr, G, kv_row0);
+}
+
+extern "C" int rv_llm_prefill_pool_groups_ragged(rv_ctx* c, float* h, int32_t G, int32_t B, int32_t P0, int32_t S, void* kv, int32_t kv_rows,
+                                                 const int32_t* kv_row0, int32_t Smax, const int32_t* last_rows, float* logits, void* ws, size_t ws_bytes,
+                                                 void* stream) {
+    RV_CHECK_ARG(c && h && kv && logits && ws && kv_row0 && last_rows, "rv_llm_prefill_pool_groups_ragged: null argument");
+    RvOptScope scope(&c->opt);
+    RV_CHECK_ARG(G >= 1 && G <= RV_MAX_PREFILL_GROUPS && B > 0 && S > 0 && P0 >= 0, "rv_llm_prefill_pool_groups_ragged: 1 .. %d groups, non-empty", RV_MAX_PREFILL_GROUPS);
+    for (int gi = 0; gi < G; ++gi)
+        RV_CHECK_ARG(kv_row0[gi] >= 0 && kv_row0[gi] + B <= kv_rows, "rv_llm_prefill_pool_groups_ragged: rows %d..%d outside a pool of %d rows", kv_row0[gi],
+                     kv_row0[gi] + B, kv_rows);
+    RV_CHECK_ARG(Smax % 32 == 0 && P0 + S <= Smax, "rv_llm_prefill_pool_groups_ragged: Smax=%d must be a multiple of 32 and >= P0+S=%d", Smax, P0 + S);
+    return llm_forward_impl(c, h, B, S, P0, P0, kv, Smax, logits, ws, ws_bytes, as_stream(stream), kv_rows, kv_row0[0], nullptr, G, kv_row0, 0, -1, nullptr, last_rows);
 }
 
 extern "C" int rv_llm_decode_rows(rv_ctx* c, float* h, int32_t R, const int32_t* row_pos, void* kv, int32_t Smax, float* logits, void* ws,

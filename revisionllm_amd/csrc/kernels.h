@@ -220,9 +220,10 @@ int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* 
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
 int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st,
-              int out_packed = 0);   // out_packed: 0, or the row blocks (2 / 4 / 8) of the fragment-packed decode layout y16 is written in (rv_xp_index)
+              int out_packed = 0, const int* row_idx = nullptr);   // row_idx (device): output row i normalises input row row_idx[i] (gather)   // out_packed: 0, or the row blocks (2 / 4 / 8) of the fragment-packed decode layout y16 is written in (rv_xp_index)
 // parity precision (RvOpts::precision = 1): split-bf16 operands y [rows, 2 * d] = [hi | lo], hi = bf16(v), lo = bf16(v - hi)
-int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed = 0);   // out_packed: row blocks of the fragment-packed decode layout (K = 2 * d)
+int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed = 0,
+                    const int* row_idx = nullptr);   // out_packed: row blocks of the fragment-packed decode layout (K = 2 * d)
 int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hipStream_t st);   // f32 [rows, n] -> bf16 [rows, 2 * n]
 // f32 q/k/v [M, 3D] (row stride ld; q / k rows pair-interleaved like the fused epilogue's) -> RoPE, Q as the split pair (qr.q_ld, qr.q_lo), K / V^T cache append
 int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t M, int64_t D, hipStream_t st);

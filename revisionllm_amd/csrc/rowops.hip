@@ -56,11 +56,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
                                                       const float* __restrict__ w, bf16_t* __restrict__ y, int64_t rows,
-                                                      int d, float eps, int packed) {
+                                                      int d, float eps, int packed, const int* __restrict__ row_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * x_row_stride;
+    const float* xr = x + (row_idx ? (int64_t)row_idx[row] : row) * x_row_stride;     // (row_idx: output row `row` normalises input row row_idx[row])
     if constexpr (NV > 0) {
         f32x4 v[NV], ww[NV];
 #pragma unroll
@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // ---- parity precision: RMSNorm whose output is the split pair [hi | lo] (row stride 2 * d), one wave per row, two passes;
 // and the plain split of an f32 matrix (the gated MLP activation computed in f32) ----
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* __restrict__ x, int64_t x_row_stride, const float* __restrict__ w,
-                                                            bf16_t* __restrict__ y, int64_t rows, int d, float eps, int packed) {
+                                                            bf16_t* __restrict__ y, int64_t rows, int d, float eps, int packed,
+                                                            const int* __restrict__ row_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * x_row_stride;
+    const float* xr = x + (row_idx ? (int64_t)row_idx[row] : row) * x_row_stride;
     float s = 0.f;
     for (int c = lane * 4; c < d; c += 256) {
         const f32x4 v = *(const f32x4*)(xr + c);
@@ -375,26 +376,26 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
     return RV_OK;
 }
 
-int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed) {
+int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed, const int* row_idx) {
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm: bad arguments");
     RV_CHECK_ARG(!out_packed || (rows <= 16 * out_packed && d % 32 == 0), "rmsnorm: the packed decode layout holds <= 16 rows per block");
     if (rows == 0) return RV_OK;
     const dim3 grid((unsigned)cdiv(rows, 4));
     if (d == 4096)
-        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
     else if (d == 512)
-        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
     else
-        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
+        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
     RV_CHECK_LAUNCH("rmsnorm");
     return RV_OK;
 }
 
-int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed) {
+int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* y16, int64_t rows, int d, float eps, hipStream_t st, int out_packed, const int* row_idx) {
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm_split: bad arguments");
     RV_CHECK_ARG(!out_packed || (rows <= 16 * out_packed && d % 32 == 0), "rmsnorm_split: the packed decode layout holds <= 16 rows per block");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed);
+    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
     RV_CHECK_LAUNCH("rmsnorm_split");
     return RV_OK;
 }

@@ -370,9 +370,10 @@ class Engine:
         self._persist_end()
         return logits
 
-    def llm_prefill_pool_groups(self, h, G, B, P0, kv, kv_rows, row0s, Smax, logits=None):
+    def llm_prefill_pool_groups(self, h, G, B, P0, kv, kv_rows, row0s, Smax, logits=None, last_rows=None):
         """G prefills of identical geometry in one pass: h f32 [G * (P0 + B*S), D], block g's cache rows start at row0s[g].
-        -> logits f32 [G * B, V] (group-major)."""
+        -> logits f32 [G * B, V] (group-major).  ``last_rows`` (device int32 [G * B]): the sequences are right-padded to S rows and the
+        head reads row last_rows[i] of h for sequence i (rv_llm_prefill_pool_groups_ragged)."""
         import ctypes
         assert h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] % G == 0 and (h.shape[0] // G - P0) % B == 0
         S = (h.shape[0] // G - P0) // B
@@ -381,8 +382,13 @@ class Engine:
         ws = self._workspace("llm", self.lib.rv_llm_ws_bytes(self._ctx, h.shape[0], 1))
         rows = (ctypes.c_int32 * G)(*[int(r) for r in row0s])
         self._persist_begin()
-        hip.check(self.lib.rv_llm_prefill_pool_groups(self._ctx, hip.ptr(h), G, B, P0, S, hip.ptr(kv), kv_rows, rows, Smax, hip.ptr(logits), hip.ptr(ws),
-                                                      ws.numel(), hip.stream()), "rv_llm_prefill_pool_groups")
+        if last_rows is not None:
+            assert last_rows.dtype == torch.int32 and last_rows.is_cuda and last_rows.numel() == G * B
+            hip.check(self.lib.rv_llm_prefill_pool_groups_ragged(self._ctx, hip.ptr(h), G, B, P0, S, hip.ptr(kv), kv_rows, rows, Smax, hip.ptr(last_rows),
+                                                                 hip.ptr(logits), hip.ptr(ws), ws.numel(), hip.stream()), "rv_llm_prefill_pool_groups_ragged")
+        else:
+            hip.check(self.lib.rv_llm_prefill_pool_groups(self._ctx, hip.ptr(h), G, B, P0, S, hip.ptr(kv), kv_rows, rows, Smax, hip.ptr(logits), hip.ptr(ws),
+                                                          ws.numel(), hip.stream()), "rv_llm_prefill_pool_groups")
         self._persist_end()
         return logits
 

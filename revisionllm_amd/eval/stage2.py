@@ -194,13 +194,19 @@ def launch_calls_steps(model, tokenizer, query, rows, calls, uniforms=None, max_
             ids_of[q] = _prompt_ids(q, tokenizer, 1)[0]
         return ids_of[q]
 
+    # Calls whose prompts have the same length run as one batched generate.  Through a DecodeServer with batched prefills that includes calls that
+    # present DIFFERENT numbers of video rows (W = 33, batch 33: 8 calls of 32 video tokens and one of 33): a ragged generate of right-padded
+    # sequences (model.generate_steps) - one prefill pass and one gang of rows instead of two of each.
+    ragged = server is not None and getattr(server, "prefill_batch", 1) > 1 and getattr(server, "ragged", True)
     groups = {}
     for c in calls:
-        groups.setdefault((rows[c].shape[0], prompt_ids(c).shape[1]), []).append(c)
+        groups.setdefault((None if ragged else rows[c].shape[0], prompt_ids(c).shape[1]), []).append(c)
     order, toks, ents = [], [], []
-    for (n_rows, _), cs in groups.items():
+    for (_, _), cs in groups.items():
         for c0 in range(0, len(cs), max_calls_per_generate):
             sel = cs[c0:c0 + max_calls_per_generate]
+            counts = [int(rows[c].shape[0]) for c in sel]
+            n_rows = counts[0] if len(set(counts)) == 1 else counts
             ids = torch.cat([prompt_ids(c) for c in sel], 0)
             u = None if uniforms is None else uniforms[:, sel]
             forced = None if forced_tokens is None else forced_tokens[:, sel]       # [G, calls]: teacher forcing (parity tests)

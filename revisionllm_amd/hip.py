@@ -71,6 +71,7 @@ SIGNATURES = {
     "rv_llm_prefill_shared": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_prefill_pool": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "rv_llm_prefill_pool_groups": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p, _sz, _p]),
+    "rv_llm_prefill_pool_groups_ragged": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p, _p, _sz, _p]),
     "rv_llm_decode_rows": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_decode_rows_shared": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i32, _p, _p, _sz, _p]),
     "rv_sample": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),

@@ -217,6 +217,22 @@ class ReVisionLlamaForCausalLM:
         return y.reshape(-1, self.shape.hidden), images.shape[1] + 1
 
     @staticmethod
+    def build_row_map_ragged(input_ids, rows_per_sample, pad_id=0):
+        """``build_row_map`` for samples with DIFFERENT numbers of video rows (``rows_per_sample``: one count per sample; the video rows of
+        sample b follow those of sample b - 1): rows are right-padded with ``pad_id`` to the longest one.  -> (int32 [B, S], lengths)."""
+        out, lens, off = [], [], 0
+        for b, row in enumerate(input_ids.cpu().tolist()):
+            if MEMORY_TOKEN_INDEX in row or row.count(IMAGE_TOKEN_INDEX) != 1:
+                raise NotImplementedError("ragged generates take exactly one <video> per sample and no <memory>")
+            n = int(rows_per_sample[b])
+            i = row.index(IMAGE_TOKEN_INDEX)
+            out.append(row[:i] + [-(off + k + 1) for k in range(n)] + row[i + 1:])
+            off += n
+            lens.append(len(out[-1]))
+        S = max(lens)
+        return torch.tensor([r + [pad_id] * (S - len(r)) for r in out], dtype=torch.int32), lens
+
+    @staticmethod
     def build_row_map(input_ids, rows_per_sample, attention_mask=None):
         """Splice plan (vtimellm_arch.py:149-238): int32 [B,S]; >= 0 token id, < 0 -> video row -(v+1).
         Sample b consumes video rows [b*rows_per_sample, (b+1)*rows_per_sample) at its -200 slot."""
@@ -305,7 +321,19 @@ class ReVisionLlamaForCausalLM:
             uniforms = ops.h2d(uniforms, dev, torch.float32)
         if forced_tokens is not None:
             forced_tokens = ops.h2d(forced_tokens, dev, torch.long)
-        row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
+        lens = None
+        if isinstance(rows_per_sample, (list, tuple)) and len(set(rows_per_sample)) > 1:
+            # Samples with different numbers of video rows (the 9 calls of a 33-window recursion: 8 x 32 and 1 x 33): one generate of
+            # right-padded sequences - under causal attention a valid position never sees a later (pad) one, so every row's tokens are what
+            # its own generate would produce.  Only through a DecodeServer (rows decode at their own positions there anyway).
+            if server is None or attention_mask is not None or output_scores or output_logits or self.after_prefill is not None:
+                raise NotImplementedError("ragged generates (different numbers of video rows per sample) run through a serve.DecodeServer only, "
+                                          "without output_scores / output_logits / attention_mask")
+            row_map, lens = self.build_row_map_ragged(input_ids, rows_per_sample, pad if pad is not None else 0)
+        else:
+            if isinstance(rows_per_sample, (list, tuple)):
+                rows_per_sample = int(rows_per_sample[0]) if len(rows_per_sample) else 0
+            row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
         B, S = row_map.shape
         P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
         job = None
@@ -319,10 +347,12 @@ class ReVisionLlamaForCausalLM:
         if job is not None:
             try:
                 return (yield from self._generate_in_pool(server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k,
-                                                          top_p, max_new_tokens, uniforms, forced_tokens, return_dict_in_generate))
+                                                          top_p, max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens))
             finally:
                 if not job.finished:        # an exception here or in a task this one was pumped from, or the task was cancelled
                     server.abandon(job)
+        if lens is not None:
+            raise NotImplementedError("ragged generate: the DecodeServer had no room for it (pool rows / Smax / gmax too small)")
         # A generate that decodes alone owns its engine slot's KV cache and workspace from its prefill to its last step.  Under a cooperative
         # scheduler (it yields at the EOS flag polls) a second generate started on the SAME slot meanwhile would be handed the same recycled
         # cache and overwrite it: refuse loudly - every call in flight needs its own slot (sched.Task(..., slot=i); engine.slot).
@@ -339,7 +369,7 @@ class ReVisionLlamaForCausalLM:
             eng.slots_in_flight.discard(slot)
 
     def _generate_in_pool(self, server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
-                          max_new_tokens, uniforms, forced_tokens, return_dict_in_generate):
+                          max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens=None):
         """The merged-decode path of ``generate_steps``: prefill into the server's pool, its merged steps do the rest."""
         pool = job.pool
         for ev in job.free_events:
@@ -354,8 +384,10 @@ class ReVisionLlamaForCausalLM:
             h, p0 = eng.splice_embed(flat, video_rows)[0], P0
         else:
             h, p0 = eng.splice_embed(row_map, video_rows).view(B * S, -1), 0
+        if lens is not None and not batched:
+            raise NotImplementedError("ragged generates need a DecodeServer with prefill_batch > 1 (its prefill passes carry the per-sequence last rows)")
         if batched:      # the server batches the waiting prefills of identical geometry into one pass (its own stream, FIFO)
-            ticket = server.submit_prefill(job, h, B, p0)
+            ticket = server.submit_prefill(job, h, B, p0, lens)
             from .. import sched
             while ticket.ready is None:
                 yield sched.RETRY
@@ -373,7 +405,8 @@ class ReVisionLlamaForCausalLM:
             if getattr(server, "fifo_prefill", False):
                 server.prefill_tail = ready
         yield ready                     # join only once the prefill has COMPLETED: the decode stream never waits for a prefill
-        server.join(job, S, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
+        start = S if lens is None else [int(n) for n in lens]      # (ragged: every row decodes from its own length; the server uploads it on ITS stream)
+        server.join(job, start, first, ready, max_new_tokens, (bool(do_sample), float(temperature), int(top_k), float(top_p if top_p is not None else 1.0)),
                     uniforms=uniforms if do_sample else None, forced=forced_tokens, shared_prefix=p0)
         from .. import sched
         while not job.finished:

@@ -148,7 +148,8 @@ class DecodePool:
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready_event)
             self.logits[r].copy_(first_logits)
-            self.pos[r] = S
+            # (a ragged generate: every row starts at its own length - uploaded HERE, on the decode stream the merged steps run on)
+            self.pos[r] = S if not isinstance(S, (list, tuple)) else ops.h2d(torch.tensor(S, dtype=torch.int32), self.eng.device)
             self.stepidx[r] = 0
             self.unfinished[r] = 1
             if uniforms is not None:        # one copy per generate instead of one per generate AND step (twenty tiny launches in front of every merged step)
@@ -294,13 +295,14 @@ class PrefillTicket:
     """One generate's prefill handed to the server (``DecodeServer.submit_prefill``): ``ready`` (event) / ``first`` (its last-position
     logits [B, V]) are set once the batch it rides in has been enqueued."""
 
-    def __init__(self, job, h, B, P0, event):
+    def __init__(self, job, h, B, P0, event, lens=None):
         self.job, self.h, self.B, self.P0, self.event = job, h, B, P0, event
+        self.lens = tuple(int(n) for n in lens) if lens is not None else None     # ragged generate: valid length of every (right-padded) sequence
         self.ready = self.first = None
 
     @property
     def key(self):
-        return (id(self.job.pool), self.B, self.P0, self.h.shape[0])
+        return (id(self.job.pool), self.B, self.P0, self.h.shape[0], self.lens)
 
 
 class DecodeServer:
@@ -393,11 +395,12 @@ class DecodeServer:
         job.pool.abandon(job, extra_streams=(self.pf_stream,) if self.pf_stream is not None else ())
 
     # ---- batched prefills ------------------------------------------------------------------------------------------------------
-    def submit_prefill(self, job, h, B, P0):
-        """h f32 [P0 + B * S, D] (written on the caller's current stream) -> ticket; poll ``ticket.ready``."""
+    def submit_prefill(self, job, h, B, P0, lens=None):
+        """h f32 [P0 + B * S, D] (written on the caller's current stream) -> ticket; poll ``ticket.ready``.  ``lens``: a ragged generate - the
+        sequences are right-padded to S positions, sequence b is ``lens[b]`` positions long (prefix included)."""
         ev = torch.cuda.Event()
         ev.record()
-        t = PrefillTicket(job, h, B, P0, ev)
+        t = PrefillTicket(job, h, B, P0, ev, lens)
         self.pf_queue.append(t)
         return t
 
@@ -424,7 +427,13 @@ class DecodeServer:
             for t in batch:
                 self.pf_stream.wait_event(t.event)
                 t.h.record_stream(self.pf_stream)
-            if n == 1:
+            if lead.lens is not None:     # right-padded sequences: the head reads every sequence's last VALID row
+                Mg = lead.h.shape[0]
+                S_ = (Mg - lead.P0) // lead.B
+                last = [g * Mg + lead.P0 + b * S_ + (lead.lens[b] - lead.P0 - 1) for g in range(n) for b in range(lead.B)]
+                logits = eng.llm_prefill_pool_groups(torch.cat([t.h for t in batch]) if n > 1 else lead.h, n, lead.B, lead.P0, pool.kv, pool.R,
+                                                     [t.job.r0 for t in batch], pool.Smax, last_rows=ops.h2d(torch.tensor(last, dtype=torch.int32), eng.device))
+            elif n == 1:
                 logits = eng.llm_prefill_pool(lead.h, lead.B, lead.P0, pool.kv, pool.R, lead.job.r0, pool.Smax)
             else:
                 logits = eng.llm_prefill_pool_groups(torch.cat([t.h for t in batch]), n, lead.B, lead.P0, pool.kv, pool.R,

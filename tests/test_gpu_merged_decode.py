@@ -244,6 +244,53 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     assert not server.jobs and sum(n for _, n, _ in server.free) == 32 * pools                     # every row was given back
 
 
+def test_ragged_generate_of_a_33_window_recursion_equals_the_two_generate_form():
+    """A 33-window recursion at batch 33 has 9 calls: 8 present 32 video tokens, one 33.  Through a DecodeServer with batched prefills they now
+    run as ONE generate of right-padded sequences (``rv_llm_prefill_pool_groups_ragged``: the head reads every sequence's last VALID row; every
+    row then decodes from its own length) instead of two generates with two prefill passes.  Records of 4 recursions in flight: the ragged form
+    against the two-generate form (``server.ragged = False``) and against the sequential classic loop - answers equal, entropies to 1e-5 (the
+    prefill GEMMs see other row counts), and the ragged run really used one ticket per recursion."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    tok = synth.FakeTokenizer(vocab=synth.TINY.vocab)
+    st = parallel.HipStages(m, tok)
+    W, batch, n = 33, 33, 4
+    plan = stage2.plan_groups(W, batch)
+    assert len(plan) == 9
+    feat = feats("rg.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
+    qfs = [feats(f"rg.q{i}", (5 + i % 3, 768), bf16=True).to(torch.bfloat16).cuda() for i in range(n)]
+    qc = feats("rg.qc", (768,)).cuda()
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(2), W=W)
+    unis = [torch.rand(6, len(plan), generator=torch.Generator().manual_seed(20 + i)) for i in range(n)]
+    kw = dict(batch=batch, perms=[perms], max_new_tokens=6)
+    seq = [parallel.run_queries_sharded(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], uniforms=unis[i], **kw)[0] for i in range(n)]
+
+    def pipeline(ragged):
+        server = serve.DecodeServer(m, rows=27, smax=160, gmax=16, pools=2, gang=True, prefill_batch=4)      # (<= 32 rows: the tiny model's K = 512 is below the wide kernel's)
+        server.ragged = ragged
+        st.server = server
+        hs = [torch.cuda.Stream("cuda:0") for _ in range(n)]
+        torch.cuda.synchronize()
+        inter = sched.Interleaver(servers=[server])
+        tasks = [inter.add(sched.Task(lambda t, i=i: parallel.launch_queries_sharded_steps(st, tok, feat, W, [(qfs[i], qc, f"query {i}")], uniforms=unis[i],
+                                                                                           turn=t, **kw), hs[i], m.engine, i)) for i in range(n)]
+        recs = [parallel.collect_queries(inter.finish(t))[0] for t in tasks]
+        m.engine.slot = 0
+        st.server = None
+        assert not server.jobs and sum(k for _, k, _ in server.free) == 27 * 2
+        return recs, server
+    rag, sv_r = pipeline(True)
+    two, sv_t = pipeline(False)
+    assert sv_r.pf_tickets == n and sv_t.pf_tickets == 2 * n                     # one generate per recursion instead of two
+    for a, b, c in zip(seq, rag, two):
+        assert a["answers"] == b["answers"] == c["answers"]
+        assert a["starts"] == b["starts"] and a["hierarchy_zooms"] == b["hierarchy_zooms"] and a["score_cos"] == b["score_cos"]
+        for k in ("max_entropy", "mean_entropy"):
+            assert rel_err(b[k], a[k]) < 1e-5 and rel_err(c[k], a[k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("pools", [1, 2])
 def test_decode_server_with_eos_equals_classic_loop(pools):
     """EOS in the merged path (``pools`` = 2: under the gang policy, the partly filled pool sealed when the scheduler runs dry): generates whose rows emit EOS at different steps (teacher-forced) leave the pool early; sequences and
