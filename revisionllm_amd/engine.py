@@ -228,16 +228,41 @@ class Engine:
             self._ws[key] = t
         return t
 
-    def check_handoff_status(self):
+    def _status_words(self):
+        return [(key, ws[8188:8192].view(torch.int32)) for key, ws in list(self._ws.items())
+                if isinstance(key, tuple) and key[0] != "kv" and key[1] in ("llm", "clip") and ws.numel() >= 8192]
+
+    def handoff_status_async(self):
+        """Snapshot of every workspace's hand-off status word, copied to pinned host memory on the CURRENT stream (no host wait): a pipeline
+        that copies its results to the host anyway adds this behind them and hands it to ``check_handoff_status`` once its event has fired."""
+        words = self._status_words()
+        if not words:
+            return None
+        host = torch.empty(len(words), dtype=torch.int32, pin_memory=True)
+        host.copy_(torch.cat([w for _, w in words]), non_blocking=True)
+        return [k for k, _ in words], host
+
+    def check_handoff_status(self, snapshot=None):
         """Raise if a bounded in-kernel wait of the stream-K GEMMs / fused decode kernel ever gave up (a workgroup that never
         arrived would otherwise show up as silently wrong numbers).  The status word sits at int 2047 of the hand-off header
-        at the start of every workspace; reading it synchronises, so call it where the host waits for results anyway."""
-        for key, ws in list(self._ws.items()):
-            if isinstance(key, tuple) and key[0] != "kv" and key[1] in ("llm", "clip") and ws.numel() >= 8192:
-                st = int(ws[8188:8192].view(torch.int32).item())
-                if st != 0:
+        at the start of every workspace; reading it synchronises (ONE device -> host copy for all workspaces), so call it where the host
+        waits for results anyway - or pass the ``handoff_status_async`` snapshot that travelled with the results (no wait at all:
+        with twenty recursions in flight the per-workspace reads were 22 host round trips per collected recursion, round 4)."""
+        if snapshot is None:
+            words = self._status_words()
+            if not words:
+                return
+            keys, vals = [k for k, _ in words], torch.cat([w for _, w in words]).cpu()
+        else:
+            keys, vals = snapshot
+        bad = [(k, int(v)) for k, v in zip(keys, vals.tolist()) if v != 0]
+        if bad:
+            for k, _ in bad:
+                ws = self._ws.get(k)
+                if ws is not None:
                     ws[8188:8192].zero_()
-                    raise hip.HipLibraryError(f"workspace '{key}': an in-kernel hand-off wait timed out (status {st}); results of the last calls are invalid")
+            key, st = bad[0]
+            raise hip.HipLibraryError(f"workspace '{key}': an in-kernel hand-off wait timed out (status {st}); results of the last calls are invalid")
 
     # ---- adapter ---------------------------------------------------------------------------------
     def project_dense(self, x, out_dtype=torch.float32):

@@ -213,15 +213,19 @@ def launch_calls_steps(model, tokenizer, query, rows, calls, uniforms=None, max_
             out = yield from model.generate_steps(ids, video_rows=torch.cat([rows[c] for c in sel], 0), rows_per_sample=n_rows,
                                                   do_sample=True, temperature=0.05, num_beams=1, max_new_tokens=max_new_tokens,
                                                   output_scores=False, return_dict_in_generate=True, uniforms=u, forced_tokens=forced,
-                                                  server=server)
+                                                  server=server, new_tokens_only=True)
             order.extend(sel)
-            toks.append(out["sequences"][:, ids.shape[1]:])
+            toks.append(out["new_tokens"] if out.get("new_tokens") is not None else out["sequences"][:, ids.shape[1]:])
             ents.append(out["entropy"])
     dev = model.engine.device
     if not order:
         w0 = width or 0
         return [], torch.zeros(0, w0, dtype=torch.int32, device=dev), torch.zeros(0, w0, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
     width = width or max(t.shape[1] for t in toks)
+    if len(toks) == 1 and toks[0].shape[1] == width and toks[0].dtype == torch.int32:
+        # one generate that fills the wire width (every batched recursion of the drivers): its tensors ARE the result - no assembly launches
+        # behind the last decode step, where the device has nothing else to run
+        return order, toks[0], ents[0], torch.full((len(order),), width, dtype=torch.int32, device=dev)
     tok = torch.zeros(len(order), width, dtype=torch.int32, device=dev)
     ent = torch.zeros(len(order), width, dtype=torch.float32, device=dev)
     nst = torch.empty(len(order), dtype=torch.int32, device=dev)

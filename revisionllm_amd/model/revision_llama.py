@@ -277,7 +277,7 @@ class ReVisionLlamaForCausalLM:
                        max_new_tokens=None, use_cache=True, visual_memory=None, prefix_memory=None, output_scores=False,
                        return_dict_in_generate=False, output_hidden_states=False, output_logits=False, top_k=None, top_p=None,
                        attention_mask=None, uniforms=None, forced_tokens=None, video_rows=None, rows_per_sample=None,
-                       share_prefix=True, eos_lookahead=1, server=None, iteration_step=None, **kwargs):
+                       share_prefix=True, eos_lookahead=1, server=None, iteration_step=None, new_tokens_only=False, **kwargs):
         """``generate`` as a generator: enqueues device work and YIELDS a ``torch.cuda.Event`` whenever the host has to learn
         something from the device before it may enqueue more - which only happens with an EOS id configured: the "all rows
         finished" flag of step s is copied to pinned host memory asynchronously and looked at only after step s + ``eos_lookahead``
@@ -295,6 +295,8 @@ class ReVisionLlamaForCausalLM:
         together with the other generates in flight - same tokens / entropies, one pass over the weights per step for all of
         them; only under ``sched.Interleaver(servers=[server])``; falls back to the loop below when it does not apply).
         ``iteration_step``: the reference's ``forward`` kwarg for ``clip_adapter_feature='alternate'`` (vtimellm_llama.py:55).
+        ``new_tokens_only`` (with ``return_dict_in_generate``, through a server): ``out['new_tokens']`` int32 [B, G] and no ``sequences``
+        (the prompt is not copied in front of them: the recursion drivers read only the new tokens).
         ``output_hidden_states`` is accepted and ignored: nothing on the path reads it.
         """
         if num_beams != 1:
@@ -347,7 +349,8 @@ class ReVisionLlamaForCausalLM:
         if job is not None:
             try:
                 return (yield from self._generate_in_pool(server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k,
-                                                          top_p, max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens))
+                                                          top_p, max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens,
+                                                          new_tokens_only))
             finally:
                 if not job.finished:        # an exception here or in a task this one was pumped from, or the task was cancelled
                     server.abandon(job)
@@ -369,7 +372,7 @@ class ReVisionLlamaForCausalLM:
             eng.slots_in_flight.discard(slot)
 
     def _generate_in_pool(self, server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
-                          max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens=None):
+                          max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens=None, new_tokens_only=False):
         """The merged-decode path of ``generate_steps``: prefill into the server's pool, its merged steps do the rest."""
         pool = job.pool
         for ev in job.free_events:
@@ -412,6 +415,8 @@ class ReVisionLlamaForCausalLM:
         while not job.finished:
             yield sched.RETRY           # the scheduler pumps the server's merged steps
         yield job.done_event
+        if new_tokens_only and return_dict_in_generate:
+            return GenerateOutput(sequences=None, new_tokens=job.tokens, entropy=job.entropy, entropy_raw=job.entropy_raw)
         seqs = torch.cat([ops.h2d(input_ids, dev, torch.long), job.tokens.long()], dim=1)
         if not return_dict_in_generate:
             return seqs

@@ -133,8 +133,11 @@ class HipStages:
     def eos(self):
         return self.model.generation_config.eos_token_id
 
-    def check(self):
-        self.model.engine.check_handoff_status()
+    def check(self, snapshot=None):
+        self.model.engine.check_handoff_status(snapshot)
+
+    def status_async(self):
+        return self.model.engine.handoff_status_async()
 
 
 class PendingQuery:
@@ -219,6 +222,18 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
             order, tok, ent, nst = yield from stages.generate_steps(prompts, rows, mine, uniforms, max_new_tokens, width)
         else:
             order, tok, ent, nst = stages.generate_async(prompts, rows, mine, uniforms, max_new_tokens, width)
+        if not exchange and dev.type == "cuda":
+            # one rank, nothing to exchange: the generate's own tensors go to pinned host memory as they are (4 copies + the status snapshot
+            # behind the last decode step - the wire assembly below was 11 more launches per recursion with nothing else left to run)
+            p.order = list(order)
+            src = (tok, ent, nst, cos)
+            p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in src)
+            for h, t in zip(p.host, src):
+                h.copy_(t, non_blocking=True)
+            p.status = stages.status_async() if hasattr(stages, "status_async") else None
+            p.event = torch.cuda.Event()
+            p.event.record()
+            return p
         per = -(-(nc * nq) // world)
         # wire: int32 [per, 2 + width] = (call id or -1, produced steps, tokens...) and f32 [per, width] step entropies
         tw = torch.full((per, 2 + width), -1, dtype=torch.int32, device=dev)
@@ -235,6 +250,7 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
             p.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (tw, ew, cos))
             for h, t in zip(p.host, (tw, ew, cos)):
                 h.copy_(t, non_blocking=True)
+            p.status = stages.status_async() if hasattr(stages, "status_async") else None
             p.event = torch.cuda.Event()
             p.event.record()
         else:                                               # CPU stand-in stages (tests): nothing to wait for
@@ -254,10 +270,17 @@ def collect_queries(p):
     if hasattr(p, "event"):
         if p.event is not None:
             p.event.synchronize()
-        tw, ew, cos = p.host
-        rows_ = [j for j in range(tw.shape[0]) if int(tw[j, 0]) >= 0]
-        res = stage2.finish_calls([int(tw[j, 0]) for j in rows_], tw[rows_][:, 2:], ew[rows_], tw[rows_][:, 1], p.stages.eos)
-        p.stages.check()
+        if getattr(p, "order", None) is not None:          # one rank: the generate's own tensors
+            tok, ent, nst, cos = p.host
+            res = stage2.finish_calls(p.order, tok, ent, nst, p.stages.eos)
+        else:
+            tw, ew, cos = p.host
+            rows_ = [j for j in range(tw.shape[0]) if int(tw[j, 0]) >= 0]
+            res = stage2.finish_calls([int(tw[j, 0]) for j in rows_], tw[rows_][:, 2:], ew[rows_], tw[rows_][:, 1], p.stages.eos)
+        if getattr(p, "status", None) is not None:
+            p.stages.check(p.status)
+        else:
+            p.stages.check()
     else:
         res, cos = p.res, p.cos
     return [stage2.assemble(plan, perms[qi], {c: res[qi * nc + c] for c in range(nc)}, cos[qi], tokenizer, zooms, grounding_windows, single)
