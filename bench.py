@@ -94,6 +94,11 @@ def parse():
                         "K-duplicated weights; the mode whose scores meet the north star's 1e-3 against the fp32 reference)")
     p.add_argument("--gemm-waves", type=int, default=0, choices=(0, 4, 8), help="waves per workgroup of the persistent prefill GEMMs (0 = the library default; see include/revision_hip.h)")
     p.add_argument("--gemm-cus", type=int, default=0, help="CUs the persistent prefill GEMMs occupy (0 = all); with --streams 2 the rest stay free for the other recursion's decode")
+    p.add_argument("--s1-inflight", type=int, default=128,
+                   help="stage-1 workloads: one-row generates (windows) in flight; they share KV pools of min(this, 128) rows, so a merged decode step serves "
+                        "that many windows per pass over the weights (round 3: 32)")
+    p.add_argument("--s1-prefill-batch", type=int, default=0, help="stage-1 workloads: prefills per pass (0 = 8 for stage1_sparse: 8 x 72 rows, 6 for stage1_dense: 6 x 327 rows = 8 row tiles)")
+    p.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="rv_ctx_set_option KEY VALUE on the engine (measurement knob, repeatable): e.g. --opt gemm_mhalf=0")
     p.add_argument("--gemm-variant", type=int, default=2, help="rv_ctx_set_option gemm_tile_variant (2 = auto; 6 = ring kernel only: measurement knob)")
     p.add_argument("--settle", type=int, default=16,
                    help="untimed steps run as part of the set-up, before the W warm-up steps (a fresh box starts at idle clocks; ~0.5 s)")
@@ -425,6 +430,9 @@ def main():
         # wait in-kernel for ALL their workgroups, and two PROCESSES on one device would each hold half the CUs - output-tiled kernels only
         args.gemm_variant = 6
     eng.set_option("gemm_tile_variant", args.gemm_variant)
+    for kv in args.opt:
+        k_, v_ = kv.split("=", 1)
+        eng.set_option(k_, int(v_))
     model.generation_config.eos_token_id = 2 if args.eos else None     # None: forced decode length
     tok = synth.FakeTokenizer()
     G = args.decode_steps
@@ -587,15 +595,16 @@ def main():
             # windows in flight share the weight passes like the stage-2 recursions do: one-row generates fill a 32-row KV pool
             # (gang policy), their prefills ride four to a pass, a merged decode step serves up to 32 windows
             from revisionllm_amd import serve
-            server1 = serve.DecodeServer(m1, rows=32, smax=(S + G + 31) // 32 * 32, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch,
+            NB = max(1, args.s1_inflight)
+            pb1 = args.s1_prefill_batch or (8 if kind == "stage1_sparse" else 6)
+            server1 = serve.DecodeServer(m1, rows=min(NB, 128), smax=(S + G + 31) // 32 * 32, gmax=max(16, G), pools=2, gang=True, prefill_batch=pb1,
                                          slot=150)
             inter1 = sched.Interleaver(servers=[server1])
-            streams1 = [torch.cuda.Stream(dev) for _ in range(32)]
+            streams1 = [torch.cuda.Stream(dev) for _ in range(NB)]
 
             # every window in flight is its OWN window (32 distinct ones, window i of a step group = set i); the adapter of a group of
             # windows runs as ONE call over [group, frames, 768] - the reference's stage-1 driver hands inference() a batch of windows
             # too (eval_nlq_negative.py:281-298) - and each window then decodes as its own one-row generate through the server
-            NB = len(streams1)
             xs = ops.init_hash_(torch.empty(NB, frames, 768, dtype=torch.bfloat16, device=dev), f"bench.s1.{kind}.windows", args.seed, synth.SQRT3)
             enc_stream = torch.cuda.Stream(dev)
             gkw1 = {k_: v_ for k_, v_ in gkw.items() if k_ not in ("images", "query_feats")}
@@ -618,17 +627,17 @@ def main():
                         k = (base + i) % NB
                         streams1[k].wait_event(enc_done)
                         pending.append(inter1.add(sched.Task(m1.generate_steps(ids, video_rows=rows[i], rows_per_sample=rps, server=server1, **gkw1),
-                                                             streams1[k], eng, 32 + k)))
+                                                             streams1[k], eng, 200 + k)))
                         if len(pending) > NB:
                             out = inter1.finish(pending.pop(0))
                 while pending:
                     out = inter1.finish(pending.pop(0))
                 eng.slot = 0
                 return out
-            return run1, dict(prompt_tokens=int(ids.shape[1]), prefill_len=int(S), frames=frames, windows_per_step=1, windows_in_flight=32,
-                              inputs="32 distinct windows in flight",
-                              adapter="one call per group of up to 32 windows in flight ([32, %d, 768] -> %s)" % (frames, "ClipEncoder, CLS out" if kind != "stage1_dense" else "Linear projector"),
-                              decode="merged (serve.DecodeServer: 32-row pools, prefills four to a pass)")
+            return run1, dict(prompt_tokens=int(ids.shape[1]), prefill_len=int(S), frames=frames, windows_per_step=1, windows_in_flight=NB,
+                              inputs="%d distinct windows in flight" % NB,
+                              adapter="one call per group of up to %d windows in flight ([%d, %d, 768] -> %s)" % (NB, NB, frames, "ClipEncoder, CLS out" if kind != "stage1_dense" else "Linear projector"),
+                              decode="merged (serve.DecodeServer: %d-row pools, prefills %d to a pass)" % (min(NB, 128), pb1))
 
         def run1(n):
             out = None
@@ -794,9 +803,10 @@ def main():
         for kind in ("stage1_dense", "stage1_sparse"):
             try:
                 run1, cfg1 = stage1_runner(kind)
-                t, _ = timed(run1)
+                n1 = max(args.steps, 2 * cfg1.get("windows_in_flight", 32))      # two full gangs of windows: a K = 20 run is pipeline fill and drain only
+                t, _ = timed(run1, steps=n1, warm=n1 // 2)
                 S1 = cfg1["prefill_len"]
-                entry = {"value": args.steps / t, "unit": "segments/s", "ms_per_step": t / args.steps * 1e3, "config": cfg1,
+                entry = {"value": n1 / t, "unit": "segments/s", "ms_per_step": t / n1 * 1e3, "steps": n1, "warmup": n1 // 2, "config": cfg1,
                          "prefill_flops": 2.0 * S1 * 6.476e9 + 2.6e5 * S1 * S1 + 2.6e8}
                 if kind == "stage1_sparse":      # adapter alone: SURVEY 8d: 46.9 GFLOP per 1024-frame segment (MFMA-bound)
                     x1 = ops.init_hash_(torch.empty(32, 1024, 768, dtype=torch.bfloat16, device=dev), "bench.s1.a", args.seed, synth.SQRT3)

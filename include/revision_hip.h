@@ -81,6 +81,10 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        in ping-pong (128 x 64 outputs each); 4 = one wave per SIMD owning 128 x 128 outputs (accumulators in the AGPR half of
  *                        the register file; 128 instead of 192 KiB of LDS fragment reads per k-tile).  Bit-identical results; measured level
  *                        with 8 up to ~4000 rows (0 .. -2.5 %) and ahead for more rows (8192^3: +30 %).  FP8 x FP8 and 192-column forms: always 8.
+ *   "gemm_mhalf"         1 (default): a persistent prefill GEMM over >= 10 row tiles of 256 (batched prefills) lets one XCD's team of workgroups cover HALF the
+ *                        row tiles of twice as many weight panels (16 row tiles: 8 x 4 instead of 16 x 2 tiles per team) - fewer activation bytes
+ *                        re-fetched per tile.  0: the round-3 teams.  The stream-K split points move with the team shape, so results may differ in the
+ *                        last bit between the two settings (each is deterministic).
  *   "rows_single"        1 (default): an 81 .. 144-row decode projection whose 64-column groups alone fill >= 3/4 of the CUs (the fused QKV projection:
  *                        192 groups) runs WITHOUT a K split - one workgroup walks all 8 virtual k-waves and finishes its own columns: no partial
  *                        planes, no hand-over (140 rows: 84 -> 64 us per launch, step 10.06 -> 9.47 ms).  Same bits either way.  0: always split.

@@ -264,6 +264,21 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const
     return RV_OK;
 }
 
+// G copies of one prefill problem (batched prefills WITHOUT a shared prefix: one-row generates, the stage-1 windows) in one launch: the pair
+// kernel with an empty first problem.  Per group these were G launches of 7 - 18 us each per layer (8 x 72-row windows: 60 of a layer's 440 us).
+int k_attention_groups(const AttnArgs& b, hipStream_t st, const AttnGroups& gr) {
+    if (int rc = attn_check(b)) return rc;
+    RV_CHECK_ARG(b.dh == 128 && b.Lq > 16 && !b.key_pad && !b.row_pos, "attention groups: 128-wide heads, prefill lengths, no key padding, no per-row positions");
+    RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention groups: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
+    AttnArgs a = b;
+    a.B = 0;      // every workgroup takes problem b
+    const int tiles = (int)cdiv(b.Lq, 64);
+    if (b.q_lo) hipLaunchKernelGGL((attn_kernel_pair<128, true>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    else hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    RV_CHECK_LAUNCH("attention groups");
+    return RV_OK;
+}
+
 int k_attention(const AttnArgs& a, hipStream_t st) {
     RV_CHECK_ARG(a.q && a.k && a.vt && a.out, "attention: null tensor");
     RV_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_div > 0, "attention: empty problem");

@@ -298,6 +298,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "rows_persistent") return &o.rows_persistent;
     if (k == "rows_single") return &o.rows_single;
     if (k == "gemm_waves") return &o.gemm_waves;
+    if (k == "gemm_mhalf") return &o.gemm_mhalf;
     if (k == "precision") return &o.precision;
     if (k == "lm_head_split") return &o.lm_head_split;
     return nullptr;
@@ -655,6 +656,23 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         produce.planes = w.planes;
         produce.arrive = w.arrive;
         {
+            if (!prefix_done && G > 1 && P0 == 0 && S > 16 && dh == 128 && !row_pos) {
+                // batched prefills without a shared prefix (one-row generates: the stage-1 windows): all G groups in ONE launch
+                AttnArgs a{w.q16, qd, (int64_t)S * qd, kc, dh, (int64_t)H * Smax * dh, (int64_t)Smax * dh, vtc, (int64_t)H * dh * Smax,
+                           (int64_t)dh * Smax, Smax, w.a16, od, (int64_t)S * od, nullptr, B, H, dh, S, pos0 + S, 1, pos0, 1, scale};
+                a.out_lo = olo;
+                a.q_lo = qlo;
+                blocked_vt(a);
+                AttnGroups gr;
+                gr.G = G;
+                for (int gi = 0; gi < G; ++gi) {
+                    gr.q_off[gi] = (int64_t)gi * Mg * qd;
+                    gr.o_off[gi] = (int64_t)gi * Mg * od;
+                    gr.kv_off[gi] = (int64_t)(grow[gi] - grow[0]) * D * Smax;
+                }
+                RV_TRY(k_attention_groups(a, st, gr));
+                prefix_done = true;
+            }
             for (int gi = 0; gi < G && !prefix_done; ++gi) {
                 const int64_t r0 = (int64_t)gi * Mg + P0;  // first row of the per-sequence part
                 const int64_t co = (int64_t)(G > 1 ? grow[gi] - grow[0] : 0) * D * Smax;

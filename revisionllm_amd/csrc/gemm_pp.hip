@@ -719,7 +719,7 @@ __device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t
                                            const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                            int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
                                            int total_units, f32x4* partial, int* flags, int* status, int epoch, const QkvRope& qr,
-                                           const PpScale& sc, int PG, int tiles_n) {
+                                           const PpScale& sc, int PGx, int tiles_n) {
     static_assert(!W4 || (NF == 4 && !F8), "the four-wave form: bf16 operands, 256-column panels");
     // PG > 1 (many-row problems: batched prefills): a team is tiles_m x PG workgroups - the m-tiles of PG ADJACENT panels walk the same
     // k-range together, so an activation k-slice is fetched once per PG panels too (with one panel per team the 33 MB activation panel
@@ -730,10 +730,16 @@ __device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int teams_per_x = (gridDim.x >> 3) / TS;
+    // PGx = PG | MHS << 8.  MHS = 1 (round 4): a team covers HALF the m-tiles (tiles_m of them - the caller passes the per-team count) of twice as
+    // many panels: a unit of the panel / stream-K space is then (panel group v >> 1, m-half v & 1).  With 16 m-tiles (4 x 1005 rows) a team is
+    // 8 x 4 tiles instead of 16 x 2: per 32 tiles an XCD fetches half the activation panel + 4 weight panels (24.8 MB at K = 4096) instead of all
+    // of it + 2 (37.6 MB) - the activation re-reads out of the infinity cache were 6.2x the algorithmic bytes of a gate/up launch.
+    const int PG = PGx & 255, MHS = PGx >> 8;
     const int team = xcd * teams_per_x + slot / TS, tsl = slot % TS, tm = tsl % tiles_m, pgi = tsl / tiles_m;
     const int T = 8 * teams_per_x;
     if (pgi >= PG || slot >= teams_per_x * TS) return;
-    const int m0_wg = tm * PBM;
+    auto unit_m0 = [&](int v) { return ((v & ((1 << MHS) - 1)) * tiles_m + tm) * PBM; };      // first row of this workgroup's tile of unit v
+    auto unit_panel = [&](int v) { return (v >> MHS) * PG + pgi; };                            // ... and its panel
     auto ub = [&](int t) { return (int)((int64_t)t * total_units / T); };   // first unit of team t's range
     const int u_begin = ub(team), u_end = ub(team + 1);
     int shared_panel[2] = {-1, -1};   // stream-K panels this workgroup published a partial of: slot 0 = entered mid-panel, 1 = head
@@ -757,12 +763,12 @@ __device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t
         } else {
             break;
         }
-        const int tpanel = panel * PG + pgi;     // this workgroup's panel of the group
+        const int tpanel = unit_panel(panel);     // this workgroup's panel of the group
         if (tpanel >= tiles_n) continue;
         const int n0 = tpanel * (NF * 64);
-        // m0 is the same for every segment: launder it so that the row-dependent address math of the epilogue is not hoisted
-        // out of this loop (it would stay live across the main loop and push the accumulators into scratch)
-        int m0 = m0_wg;
+        // launder m0 so that the row-dependent address math of the epilogue is not hoisted out of this loop (it would stay live across
+        // the main loop and push the accumulators into scratch)
+        int m0 = unit_m0(panel);
         asm volatile("" : "+s"(m0));
         constexpr int NFW = W4 ? 8 : NF;   // fragments per wave along N
         f32x4 acc[NFW][8];
@@ -836,7 +842,7 @@ __device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t
         }
         __syncthreads();
         const float poison = ids[1024] ? __int_as_float(0x7fc00000) : 0.f;   // a missing partial poisons this share (never a silent partial sum)
-        const int m0 = m0_wg, n0 = ((dp_panels + panel) * PG + pgi) * PBN;
+        const int m0 = unit_m0(dp_panels + panel), n0 = unit_panel(dp_panels + panel) * PBN;
         if (c == 2) pp_reduce_share<2, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
         else if (c == 3) pp_reduce_share<3, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
         else if (c == 4) pp_reduce_share<4, OUT_BF16, ACT, ROPE, F8, W4>(partial, ids, c, j, wave, lane, bias, res, ldr, Cv, ldc, M, m0, n0, qr, sc, poison);
@@ -926,10 +932,21 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     const int G = pp_num_cus() & ~7, per_x = G >> 3;
     // team = the m-tiles of one panel; G/8 - (G/8) / TS * TS workgroups per XCD stay idle.  From 8 m-tiles on (batched prefills) with
     // 256-column panels: the m-tiles of PG adjacent panels - one team per XCD (see the kernel)
-    const int PG = (NF == 4 && tiles_m >= 8 && per_x / tiles_m >= 2) ? per_x / tiles_m : 1;
-    const int TS = tiles_m * PG;
-    const int T = PG > 1 ? 8 * (per_x / TS) : pp_teams(M);
-    const int groups = (tiles_n + PG - 1) / PG, dp_panels = groups / T * T;      // (in panel groups)
+    int PG = (NF == 4 && tiles_m >= 8 && per_x / tiles_m >= 2) ? per_x / tiles_m : 1;
+    int tm_team = tiles_m, MHS = 0;
+    // half the m-tiles x twice the panels per team when that fills the XCD at least as well with fewer bytes per tile (see the kernel):
+    // 16 m-tiles: 8 x 4 instead of 16 x 2; 12: 6 x 5 = 30 workgroups per XCD instead of 12 x 2 = 24; 10: 5 x 6 instead of 10 x 3
+    if (NF == 4 && rv_cur_opts().gemm_mhalf && tiles_m >= 10 && tiles_m % 2 == 0 && tiles_m <= per_x) {
+        const int tm2 = tiles_m / 2, pg2 = per_x / tm2;
+        if (pg2 <= 255 && (tm2 * pg2 > tiles_m * PG || (tm2 * pg2 == tiles_m * PG && tm2 + pg2 < tiles_m + PG))) {
+            tm_team = tm2;
+            PG = pg2;
+            MHS = 1;
+        }
+    }
+    const int TS = tm_team * PG;
+    const int T = (PG > 1 || MHS) ? 8 * (per_x / TS) : pp_teams(M);
+    const int groups = ((tiles_n + PG - 1) / PG) << MHS, dp_panels = groups / T * T;      // (in panel groups x m-halves)
     if (NF != 4 && dp_panels != tiles_n) {
         rv_set_error("gemm_pp: 192-column panels need a panel count that is a multiple of the %d teams", T);
         return RV_ERR_ARG;
@@ -941,13 +958,13 @@ int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias,
     f32x4* partial = (f32x4*)((char*)ws + PP_HDR);
     if constexpr (can4) {
         if (w4) {
-            hipLaunchKernelGGL((gemm_pp4_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(256), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K, tiles_m, TS,
-                               nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG, tiles_n);
+            hipLaunchKernelGGL((gemm_pp4_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(256), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K, tm_team, TS,
+                               nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG | MHS << 8, tiles_n);
             return RV_OK;
         }
     }
     hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, ROPE, NF, F8>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
-                       tiles_m, TS, nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG, tiles_n);
+                       tm_team, TS, nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG | MHS << 8, tiles_n);
     return RV_OK;
 }
 

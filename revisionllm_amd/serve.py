@@ -291,6 +291,33 @@ class DecodePool:
         eng.slot = prev_slot
 
 
+def team_fill(tiles_m, per_x=32):
+    """Share of an XCD's CUs the persistent stream-K prefill GEMMs keep busy for ``tiles_m`` row tiles of 256 (csrc/gemm_pp.hip launch_sk: a team =
+    the row tiles of one weight panel - or of a group of adjacent panels from 8 row tiles on, or half the row tiles of twice as many panels from
+    10 on - and whole teams per XCD)."""
+    if tiles_m > per_x:
+        return 0.5                                   # (no persistent plan: output-tiled / ring kernels)
+    ts = (per_x // tiles_m) * tiles_m
+    if tiles_m >= 10 and tiles_m % 2 == 0:
+        ts = max(ts, (tiles_m // 2) * (per_x // (tiles_m // 2)))
+    return ts / per_x
+
+
+def best_prefill_batch(avail, rows, per_x=32):
+    """How many of the ``avail`` waiting prefills of ``rows`` GEMM rows each go into one pass: the count with the lowest cost per prefill, cost =
+    row tiles of 256 (padding included) / (CU fill of the stream-K teams x prefills); ties go to the larger batch.  The headline's 4 x 1005 rows
+    stay 4 (16 row tiles: every CU busy, 2 % padding; 3 x 1005 rows = 12 tiles fill 30 of 32 CUs); 8 waiting one-row stage-1 prefills
+    of 327 rows go 6 to a pass (8 row tiles instead of 11 with a quarter of the CUs idle), of 72 rows 7 (2 row tiles, 504 of 512 rows used).
+    (Round 3 took 1 / 2 / 4 / 8 only.)"""
+    best, best_cost = 1, None
+    for n in range(1, max(1, avail) + 1):
+        tiles = -(-n * rows // 256)
+        cost = tiles / (team_fill(tiles, per_x) * n)
+        if best_cost is None or cost <= best_cost * 1.0001:
+            best, best_cost = n, cost
+    return best
+
+
 class PrefillTicket:
     """One generate's prefill handed to the server (``DecodeServer.submit_prefill``): ``ready`` (event) / ``first`` (its last-position
     logits [B, V]) are set once the batch it rides in has been enqueued."""
@@ -315,7 +342,8 @@ class DecodeServer:
         geometry (rows, shared-prefix length, length) ride in ONE pass (``rv_llm_prefill_pool_groups``: the GEMMs see G x 1005 rows
         instead of 1005, which the N = 4096 projections in particular are too small for), on one prefill stream in submission order.
         A batch is enqueued as soon as ``prefill_batch`` tickets wait, or whatever waits when no earlier batch is still running (the
-        stream never idles for the sake of a fuller batch).  Per-row results equal the separate prefills up to GEMM summation order."""
+        stream never idles for the sake of a fuller batch); of the waiting tickets a pass takes the count that costs least per prefill
+        (``best_prefill_batch``: row-tile padding and the CU fill of the stream-K teams).  Per-row results equal the separate prefills up to GEMM summation order."""
         assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
         assert 1 <= prefill_batch <= 8
         self.prefill_batch, self.pf_queue, self.pf_inflight = prefill_batch, [], []
@@ -323,6 +351,9 @@ class DecodeServer:
         self.pf_slot = slot + 16
         self.pf_batches = self.pf_tickets = 0
         self.pf_hist = {}            # groups per pass -> tickets served by passes of that size
+        dev_ = getattr(getattr(model, "engine", None), "device", None)      # (tests drive the policy with model = None and stand-in pools)
+        self.cus_per_xcd = (max(8, torch.cuda.get_device_properties(dev_).multi_processor_count // 8)
+                            if getattr(dev_, "type", "cpu") == "cuda" and torch.cuda.is_available() else 32)
         make = pool_factory or DecodePool           # (tests: a stand-in without device memory)
         self.pools = [make(model, rows, smax, gmax, max_ahead, slot + i, gang) for i in range(pools)]
         self.gang, self.blocking, self.fill = gang, gang, 0
@@ -417,8 +448,7 @@ class DecodeServer:
         full = n == self.prefill_batch or n < len(self.pf_queue)      # (a ticket of another geometry behind the group closes it)
         if not full and not force and not (partial and not self.pf_inflight):
             return False
-        while n & (n - 1):          # 1, 2, 4 or 8 groups: their 4 / 8 / 16 / 32 row tiles of 256 divide the 32 CUs of an XCD, so the stream-K
-            n -= 1                  # teams (one per weight panel, gemm_pp.hip) leave no CU idle - 3 x 1005 rows ran 25 % slower than 4 x
+        n = best_prefill_batch(n, int(lead.h.shape[0]), self.cus_per_xcd)
         batch, self.pf_queue = self.pf_queue[:n], self.pf_queue[n:]
         eng, pool = self.model.engine, lead.job.pool
         prev = eng.slot
