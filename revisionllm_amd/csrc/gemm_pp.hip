@@ -22,6 +22,7 @@
 //     read back with conflict-free ds_read_b128.
 //   * slots = barrier-to-barrier intervals; group 0 runs the memory part of phase k in slot 2k, group 1 in slot 2k+1.  RAW: a
 //     unit is read in slot >= 2k only after every wave waited for its own pieces of it before the barrier ending slot 2k-1.
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -997,7 +998,10 @@ bool gemm_pp_sk_supported(int w_layout, int64_t M, int64_t N, int64_t K) {
 int gemm_pp_sk_plan(int64_t M, int64_t N, int64_t K, bool gated) {
     const int tiles_m = (int)cdiv(M, PBM), per_x = pp_num_cus() >> 3;
     const int64_t T = pp_teams(M), nk = K / PBK;
-    if (T == 0 || K < 2048 || (per_x % tiles_m) * 10 > per_x) return 0;   // short K, or > 10 % of the CUs left without a team
+    if (T == 0 || K < 2048) return 0;
+    int ts = per_x / tiles_m * tiles_m;                                   // workgroups per XCD that belong to a team (launch_sk)
+    if (rv_cur_opts().gemm_mhalf && tiles_m >= 10 && tiles_m % 2 == 0) ts = std::max(ts, tiles_m / 2 * (per_x / (tiles_m / 2)));
+    if ((per_x - ts) * 10 > per_x) return 0;                              // > 10 % of the CUs left without a team
     const int64_t panels = N / PBN, sk_panels = panels % T;
     if (sk_panels == 0 && panels >= T) return 4;                     // 256-column panels deal out exactly (batched prefills: 48 qkv panels on 16 teams)
     if (!gated && N % 192 == 0 && (N / 192) % T == 0) return 3;

@@ -172,6 +172,43 @@ def test_four_wave_persistent_gemm_is_bit_identical_to_the_eight_wave_form(dev, 
     assert rel_err(y4[sel].float().cpu(), z.cpu()) < (BF16_TOL if out == "bf16" else F32_TOL * 5)
 
 
+@pytest.mark.parametrize("M,N,K,act,out,res", [
+    (4020, 22016, 4096, 2, "bf16", False),     # 16 row tiles: teams of 8 x 4 tiles instead of 16 x 2; 86 panels: ragged last panel group + stream-K tail
+    (4020, 4096, 11008, 0, "f32", True),       # down projection: 16 panels = 8 units of (4 panels, m-half), one per team
+    (4020, 12288, 4096, 0, "f32", False),
+    (3015, 4096, 4096, 0, "f32", True),        # 12 row tiles: 6 x 5 (30 workgroups per XCD instead of 24), 16 panels in groups of 5: ragged
+    (2500, 22016, 4096, 2, "bf16", False),     # 10 row tiles: 5 x 6
+])
+def test_half_height_stream_k_teams_equal_the_full_height_teams(dev, M, N, K, act, out, res):
+    """Option gemm_mhalf (round 4, gemm_pp.hip pp_sk_body): a team of the persistent stream-K GEMM covers half the row tiles of twice as many
+    panels.  A tile that is computed whole sums the same k-tiles in the same order under both team shapes - bit-identical; only the panels
+    of the stream-K tail (cut at different k) may differ in the last bits.  Both settings are checked against float64 on sampled rows."""
+    from revisionllm_amd import hip, ops
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(torch.bfloat16).to(dev)
+    n_out = N // 2 if act == hip.RV_ACT_SILU_MUL else N
+    r = torch.randn(M, n_out, generator=g).to(dev) if res else None
+    od = torch.bfloat16 if out == "bf16" else torch.float32
+    wp = ops.pack_fragments(w)
+    y1 = ops.gemm(a, wp, residual=r, out_dtype=od, act=act, w_packed=True, ctx=hip.Options(gemm_mhalf=1, gemm_tile_variant=5))
+    y0 = ops.gemm(a, wp, residual=r, out_dtype=od, act=act, w_packed=True, ctx=hip.Options(gemm_mhalf=0, gemm_tile_variant=5))
+    y1b = ops.gemm(a, wp, residual=r, out_dtype=od, act=act, w_packed=True, ctx=hip.Options(gemm_mhalf=1, gemm_tile_variant=5))
+    assert torch.equal(y1, y1b)                                       # deterministic for a given shape
+    same = (y1 == y0).float().mean().item()
+    assert same > 0.80, same                                          # whole panels: identical bits
+    assert rel_err(y1.float().cpu(), y0.float().cpu()) < (BF16_TOL if out == "bf16" else 1e-5)
+    sel = torch.arange(0, M, max(1, M // 61), device=dev)
+    z = a[sel].double() @ w.double().t()
+    if act == hip.RV_ACT_SILU_MUL:
+        z = z.view(len(sel), N // 32, 2, 16)
+        z = (torch.nn.functional.silu(z[:, :, 0]) * z[:, :, 1]).reshape(len(sel), N // 2)
+    if res:
+        z = z + r[sel].double()
+    for y in (y1, y0):
+        assert rel_err(y[sel].float().cpu(), z.cpu()) < (BF16_TOL if out == "bf16" else F32_TOL * 5)
+
+
 @pytest.mark.parametrize("M,N,K", [(9, 1024, 256), (771, 4096, 1024), (1000, 1024, 4096)])
 def test_gemm_quick_gelu_epilogue(dev, M, N, K):
     """bias + QuickGELU (x * sigmoid(1.702 x), the CLIP MLP activation) fused into the GEMM epilogue: every kernel family."""

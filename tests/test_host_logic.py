@@ -323,6 +323,21 @@ def test_options_are_per_context():
     assert hip.lib().rv_weights_bind(a._ctx, b"llm.embed", ctypes.c_void_p(256), 1, 16) < 0
 
 
+def test_prefill_passes_take_the_cheapest_batch_size():
+    """serve.best_prefill_batch / team_fill: the pass size is the count of waiting prefills with the lowest (row tiles incl. padding) / (CU fill
+    of the stream-K teams x prefills); the headline's geometry keeps the sizes it was measured with (1 / 2 / 2 / 4 of 1 .. 4 waiting)."""
+    from revisionllm_amd.serve import best_prefill_batch, team_fill
+    assert [team_fill(t) for t in (1, 4, 6, 8, 11, 12, 16, 20, 32)] == [1.0, 1.0, 30 / 32, 1.0, 22 / 32, 30 / 32, 1.0, 30 / 32, 1.0]
+    assert team_fill(33) == 0.5                                                  # no persistent plan beyond one row tile per CU of an XCD
+    assert [best_prefill_batch(a, 1005) for a in range(1, 5)] == [1, 2, 2, 4]    # stage-2 recursion, 100 windows: 4 x 1005 rows = 16 row tiles
+    assert best_prefill_batch(8, 327) == 6                                       # stage-1 dense windows: 6 x 327 rows = 8 row tiles (8 x = 11 tiles, 22 of 32 CUs)
+    assert best_prefill_batch(8, 72) == 7                                        # stage-1 sparse windows: 7 x 72 = 504 of 512 rows
+    assert best_prefill_batch(1, 72) == 1 and best_prefill_batch(0, 72) == 1
+    for rows in (40, 200, 650, 1005, 2392):
+        for avail in range(1, 9):
+            assert 1 <= best_prefill_batch(avail, rows) <= avail
+
+
 def test_decode_server_gang_policy_fills_seals_and_alternates_pools():
     """Host logic of ``serve.DecodeServer(gang=True)`` on stand-in pools (no device): generates reserve rows in the FILLING pool, a pool
     that cannot take another one of that size is sealed, the next reservations go to the other pool once it is idle, a generate that
