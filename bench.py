@@ -592,8 +592,8 @@ def main():
 
         S = ids.shape[1] - 1 + (frames if kind == "stage1_dense" else 1)
         if args.merge_decode and streams is not None:
-            # windows in flight share the weight passes like the stage-2 recursions do: one-row generates fill a 32-row KV pool
-            # (gang policy), their prefills ride four to a pass, a merged decode step serves up to 32 windows
+            # windows in flight share the weight passes like the stage-2 recursions do: one-row generates fill a KV pool of up to 128 rows
+            # (gang policy), their prefills ride 6 / 7 to a pass (serve.best_prefill_batch), a merged decode step serves the whole pool
             from revisionllm_amd import serve
             NB = max(1, args.s1_inflight)
             pb1 = args.s1_prefill_batch or (8 if kind == "stage1_sparse" else 6)

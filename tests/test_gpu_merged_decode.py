@@ -481,3 +481,35 @@ def test_fp8_decode_weights_in_wide_merged_steps_7b_layer(R):
     p2 = torch.full((R,), S + steps, dtype=torch.int32, device="cuda:0")
     a8 = eng.llm_decode_rows(hrow + 0.01, p2, pool, Smax)
     assert not torch.equal(a16, a8)
+
+
+def test_handoff_status_travels_as_one_snapshot_and_still_raises():
+    """Round 4: the hand-off status words of all workspaces go to pinned host memory as ONE snapshot behind a recursion's results
+    (``Engine.handoff_status_async``) instead of one ``.item()`` per workspace when the record is collected.  A clean run yields a clean
+    snapshot; a status word that a kernel's bounded wait would have set is reported through the snapshot AND through the synchronous
+    form, names its workspace, and is cleared so that the next check is clean again."""
+    from revisionllm_amd import hip
+    m = _tiny_model()
+    eng = m.engine
+    P = 40
+    from revisionllm_amd.utils import synth
+    ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
+    feat = feats("status.feat", (1, 6, 16, 768), bf16=True)
+    q = (feats("status.q", (1, 5, 768), bf16=True), torch.ones(1, 5))
+    m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=3)       # workspaces exist now
+    snap = eng.handoff_status_async()
+    assert snap is not None and len(snap[0]) == snap[1].numel() >= 1
+    torch.cuda.synchronize()
+    eng.check_handoff_status(snap)                                                         # clean
+    eng.check_handoff_status()
+    key = snap[0][0]
+    eng._ws[key][8188:8192].view(torch.int32).fill_(1)                                     # what a timed-out in-kernel wait writes
+    bad = eng.handoff_status_async()
+    torch.cuda.synchronize()
+    with pytest.raises(hip.HipLibraryError, match="hand-off wait timed out"):
+        eng.check_handoff_status(bad)
+    eng.check_handoff_status()                                                             # cleared by the failed check
+    eng._ws[key][8188:8192].view(torch.int32).fill_(1)
+    with pytest.raises(hip.HipLibraryError, match="hand-off wait timed out"):
+        eng.check_handoff_status()
+    eng.check_handoff_status()
