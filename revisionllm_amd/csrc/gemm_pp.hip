@@ -156,6 +156,10 @@ __device__ __forceinline__ void wait_vm() {
 //   end of ph3: U0(c+1) landed (and the older U1(c+1))  -> U2(c+1), U3(c+1), U1 U0 U2 (c+2)     = n2 ? 6 + 2j : 2 + j      (n1 only)
 // WAR: U3(c+1) overwrites U3(c-1), last read in phase 2 of tile c-1 (>= 3 slots earlier); U0(c+2) overwrites U0(c), read in phase 0 of
 // this tile by both groups (slots 0, 1; the issue is in slots 4, 5); a W stage is rewritten >= 1 tile after its last read.
+#ifndef PP_ISSUE_MID
+#define PP_ISSUE_MID 0
+#endif
+#define _PP_C ,
 constexpr int PP_A_STAGE = 2 * UNIT, PP_W_BASE = 2 * PP_A_STAGE, PP_W_STAGE = 2 * UNIT;
 // F8: the operands are FP8 (e4m3fn) bytes addressed as if they were bf16 matrices of K / 2 columns - a 128-byte staged row is
 // then 128 k instead of 64 and a W piece holds, per lane, k = 16 kg .. + 15 of each 64-k half (the bf16 fragment packing of the
@@ -208,18 +212,31 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         char* wnn = smem + PP_W_BASE + (ws == 0 ? 2 : ws - 1) * PP_W_STAGE;   // (c + 2) % 3
         const int k1 = (kt0 + c + 1) * PBK, k2 = k1 + PBK;
 
-#define PP_MFMA(B, NI, MI0, NJ)                                                                                     \
+        // PART 0 / 1: the two halves of a phase's MFMAs (bf16: k32 half ks = PART of every fragment pair, i.e. the order every accumulator
+        // sees is unchanged; FP8: fragment columns j < NJ / 2 | the rest).  PP_ISSUE_MID: the phase's LDS-DMA unit is issued BETWEEN the halves.
+#define PP_MFMA_PART(B, NI, MI0, NJ, PART)                                                                          \
     do {                                                                                                            \
-        __builtin_amdgcn_s_setprio(1);                                                                              \
         if constexpr (F8) {                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int f = 0; f < 4; ++f)           \
+            _Pragma("unroll") for (int j = (PART) * ((NJ) / 2); j < ((PART) ? (NJ) : (NJ) / 2); ++j)                 \
+                _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                        \
                 acc[(NI) + j][(MI0) + f] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                        \
                     pp_cat(B[j][0], B[j][1]), pp_cat(af[f][0], af[f][1]), acc[(NI) + j][(MI0) + f], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
         } else {                                                                                                    \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < (NJ); ++j)        \
+            _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                         \
                 _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                             \
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][ks], af[f][ks], acc[(NI) + j][(MI0) + f], 0, 0, 0); \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][(PART)], af[f][(PART)], acc[(NI) + j][(MI0) + f], 0, 0, 0); \
         }                                                                                                           \
+    } while (0)
+#define PP_MFMA(B, NI, MI0, NJ, MID_ISSUE)                                                                          \
+    do {                                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        PP_MFMA_PART(B, NI, MI0, NJ, 0);                                                                            \
+        if constexpr (PP_ISSUE_MID) {                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            MID_ISSUE;                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
+        PP_MFMA_PART(B, NI, MI0, NJ, 1);                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                              \
     } while (0)
 #define PP_READ_A(BASE)                                                                                             \
@@ -243,29 +260,33 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
 
+        // PP_ISSUE_MID = 1: the unit of a phase is issued in the MIDDLE of its compute part (between the two halves of its MFMAs, which run on
+        // while the wave issues) instead of in its memory part.  Group 1 waits at the end of its memory part, i.e. BEFORE that issue: its counts
+        // exclude the unit (2 loads; NJ1 for U2); group 0 waits behind its compute part: unchanged.
+        constexpr int MID = PP_ISSUE_MID;
         // ---- phase 0: quadrant (m0, n0) ----
         PP_READ_W(b0, wcur, w_rd, 2)
         PP_READ_A(acur)
-        if constexpr (m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
-        PP_SYNC_M(wait_vm<m1 ? 8 + NJ1 : 2>())                    // U2 of this tile
-        PP_MFMA(b0, 0, 0, 2);
+        if constexpr (!MID && m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
+        PP_SYNC_M(wait_vm<m1 ? 8 + NJ1 - 2 * MID : 2>())          // U2 of this tile
+        PP_MFMA(b0, 0, 0, 2, if constexpr (m1) issue_unit<3 _PP_C NF>(src, k1, anxt + UNIT, wave));
         PP_SYNC_C(wait_vm<m1 ? 8 + NJ1 : 2>())
         // ---- phase 1: quadrant (m0, n1) ----
         PP_READ_W(b1, wcur + UNIT, w_rd1, NJ1)
-        if constexpr (m2) issue_unit<1, NF>(src, k2, wnn, wave);
-        PP_SYNC_M(wait_vm<m2 ? 8 + NJ1 : m1 ? 6 + NJ1 : 0>())     // U3 of this tile
-        PP_MFMA(b1, 2, 0, NJ1);
+        if constexpr (!MID && m2) issue_unit<1, NF>(src, k2, wnn, wave);
+        PP_SYNC_M(wait_vm<m2 ? 8 + NJ1 - 2 * MID : m1 ? 6 + NJ1 : 0>())     // U3 of this tile
+        PP_MFMA(b1, 2, 0, NJ1, if constexpr (m2) issue_unit<1 _PP_C NF>(src, k2, wnn, wave));
         PP_SYNC_C(wait_vm<m2 ? 8 + NJ1 : m1 ? 6 + NJ1 : 0>())
         // ---- phase 2: quadrant (m1, n1) ----
         PP_READ_A(acur + UNIT)
-        if constexpr (m2) issue_unit<0, NF>(src, k2, acur, wave);   // U0(c+2) into the slot U0(c) left in phase 0
+        if constexpr (!MID && m2) issue_unit<0, NF>(src, k2, acur, wave);   // U0(c+2) into the slot U0(c) left in phase 0
         PP_SYNC_M((void)0)
-        PP_MFMA(b1, 2, 4, NJ1);
+        PP_MFMA(b1, 2, 4, NJ1, if constexpr (m2) issue_unit<0 _PP_C NF>(src, k2, acur, wave));
         PP_SYNC_C((void)0)
         // ---- phase 3: quadrant (m1, n0) ----
-        if constexpr (m2) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
-        PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 : 2 + NJ1>())  // U0 (and the older U1) of the next tile
-        PP_MFMA(b0, 0, 4, 2);
+        if constexpr (!MID && m2) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
+        PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 - NJ1 * MID : 2 + NJ1>())  // U0 (and the older U1) of the next tile
+        PP_MFMA(b0, 0, 4, 2, if constexpr (m2) issue_unit<2 _PP_C NF>(src, k2, wnn + UNIT, wave));
         PP_SYNC_C(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 : 2 + NJ1>())
     };
     auto run = [&](auto group_c) {
@@ -284,6 +305,7 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     if (wr == 0) run(std::integral_constant<int, 0>{});   // the two groups run separate copies of the loop
     else run(std::integral_constant<int, 1>{});
 #undef PP_MFMA
+#undef PP_MFMA_PART
 #undef PP_READ_A
 #undef PP_READ_W
 #undef PP_SYNC_M
