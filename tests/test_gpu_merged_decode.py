@@ -179,14 +179,16 @@ def test_batched_prefill_groups_match_separate_prefills(G, P0):
     assert rel_err(lb[3:3 + 7 * G].cpu(), la[3:3 + 7 * G].cpu()) < 1e-2
 
 
-def _tiny_model():
+def _tiny_model(parity=False):
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
     m = ReVisionLlamaForCausalLM(synth.TINY, device="cuda:0")
     m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None,
                                                             pretrain_mm_mlp_adapter=None, clip_adapter_text=True, clip_adapter_feature="cls",
                                                             hierarchy=True, adapter_input_dim=768))
-    m.engine.init_synthetic(seed=SEED, llm=True, clip=True)
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=True, parity=parity)
+    if parity:
+        m.engine.set_option("precision", 1)
     m.generation_config.eos_token_id = None
     return m
 
@@ -325,13 +327,15 @@ def test_decode_server_with_eos_equals_classic_loop(pools):
     assert not server.jobs and not server.draining and sum(n for _, n, _ in server.free) == 16 * pools
 
 
-def test_one_row_generates_in_flight_share_prefill_passes_and_decode_steps():
+@pytest.mark.parametrize("parity", [False, True])
+def test_one_row_generates_in_flight_share_prefill_passes_and_decode_steps(parity):
     """The stage-1 shape of the pipeline (bench.py ``workload_stage1_*``): six ONE-row generates (own window features each, no shared
-    prefix) in flight - prefills of identical geometry ride four / two to a pass with P0 = 0, decode steps merged in a gang-filled
-    pool - against the classic loop: same sequences and entropies (tiny model: the tile GEMM serves every pass size)."""
+    prefix) in flight - prefills of identical geometry ride four / two to a pass with P0 = 0 (their attention in ONE launch for all groups,
+    ``k_attention_groups``), decode steps merged in a gang-filled pool - against the classic loop: same sequences and entropies (tiny
+    model: the tile GEMM serves every pass size).  ``parity``: the same in the parity precision (split Q, split attention output)."""
     from revisionllm_amd import sched, serve
     from revisionllm_amd.utils import synth
-    m = _tiny_model()
+    m = _tiny_model(parity)
     P = 40
     ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
     cases = []
