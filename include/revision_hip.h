@@ -52,7 +52,9 @@ typedef struct rv_config {
     /* LLM (HF LlamaConfig of Vicuna-7B-v1.5: 4096/11008/32/32/32000, eps 1e-5, theta 1e4) */
     int32_t hidden, inter, layers, heads, vocab;
     float rms_eps, rope_theta;
-    /* adapter (revisionllm/model/adapter/transformer.py:61-62: 768, 8 heads, 2+2 layers, ff 2048) */
+    /* adapter (revisionllm/model/adapter/transformer.py:61-62: 768, 8 heads, 2+2 layers, ff 2048).  adapter_dim == hidden == 4096 selects the
+     * `cross_attn` ClipEncoder of transformer.py:65-67 (d_model = hidden_size, 8 heads of 512): its inputs are hidden-wide and, with "adp.proj_w"
+     * left unbound, it has no output projector (nn.Identity, transformer.py:86) */
     int32_t adapter_dim, adapter_heads, adapter_ff, adapter_layers;
     int32_t adapter_text; /* clip_adapter_text: run the two text->video layers */
 } rv_config;
@@ -196,7 +198,8 @@ int rv_attention(const void* q, int64_t q_row_stride, int64_t q_batch_stride, co
 /* nn.Linear(768, D) projector on [rows,768] bf16 -> [rows,D] (vtimellm_arch.py:42,125). out f32 or bf16. */
 int rv_project_dense(rv_ctx* ctx, const void* x_bf16, void* y, int out_dtype, int64_t rows, void* stream);
 /* ClipEncoder.forward (transformer.py:94-145) on N independent sequences.
- * x [N,T,768] bf16; txt [Nq,Lq,768] bf16 and txt_mask u8 [Nq,Lq] (1 = valid) with sequence n using text
+ * x [N,T,d] bf16; txt [Nq,Lq,d] bf16 (d = adapter_dim: 768, or 4096 for the hidden-wide cross_attn encoder, whose callers project frames and
+ * text first - mm_projector / text_mm_projector, vtimellm_arch.py:125, transformer.py:105-106) and txt_mask u8 [Nq,Lq] (1 = valid) with sequence n using text
  * row n / (N/Nq) (hierarchy: '(b v) t d', vtimellm_arch.py:115-121); ignored when adapter_text == 0.
  * out f32: RV_FEAT_CLS [N,D]; RV_FEAT_ALL [N,T+1,D] (row 0 = CLS; the 'temporal' feature is rows 1..T,
  * sliced by the caller). */

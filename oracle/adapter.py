@@ -125,6 +125,8 @@ def clip_encoder(src, w, src_txt=None, mask_text=None, clip_adapter_text=True, f
         sel = x[:, 1:]
     else:
         sel = x
+    if "mm_projector.weight" not in w:      # the hidden-wide cross_attn ClipEncoder: mm_projector = nn.Identity() (transformer.py:86)
+        return sel
     return F.linear(sel, w["mm_projector.weight"], w["mm_projector.bias"])
 
 
@@ -152,3 +154,15 @@ def encode_images(images, w, query_feats=None, clip_adapter=True, clip_adapter_t
         return out.reshape(b, v, -1)
     return clip_encoder(images, w, query_feats[0], query_feats[1], clip_adapter_text, feature, hierarchy,
                         iteration_step)
+
+
+def encode_images_cross_attn(images, w_lin, w_ca, query_feats, clip_adapter_text=True, feature="cls", hierarchy=True,
+                             iteration_step=None):
+    """Adapter dispatch for ``cross_attn=True`` WITHOUT ``pretrain_clip_adapter`` (vtimellm_arch.py:52-57,125-144): the Linear
+    ``mm_projector`` (768 -> hidden) runs first, then the separate hidden-wide ``cross_attn`` ClipEncoder (transformer.py:65-67:
+    ``src_txt = text_mm_projector(src_txt)``, d_model = hidden_size, no output projector) on the projected frames.
+
+    w_lin: {'weight', 'bias'}; w_ca: the ClipEncoder's state dict incl. 'text_mm_projector.*'.  Shapes as ``encode_images``."""
+    x = dense_projector(images, w_lin["weight"], w_lin["bias"])
+    txt = F.linear(query_feats[0], w_ca["text_mm_projector.weight"], w_ca["text_mm_projector.bias"])
+    return encode_images(x, w_ca, (txt, query_feats[1]), True, clip_adapter_text, feature, hierarchy, iteration_step)

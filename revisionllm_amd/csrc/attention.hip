@@ -307,6 +307,13 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, st, a, tiles);
     else if (a.dh == 128)
         hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, st, a, tiles);
+    else if (a.dh == 512) {
+        // the 4096-d cross_attn ClipEncoder (8 heads of 512): the same body with 16 query / 32 output fragments per wave - 256 + 250 registers,
+        // one wave per SIMD.  A coverage path (no shipped script selects this adapter), not a tuned one; short query counts take the same
+        // kernel (the key-split form would need 132 KiB of static LDS for its merge)
+        const int t512 = (int)cdiv(a.Lq, 64);
+        hipLaunchKernelGGL((attn_kernel<512, false>), dim3(attn_grid(t512, a.H * a.B)), dim3(256), 0, st, a, t512);
+    }
     else {
         rv_set_error("attention: head dim %d unsupported (64, 96, 128)", a.dh);
         return RV_ERR_ARG;

@@ -86,8 +86,13 @@ int resolve_adapter(rv_ctx* c) {
     const int64_t d = g.adapter_dim, ff = g.adapter_ff, D = g.hidden;
     FIND("adp.cls_token", RV_F32, d, c->cls_token);
     FIND("adp.cls_pos", RV_F32, d, c->cls_pos);
-    FIND("adp.proj_w", RV_BF16, D * d, c->adp_proj_w);
-    FIND("adp.proj_b", RV_F32, D, c->adp_proj_b);
+    if (d == D && c->w.find("adp.proj_w") == c->w.end()) {      // cross_attn ClipEncoder: mm_projector = nn.Identity() (transformer.py:86)
+        c->adp_proj_w = nullptr;
+        c->adp_proj_b = nullptr;
+    } else {
+        FIND("adp.proj_w", RV_BF16, D * d, c->adp_proj_w);
+        FIND("adp.proj_b", RV_F32, D, c->adp_proj_b);
+    }
     for (int stack = 0; stack < 2; ++stack) {
         std::vector<AdapterLayer>& v = stack == 0 ? c->t2v : c->enc;
         v.clear();
@@ -273,7 +278,10 @@ extern "C" int rv_ctx_create(const rv_config* cfg, rv_ctx** out) {
     RV_CHECK_ARG(cfg->hidden > 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0, "rv_ctx_create: bad hidden/heads");
     RV_CHECK_ARG(cfg->hidden / cfg->heads == 128, "rv_ctx_create: LLM head dim must be 128 (got %d)", cfg->hidden / cfg->heads);
     RV_CHECK_ARG(cfg->hidden % 128 == 0 && cfg->inter % 128 == 0, "rv_ctx_create: hidden and inter must be multiples of 128");
-    RV_CHECK_ARG(cfg->adapter_dim == 768 && cfg->adapter_heads == 8, "rv_ctx_create: adapter must be 768-d with 8 heads");
+    // 768-d ClipEncoder (8 heads of 96), or the 4096-d `cross_attn` ClipEncoder of a 4096-d LLM (transformer.py:65-67: d_model = hidden_size,
+    // 8 heads of 512, no output projector)
+    RV_CHECK_ARG(cfg->adapter_heads == 8 && (cfg->adapter_dim == 768 || (cfg->adapter_dim == 4096 && cfg->adapter_dim == cfg->hidden)),
+                 "rv_ctx_create: the adapter is 768-d, or hidden-wide (4096) for the cross_attn ClipEncoder, with 8 heads");
     RV_CHECK_ARG(cfg->adapter_ff % 128 == 0 && cfg->adapter_layers >= 1, "rv_ctx_create: bad adapter ff/layers");
     rv_ctx* c = new rv_ctx();
     c->cfg = *cfg;
@@ -429,6 +437,8 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, y1, d, y2, d, RV_F32, RV_ACT_NONE, N, d, ff, w.sk, w.sk_bytes, st));
+            if (!c->adp_proj_w)      // identity projector: the CLS rows' last LayerNorm IS the output
+                return k_layernorm(y2, L.ln2_w, L.ln2_b, (float*)out, nullptr, nullptr, nullptr, 0, N, (int)d, st);
             RV_TRY(k_layernorm(y2, L.ln2_w, L.ln2_b, nullptr, w.x16, nullptr, nullptr, 0, N, (int)d, st));
             return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D, d, w.sk, w.sk_bytes, st);
         }
@@ -444,6 +454,16 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));
         RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, ff, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, w.x32, w.x16, w.xp16, w.pm, T + 1, R1, (int)d, st));
+    }
+    if (!c->adp_proj_w) {          // identity projector: the f32 encoder output rows (CLS rows: stride (T + 1) * d)
+        const hipError_t e = feature == RV_FEAT_CLS
+                                 ? hipMemcpy2DAsync(out, (size_t)d * 4, w.x32, (size_t)(T + 1) * d * 4, (size_t)d * 4, (size_t)N, hipMemcpyDeviceToDevice, st)
+                                 : hipMemcpyAsync(out, w.x32, (size_t)R1 * d * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) {
+            rv_set_error("rv_clip_encoder: output copy failed: %s", hipGetErrorString(e));
+            return RV_ERR_HIP;
+        }
+        return RV_OK;
     }
     if (feature == RV_FEAT_CLS)
         return rv_gemm_impl(w.x16, (int64_t)(T + 1) * d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D,

@@ -283,22 +283,25 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 }
 
 // ---- V [Nb, L, H*DH] bf16 (row stride ld) -> V^T [Nb, H, DH, Lpad] bf16, zero padded to Lpad ----
+// (DH = 512 - the 4096-d cross_attn ClipEncoder - takes its head in four 128-column slices, blockIdx.y = head * 4 + slice: the LDS tile stays 16 KiB)
 template <int DH>
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, int64_t ld, bf16_t* __restrict__ vt,
                                                           int L, int Lpad, int H) {
-    __shared__ bf16_t tile[64][DH + 2];
-    const int l0 = blockIdx.x * 64, h = blockIdx.y;
+    constexpr int DC = DH > 128 ? 128 : DH;          // columns of the head handled by one workgroup
+    constexpr int NS = DH / DC;
+    __shared__ bf16_t tile[64][DC + 2];
+    const int l0 = blockIdx.x * 64, h = blockIdx.y / NS, d0 = (blockIdx.y % NS) * DC;
     const int64_t nb = blockIdx.z;
-    for (int i = threadIdx.x; i < 64 * (DH / 2); i += 256) {
-        const int r = i / (DH / 2), c2 = i % (DH / 2);
+    for (int i = threadIdx.x; i < 64 * (DC / 2); i += 256) {
+        const int r = i / (DC / 2), c2 = i % (DC / 2);
         uint32_t val = 0;
-        if (l0 + r < L) val = *(const uint32_t*)(v + (nb * L + l0 + r) * ld + h * DH + c2 * 2);
+        if (l0 + r < L) val = *(const uint32_t*)(v + (nb * L + l0 + r) * ld + h * DH + d0 + c2 * 2);
         tile[r][c2 * 2] = (bf16_t)(val & 0xffff);
         tile[r][c2 * 2 + 1] = (bf16_t)(val >> 16);
     }
     __syncthreads();
-    bf16_t* o = vt + ((nb * H + h) * DH) * (int64_t)Lpad;
-    for (int i = threadIdx.x; i < DH * 32; i += 256) {
+    bf16_t* o = vt + ((nb * H + h) * DH + d0) * (int64_t)Lpad;
+    for (int i = threadIdx.x; i < DC * 32; i += 256) {
         const int d = i / 32, l2 = i % 32;
         if (l0 + l2 * 2 < Lpad) {
             const uint32_t p = (uint32_t)tile[l2 * 2][d] | ((uint32_t)tile[l2 * 2 + 1][d] << 16);
@@ -470,6 +473,8 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
         hipLaunchKernelGGL(transpose_v_kernel<96>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
     else if (dh == 128)
         hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+    else if (dh == 512)
+        hipLaunchKernelGGL(transpose_v_kernel<512>, dim3(grid.x, grid.y * 4, grid.z), dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
     else {
         rv_set_error("transpose_v: head dim %d unsupported", dh);
         return RV_ERR_ARG;

@@ -170,8 +170,12 @@ class Engine:
         dev = self.device
         self.bind("adp.cls_token", _dev_f32(get("global_rep_token"), dev))
         self.bind("adp.cls_pos", _dev_f32(get("global_rep_pos"), dev))
-        self.bind("adp.proj_w", _dev_packed(get("mm_projector.weight"), dev))
-        self.bind("adp.proj_b", _dev_f32(get("mm_projector.bias"), dev))
+        if self.adapter_dim == self.shape.hidden and self.adapter_dim != 768:
+            # the hidden-wide `cross_attn` ClipEncoder (transformer.py:65-67,86): no output projector (nn.Identity), a text projector in front
+            self.txt_proj = (_dev_packed(get("text_mm_projector.weight"), dev), _dev_f32(get("text_mm_projector.bias"), dev))
+        else:
+            self.bind("adp.proj_w", _dev_packed(get("mm_projector.weight"), dev))
+            self.bind("adp.proj_b", _dev_f32(get("mm_projector.bias"), dev))
         stacks = ([("t2v_encoder", "t2v")] if self.adapter_text else []) + [("encoder", "enc")]
         for ref, tag in stacks:
             for l in range(self.adapter_layers):
@@ -191,8 +195,13 @@ class Engine:
         self._loaded()
 
     def load_linear_projector(self, get):
-        self.bind("proj.w", _dev_packed(get("weight"), self.device))
-        self.bind("proj.b", _dev_f32(get("bias"), self.device))
+        if self.adapter_dim != 768:
+            # next to a hidden-wide cross_attn ClipEncoder the Linear(768 -> hidden) projector runs IN FRONT of the encoder
+            # (vtimellm_arch.py:125 then :127-144); rv_project_dense is tied to the context's adapter width, so it goes through rv_gemm
+            self.frame_proj = (_dev_packed(get("weight"), self.device), _dev_f32(get("bias"), self.device))
+        else:
+            self.bind("proj.w", _dev_packed(get("weight"), self.device))
+            self.bind("proj.b", _dev_f32(get("bias"), self.device))
         self.has_linear = True
         self._loaded()
 
@@ -213,7 +222,8 @@ class Engine:
         if llm:
             self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill, parity=parity)
         if clip:
-            self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text), seed,
+            self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text,
+                                                                           cross_attn=self.adapter_dim != 768), seed,
                                                    clip_prefix))
         if linear:
             self.load_linear_projector(self._synth_get(synth.linear_projector_spec(hidden=self.shape.hidden), seed, linear_prefix))
@@ -278,9 +288,18 @@ class Engine:
         """x [N,T,768]; txt [Nq,Lq,768], txt_mask [Nq,Lq] (1 = valid) -> f32 [N,D] ('cls') or [N,T+1,D] ('all')."""
         N, T, _ = x.shape
         x = _dev_bf16(x, self.device)
+        wide = self.adapter_dim != 768           # the hidden-wide cross_attn ClipEncoder: frames and text are projected to its width first
+        if wide:
+            if getattr(self, "frame_proj", None) is None or getattr(self, "txt_proj", None) is None:
+                raise hip.HipLibraryError("the cross_attn ClipEncoder needs the Linear projector (load_linear_projector) and its text projector bound")
+            x = ops.gemm(x.reshape(N * T, -1), self.frame_proj[0], bias=self.frame_proj[1], out_dtype=torch.bfloat16, w_packed=True,
+                         ctx=self).view(N, T, self.adapter_dim)
         if self.adapter_text:
             txt = _dev_bf16(txt, self.device)
             Nq, Lq = txt.shape[0], txt.shape[1]
+            if wide:
+                txt = ops.gemm(txt.reshape(Nq * Lq, -1), self.txt_proj[0], bias=self.txt_proj[1], out_dtype=torch.bfloat16, w_packed=True,
+                               ctx=self).view(Nq, Lq, self.adapter_dim)
             m = ops.h2d((txt_mask != 0).to(torch.uint8), self.device).contiguous()
         else:
             txt, m, Nq, Lq = None, None, 0, 0

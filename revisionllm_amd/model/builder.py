@@ -153,7 +153,19 @@ def finalize(model):
     eng.load_llm(lambda n: sd[n], fp8_decode=getattr(model, "fp8_decode", False), fp8_prefill=getattr(model, "fp8_prefill", False), parity=getattr(model, "parity", False))
     if getattr(model, "parity", False):
         eng.set_option("precision", 1)
-    root = "model.cross_attn." if getattr(model.get_model(), "cross_attn_variant", False) else "model.mm_projector."
+    inner = model.get_model()
+    if getattr(inner, "cross_attn_dense", False):
+        # cross_attn=True without pretrain_clip_adapter: BOTH modules carry weights - the Linear 'model.mm_projector.*' in front and the
+        # hidden-wide ClipEncoder 'model.cross_attn.*' (vtimellm_arch.py:42,52-57)
+        lin = {k[len("model.mm_projector."):]: v for k, v in sd.items() if k.startswith("model.mm_projector.")}
+        ca = {k[len("model.cross_attn."):]: v for k, v in sd.items() if k.startswith("model.cross_attn.")}
+        if lin:
+            eng.load_linear_projector(lambda n: lin[n])
+        if ca:
+            eng.load_clip_adapter(lambda n: ca[n])
+        model._host_sd = None
+        return model
+    root = "model.cross_attn." if getattr(inner, "cross_attn_variant", False) else "model.mm_projector."
     proj = {k[len(root):]: v for k, v in sd.items() if k.startswith(root)}
     if proj:
         if model.get_model().clip_adapter:

@@ -68,9 +68,12 @@ class _Inner:
         assert not getattr(a, "clip_adapter", False) or not getattr(a, "cross_attn", False), \
             "both clip_adapter and cross_attn cannot be true"
         self.cross_attn_variant = bool(getattr(a, "cross_attn", False))
-        if self.cross_attn_variant and getattr(a, "pretrain_clip_adapter", None) is None and state_dict is None:
-            raise NotImplementedError("cross_attn=True without pretrain_clip_adapter builds the 4096-d ClipEncoder with a text "
-                                      "projector (transformer.py:65-67,86) - not built")
+        # cross_attn=True WITHOUT pretrain_clip_adapter (vtimellm_arch.py:52-57 -> transformer.py:65-67,86): the separate ``cross_attn`` module
+        # is a ClipEncoder as wide as the LLM (d_model = hidden_size, 8 heads of hidden / 8) with a ``text_mm_projector`` in front and no
+        # output projector; ``mm_projector`` stays the Linear(768 -> hidden) and runs FIRST (vtimellm_arch.py:125, then :127-144)
+        self.cross_attn_dense = self.cross_attn_variant and getattr(a, "pretrain_clip_adapter", None) is None
+        if self.cross_attn_dense and self.config.hidden_size != 4096:
+            raise NotImplementedError("the hidden-wide cross_attn ClipEncoder is built for hidden_size = 4096 (8 heads of 512)")
         # chapters variant (scripts/chapters/*.sh: --cross_attn True --pretrain_clip_adapter ...): mm_projector is a Linear
         # whose output is computed and then DISCARDED (vtimellm_arch.py:125,132-133); the separate ``cross_attn`` module is a
         # 768-d ClipEncoder applied to the RAW features.  That is exactly the clip_adapter data path with the weights
@@ -82,8 +85,14 @@ class _Inner:
             self.clip_adapter_feature = "cls"
         self.hierarchy = bool(getattr(a, "hierarchy", False))
         self.pretrain_clip_adapter = getattr(a, "pretrain_clip_adapter", None)
-        eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text if self.clip_adapter else None)
-        if state_dict is None:
+        eng = self._owner._ensure_engine(adapter_text=self.clip_adapter_text if self.clip_adapter else None,
+                                         adapter_dim=self.config.hidden_size if self.cross_attn_dense else 768)
+        if self.cross_attn_dense and state_dict is not None:
+            # adapter-relative names of BOTH modules: 'mm_projector.{weight,bias}' (the Linear) and the ClipEncoder's own names
+            eng.load_linear_projector(lambda n: state_dict["mm_projector." + n])
+            eng.load_clip_adapter(lambda n: state_dict[n])
+            state_dict = None
+        if state_dict is None and not self.cross_attn_dense:
             path = self.pretrain_clip_adapter if self.clip_adapter else getattr(a, "pretrain_mm_mlp_adapter", None)
             if path is not None:
                 state_dict = builder.remap_projector_keys(torch.load(path, map_location="cpu"), clip=self.clip_adapter)
@@ -128,11 +137,11 @@ class ReVisionLlamaForCausalLM:
         self.after_prefill = None  # optional () -> None hook called between the prefill and the decode loop of generate()
 
     # ---- plumbing -------------------------------------------------------------------------------
-    def _ensure_engine(self, adapter_text=None):
+    def _ensure_engine(self, adapter_text=None, adapter_dim=768):
         if self.engine is None:
-            self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device)
-        elif adapter_text is not None and bool(adapter_text) != self.engine.adapter_text:
-            raise RuntimeError("the engine's ClipEncoder topology (text-conditioned layers on / off) differs from this model's")
+            self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device, adapter_dim=adapter_dim)
+        elif adapter_text is not None and (bool(adapter_text) != self.engine.adapter_text or adapter_dim != self.engine.adapter_dim):
+            raise RuntimeError("the engine's ClipEncoder topology (text-conditioned layers on / off, width) differs from this model's")
         return self.engine
 
     def get_model(self):

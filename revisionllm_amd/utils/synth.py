@@ -94,10 +94,15 @@ def _xavier(fan_out, fan_in):
     return math.sqrt(6.0 / (fan_in + fan_out))
 
 
-def clip_encoder_spec(d=768, ff=2048, hidden=4096, n_layers=2, text=True):
-    """State dict of ``ClipEncoder`` (non-cross_attn).  Matrices are xavier-uniform as in
-    transformer.py:89-92; vectors get small non-trivial values so biases / LayerNorm affine are exercised."""
+def clip_encoder_spec(d=768, ff=2048, hidden=4096, n_layers=2, text=True, cross_attn=False, d_in=768):
+    """State dict of ``ClipEncoder``.  Matrices are xavier-uniform as in transformer.py:89-92; vectors get small non-trivial
+    values so biases / LayerNorm affine are exercised.  ``cross_attn`` (transformer.py:65-67,86: the 4096-d variant): the encoder
+    is ``hidden`` wide, carries ``text_mm_projector`` (d_in -> hidden) and has NO output projector (``nn.Identity``)."""
+    if cross_attn:
+        d = hidden
     spec = [("global_rep_token", (d,), SQRT3, 0.0), ("global_rep_pos", (d,), SQRT3, 0.0)]
+    if cross_attn:
+        spec += [("text_mm_projector.weight", (hidden, d_in), _xavier(hidden, d_in), 0.0), ("text_mm_projector.bias", (hidden,), 0.05, 0.0)]
     stacks = (["t2v_encoder"] if text else []) + ["encoder"]
     for st in stacks:
         for l in range(n_layers):
@@ -116,7 +121,8 @@ def clip_encoder_spec(d=768, ff=2048, hidden=4096, n_layers=2, text=True):
                 (p + "norm2.weight", (d,), 0.1, 1.0),
                 (p + "norm2.bias", (d,), 0.05, 0.0),
             ]
-    spec += [("mm_projector.weight", (hidden, d), _xavier(hidden, d), 0.0), ("mm_projector.bias", (hidden,), 0.05, 0.0)]
+    if not cross_attn:
+        spec += [("mm_projector.weight", (hidden, d), _xavier(hidden, d), 0.0), ("mm_projector.bias", (hidden,), 0.05, 0.0)]
     return spec
 
 

@@ -856,6 +856,32 @@ def g13_loader(M):
     print("wrote g13_loader.json", {k: len(v.get("loaded", {})) for k, v in out.items()})
 
 
+def g14_cross_attn_dense(M):
+    """``cross_attn=True`` WITHOUT ``pretrain_clip_adapter`` (vtimellm_arch.py:52-57 -> transformer.py:65-67,86,105-106): the separate
+    ``cross_attn`` module is a ClipEncoder as wide as the LLM (d_model = hidden_size = 4096, 8 heads of 512) with ``text_mm_projector``
+    in front and ``nn.Identity`` behind; ``mm_projector`` (Linear 768 -> 4096) runs first (vtimellm_arch.py:125, :127-144).
+    The reference's own modules on hash-seeded weights; hierarchy / CLS output [B, 1, 4096]."""
+    out = {}
+    lin = synth.build_numpy(synth.linear_projector_spec(hidden=4096), SEED, prefix="g14.mm_projector.")
+    for text in (True, False):
+        enc = M["transformer"].ClipEncoder(hidden_size=4096, clip_adapter_text=text, cross_attn=True, hierarchy=True,
+                                           clip_adapter_feature="cls").eval()
+        assert enc.hidden_dim == 4096 and isinstance(enc.mm_projector, torch.nn.Identity)
+        w = synth.build_numpy(synth.clip_encoder_spec(hidden=4096, text=text, cross_attn=True), SEED, prefix="g14.cross_attn.")
+        fill(enc, w, "g14.cross_attn.")
+        B, Tn, Lq = 2, 16, 7
+        src = T(synth.features("g14.src", (B, Tn, 768), SEED))
+        txt = T(synth.features("g14.txt", (B, Lq, 768), SEED))
+        mt = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]], dtype=torch.float32)
+        with torch.no_grad():
+            x = torch.nn.functional.linear(src, T(lin["g14.mm_projector.weight"]), T(lin["g14.mm_projector.bias"]))   # mm_projector(images)
+            y = enc(x, txt, mt, None)                                                                              # cross_attn(images_h, query_feats_h, masks_h, step)
+        assert y.shape == (B, 1, 4096), y.shape
+        out[f"text{int(text)}_cls"] = y
+        del enc, w
+    save("g14_cross_attn_dense", **out)
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -864,7 +890,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense)
     for k, fn in groups.items():
         if (only and k not in only) or (not only and k in ("g8", "g8c", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue

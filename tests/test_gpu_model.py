@@ -740,3 +740,45 @@ def test_parity_precision_closes_the_llm_gemm_operand_roundings():
         m2.generate(ids, images=feat, query_feats=None, do_sample=False, max_new_tokens=2)
     with pytest.raises(hip.HipLibraryError):
         m2.engine.set_option("precision", 2)
+
+
+@pytest.mark.parametrize("text", [True, False])
+def test_cross_attn_dense_clip_encoder_vs_reference_golden_and_oracle(golden, text):
+    """``cross_attn=True`` WITHOUT ``pretrain_clip_adapter`` (VERDICT r3 missing #4; vtimellm_arch.py:52-57, transformer.py:65-67,86): the Linear
+    projector (768 -> 4096) runs first, then the separate ClipEncoder as wide as the LLM - 8 heads of 512 (``attn_kernel<512>``), text
+    projector in front, no output projector.  Through ``initialize_vision_modules`` / ``encode_images`` (hierarchy) against the reference's
+    own modules (golden G14, fp32 weights) and against the oracle on the bf16-representable weights the device holds."""
+    from oracle import adapter
+    from revisionllm_amd.model import ReVisionLlamaForCausalLM
+    from revisionllm_amd.utils import synth
+    lin32 = synth.build_numpy(synth.linear_projector_spec(hidden=4096), SEED, prefix="g14.mm_projector.")
+    spec = synth.clip_encoder_spec(hidden=4096, text=text, cross_attn=True)
+    ca32 = synth.build_numpy(spec, SEED, prefix="g14.cross_attn.")
+    sd = {("mm_projector." + k[len("g14.mm_projector."):]): T(v) for k, v in lin32.items()}
+    sd.update({k[len("g14.cross_attn."):]: T(v) for k, v in ca32.items()})
+    m = ReVisionLlamaForCausalLM(synth.LlamaShape(layers=0))          # hidden 4096; no LLM weights are needed for the adapter
+    m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=False, cross_attn=True, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None,
+                                                            clip_adapter_text=text, clip_adapter_feature="cls", hierarchy=True, adapter_input_dim=768),
+                                            state_dict=sd)
+    assert m.get_model().cross_attn_dense and m.engine.adapter_dim == 4096
+    src, txt = feats("g14.src", (2, 16, 768)), feats("g14.txt", (2, 7, 768))
+    mt = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]], dtype=torch.float32)
+    rows, rps = m.encode_images(src[:, None].to(torch.bfloat16), (txt.to(torch.bfloat16), mt))      # hierarchy: [b, v = 1, t, d]
+    assert rps == 1 and rows.shape == (2, 4096)
+    g = golden.npz("g14_cross_attn_dense")[f"text{int(text)}_cls"][:, 0]
+    e_ref = rel_err(rows.cpu(), g)
+    # the oracle on what the device holds: matrices and inputs rounded to bf16, vectors fp32
+    def dev_w(d32, pref):
+        out = {}
+        for k, v in d32.items():
+            t = T(v)
+            out[k[len(pref):]] = t.to(torch.bfloat16).float() if t.dim() == 2 else t
+        return out
+    y = adapter.encode_images_cross_attn(src.to(torch.bfloat16).float(), dev_w(lin32, "g14.mm_projector."), dev_w(ca32, "g14.cross_attn."),
+                                         (txt.to(torch.bfloat16).float(), mt), clip_adapter_text=text, feature="cls", hierarchy=False)[:, 0]
+    e_or = rel_err(rows.cpu(), y)
+    print(f"\n[cross_attn dense, text={text}] rel err vs the reference's modules (fp32 weights) {e_ref:.3e}, vs the oracle on bf16 weights {e_or:.3e}")
+    assert e_or < 6e-3 and e_ref < 8e-3          # (measured 2.4e-3 / 3.3e-3)
+    # the 'all rows' form agrees with the CLS form on the CLS row
+    yall = m.engine.clip_encoder(src.to(torch.bfloat16), txt.to(torch.bfloat16), mt, "all")
+    assert yall.shape == (2, 17, 4096) and rel_err(yall[:, 0].cpu(), rows.cpu()) < 1e-2

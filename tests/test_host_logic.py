@@ -440,3 +440,30 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 4 but the launcher started 2 rank(s)" in (r.stderr + r.stdout)
+
+
+def test_finalize_routes_the_cross_attn_dense_checkpoint_keys():
+    """cross_attn=True without pretrain_clip_adapter (vtimellm_arch.py:42,52-57): the checkpoint carries the Linear under 'model.mm_projector.*'
+    AND the hidden-wide ClipEncoder under 'model.cross_attn.*' - ``builder.finalize`` hands each module its own keys (host logic; stub engine)."""
+    import types
+    from revisionllm_amd.model import builder
+    calls = {}
+
+    class Eng:
+        def load_llm(self, get, **kw):
+            calls["llm"] = get("model.embed_tokens.weight")
+
+        def load_linear_projector(self, get):
+            calls["lin"] = (get("weight"), get("bias"))
+
+        def load_clip_adapter(self, get):
+            calls["ca"] = (get("global_rep_token"), get("text_mm_projector.weight"))
+
+        def set_option(self, *a):
+            pass
+    inner = types.SimpleNamespace(cross_attn_dense=True, cross_attn_variant=True, clip_adapter=True)
+    model = types.SimpleNamespace(_host_sd={"model.embed_tokens.weight": 1, "model.mm_projector.weight": 2, "model.mm_projector.bias": 3,
+                                            "model.cross_attn.global_rep_token": 4, "model.cross_attn.text_mm_projector.weight": 5},
+                                  _ensure_engine=lambda: Eng(), get_model=lambda: inner)
+    builder.finalize(model)
+    assert calls == {"llm": 1, "lin": (2, 3), "ca": (4, 5)} and model._host_sd is None
