@@ -404,11 +404,16 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st));
-            RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, v32, nullptr, vp16, w.pm + d, T, R0, (int)d, st));
+            if (l + 1 < c->t2v.size()) {
+                RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, v32, nullptr, vp16, w.pm + d, T, R0, (int)d, st));
+            } else {
+                // the LAST text->video LayerNorm writes X = [CLS ; frames] in place: frame rows of x32 / x16 / xp16 = bf16(x + pos) at
+                // n * (T + 1) + t + 1 (its input is y32, so overwriting v32 = x32 is safe); the CLS rows follow.  (Rounds 1 - 3: a staging copy
+                // of the frames + a re-assembly pass, 34 + 38 us per recursion of 100 x 256 frames.)  Same values, same roundings.
+                RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, w.x32, w.x16, w.xp16, w.pm + d, T, R0, (int)d, st, T));
+                RV_TRY(k_cls_rows(c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
+            }
         }
-        // X = [CLS ; frames]; y32 is free, use it as the staging copy of the frames
-        RV_TRY(k_copy_f32(v32, w.y32, R0 * d, st));
-        RV_TRY(k_build_x(nullptr, w.y32, c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
     } else {
         RV_TRY(k_build_x(x, nullptr, c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
     }

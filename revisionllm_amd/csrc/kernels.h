@@ -216,7 +216,7 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st);
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap = 0);
 int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
@@ -233,6 +233,7 @@ int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
               int64_t N, int T, int d, hipStream_t st);
 int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+int k_cls_rows(const float* cls, const float* pm, float* x32, void* x16, void* xp16, int64_t N, int T, int d, hipStream_t st);   // row 0 of every [CLS ; frames] sequence
 int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st);
 int k_rope_table_rows(float* cs, const int* row_pos, int rows, int dh, float theta, hipStream_t st);   // row m: position max(row_pos[m], 0)

@@ -11,12 +11,15 @@ template <int NV>  // d = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y32,
                                                         bf16_t* __restrict__ y16, bf16_t* __restrict__ yp16,
-                                                        const float* __restrict__ pos, int64_t period, int64_t rows) {
+                                                        const float* __restrict__ pos, int64_t period, int64_t rows, int64_t gap) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * D;
+    // gap > 0: the outputs leave one row free in front of every `gap` rows (the adapter's [CLS ; frames] layout: frame t of sequence n -> row
+    // n * (gap + 1) + t + 1), so the last text->video LayerNorm writes the encoder's input in place - no staging copy, no re-assembly pass
+    const int64_t orow = gap > 0 ? row + row / gap + 1 : row;
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -42,11 +45,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
-        if (y32) *(f32x4*)(y32 + row * D + c) = y;
-        if (y16) *(u32x2*)(y16 + row * D + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        if (y32) *(f32x4*)(y32 + orow * D + c) = y;
+        if (y16) *(u32x2*)(y16 + orow * D + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
         if (yp16) {
             const f32x4 p = *(const f32x4*)(pr + c);
-            *(u32x2*)(yp16 + row * D + c) = u32x2{pack_bf16x2(y[0] + p[0], y[1] + p[1]), pack_bf16x2(y[2] + p[2], y[3] + p[3])};
+            *(u32x2*)(yp16 + orow * D + c) = u32x2{pack_bf16x2(y[0] + p[0], y[1] + p[1]), pack_bf16x2(y[2] + p[2], y[3] + p[3])};
         }
     }
 }
@@ -277,6 +280,21 @@ __global__ void build_x_kernel(const bf16_t* __restrict__ src16, const float* __
     *(u32x2*)(xp16 + i) = u32x2{pack_bf16x2(v[0] + p[0], v[1] + p[1]), pack_bf16x2(v[2] + p[2], v[3] + p[3])};
 }
 
+// the CLS rows of X = [cls ; frames] alone (row n * (T + 1) of x32 / x16 / xp16): the frame rows were written in place by the last
+// text->video LayerNorm (layernorm_kernel, gap = T)
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pm, float* __restrict__ x32, bf16_t* __restrict__ x16,
+                                bf16_t* __restrict__ xp16, int64_t N, int T, int d) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= N * d) return;
+    const int64_t n = i / d;
+    const int c = (int)(i % d);
+    const int64_t o = n * (T + 1) * d + c;
+    const f32x4 v = *(const f32x4*)(cls + c), p = *(const f32x4*)(pm + c);
+    *(f32x4*)(x32 + o) = v;
+    *(u32x2*)(x16 + o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)(xp16 + o) = u32x2{pack_bf16x2(v[0] + p[0], v[1] + p[1]), pack_bf16x2(v[2] + p[2], v[3] + p[3])};
+}
+
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -356,21 +374,21 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __rest
 }  // namespace
 
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st) {
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap) {
     RV_CHECK_ARG(x && w && b && rows >= 0, "layernorm: bad arguments");
     RV_CHECK_ARG(!yp16 || (pos && period > 0), "layernorm: y_pos needs pos table and period");
     if (rows == 0) return RV_OK;
     const unsigned blocks = (unsigned)cdiv(rows, 4);
     if (d == 768)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
     else if (d == 4096)
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
     else if (d == 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows);
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
     else {
         rv_set_error("layernorm: unsupported width %d (256, 512, 768, 1024, 4096)", d);
         return RV_ERR_ARG;
@@ -457,6 +475,12 @@ int k_build_x(const void* src16, const float* src32, const float* cls, const flo
     hipLaunchKernelGGL(build_x_kernel, dim3((unsigned)cdiv(N * (T + 1) * d / 4, 256)), dim3(256), 0, st, (const bf16_t*)src16,
                        src32, cls, pm, x32, (bf16_t*)x16, (bf16_t*)xp16, N, T, d);
     RV_CHECK_LAUNCH("build_x");
+    return RV_OK;
+}
+
+int k_cls_rows(const float* cls, const float* pm, float* x32, void* x16, void* xp16, int64_t N, int T, int d, hipStream_t st) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)cdiv(N * d / 4, 256)), dim3(256), 0, st, cls, pm, x32, (bf16_t*)x16, (bf16_t*)xp16, N, T, d);
+    RV_CHECK_LAUNCH("cls_rows");
     return RV_OK;
 }
 
