@@ -12,6 +12,13 @@
 // K / V^T tiles come straight from L2 (a head's K/V is <= 64 KB at the path's sequence lengths).
 #include "kernels.h"
 
+// compile-time probe: 1 = the prefill pair / groups kernel takes 32 query rows per wave (attn_body2: a key block's K / V^T loaded once for two
+// query tiles; 204 registers, needs __launch_bounds__(256, 2) on the kernel to keep two waves per SIMD), 0 (default) = 16 rows (attn_body, three
+// waves per SIMD).  Measured at 4 x 1005 rows: 67.0 vs 62 us per layer - the launch lives on waves in flight, not on L2 bytes.  Bit-identical.
+#ifndef ATTN_PAIR_Q32
+#define ATTN_PAIR_Q32 0
+#endif
+
 namespace {
 
 // SPLIT (Lq <= 16, i.e. KV-cached decode): the block's 4 waves share the same 16 queries and take key blocks
@@ -196,6 +203,129 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     }
 }
 
+// Prefill form with TWO 16-row query tiles per wave (32 rows; a workgroup = 128 rows): a key block's K rows and V^T rows are loaded once and used
+// by both tiles - half the L2 -> CU bytes per query row.  No key split, no padding mask, no per-row positions, bf16 queries: the LLM prefill.
+// Per tile exactly the operations of attn_body in the same order (a tile skips the key blocks past its own causal range): bit-identical rows.
+template <int DH>
+__device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int b) {
+    constexpr int NC = DH / 32, ND = DH / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int q0 = bx * 128 + wave * 32;
+    if (q0 >= a.Lq) return;
+    const int kb_ = b / a.kv_div;
+    const int Lk = a.Lk, q_pos0 = a.q_pos0;
+    bf16x8 qf[2][NC];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + qt * 16 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const bf16x8*)(qp + c * 32);
+    }
+    const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    const int krow = (fr >> 2) * 8 + (fr & 3);
+    f32x4 o[2][ND];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const bool two = q0 + 16 < a.Lq;                      // (wave-uniform) the second tile holds rows
+    int kend_t[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) kend_t[qt] = a.causal ? min(Lk, q_pos0 + q0 + qt * 16 + 16) : Lk;
+    const int kend = two ? kend_t[1] : kend_t[0];
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+        bf16x8 kf[2][NC];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = min(k0 + krow + t * 4, Lk - 1);
+            const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
+        }
+        bf16x8 vf[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (k0 >= kend_t[qt] || (qt == 1 && !two)) continue;      // (wave-uniform)
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[qt][c], s[t], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+            const int qbase = q_pos0 + q0 + qt * 16;
+            const bool interior = k0 + 32 <= Lk && (!a.causal || k0 + 31 <= qbase);
+            if (interior) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s[t][r] *= a.scale;
+                        mx = fmaxf(mx, s[t][r]);
+                    }
+            } else {
+                const int qpos = qbase + fr;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + g * 8 + t * 4 + r;
+                        const bool dead = key >= Lk || (a.causal && key > qpos);
+                        const float v = dead ? -INFINITY : s[t][r] * a.scale;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __expf(m_run[qt] - m_use);
+            float psum = 0.f;
+            float pp[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[t][r] - m_use);
+                    pp[t * 4 + r] = e;
+                    psum += e;
+                }
+            l_run[qt] = l_run[qt] * alpha + psum;
+            m_run[qt] = m_new;
+            union { bf16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(pp[2 * i], pp[2 * i + 1]);
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) o[qt][dt] *= alpha;
+            }
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[qt][dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int row = q0 + qt * 16 + fr;
+        if (row >= a.Lq) continue;
+        const float inv = 1.0f / l;
+        bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)row * a.o_rs + h * DH + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+            *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
+    }
+}
+
 // 1-D grid, XCD-aware: workgroup id lands on XCD id % 8 (private L2), so the query tiles of one (batch, head) - which read
 // the same K / V^T - get ids that differ by multiples of 8, and an XCD only ever touches 1/8 of the (batch, head) pairs.
 __device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, int& h, int& b) {
@@ -210,7 +340,7 @@ __device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, i
 __host__ inline unsigned attn_grid(int tiles, int pairs) { return (unsigned)(tiles * ((pairs + 7) / 8) * 8); }
 
 template <int DH, bool SPLIT, bool QS = false>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
+__global__ __launch_bounds__(256, DH <= 128 ? 3 : 1) void attn_kernel(AttnArgs a, int tiles) {
     int bx, h, b;
     if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;
     if constexpr (QS) attn_body<DH, SPLIT, false, true>(a, bx, h, b);      // (the LLM has no key padding: checked by the launcher)
@@ -221,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a, int tiles) {
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
 // themselves, the per-call rows attend to prefix + own keys): blockIdx.z < a.B -> problem a, else problem b.
 template <int DH, bool QS = false>
-__global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles, AttnGroups gr) {
+__global__ __launch_bounds__(256, 3) void attn_kernel_pair(AttnArgs a, AttnArgs b, int tiles, AttnGroups gr) {
     int bx, h, z;
     const int per = a.B + b.B;
     if (!attn_map(tiles, a.H, a.H * per * gr.G, bx, h, z)) return;
@@ -234,8 +364,13 @@ __global__ __launch_bounds__(256) void attn_kernel_pair(AttnArgs a, AttnArgs b, 
         p.k = (const bf16_t*)p.k + gr.kv_off[g];
         p.vt = (const bf16_t*)p.vt + gr.kv_off[g];
     }
-    if (z < a.B) attn_body<DH, false, false, QS>(p, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
-    else attn_body<DH, false, false, QS>(p, bx, h, z - a.B);
+    if constexpr (!QS && ATTN_PAIR_Q32) {
+        if (bx * 128 >= p.Lq) return;       // (the two problems may differ in length: tiles counts the longer one)
+        attn_body2<DH>(p, bx, h, z < a.B ? z : z - a.B);
+    } else {
+        if (z < a.B) attn_body<DH, false, false, QS>(p, bx, h, z);   // (the LLM prefill has no key padding: checked by the launcher)
+        else attn_body<DH, false, false, QS>(p, bx, h, z - a.B);
+    }
 }
 
 }  // namespace
@@ -254,7 +389,7 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const
     if (int rc = attn_check(b)) return rc;
     RV_CHECK_ARG(a.dh == 128 && b.dh == 128 && a.H == b.H && a.Lq > 16 && b.Lq > 16, "attention pair: 128-wide heads, same head count, prefill lengths only");
     RV_CHECK_ARG(!a.key_pad && !b.key_pad, "attention pair: key padding is not supported");
-    const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, 64);
+    const int tiles = (int)cdiv(a.Lq > b.Lq ? a.Lq : b.Lq, (ATTN_PAIR_Q32 && !a.q_lo) ? 128 : 64);
     const AttnGroups gr = groups ? *groups : AttnGroups{};
     RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention pair: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
     RV_CHECK_ARG((a.q_lo != 0) == (b.q_lo != 0), "attention pair: both problems or neither carry split queries");
@@ -272,7 +407,7 @@ int k_attention_groups(const AttnArgs& b, hipStream_t st, const AttnGroups& gr) 
     RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention groups: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
     AttnArgs a = b;
     a.B = 0;      // every workgroup takes problem b
-    const int tiles = (int)cdiv(b.Lq, 64);
+    const int tiles = (int)cdiv(b.Lq, (ATTN_PAIR_Q32 && !b.q_lo) ? 128 : 64);
     if (b.q_lo) hipLaunchKernelGGL((attn_kernel_pair<128, true>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     else hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     RV_CHECK_LAUNCH("attention groups");
