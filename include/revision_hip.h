@@ -25,7 +25,15 @@
  *     flight per device at a time: callers that use several streams order those launches (Engine does, with an event);
  *   - return 0 on success, negative rv_status on error; rv_last_error() gives the message of the
  *     last failure on the calling thread;
- *   - dtypes: RV_BF16 activations/weights, RV_F32 residual streams, statistics and logits.
+ *   - dtypes: 16-bit OPERANDS (activations / weights / KV caches), RV_F32 residual streams, statistics and logits.  The library is
+ *     built in two flavours with this same ABI (same entry points, same layouts - both operand types are 2 bytes wide):
+ *         librevision_hip.so       fp16 operands (RV_F16; v_mfma_f32_16x16x32_f16).  The default: Vicuna checkpoints ARE fp16
+ *                                  (builder.py:22 loads them with torch_dtype=float16, e2e2.py:185 widens them to fp32 on the CPU), so the weights
+ *                                  are held exactly, and activations keep 11 significand bits - the reference's fp32 scores to 1e-3;
+ *         librevision_hip_bf16.so  bf16 operands (RV_BF16; v_mfma_f32_16x16x32_bf16): the reference's own GPU dtype (e2e2.py:181-185), 8 bits.
+ *     rv_operand_dtype() says which one a loaded library is; wherever this header says "bf16" for a buffer it means "the library's operand
+ *     type".  A library REFUSES the other flavour's dtype code (rv_weights_bind, rv_init_hash, rv_gemm out_dtype, ...): a bf16 tensor can
+ *     never be read as fp16 bits silently.  f32 -> fp16 conversions saturate at +-65504 (no inf is ever produced by a conversion).
  */
 #ifndef REVISION_HIP_H
 #define REVISION_HIP_H
@@ -37,10 +45,10 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 3
+#define RV_ABI_VERSION 4
 
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
-typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4 } rv_dtype;
+typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4, RV_F16 = 5 } rv_dtype;
 typedef enum { RV_ACT_NONE = 0, RV_ACT_RELU = 1, RV_ACT_SILU_MUL = 2, RV_ACT_QUICK_GELU = 3 } rv_act;
 typedef enum { RV_W_ROWMAJOR = 0, RV_W_PACKED = 1 } rv_wlayout;
 /* ClipEncoder output selection, revisionllm/model/adapter/transformer.py:134-145 */
@@ -59,7 +67,14 @@ typedef struct rv_config {
     int32_t adapter_text; /* clip_adapter_text: run the two text->video layers */
 } rv_config;
 
+/* Everything below is exported; nothing else is (the library is built with -fvisibility=hidden). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 int rv_abi_version(void);
+/* RV_F16 or RV_BF16: the 16-bit operand type this build of the library computes in (see "dtypes" above). */
+int rv_operand_dtype(void);
 int rv_last_error(char* buf, size_t n);
 
 /* ---- context + weights ------------------------------------------------------------------- */
@@ -301,6 +316,10 @@ int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t
  * out_idx i32 [Nv,Nt,k] (the selected frames, optional).  1 <= k <= min(64, T). */
 int rv_topk_pool(const void* video, int dtype, const float* text, int32_t Nv, int32_t T, int32_t d, int32_t Nt, int32_t k,
                  float* out, int32_t* out_idx, void* stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

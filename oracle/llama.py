@@ -85,16 +85,20 @@ class KVCache:
 ROUNDING_POINTS = ("norm_out", "q", "k_cache", "v_cache", "p", "attn_out", "mlp_act", "lm_in")
 
 
-def _bf16(t):
-    return t.to(torch.bfloat16).to(t.dtype)
+def _round16(t, dt=torch.bfloat16):
+    """Emulated rounding to a 16-bit operand type (bf16, or fp16 with the kernels' saturation at +-65504)."""
+    if dt == torch.float16:
+        t = t.clamp(-65504.0, 65504.0)
+    return t.to(dt).to(t.dtype)
 
 
-def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None, act_quant=None, rnd=()):
+def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = None, act_quant=None, rnd=(), rnd_dtype=torch.bfloat16):
     """One Llama block: x + Wo(softmax(QK^T/sqrt(dh) + mask) V); then + W_down(silu(W_gate n) * W_up n).
     ``act_quant`` (build-defined, opt-in FP8 prefill mirror): applied to the input rows of the four projections.
-    ``rnd``: names of ``ROUNDING_POINTS`` at which a bf16 rounding is emulated (error budget; default: none)."""
+    ``rnd``: names of ``ROUNDING_POINTS`` at which a rounding to ``rnd_dtype`` (the build's operand type: bf16 / fp16) is emulated (error
+    budget; default: none)."""
     aq = act_quant if act_quant is not None else (lambda t: t)
-    r = (lambda name, t: _bf16(t) if name in rnd else t)
+    r = (lambda name, t: _round16(t, rnd_dtype) if name in rnd else t)
     p = f"model.layers.{i}."
     B, S, D = h.shape
     H, dh = cfg.heads, cfg.head_dim
@@ -111,7 +115,7 @@ def decoder_layer(h, w, i, cfg: LlamaCfg, cos, sin, attn_bias, cache: KVCache = 
         s = s + attn_bias
     if "p" in rnd:      # the build's kernel: exp(s - max) rounded to bf16 in front of P.V, the row sum kept in f32, one division at the end
         e = torch.exp(s - s.amax(dim=-1, keepdim=True))
-        o = (_bf16(e) @ v) / e.sum(dim=-1, keepdim=True)
+        o = (_round16(e, rnd_dtype) @ v) / e.sum(dim=-1, keepdim=True)
     else:
         pr = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
         o = pr @ v
@@ -136,7 +140,7 @@ def _bias_from_mask(attention_mask, q_len, past_len, dtype):
 
 
 def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=None, cache: KVCache = None,
-            last_only=False, n_layers=None, act_quant=None, rnd=()):
+            last_only=False, n_layers=None, act_quant=None, rnd=(), rnd_dtype=torch.bfloat16):
     """``LlamaForCausalLM.forward(inputs_embeds=...)`` -> logits [B,S,V] (or [B,1,V] if last_only).
 
     attention_mask [B, past+S] (1 = real token); position_ids [B,S]; cache is updated in place.
@@ -152,12 +156,12 @@ def forward(inputs_embeds, w, cfg: LlamaCfg, attention_mask=None, position_ids=N
     bias = _bias_from_mask(attention_mask, S, past, inputs_embeds.dtype)
     h = inputs_embeds
     for i in range(cfg.layers if n_layers is None else n_layers):
-        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache, act_quant, rnd)
+        h = decoder_layer(h, w, i, cfg, cos, sin, bias, cache, act_quant, rnd, rnd_dtype)
     if last_only:
         h = h[:, -1:]
     h = rmsnorm(h, w["model.norm.weight"], cfg.eps)
     if "lm_in" in rnd:
-        h = _bf16(h)
+        h = _round16(h, rnd_dtype)
     return F.linear(h, w["lm_head.weight"])
 
 
@@ -172,11 +176,11 @@ def fp8_rows(w):
     return q.float() * scale[:, None]
 
 
-def fp8_act_rows(x):
-    """Mirror of the build's FP8 prefill activation quantiser (rv_quant_rows_fp8): the activation is rounded to bf16 (what the
-    bf16 path hands to its GEMM), then per row over the last dim: scale = max|row| / 448 (1 for a zero row), q =
+def fp8_act_rows(x, op_dtype=torch.bfloat16):
+    """Mirror of the build's FP8 prefill activation quantiser (rv_quant_rows_fp8): the activation is rounded to the operand type (what the
+    16-bit path hands to its GEMM: bf16, or fp16 in that flavour), then per row over the last dim: scale = max|row| / 448 (1 for a zero row), q =
     RNE_e4m3(x * (1 / scale)), IEEE f32; returns the dequantised q * scale."""
-    xb = x.to(torch.bfloat16).float()
+    xb = _round16(x.float(), op_dtype)
     amax = xb.abs().amax(dim=-1, keepdim=True)
     scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
     return (xb * (1.0 / scale)).to(torch.float8_e4m3fn).float() * scale

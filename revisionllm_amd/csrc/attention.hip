@@ -40,18 +40,18 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     if (Lk <= 0 || (a.row_pos && Lk > a.Lk)) return;   // inactive row; a row past the pool's capacity (a.Lk = Smax) is treated like one
     const int q_pos0 = a.row_pos ? Lk - a.Lq : a.q_pos0;
 
-    const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
-    bf16x8 qf[NC];
+    const op16_t* qp = (const op16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+    op16x8 qf[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) qf[c] = *(const bf16x8*)(qp + c * 32);
-    bf16x8 ql[QS ? NC : 1];      // parity precision: the low halves of the query row (scores = K.(Qhi + Qlo))
+    for (int c = 0; c < NC; ++c) qf[c] = *(const op16x8*)(qp + c * 32);
+    op16x8 ql[QS ? NC : 1];      // parity precision: the low halves of the query row (scores = K.(Qhi + Qlo))
     if constexpr (QS) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) ql[c] = *(const bf16x8*)(qp + a.q_lo + c * 32);
+        for (int c = 0; c < NC; ++c) ql[c] = *(const op16x8*)(qp + a.q_lo + c * 32);
     }
 
-    const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
-    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    const op16_t* kbase = (const op16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const op16_t* vbase = (const op16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
     // key blocks inside the prefix this row shares with a sibling row are read from the sibling's (bit-identical) cache rows: L2 hits
     int share_len = 0;
     int64_t share_k = 0, share_v = 0;       // element offsets from this row's bases to the sibling's
@@ -75,28 +75,28 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     for (int k0 = SPLIT ? wave * 32 : 0; k0 < kend; k0 += SPLIT ? 128 : 32) {
         // issue every load of this key block up front (K rows and V^T rows are independent of the softmax), so the
         // block costs one memory round trip instead of two
-        bf16x8 kf[2][NC];
+        op16x8 kf[2][NC];
         const bool shared_blk = SPLIT && k0 + 32 <= share_len;      // (wave-uniform) the whole block lies inside the shared prefix
         const int64_t sk = shared_blk ? share_k : 0, svo = shared_blk ? share_v : 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = min(k0 + krow + t * 4, Lk - 1);
-            const bf16_t* kp = kbase + sk + (int64_t)key * a.k_rs;
+            const op16_t* kp = kbase + sk + (int64_t)key * a.k_rs;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const op16x8*)(kp + c * 32);
         }
-        bf16x8 vf[ND];
+        op16x8 vf[ND];
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + svo + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const op16x8*)(vbase + svo + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s[t], 0, 0, 0);
+            for (int c = 0; c < NC; ++c) s[t] = rv_mfma16(kf[t][c], qf[c], s[t]);
             if constexpr (QS) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], ql[c], s[t], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) s[t] = rv_mfma16(kf[t][c], ql[c], s[t]);
             }
         }
         float mx = -INFINITY;
@@ -140,15 +140,15 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        union { bf16x8 v; uint32_t u[4]; } pf;
+        union { op16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(p[2 * i], p[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2(p[2 * i], p[2 * i + 1]);
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running maximum moved for some row of this wave
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
         }
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[dt], 0, 0, 0);
+        for (int dt = 0; dt < ND; ++dt) o[dt] = rv_mfma16(vf[dt], pf.v, o[dt]);
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
             lt += sm_l[w][q] * sc[w];
         }
         const float inv = 1.0f / lt;
-        bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + q) * a.o_rs + h * DH + dc;
+        op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + q) * a.o_rs + h * DH + dc;
 #pragma unroll
         for (int j = 0; j < DH / 16; j += 2) {
             float v0 = 0.f, v1 = 0.f;
@@ -184,22 +184,22 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
                 v0 += sm_o[w][q][dc + j] * sc[w];
                 v1 += sm_o[w][q][dc + j + 1] * sc[w];
             }
-            if (a.out_packed) *(uint32_t*)((bf16_t*)a.out + rv_xp_index(b, h * DH + dc + j, a.out_packed)) = pack_bf16x2(v0 * inv, v1 * inv);   // (Lq = 1)
-            else *(uint32_t*)(op + j) = pack_bf16x2(v0 * inv, v1 * inv);
-            if (a.out_lo) *(uint32_t*)(op + a.out_lo + j) = pack_bf16x2_lo(v0 * inv, v1 * inv);
+            if (a.out_packed) *(uint32_t*)((op16_t*)a.out + rv_xp_index(b, h * DH + dc + j, a.out_packed)) = pack_op16x2(v0 * inv, v1 * inv);   // (Lq = 1)
+            else *(uint32_t*)(op + j) = pack_op16x2(v0 * inv, v1 * inv);
+            if (a.out_lo) *(uint32_t*)(op + a.out_lo + j) = pack_op16x2_lo(v0 * inv, v1 * inv);
         }
         return;
     }
     if (q0 + fr >= a.Lq) return;
     const float inv = 1.0f / l_run;
-    bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
+    op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
-        *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+        *(u32x2*)(op + dt * 16) = u32x2{pack_op16x2(o[dt][0] * inv, o[dt][1] * inv), pack_op16x2(o[dt][2] * inv, o[dt][3] * inv)};
     if (a.out_lo) {
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
-            *(u32x2*)(op + a.out_lo + dt * 16) = u32x2{pack_bf16x2_lo(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2_lo(o[dt][2] * inv, o[dt][3] * inv)};
+            *(u32x2*)(op + a.out_lo + dt * 16) = u32x2{pack_op16x2_lo(o[dt][0] * inv, o[dt][1] * inv), pack_op16x2_lo(o[dt][2] * inv, o[dt][3] * inv)};
     }
 }
 
@@ -216,15 +216,15 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
     if (q0 >= a.Lq) return;
     const int kb_ = b / a.kv_div;
     const int Lk = a.Lk, q_pos0 = a.q_pos0;
-    bf16x8 qf[2][NC];
+    op16x8 qf[2][NC];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const bf16_t* qp = (const bf16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + qt * 16 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+        const op16_t* qp = (const op16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + qt * 16 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const bf16x8*)(qp + c * 32);
+        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const op16x8*)(qp + c * 32);
     }
-    const bf16_t* kbase = (const bf16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
-    const bf16_t* vbase = (const bf16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    const op16_t* kbase = (const op16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const op16_t* vbase = (const op16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
     const int krow = (fr >> 2) * 8 + (fr & 3);
     f32x4 o[2][ND];
 #pragma unroll
@@ -238,17 +238,17 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
     for (int qt = 0; qt < 2; ++qt) kend_t[qt] = a.causal ? min(Lk, q_pos0 + q0 + qt * 16 + 16) : Lk;
     const int kend = two ? kend_t[1] : kend_t[0];
     for (int k0 = 0; k0 < kend; k0 += 32) {
-        bf16x8 kf[2][NC];
+        op16x8 kf[2][NC];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = min(k0 + krow + t * 4, Lk - 1);
-            const bf16_t* kp = kbase + (int64_t)key * a.k_rs;
+            const op16_t* kp = kbase + (int64_t)key * a.k_rs;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) kf[t][c] = *(const bf16x8*)(kp + c * 32);
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const op16x8*)(kp + c * 32);
         }
-        bf16x8 vf[ND];
+        op16x8 vf[ND];
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const bf16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const op16x8*)(vbase + (int64_t)dt * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             if (k0 >= kend_t[qt] || (qt == 1 && !two)) continue;      // (wave-uniform)
@@ -257,7 +257,7 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
             for (int t = 0; t < 2; ++t) {
                 s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < NC; ++c) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[qt][c], s[t], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) s[t] = rv_mfma16(kf[t][c], qf[qt][c], s[t]);
             }
             float mx = -INFINITY;
             const int qbase = q_pos0 + q0 + qt * 16;
@@ -300,15 +300,15 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
                 }
             l_run[qt] = l_run[qt] * alpha + psum;
             m_run[qt] = m_new;
-            union { bf16x8 v; uint32_t u[4]; } pf;
+            union { op16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(pp[2 * i], pp[2 * i + 1]);
+            for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2(pp[2 * i], pp[2 * i + 1]);
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) o[qt][dt] *= alpha;
             }
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf.v, o[qt][dt], 0, 0, 0);
+            for (int dt = 0; dt < ND; ++dt) o[qt][dt] = rv_mfma16(vf[dt], pf.v, o[qt][dt]);
         }
     }
 #pragma unroll
@@ -319,10 +319,10 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
         const int row = q0 + qt * 16 + fr;
         if (row >= a.Lq) continue;
         const float inv = 1.0f / l;
-        bf16_t* op = (bf16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)row * a.o_rs + h * DH + g * 4;
+        op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)row * a.o_rs + h * DH + g * 4;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
-            *(u32x2*)(op + dt * 16) = u32x2{pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
+            *(u32x2*)(op + dt * 16) = u32x2{pack_op16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_op16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
     }
 }
 
@@ -359,10 +359,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_pair(AttnArgs a, AttnArgs 
     z -= g * per;
     AttnArgs& p = z < a.B ? a : b;
     if (gr.G > 1) {      // (uniform per workgroup)
-        p.q = (const bf16_t*)p.q + gr.q_off[g];
-        p.out = (bf16_t*)p.out + gr.o_off[g];
-        p.k = (const bf16_t*)p.k + gr.kv_off[g];
-        p.vt = (const bf16_t*)p.vt + gr.kv_off[g];
+        p.q = (const op16_t*)p.q + gr.q_off[g];
+        p.out = (op16_t*)p.out + gr.o_off[g];
+        p.k = (const op16_t*)p.k + gr.kv_off[g];
+        p.vt = (const op16_t*)p.vt + gr.kv_off[g];
     }
     if constexpr (!QS && ATTN_PAIR_Q32) {
         if (bx * 128 >= p.Lq) return;       // (the two problems may differ in length: tiles counts the longer one)

@@ -15,11 +15,11 @@ struct Tensor {
 };
 
 struct AdapterLayer {
-    const bf16_t *w_in, *w_out, *w1, *w2;
+    const op16_t *w_in, *w_out, *w1, *w2;
     const float *b_in, *b_out, *b1, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
 };
 struct LlmLayer {
-    const bf16_t *wqkv, *wo, *wgu, *wdown;
+    const op16_t *wqkv, *wo, *wgu, *wdown;
     const float *norm1, *norm2;
     // optional FP8 copies for the decode kernels ("<name>.f8" e4m3fn bytes, "<name>.s8" per-row scales); all or none
     const uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *wgu8 = nullptr, *wdown8 = nullptr;
@@ -29,7 +29,7 @@ struct LlmLayer {
     const uint8_t *wqkv8p = nullptr, *wo8p = nullptr, *wgu8p = nullptr, *wdown8p = nullptr;
     // optional K-DUPLICATED copies ("<name>.p2" = [W | W] along K, fragment-packed) for the parity precision: a GEMM over the split
     // operand [hi | lo] (K doubled) against [W | W] is W.hi + W.lo in one launch of the unchanged kernels; all or none
-    const bf16_t *wqkv2 = nullptr, *wo2 = nullptr, *wgu2 = nullptr, *wdown2 = nullptr;
+    const op16_t *wqkv2 = nullptr, *wo2 = nullptr, *wgu2 = nullptr, *wdown2 = nullptr;
 };
 
 struct rv_ctx {
@@ -39,15 +39,15 @@ struct rv_ctx {
     bool resolved_adapter = false, resolved_llm = false, resolved_proj = false;
     std::vector<AdapterLayer> t2v, enc;
     const float *cls_token = nullptr, *cls_pos = nullptr, *adp_proj_b = nullptr, *proj_b = nullptr;
-    const bf16_t *adp_proj_w = nullptr, *proj_w = nullptr;
+    const op16_t *adp_proj_w = nullptr, *proj_w = nullptr;
     std::vector<LlmLayer> layers;
-    const bf16_t *embed = nullptr, *lm_head = nullptr;
+    const op16_t *embed = nullptr, *lm_head = nullptr;
     const float* final_norm = nullptr;
     const uint8_t* lm_head8 = nullptr;   // FP8 decode copies bound for every projection -> fp8_decode
     const float* slm_head = nullptr;
     bool fp8_decode = false;
     bool fp8_prefill = false;   // ".f8p" copies bound for every layer projection
-    const bf16_t* lm_head2 = nullptr;
+    const op16_t* lm_head2 = nullptr;
     bool parity = false;        // ".p2" copies bound for every projection + lm_head (the parity precision can be switched on)
     bool options_only = false;  // created without a model configuration: carries tunables for the building-block entry points
     RvOpts opt;                 // per-context tunables (rv_ctx_set_option)
@@ -90,7 +90,7 @@ int resolve_adapter(rv_ctx* c) {
         c->adp_proj_w = nullptr;
         c->adp_proj_b = nullptr;
     } else {
-        FIND("adp.proj_w", RV_BF16, D * d, c->adp_proj_w);
+        FIND("adp.proj_w", RV_OP16, D * d, c->adp_proj_w);
         FIND("adp.proj_b", RV_F32, D, c->adp_proj_b);
     }
     for (int stack = 0; stack < 2; ++stack) {
@@ -100,13 +100,13 @@ int resolve_adapter(rv_ctx* c) {
         for (int l = 0; l < g.adapter_layers; ++l) {
             const std::string p = std::string("adp.") + (stack == 0 ? "t2v." : "enc.") + std::to_string(l) + ".";
             AdapterLayer L;
-            FIND(p + "w_in", RV_BF16, 3 * d * d, L.w_in);
+            FIND(p + "w_in", RV_OP16, 3 * d * d, L.w_in);
             FIND(p + "b_in", RV_F32, 3 * d, L.b_in);
-            FIND(p + "w_out", RV_BF16, d * d, L.w_out);
+            FIND(p + "w_out", RV_OP16, d * d, L.w_out);
             FIND(p + "b_out", RV_F32, d, L.b_out);
-            FIND(p + "w1", RV_BF16, ff * d, L.w1);
+            FIND(p + "w1", RV_OP16, ff * d, L.w1);
             FIND(p + "b1", RV_F32, ff, L.b1);
-            FIND(p + "w2", RV_BF16, d * ff, L.w2);
+            FIND(p + "w2", RV_OP16, d * ff, L.w2);
             FIND(p + "b2", RV_F32, d, L.b2);
             FIND(p + "ln1_w", RV_F32, d, L.ln1_w);
             FIND(p + "ln1_b", RV_F32, d, L.ln1_b);
@@ -121,7 +121,7 @@ int resolve_adapter(rv_ctx* c) {
 
 int resolve_proj(rv_ctx* c) {
     if (c->resolved_proj) return RV_OK;
-    FIND("proj.w", RV_BF16, (int64_t)c->cfg.hidden * c->cfg.adapter_dim, c->proj_w);
+    FIND("proj.w", RV_OP16, (int64_t)c->cfg.hidden * c->cfg.adapter_dim, c->proj_w);
     FIND("proj.b", RV_F32, c->cfg.hidden, c->proj_b);
     c->resolved_proj = true;
     return RV_OK;
@@ -131,17 +131,17 @@ int resolve_llm(rv_ctx* c) {
     if (c->resolved_llm) return RV_OK;
     const rv_config& g = c->cfg;
     const int64_t D = g.hidden, F = g.inter, V = g.vocab;
-    FIND("llm.embed", RV_BF16, V * D, c->embed);
-    FIND("llm.lm_head", RV_BF16, V * D, c->lm_head);
+    FIND("llm.embed", RV_OP16, V * D, c->embed);
+    FIND("llm.lm_head", RV_OP16, V * D, c->lm_head);
     FIND("llm.norm", RV_F32, D, c->final_norm);
     c->layers.clear();
     for (int l = 0; l < g.layers; ++l) {
         const std::string p = "llm.L" + std::to_string(l) + ".";
         LlmLayer L;
-        FIND(p + "wqkv", RV_BF16, 3 * D * D, L.wqkv);
-        FIND(p + "wo", RV_BF16, D * D, L.wo);
-        FIND(p + "wgu", RV_BF16, 2 * F * D, L.wgu);
-        FIND(p + "wdown", RV_BF16, D * F, L.wdown);
+        FIND(p + "wqkv", RV_OP16, 3 * D * D, L.wqkv);
+        FIND(p + "wo", RV_OP16, D * D, L.wo);
+        FIND(p + "wgu", RV_OP16, 2 * F * D, L.wgu);
+        FIND(p + "wdown", RV_OP16, D * F, L.wdown);
         FIND(p + "norm1", RV_F32, D, L.norm1);
         FIND(p + "norm2", RV_F32, D, L.norm2);
         c->layers.push_back(L);
@@ -184,16 +184,16 @@ int resolve_llm(rv_ctx* c) {
     // (the lm_head copy alone is bound by default: the lm_head input is a split pair in EVERY precision - the error budget names its bf16
     //  rounding as the owner of two thirds of the default path's distance from the fp32 reference, and it costs one doubled-K launch per step)
     c->lm_head2 = nullptr;
-    if (c->w.count("llm.lm_head.p2") != 0) FIND("llm.lm_head.p2", RV_BF16, 2 * V * D, c->lm_head2);
+    if (c->w.count("llm.lm_head.p2") != 0) FIND("llm.lm_head.p2", RV_OP16, 2 * V * D, c->lm_head2);
     c->parity = c->lm_head2 && c->w.count("llm.L0.wqkv.p2") != 0;
     if (c->parity) {
         for (int l = 0; l < g.layers; ++l) {
             const std::string p = "llm.L" + std::to_string(l) + ".";
             LlmLayer& L = c->layers[l];
-            FIND(p + "wqkv.p2", RV_BF16, 2 * 3 * D * D, L.wqkv2);
-            FIND(p + "wo.p2", RV_BF16, 2 * D * D, L.wo2);
-            FIND(p + "wgu.p2", RV_BF16, 2 * 2 * F * D, L.wgu2);
-            FIND(p + "wdown.p2", RV_BF16, 2 * D * F, L.wdown2);
+            FIND(p + "wqkv.p2", RV_OP16, 2 * 3 * D * D, L.wqkv2);
+            FIND(p + "wo.p2", RV_OP16, 2 * D * D, L.wo2);
+            FIND(p + "wgu.p2", RV_OP16, 2 * 2 * F * D, L.wgu2);
+            FIND(p + "wdown.p2", RV_OP16, 2 * D * F, L.wdown2);
         }
     }
     c->resolved_llm = true;
@@ -220,7 +220,7 @@ __global__ void invert_mask_kernel(const uint8_t* __restrict__ valid, uint8_t* _
 
 struct ClipWs {
     float *pm, *x32, *y32;
-    bf16_t *x16, *xp16, *qk16, *vv16, *vt16, *a16, *h16, *tk16, *tv16, *tvt16;
+    op16_t *x16, *xp16, *qk16, *vv16, *vt16, *a16, *h16, *tk16, *tv16, *tvt16;
     uint8_t* pad;
     void* sk;  // stream-K GEMM workspace (flags must be zero: the engine's Python owner allocates it zeroed)
     size_t sk_bytes;
@@ -240,17 +240,17 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
     w.pm = (float*)k.take((size_t)(T + 1) * d * 4);
     w.x32 = (float*)k.take((size_t)R1 * d * 4);
     w.y32 = (float*)k.take((size_t)R1 * d * 4);
-    w.x16 = (bf16_t*)k.take((size_t)R1 * d * 2);
-    w.xp16 = (bf16_t*)k.take((size_t)R1 * d * 2);
-    w.qk16 = (bf16_t*)k.take((size_t)R1 * 2 * d * 2);
-    w.vv16 = (bf16_t*)k.take((size_t)R1 * d * 2);
-    w.vt16 = (bf16_t*)k.take((size_t)N * d * w.Lpad * 2);
-    w.a16 = (bf16_t*)k.take((size_t)R1 * d * 2);
-    w.h16 = (bf16_t*)k.take((size_t)R1 * ff * 2);
+    w.x16 = (op16_t*)k.take((size_t)R1 * d * 2);
+    w.xp16 = (op16_t*)k.take((size_t)R1 * d * 2);
+    w.qk16 = (op16_t*)k.take((size_t)R1 * 2 * d * 2);
+    w.vv16 = (op16_t*)k.take((size_t)R1 * d * 2);
+    w.vt16 = (op16_t*)k.take((size_t)N * d * w.Lpad * 2);
+    w.a16 = (op16_t*)k.take((size_t)R1 * d * 2);
+    w.h16 = (op16_t*)k.take((size_t)R1 * ff * 2);
     const int64_t RT = (int64_t)(Nq > 0 ? Nq : 1) * (Lq > 0 ? Lq : 1);
-    w.tk16 = (bf16_t*)k.take((size_t)RT * d * 2);
-    w.tv16 = (bf16_t*)k.take((size_t)RT * d * 2);
-    w.tvt16 = (bf16_t*)k.take((size_t)(Nq > 0 ? Nq : 1) * d * w.Lqpad * 2);
+    w.tk16 = (op16_t*)k.take((size_t)RT * d * 2);
+    w.tv16 = (op16_t*)k.take((size_t)RT * d * 2);
+    w.tvt16 = (op16_t*)k.take((size_t)(Nq > 0 ? Nq : 1) * d * w.Lqpad * 2);
     w.pad = (uint8_t*)k.take((size_t)RT);
     (void)H;
     w.bytes = k.off;
@@ -388,21 +388,21 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         hipLaunchKernelGGL(invert_mask_kernel, dim3((unsigned)cdiv(RT, 256)), dim3(256), 0, st, txt_mask, w.pad, (int)RT);
         RV_CHECK_LAUNCH("invert_mask");
         float* v32 = w.x32;
-        bf16_t* vp16 = w.xp16;
+        op16_t* vp16 = w.xp16;
         RV_TRY(k_frames_in(x, w.pm + d, v32, vp16, R0, T, (int)d, st));
         for (size_t l = 0; l < c->t2v.size(); ++l) {
             const AdapterLayer& L = c->t2v[l];
-            bf16_t* q16 = w.qk16;
-            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_BF16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_BF16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_BF16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
+            op16_t* q16 = w.qk16;
+            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
             AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
                        w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
             RV_TRY(k_attention(a, st));
             RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
-            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st));
             if (l + 1 < c->t2v.size()) {
                 RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, v32, nullptr, vp16, w.pm + d, T, R0, (int)d, st));
@@ -426,29 +426,29 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             // GEMM work gone).  Same kernels and summation orders as the full-length launches (N > 16 keeps the GEMMs on the
             // tiled kernel, the attention keeps the non-split variant), so the CLS rows are bit-identical to the full layer's.
             const int64_t sx = (int64_t)(T + 1) * d;   // row stride between the CLS rows of consecutive sequences
-            bf16_t* kk16 = w.qk16;                      // K  [R1, d]
-            bf16_t* qc16 = w.h16;                       // Q of the CLS rows [N, d] (h16 is free until the FFN)
+            op16_t* kk16 = w.qk16;                      // K  [R1, d]
+            op16_t* qc16 = w.h16;                       // Q of the CLS rows [N, d] (h16 is free until the FFN)
             float* y0 = w.y32;                          // [N, d] attention + residual
             float* y1 = w.y32 + (int64_t)N * d;         // [N, d] LN1 output (FFN residual)
             float* y2 = w.y32 + (int64_t)2 * N * d;     // [N, d] FFN + residual
-            RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, kk16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(rv_gemm_impl(w.xp16, sx, L.w_in, d, 1, L.b_in, nullptr, 0, qc16, d, RV_BF16, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, kk16, d, RV_OP16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.xp16, sx, L.w_in, d, 1, L.b_in, nullptr, 0, qc16, d, RV_OP16, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_OP16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));
             AttnArgs a{qc16, d, d, kk16, d, (int64_t)(T + 1) * d, dh, w.vt16, (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, d,
                        nullptr, N, H, dh, 1, T + 1, 0, 0, 1, scale, 1};
             RV_TRY(k_attention(a, st));
             RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, sx, y0, d, RV_F32, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st));
-            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, y1, d, y2, d, RV_F32, RV_ACT_NONE, N, d, ff, w.sk, w.sk_bytes, st));
             if (!c->adp_proj_w)      // identity projector: the CLS rows' last LayerNorm IS the output
                 return k_layernorm(y2, L.ln2_w, L.ln2_b, (float*)out, nullptr, nullptr, nullptr, 0, N, (int)d, st);
             RV_TRY(k_layernorm(y2, L.ln2_w, L.ln2_b, nullptr, w.x16, nullptr, nullptr, 0, N, (int)d, st));
             return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D, d, w.sk, w.sk_bytes, st);
         }
-        RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_BF16, RV_ACT_NONE, R1, 2 * d, d, w.sk, w.sk_bytes, st));
-        RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_BF16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_OP16, RV_ACT_NONE, R1, 2 * d, d, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.vv16, d, RV_OP16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_transpose_v(w.vv16, d, w.vt16, N, T + 1, w.Lpad, H, dh, st));
         AttnArgs a{w.qk16, 2 * d, (int64_t)(T + 1) * 2 * d, w.qk16 + d, 2 * d, (int64_t)(T + 1) * 2 * d, dh, w.vt16,
                    (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, (int64_t)(T + 1) * d, nullptr, N, H, dh, T + 1,
@@ -456,7 +456,7 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         RV_TRY(k_attention(a, st));
         RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, w.x32, w.x16, nullptr, nullptr, 0, R1, (int)d, st));
-        RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_BF16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));
+        RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));
         RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, ff, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln2_w, L.ln2_b, w.x32, w.x16, w.xp16, w.pm, T + 1, R1, (int)d, st));
     }
@@ -491,7 +491,7 @@ namespace {
 // the parity precision applies when its weight copies are bound AND the context asks for it
 inline bool llm_parity(const rv_ctx* c) { return c->opt.precision == 1 && c->w.count("llm.L0.wqkv.p2") != 0 && c->w.count("llm.lm_head.p2") != 0; }
 struct LlmWs {
-    bf16_t *xn16, *q16, *a16, *act16, *xl16;
+    op16_t *xn16, *q16, *a16, *act16, *xl16;
     float* g32;      // parity precision: the gated MLP activation silu(gate) * up in f32 [M, F] (split into act16 [M, 2F] afterwards)
     float *cs, *ss;  // ss: per-workgroup partial sums of squares of the fused decode RMSNorm
     float* planes;   // split-K partial planes of the 33 .. 144-row decode kernel
@@ -511,11 +511,11 @@ LlmWs carve_llm(const rv_ctx* c, void* ws, size_t cap, int B, int S) {
     w.arrive = (int*)k.take((size_t)RV_ROWS_COUNTERS * 4);
     const int64_t Mp = M <= RV_ROWS_MAX ? 16 * rv_xp_blocks(M) : M;   // the fragment-packed decode layout spans whole row blocks
     const size_t par = llm_parity(c) ? 2 : 1;                         // split operands [hi | lo]: every bf16 GEMM input is twice as wide
-    w.xn16 = (bf16_t*)k.take((size_t)Mp * D * 2 * par);
-    w.q16 = (bf16_t*)k.take((size_t)M * D * 2 * par);
-    w.a16 = (bf16_t*)k.take((size_t)Mp * D * 2 * par);
-    w.act16 = (bf16_t*)k.take((size_t)Mp * F * 2 * par);
-    w.xl16 = (bf16_t*)k.take((size_t)Mp * D * 2 * 2);  // >= one row per sequence, as the split pair [hi | lo] (whole row blocks in the packed decode layout)
+    w.xn16 = (op16_t*)k.take((size_t)Mp * D * 2 * par);
+    w.q16 = (op16_t*)k.take((size_t)M * D * 2 * par);
+    w.a16 = (op16_t*)k.take((size_t)Mp * D * 2 * par);
+    w.act16 = (op16_t*)k.take((size_t)Mp * F * 2 * par);
+    w.xl16 = (op16_t*)k.take((size_t)Mp * D * 2 * 2);  // >= one row per sequence, as the split pair [hi | lo] (whole row blocks in the packed decode layout)
     w.g32 = (float*)k.take(par == 2 ? (size_t)M * (F > 3 * D ? F : 3 * D) * 4 : 0);   // f32 q/k/v [M, 3D], then silu(gate) * up [M, F]
     w.cs = (float*)k.take((size_t)S * (D / c->cfg.heads) * 4);
     w.ss = (float*)k.take((size_t)RV_XP_MAX_BLOCKS * (D / 16) * 16 * 4);   // [<= 9 row blocks][D/16 workgroups][16]
@@ -556,8 +556,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     const int H = g.heads, dh = (int)(D / H);
     if (kv_rows <= 0) kv_rows = B;
     const int64_t per_layer = (int64_t)kv_rows * D * Smax;  // elements of one layer's K (= V^T)
-    bf16_t* kbase = (bf16_t*)kv + (int64_t)kv_row0 * D * Smax;
-    bf16_t* vbase = (bf16_t*)kv + (int64_t)g.layers * per_layer + (int64_t)kv_row0 * D * Smax;
+    op16_t* kbase = (op16_t*)kv + (int64_t)kv_row0 * D * Smax;
+    op16_t* vbase = (op16_t*)kv + (int64_t)g.layers * per_layer + (int64_t)kv_row0 * D * Smax;
     const float scale = 1.0f / sqrtf((float)dh);
     // (cos, sin) table for positions [P0 ? 0 : pos0, pos0 + S)
     const int tab0 = P0 > 0 ? 0 : pos0;
@@ -600,8 +600,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     if (l1 < 0 || l1 > g.layers) l1 = g.layers;
     for (int l = l0; l < l1; ++l) {
         const LlmLayer& L = c->layers[l];
-        bf16_t* kc = kbase + l * per_layer;
-        bf16_t* vtc = vbase + l * per_layer;
+        op16_t* kc = kbase + l * per_layer;
+        op16_t* vtc = vbase + l * per_layer;
         if (par) RV_TRY(k_rmsnorm_split(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st));
         else if (p8_qkv) RV_TRY(norm_quant(L.norm1));
         else if (!fuse_norm || l == l0) RV_TRY(k_rmsnorm(h, D, L.norm1, w.xn16, M, (int)D, g.rms_eps, st, xp));
@@ -737,8 +737,8 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
         else if (!fuse_norm) RV_TRY(k_rmsnorm(h, D, L.norm2, w.xn16, M, (int)D, g.rms_eps, st));
         produce.w_next = l + 1 < g.layers ? c->layers[l + 1].norm1 : c->final_norm;
         if (p8_gu || p8_down) {
-            if (p8_gu) RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wgu8p, L.sgu, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, w.sk, st));
-            else RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
+            if (p8_gu) RV_TRY(gemm_pp_fp8(w.x8, D, w.sa, L.wgu8p, L.sgu, nullptr, 0, w.act16, F, RV_OP16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, w.sk, st));
+            else RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_OP16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
             if (p8_down) {
                 RV_TRY(k_quant_rows_fp8(w.act16, F, w.x8, F, w.sa, M, (int)F, st));
                 RV_TRY(gemm_pp_fp8(w.x8, F, w.sa, L.wdown8p, L.sdown, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, nullptr, w.sk, st));
@@ -749,10 +749,10 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
             GemvNorm cg = consume, pd = produce;
             cg.w_scale = L.sgu;
             pd.w_scale = L.sdown;
-            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu8, D, 2, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, 0, st, &cg));
+            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu8, D, 2, nullptr, nullptr, 0, w.act16, F, RV_OP16, RV_ACT_SILU_MUL, M, 2 * F, D, nullptr, 0, st, &cg));
             RV_TRY(rv_gemm_impl(w.act16, F, L.wdown8, F, 2, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, nullptr, 0, st, &pd));
         } else {
-            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_BF16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
+            RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, w.act16, F, RV_OP16, RV_ACT_SILU_MUL, M, 2 * F, D, w.sk, w.sk_bytes, st,
                                 fuse_norm ? &consume : nullptr));
             RV_TRY(rv_gemm_impl(w.act16, F, L.wdown, F, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, F, w.sk, w.sk_bytes, st,
                                 fuse_norm ? &produce : nullptr));

@@ -13,6 +13,7 @@ void rv_set_error(const char* fmt, ...) {
 }
 
 extern "C" int rv_abi_version(void) { return RV_ABI_VERSION; }
+extern "C" int rv_operand_dtype(void) { return RV_OP16; }
 
 extern "C" int rv_last_error(char* buf, size_t n) {
     if (!buf || n == 0) return RV_ERR_ARG;

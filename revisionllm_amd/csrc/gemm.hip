@@ -39,7 +39,7 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 // Stage one 128x64 bf16 operand tile: wave w loads rows [32w, 32w+32), 8 rows (8 x 128 B) per instruction.
 // LDS slot (row, c') holds global 16-byte chunk c = c' ^ ((row >> 1) & 7).
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int row0, int row_max, int k0,
+__device__ __forceinline__ void stage_tile(const op16_t* __restrict__ base, int64_t ld, int row0, int row_max, int k0,
                                            char* lds, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -47,18 +47,18 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int6
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         int grow = row0 + row;
         grow = grow < row_max ? grow : row_max - 1;
-        const bf16_t* g = base + (int64_t)grow * ld + k0 + c * 8;
+        const op16_t* g = base + (int64_t)grow * ld + k0 + c * 8;
         glds16(g, lds + (wave * 32 + i * 8) * (BK * 2));
     }
 }
 
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
-    return *(const bf16x8*)(lds + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+__device__ __forceinline__ op16x8 read_frag(const char* lds, int row, int chunk) {
+    return *(const op16x8*)(lds + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
 // Packed W: the 128x64 tile is 8 n-tiles x 2 k-fragments = 16 fragments of 1 KiB; wave w moves fragments 4w..4w+3,
 // LDS image = fragment f at f*1024 (lane-linear inside), f = ntl*2 + kbl.
-__device__ __forceinline__ void stage_tile_packed(const bf16_t* __restrict__ Wp, int K, int n0, int N, int k0, char* lds,
+__device__ __forceinline__ void stage_tile_packed(const op16_t* __restrict__ Wp, int K, int n0, int N, int k0, char* lds,
                                                   int wave, int lane) {
     const int kfr = K >> 5, nt_max = (N >> 4) - 1;
 #pragma unroll
@@ -66,16 +66,16 @@ __device__ __forceinline__ void stage_tile_packed(const bf16_t* __restrict__ Wp,
         const int f = wave * 4 + i;
         int nt = (n0 >> 4) + (f >> 1);
         nt = nt < nt_max ? nt : nt_max;
-        const bf16_t* g = Wp + (((int64_t)nt * kfr + (k0 >> 5) + (f & 1)) * 64 + lane) * 8;
+        const op16_t* g = Wp + (((int64_t)nt * kfr + (k0 >> 5) + (f & 1)) * 64 + lane) * 8;
         glds16(g, lds + f * 1024);
     }
 }
-__device__ __forceinline__ bf16x8 read_frag_packed(const char* lds, int ntl, int ks, int lane) {
-    return *(const bf16x8*)(lds + (ntl * 2 + ks) * 1024 + lane * 16);
+__device__ __forceinline__ op16x8 read_frag_packed(const char* lds, int ntl, int ks, int lane) {
+    return *(const op16x8*)(lds + (ntl * 2 + ks) * 1024 + lane * 16);
 }
 
 template <int OUT_BF16, int ACT, int WP>
-__global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256) void gemm_tile(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ W,
                                                  int64_t ldw, const float* __restrict__ bias, const float* res,
                                                  int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K,
                                                  int tiles_m, int tiles_n) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], af[4];
+            op16x8 wf[4], af[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 wf[i] = WP ? read_frag_packed(b_cur, wc * 4 + i, ks, lane) : read_frag(b_cur, wc * 64 + i * 16 + fr, ks * 4 + kg);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = rv_mfma16(wf[ni], af[mi], acc[ni][mi]);
         }
         __syncthreads();
     }
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
                 if (OUT_BF16) {
-                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = p;
+                    u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                    *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = p;
                 } else {
                     *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
                 }
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
                 if (OUT_BF16) {
-                    u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = p;
+                    u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                    *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = p;
                 } else {
                     *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
                 }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const bf16_t* __restrict__ A, i
 // group hit 16 distinct 16-byte slots.
 constexpr int P4_BK = 32, P4_A_BYTES = BM * P4_BK * 2, P4_STAGE = 2 * P4_A_BYTES;
 
-__device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int N,
+__device__ __forceinline__ void p4_stage_load(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp, int M, int N,
                                               int K, int m0, int n0, int k0, char* slot, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void p4_stage_load(const bf16_t* __restrict__ A, int6
 // ST = ring depth: 4 (64 KiB, two workgroups per CU) or 3 (48 KiB, THREE workgroups per CU = three waves per SIMD, so
 // that one wave's MFMA burst can overlap two other waves' wait / LDS phases).
 template <int OUT_BF16, int ACT, int ST, int ROPE = 0>
-__global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ W,
                                                     const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                     int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, QkvRope qr) {
     __shared__ __attribute__((aligned(16))) char smem[ST * P4_STAGE];
@@ -273,18 +273,18 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
         }
         const char* a_s = smem + slot * P4_STAGE;
         const char* w_s = a_s + P4_A_BYTES;
-        bf16x8 wf[4], af[4];
+        op16x8 wf[4], af[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            wf[q] = *(const bf16x8*)(w_s + (wc * 4 + q) * 1024 + lane * 16);
+            wf[q] = *(const op16x8*)(w_s + (wc * 4 + q) * 1024 + lane * 16);
             const int row = wr * 64 + q * 16 + fr;
-            af[q] = *(const bf16x8*)(a_s + row * (P4_BK * 2) + ((kg ^ ((row >> 2) & 2)) << 4));
+            af[q] = *(const op16x8*)(a_s + row * (P4_BK * 2) + ((kg ^ ((row >> 2) & 2)) << 4));
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = rv_mfma16(wf[ni], af[mi], acc[ni][mi]);
         slot = slot + 1 == ST ? 0 : slot + 1;
     }
 
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                        *(u32x2*)(my + row * RS + ((ni >> 1) * 16 + kg * 4) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2*)(my + row * RS + ((ni >> 1) * 16 + kg * 4) * 2) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                     }
                 } else {
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                         }
-                        *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                     }
                 }
             }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
             for (int it = 0; it < 64 / RPI; ++it) {
                 const int row = it * RPI + lane / LPR, chunk = lane % LPR;
                 const int m = m0 + wr * 64 + row;
-                if (m < M) *(u32x4*)((bf16_t*)Cv + (int64_t)m * ldc + ncol0 + chunk * 8) = *(const u32x4*)(my + row * RS + chunk * 16);
+                if (m < M) *(u32x4*)((op16_t*)Cv + (int64_t)m * ldc + ncol0 + chunk * 8) = *(const u32x4*)(my + row * RS + chunk * 16);
             }
             return;
         }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -390,17 +390,17 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const bf16_t* __restrict__ A
         const char* a_s_ = smem + (SLOT) * P4_STAGE;                                               \
         const char* w_s_ = a_s_ + P4_A_BYTES;                                                      \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
-            WF[q] = *(const bf16x8*)(w_s_ + (wc * 4 + q) * 1024 + lane * 16);                      \
+            WF[q] = *(const op16x8*)(w_s_ + (wc * 4 + q) * 1024 + lane * 16);                      \
             const int row_ = wr * 64 + q * 16 + fr;                                                \
-            AF[q] = *(const bf16x8*)(a_s_ + row_ * (P4_BK * 2) + ((kg ^ ((row_ >> 2) & 2)) << 4)); \
+            AF[q] = *(const op16x8*)(a_s_ + row_ * (P4_BK * 2) + ((kg ^ ((row_ >> 2) & 2)) << 4)); \
         }                                                                                          \
     } while (0)
 #define P5_MMA(WF, AF)                                                                             \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ni], AF[mi], acc[ni][mi], 0, 0, 0)
+        acc[ni][mi] = rv_mfma16(WF[ni], AF[mi], acc[ni][mi])
 
 template <int OUT_BF16, int ACT>
-__global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256) void gemm_tile_p5(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ W,
                                                     const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                     int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     constexpr int ST = 4;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    bf16x8 wfA[4], afA[4], wfB[4], afB[4];
+    op16x8 wfA[4], afA[4], wfB[4], afB[4];
     P5_READ(wfA, afA, 0);
     // step i: [wait stage i+1] [barrier: also every wave has finished READING stage i] [refill slot of stage i with
     // stage i+ST] [read stage i+1 -> other register set] [MFMA stage i]
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -513,27 +513,16 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const bf16_t* __restrict__ A
 // i.e. a lane's 16-byte load holds its MFMA operand of TWO consecutive 32-k blocks; the bytes are widened to bf16 in
 // registers (exact: e4m3 has 3 mantissa bits) right before the MFMA - the decode step is HBM-bound, the weights move as
 // half the bytes and the arithmetic stays bf16 x bf16 -> f32.
-template <int WP> struct GemvW { typedef bf16x8 frag[4]; };
+template <int WP> struct GemvW { typedef op16x8 frag[4]; };
 template <> struct GemvW<2> { typedef u32x4 frag[2]; };
 
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-    union { bf16x8 v; unsigned u[4]; } r;   // f32 -> bf16 by truncation (the value came from 8 bits)
-    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
-    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
-    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
-    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
-    return r.v;
-}
 
 // x operand addressing: row-major rows (xj = 32, xkb = 128 elements per 32-k fragment / 128-k block, per-lane base = row start +
 // kg * 8) or the fragment-packed decode layout with mbp row blocks (xj = mbp * 512, xkb = mbp * 2048: fragment (kf, mb) at
 // (kf * mbp + mb) * 512, per-lane base = mb * 512 + lane * 8; GemvNorm::x_packed = mbp)
 template <int NT, int WP, int MB>
-__device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const bf16_t* const (&xp)[MB], int kb, typename GemvW<WP>::frag (&wf)[NT],
-                                          bf16x8 (&xf)[MB][4], int xj, int xkb) {
+__device__ __forceinline__ void gemv_load(const op16_t* const (&wp)[NT], const op16_t* const (&xp)[MB], int kb, typename GemvW<WP>::frag (&wf)[NT],
+                                          op16x8 (&xf)[MB][4], int xj, int xkb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (WP == 2) {
@@ -542,17 +531,17 @@ __device__ __forceinline__ void gemv_load(const bf16_t* const (&wp)[NT], const b
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                wf[t][j] = __builtin_nontemporal_load((const bf16x8*)(wp[t] + (WP ? (kb * 4 + j) * 512 : kb * 128 + j * 32)));
+                wf[t][j] = __builtin_nontemporal_load((const op16x8*)(wp[t] + (WP ? (kb * 4 + j) * 512 : kb * 128 + j * 32)));
         }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[mb][j] = *(const bf16x8*)(xp[mb] + (int64_t)kb * xkb + j * xj);
+        for (int j = 0; j < 4; ++j) xf[mb][j] = *(const op16x8*)(xp[mb] + (int64_t)kb * xkb + j * xj);
 }
 template <int WP>
-__device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, int j) {
-    if constexpr (WP == 2) return fp8x8_to_bf16x8(w[j >> 1][(j & 1) * 2], w[j >> 1][(j & 1) * 2 + 1]);
+__device__ __forceinline__ op16x8 gemv_frag(const typename GemvW<WP>::frag& w, int j) {
+    if constexpr (WP == 2) return fp8x8_to_op16x8(w[j >> 1][(j & 1) * 2], w[j >> 1][(j & 1) * 2 + 1]);
     else return w[j];
 }
 
@@ -569,7 +558,7 @@ __device__ __forceinline__ bf16x8 gemv_frag(const typename GemvW<WP>::frag& w, i
 // and its tail (cross-wave reduction + epilogue) run with nothing else resident on the CU; as TWO independent 256-thread
 // workgroups the other one keeps streaming.
 template <int NT, int OUT_BF16, int ACT, int WP, int ROPE = 0, int DEPTH = 2, int MB = 1, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf16_t* __restrict__ X, int64_t lda, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const op16_t* __restrict__ X, int64_t lda, const op16_t* __restrict__ W,
                                                    int64_t ldw, const float* __restrict__ bias, const float* res,
                                                    int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm,
                                                    QkvRope qr) {
@@ -614,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
             if (res && emb * 16 + fr < M) res_pre = *(const f32x4*)(res + (int64_t)(emb * 16 + fr) * ldr + n);
         }
     }
-    const bf16_t* xp[MB];
+    const op16_t* xp[MB];
     const int xj = nrm.x_packed ? 1024 : 32, xkb = nrm.x_packed ? 4096 : 128;   // (<= 32 rows: two row blocks; literal strides - the loop is
                                                                                //  specialised on them, generic ones cost ~20 address registers)
 #pragma unroll
@@ -622,13 +611,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
         const int xr = mb * 16 + fr < M ? mb * 16 + fr : M - 1;
         xp[mb] = nrm.x_packed ? X + mb * 512 + lane * 8 : X + (int64_t)xr * lda + kg * 8;   // (packed: rows >= M hold stale finite data, never stored)
     }
-    const bf16_t* wp[NT];
+    const op16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (WP == 2) {   // fp8: one 16-row n-block = K/64 chunks of 1 KiB
             int nt = (n0 >> 4) + t;
             nt = nt < (N >> 4) ? nt : (N >> 4) - 1;
-            wp[t] = (const bf16_t*)((const char*)W + ((int64_t)nt * (K >> 6) * 64 + lane) * 16);
+            wp[t] = (const op16_t*)((const char*)W + ((int64_t)nt * (K >> 6) * 64 + lane) * 16);
         } else if (WP) {
             int nt = (n0 >> 4) + t;
             nt = nt < (N >> 4) ? nt : (N >> 4) - 1;
@@ -654,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
     // The i-th block of a physical wave belongs to virtual wave wave + NW * (i % VW); U % VW == 0 keeps that static per stage.
     {
         typename GemvW<WP>::frag wf[DEPTH][NT];
-        bf16x8 xf[DEPTH][MB][4];
+        op16x8 xf[DEPTH][MB][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (kb + NW * d < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + NW * d, wf[d], xf[d], xj, xkb);
@@ -667,10 +656,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            const bf16x8 wfrag = gemv_frag<WP>(wf[d][t], j);
+                            const op16x8 wfrag = gemv_frag<WP>(wf[d][t], j);
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb)
-                                acc[v][mb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, xf[d][mb][j], acc[v][mb][t], 0, 0, 0);
+                                acc[v][mb][t] = rv_mfma16(wfrag, xf[d][mb][j], acc[v][mb][t]);
                         }
                     if (kb + NW * (u + DEPTH) < nkb) gemv_load<NT, WP, MB>(wp, xp, kb + NW * (u + DEPTH), wf[d], xf[d], xj, xkb);
                 }
@@ -735,7 +724,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemv_stream(const bf
 // 4 = ping-pong output-tiled wherever supported; 5 = ping-pong stream-K wherever supported (A/B measurement knobs)
 
 template <int OUT_BF16, int ACT, int WP>
-void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+void launch_tile(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
     if (WP && rv_cur_opts().gemm_tile_variant == 1) {
@@ -758,7 +747,7 @@ void launch_tile(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, con
 }
 
 template <int OUT_BF16, int ACT, int WP, int MB>
-void launch_gemv_mb(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+void launch_gemv_mb(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, const float* bias, const float* res,
                     int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
     // MB = 2 needs > 128 VGPRs (2 waves per SIMD): two independent 256-thread workgroups per CU (NW = 4) with a deeper ring
     constexpr int D2 = MB == 2 ? 3 : 2, D1 = MB == 2 ? 4 : 2, NW = MB == 2 ? 4 : 8;
@@ -774,7 +763,7 @@ void launch_gemv_mb(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, 
     }
 }
 template <int OUT_BF16, int ACT, int WP>
-void launch_gemv(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* res,
+void launch_gemv(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldr, void* C, int64_t ldc, int M, int N, int K, hipStream_t st, const GemvNorm& nrm) {
     if (M > 16) launch_gemv_mb<OUT_BF16, ACT, WP, 2>(A, lda, W, ldw, bias, res, ldr, C, ldc, M, N, K, st, nrm);
     else launch_gemv_mb<OUT_BF16, ACT, WP, 1>(A, lda, W, ldw, bias, res, ldr, C, ldc, M, N, K, st, nrm);
@@ -792,13 +781,13 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_ARG(N % 4 == 0 && lda % 8 == 0 && ldc % 4 == 0, "rv_gemm: alignment (N%%4, lda%%8, ldc%%4)");
     RV_CHECK_ARG(w_layout >= 0 && w_layout <= 2, "rv_gemm: w_layout must be 0 (row-major), 1 (fragment-packed) or 2 (fp8 fragment-packed)");
     RV_CHECK_ARG(w_layout != 0 ? (N % 16 == 0) : (ldw % 8 == 0), "rv_gemm: packed W needs N%%16==0; row-major W needs ldw%%8==0");
-    RV_CHECK_ARG(out_dtype == RV_BF16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
+    RV_CHECK_ARG(out_dtype == RV_OP16 || out_dtype == RV_F32, "rv_gemm: out dtype must be bf16 or f32");
     RV_CHECK_ARG(act >= RV_ACT_NONE && act <= RV_ACT_QUICK_GELU, "rv_gemm: bad activation %d", act);
     RV_CHECK_ARG(act != RV_ACT_SILU_MUL || (N % 32 == 0 && !bias && !residual),
                  "rv_gemm: SILU_MUL needs N%%32==0 and no bias/residual");
     RV_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "rv_gemm: dims exceed int32");
-    const bf16_t* a = (const bf16_t*)A;
-    const bf16_t* w = (const bf16_t*)W;
+    const op16_t* a = (const op16_t*)A;
+    const op16_t* w = (const op16_t*)W;
     const bool gemv = (M <= 32) && (K % 128 == 0) && (N % 16 == 0);   // 17 .. 32 rows: two MFMA column blocks per weight fragment
     if (norm && norm->planes && M > 32 && M <= RV_ROWS_MAX && w_layout >= 1)   // 33 .. 144 rows of a merged decode step: the split-K kernel (bf16 or fp8 W)
         return gemm_rows(a, w, bias, residual, ldr, C, ldc, out_dtype, act, (int)M, (int)N, (int)K, st, *norm, nullptr, w_layout);
@@ -807,7 +796,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     RV_CHECK_ARG(!gemv || nrm.x_packed == 0 || nrm.x_packed == 2, "rv_gemm: <= 32 fragment-packed rows come in two row blocks");
     if (w_layout == 2) {   // fp8 weights: the weight-streaming kernel only (decode), scales ride in the norm descriptor
         RV_CHECK_ARG(gemv && nrm.w_scale, "rv_gemm: fp8 weights need M <= 32, K %% 128 == 0 and per-row scales");
-        const int ob8 = out_dtype == RV_BF16;
+        const int ob8 = out_dtype == RV_OP16;
 #define RV_GEMV8(OB, AC) launch_gemv<OB, AC, 2>(a, lda, w, ldw, bias, residual, ldr, C, ldc, (int)M, (int)N, (int)K, st, nrm)
         if (act == RV_ACT_SILU_MUL) { if (ob8) RV_GEMV8(1, RV_ACT_SILU_MUL); else RV_GEMV8(0, RV_ACT_SILU_MUL); }
         else if (act == RV_ACT_NONE) { if (ob8) RV_GEMV8(1, RV_ACT_NONE); else RV_GEMV8(0, RV_ACT_NONE); }
@@ -839,7 +828,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
         if (w_layout) RV_DISPATCH2(OB, AC, 1); \
         else RV_DISPATCH2(OB, AC, 0);   \
     } while (0)
-    const int ob = out_dtype == RV_BF16;
+    const int ob = out_dtype == RV_OP16;
     if (ob && act == RV_ACT_NONE) RV_DISPATCH(1, RV_ACT_NONE);
     else if (ob && act == RV_ACT_RELU) RV_DISPATCH(1, RV_ACT_RELU);
     else if (ob && act == RV_ACT_SILU_MUL) RV_DISPATCH(1, RV_ACT_SILU_MUL);
@@ -860,8 +849,8 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
     RV_CHECK_ARG(Kdim == 0 || (Kdim % 128 == 0 && !norm), "gemm_qkv_rope: an explicit reduction length needs K %% 128 == 0 and no norm fusion");
     RV_CHECK_ARG(D % 128 == 0 && D == (int64_t)r.H * 128 && M == (int64_t)r.G * ((int64_t)r.P0 + (int64_t)r.B * r.S) && (r.G == 1 || r.Mg == r.P0 + r.B * r.S),
                  "gemm_qkv_rope: bad geometry");
-    const bf16_t* a = (const bf16_t*)A;
-    const bf16_t* w = (const bf16_t*)Wp;
+    const op16_t* a = (const op16_t*)A;
+    const op16_t* w = (const op16_t*)Wp;
     const int N = (int)(3 * D), K = (int)(Kdim ? Kdim : D);
     if (M <= 32 && w_layout == 2) {
         RV_CHECK_ARG(norm && norm->w_scale, "gemm_qkv_rope: fp8 weights need per-row scales");

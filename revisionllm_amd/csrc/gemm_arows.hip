@@ -34,7 +34,7 @@ constexpr int AR_PAD = 2;   // pad chunks (16 B) per LDS row: row stride = K * 2
 // NW = n-fragments (16 columns) per wave slice.  W fragments sit in a ring of 4 register slots, loaded 2 k-steps ahead with
 // the step inside its half-body (4 k-steps = 4 KiB) as the load's immediate offset.
 template <int OUT_BF16, int ACT, int MF, int NW>
-__global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+__global__ __launch_bounds__(512) void gemm_arows_kernel(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp,
                                                          const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                          int64_t ldc, int M, int N, int K, int rows_per_wg, int probe) {
     // probe (measurement only, wrong results): bit 0 = every slice re-reads the W fragments of the wave's first slice (a small
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
     // W: fragment (nt, kf) is the 1 KiB block (nt * KF + kf); this lane's 16 bytes of it.  Consumer position = (slice si, kf);
     // the producer runs 4 k-steps ahead and crosses into the wave's next slice (nt + 8 * NW) at the end of a slice.
     const int64_t slice_jump = (probe & 1) ? -(int64_t)KF * 512 : ((int64_t)8 * NW * KF - KF) * 512;     // elements: from the end of a slice to the start of the next one
-    const bf16_t *wcur[NW], *wnext[NW];       // this lane's 16 bytes of k-step 0 of the consumer's half-body / of the one after it
+    const op16_t *wcur[NW], *wnext[NW];       // this lane's 16 bytes of k-step 0 of the consumer's half-body / of the one after it
 #pragma unroll
     for (int nf = 0; nf < NW; ++nf) wnext[nf] = Wp + ((int64_t)(wave * NW + nf) * KF * 64 + lane) * 8;
     int next_kf = 0, next_si = 0;             // position of wnext
@@ -102,13 +102,13 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
 #pragma unroll
         for (int nf = 0; nf < NW; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
     // W ring of 4 slots: k-step j of a body uses slot j & 3, its fragments were loaded 2 steps earlier
-    bf16x8 wb[4][NW], afA[MF], afB[MF];
+    op16x8 wb[4][NW], afA[MF], afB[MF];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int nf = 0; nf < NW; ++nf) wb[j][nf] = *(const bf16x8*)(wcur[nf] + j * 512);
+        for (int nf = 0; nf < NW; ++nf) wb[j][nf] = *(const op16x8*)(wcur[nf] + j * 512);
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) afA[mf] = *(const bf16x8*)(smem + abase[mf]);
+    for (int mf = 0; mf < MF; ++mf) afA[mf] = *(const op16x8*)(smem + abase[mf]);
 
     // Deferred bf16 stores.  A finished slice is packed to bf16 at once (two 16-column fragments -> one 16-byte piece per lane:
     // v_permlane16_swap trades the odd 16-lane rows of the first fragment's words with the even rows of the second's, after
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
     // per k-step during the NEXT slice: vmcnt is in-order, so a burst of 14 stores in front of the W loads in flight would park
     // the wave until every store is acknowledged; one store between two loads is invisible.
     u32x4 pend[MF];
-    bf16_t* pend_ptr = nullptr;      // &C[r0 + fr][column of this lane's piece] of the pending slice; nullptr = nothing pending
+    op16_t* pend_ptr = nullptr;      // &C[r0 + fr][column of this lane's piece] of the pending slice; nullptr = nothing pending
     const int64_t mf_stride = 16 * ldc;
     const bool row_ok_last = (MF - 1) * 16 + fr < nrows;       // rows of fragments 0 .. MF-2 are always inside the block
     auto store_pending = [&](int mf) {
@@ -126,13 +126,13 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
     // one k-step: A fragments of the NEXT step -> NXT, W fragments of step +4 -> the other ring half, MFMAs of this step
 #define AR_STEP(CUR, NXT, J, AOFF, ST)                                                                        \
     do {                                                                                                      \
-        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) NXT[mf] = *(const bf16x8*)(smem + abase[mf] + (AOFF)); \
+        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) NXT[mf] = *(const op16x8*)(smem + abase[mf] + (AOFF)); \
         _Pragma("unroll") for (int nf = 0; nf < NW; ++nf)                                                     \
-            wb[((J) + 2) & 3][nf] = ((J) & 3) < 2 ? *(const bf16x8*)(wcur[nf] + (((J) & 3) + 2) * 512)        \
-                                                  : *(const bf16x8*)(wnext[nf] + (((J) & 3) - 2) * 512);      \
+            wb[((J) + 2) & 3][nf] = ((J) & 3) < 2 ? *(const op16x8*)(wcur[nf] + (((J) & 3) + 2) * 512)        \
+                                                  : *(const op16x8*)(wnext[nf] + (((J) & 3) - 2) * 512);      \
         if ((ST) >= 0 && (ST) < MF) store_pending(ST);                                                        \
         _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < NW; ++nf)   \
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(J) & 3][nf], CUR[mf], acc[mf][nf], 0, 0, 0); \
+            acc[mf][nf] = rv_mfma16(wb[(J) & 3][nf], CUR[mf], acc[mf][nf]); \
         /* interleave: one memory instruction in the shadow of each MFMA */                                  \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) {            /* W loads first: the longest latency */  \
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                  \
@@ -182,11 +182,11 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = rv_act_apply<ACT>(v0[r]); v1[r] = rv_act_apply<ACT>(v1[r]); }
                     }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pack_op16x2(v0[0], v0[1]), pack_op16x2(v1[0], v1[1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pack_op16x2(v0[2], v0[3]), pack_op16x2(v1[2], v1[3]), false, false);
                     pend[mf] = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
-                pend_ptr = (bf16_t*)Cv + (int64_t)(r0 + fr) * ldc + n0 + (kg & 1) * 16 + (kg >> 1) * 8;
+                pend_ptr = (op16_t*)Cv + (int64_t)(r0 + fr) * ldc + n0 + (kg & 1) * 16 + (kg >> 1) * 8;
                 continue;
             }
         }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const bf16_t* __restric
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + m * ldr + n);
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + m * ldc + n) = v;
             }
         }
@@ -270,7 +270,7 @@ int set_lds(Kern k, std::atomic<uint64_t>& have) {
 }
 
 template <int OUT_BF16, int ACT, int MF, int NW>
-int launch(const ArPlan& p, const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C,
+int launch(const ArPlan& p, const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C,
            int64_t ldc, int M, int N, int K, hipStream_t st) {
     static std::atomic<uint64_t> have{0};
     if (int rc = set_lds(gemm_arows_kernel<OUT_BF16, ACT, MF, NW>, have)) return rc;
@@ -280,7 +280,7 @@ int launch(const ArPlan& p, const bf16_t* A, int64_t lda, const bf16_t* Wp, cons
 }
 
 template <int OUT_BF16, int ACT, int NW>
-int launch_mf(const ArPlan& p, const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C,
+int launch_mf(const ArPlan& p, const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C,
               int64_t ldc, int M, int N, int K, hipStream_t st) {
     switch (p.mf) {
         case 4: return launch<OUT_BF16, ACT, 4, NW>(p, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K, st);
@@ -306,9 +306,9 @@ bool gemm_arows_supported(int w_layout, int act, int64_t M, int64_t N, int64_t K
 int gemm_arows_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
                       int out_dtype, int act, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const ArPlan p = plan_for(M, N, K);
-    const bf16_t* a = (const bf16_t*)A;
-    const bf16_t* w = (const bf16_t*)Wp;
-    const int ob = out_dtype == RV_BF16;
+    const op16_t* a = (const op16_t*)A;
+    const op16_t* w = (const op16_t*)Wp;
+    const int ob = out_dtype == RV_OP16;
     int rc;
 #define AR(OB, AC) rc = launch_mf<OB, AC, 2>(p, a, lda, w, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, st)
     if (ob && act == RV_ACT_NONE) AR(1, RV_ACT_NONE);

@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x4 pp_scaled(const PpScale& sc, int m, int n, f32x
 
 // NF = MFMA fragments per wave along N: 4 -> 256-column panels, 3 -> 192-column panels (n1 quadrant = one fragment)
 template <int NF>
-__device__ __forceinline__ void pp_sources(PpSrc& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M,
+__device__ __forceinline__ void pp_sources(PpSrc& s, const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp, int M,
                                            int K, int m0, int n0, int wave, int lane) {
     s.A = (const char*)A;
     s.W = (const char*)Wp;
@@ -170,7 +170,7 @@ constexpr int PP_A_STAGE = 2 * UNIT, PP_W_BASE = 2 * PP_A_STAGE, PP_W_STAGE = 2 
 // v_mfma_f32_16x16x128_f8f6f4: both operands carry the same k permutation and a dot product does not care.  Everything else
 // (addresses, LDS layout, waits) is the bf16 kernel at K / 2.
 typedef int pp_i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ pp_i32x8 pp_cat(bf16x8 lo, bf16x8 hi) {
+__device__ __forceinline__ pp_i32x8 pp_cat(op16x8 lo, op16x8 hi) {
     typedef int i32x4_ __attribute__((ext_vector_type(4)));
     const i32x4_ a = __builtin_bit_cast(i32x4_, lo), b = __builtin_bit_cast(i32x4_, hi);
     return pp_i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -203,7 +203,7 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
 
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    op16x8 af[4][2], b0[2][2], b1[2][2];
     // One k-tile.  m1 / m2 (tile c+1 / c+2 exists: their units are issued here) and the wave's M-group are compile-time
     // constants: the steady-state loop carries no branches - the last two tiles are peeled, the two groups run separate copies.
     auto tile = [&](auto m1_c, auto m2_c, auto group_c, int c, int ws) {   // ws = c % 3
@@ -227,7 +227,7 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         } else {                                                                                                    \
             _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                         \
                 _Pragma("unroll") for (int f = 0; f < 4; ++f) acc[(NI) + j][(MI0) + f] =                             \
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[j][(PART)], af[f][(PART)], acc[(NI) + j][(MI0) + f], 0, 0, 0); \
+                    rv_mfma16(B[j][(PART)], af[f][(PART)], acc[(NI) + j][(MI0) + f]); \
         }                                                                                                           \
     } while (0)
 #define PP_MFMA(B, NI, MI0, NJ, MID_ISSUE)                                                                          \
@@ -244,12 +244,12 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     } while (0)
 #define PP_READ_A(BASE)                                                                                             \
     _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                 \
-        af[f][0] = *(const bf16x8*)((BASE) + a_rd + f * 2048 + a_c0);                                               \
-        af[f][1] = *(const bf16x8*)((BASE) + a_rd + f * 2048 + a_c1);                                               \
+        af[f][0] = *(const op16x8*)((BASE) + a_rd + f * 2048 + a_c0);                                               \
+        af[f][1] = *(const op16x8*)((BASE) + a_rd + f * 2048 + a_c1);                                               \
     }
 #define PP_READ_W(B, BASE, RD, NJ)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                \
-        B[j][ks] = *(const bf16x8*)((BASE) + (RD) + j * 2048 + ks * 1024);
+        B[j][ks] = *(const op16x8*)((BASE) + (RD) + j * 2048 + ks * 1024);
         // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
         // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
 #define PP_SYNC_M(WAITN)                                   \
@@ -338,7 +338,7 @@ struct Pp4Src {
     unsigned a[8];   // this wave's 8 pieces (8 rows x 128 B) of the A tile, k = 0
     unsigned w[8];   // this wave's 8 pieces (fragment nfrag = wave * 4 + (i >> 1), k32 half i & 1) of the W tile
 };
-__device__ __forceinline__ void pp4_sources(Pp4Src& s, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, int M, int K,
+__device__ __forceinline__ void pp4_sources(Pp4Src& s, const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp, int M, int K,
                                             int m0, int n0, int wave, int lane) {
     s.A = (const char*)A;
     s.W = (const char*)Wp;
@@ -360,14 +360,14 @@ __device__ __forceinline__ void pp4_mainloop(f32x4 (&acc)[8][8], const Pp4Src& s
     const int a_rd = (wr * 128 + fr) * 128;
     const int a_c[2] = {((kg ^ (fr & 7)) << 4), (((4 + kg) ^ (fr & 7)) << 4)};
     const int w_rd = wc * 16384 + lane * 16;
-    bf16x8 fa[2][8], fw[2][8];
+    op16x8 fa[2][8], fw[2][8];
 #define P4_A_STAGE(c) (smem + ((c) & 1) * PP4_TILE)
 #define P4_W_STAGE(ws) (smem + (2 + (ws)) * PP4_TILE)
 #define P4_ISSUE_A(KT, ST, i) glds16(src.A + (int64_t)(KT) * 128 + src.a[i], (ST) + (wave * 8 + (i)) * 1024)
 #define P4_ISSUE_W(KT, ST, i) glds16(src.W + (int64_t)(KT) * 2048 + src.w[i], (ST) + (wave * 8 + (i)) * 1024)
-#define P4_READ_A(B, ST, KS, f) fa[B][f] = *(const bf16x8*)((ST) + a_rd + (f) * 2048 + a_c[KS])
-#define P4_READ_W(B, ST, KS, j) fw[B][j] = *(const bf16x8*)((ST) + w_rd + (j) * 2048 + (KS) * 1024)
-#define P4_MFMA1(B, j, f) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][f]) : "v"(fw[B][j]), "v"(fa[B][f]));
+#define P4_READ_A(B, ST, KS, f) fa[B][f] = *(const op16x8*)((ST) + a_rd + (f) * 2048 + a_c[KS])
+#define P4_READ_W(B, ST, KS, j) fw[B][j] = *(const op16x8*)((ST) + w_rd + (j) * 2048 + (KS) * 1024)
+#define P4_MFMA1(B, j, f) asm volatile(RV_MFMA16_ASM " %0, %1, %2, %0" : "+a"(acc[j][f]) : "v"(fw[B][j]), "v"(fa[B][f]));
 #define P4_MFMA2(B, j, f) P4_MFMA1(B, j, f) P4_MFMA1(B, j, (f) + 1)
 #define P4_PIN __builtin_amdgcn_sched_barrier(0);
     const int last = kt0 + nks - 1;
@@ -441,11 +441,11 @@ __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const Q
     const int p0 = slab0 + kg * 4;
     if (sec == 2) {
         for (int bb = row.b0; bb < row.b1; ++bb) {
-            bf16_t* dst = (bf16_t*)qr.vtc + ((int64_t)bb * qr.H + head) * 128 * qr.Smax + rv_vt_index(p0, row.pos);
+            op16_t* dst = (op16_t*)qr.vtc + ((int64_t)bb * qr.H + head) * 128 * qr.Smax + rv_vt_index(p0, row.pos);
 #pragma unroll
             for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(ni * 16 + e) * 8] = f32_to_bf16(v[ni][e]);
+                for (int e = 0; e < 4; ++e) dst[(ni * 16 + e) * 8] = f32_to_op16(v[ni][e]);
         }
         return;
     }
@@ -455,15 +455,15 @@ __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const Q
         const f32x4 t = *(const f32x4*)(row.cs + (p0 + ni * 16));   // pairs (p >> 1) of p = p0 + ni * 16: (c0, s0, c1, s1) at cs + (p >> 1) * 2
         const float a0 = __fmaf_rn(v[ni][0], t[0], -__fmul_rn(v[ni][1], t[1])), b0 = __fmaf_rn(v[ni][1], t[0], __fmul_rn(v[ni][0], t[1]));
         const float a1 = __fmaf_rn(v[ni][2], t[2], -__fmul_rn(v[ni][3], t[3])), b1 = __fmaf_rn(v[ni][3], t[2], __fmul_rn(v[ni][2], t[3]));
-        o[ni] = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+        o[ni] = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
     }
     if (sec == 0) {
-        bf16_t* dst = (bf16_t*)qr.q16 + (int64_t)row.mrow * (qr.H * 128) + head * 128 + p0;
+        op16_t* dst = (op16_t*)qr.q16 + (int64_t)row.mrow * (qr.H * 128) + head * 128 + p0;
 #pragma unroll
         for (int ni = 0; ni < NFR; ++ni) *(u32x2*)(dst + ni * 16) = o[ni];
     } else {
         for (int bb = row.b0; bb < row.b1; ++bb) {
-            bf16_t* dst = (bf16_t*)qr.kc + (((int64_t)bb * qr.H + head) * qr.Smax + row.pos) * 128 + p0;
+            op16_t* dst = (op16_t*)qr.kc + (((int64_t)bb * qr.H + head) * qr.Smax + row.pos) * 128 + p0;
 #pragma unroll
             for (int ni = 0; ni < NFR; ++ni) *(u32x2*)(dst + ni * 16) = o[ni];
         }
@@ -506,7 +506,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][0][r]) * acc[ni + 1][0][r];
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -520,7 +520,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -566,7 +566,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -580,7 +580,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
-                if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -589,7 +589,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
 
 // ---- output-tiled launch: one workgroup per 256 x 256 tile ------------------------------------------------------------
 template <int OUT_BF16, int ACT, int NF>
-__global__ __launch_bounds__(512) void gemm_pp(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+__global__ __launch_bounds__(512) void gemm_pp(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp,
                                                const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -676,7 +676,7 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(v0[r]) * v1[r];
-        if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
         else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
     } else {
 #pragma unroll
@@ -689,7 +689,7 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
                 for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
             if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
-            if (OUT_BF16) *(u32x2*)((bf16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
             else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
         }
     }
@@ -747,7 +747,7 @@ __device__ __forceinline__ void pp_reduce_share(f32x4* partial, const int* ids, 
 }
 
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8, int W4>
-__device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+__device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp,
                                            const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                            int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
                                            int total_units, f32x4* partial, int* flags, int* status, int epoch, const QkvRope& qr,
@@ -883,7 +883,7 @@ __device__ __forceinline__ void pp_sk_body(const bf16_t* __restrict__ A, int64_t
 }
 
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
-__global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp,
+__global__ __launch_bounds__(512) void gemm_pp_sk(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp,
                                                   const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
                                                   int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels,
                                                   int total_units, f32x4* partial, int* flags, int* status, int epoch, QkvRope qr,
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(512) void gemm_pp_sk(const bf16_t* __restrict__ A, 
 // the four-wave form (pp4_mainloop): one wave per SIMD, all 512 registers of the unified file
 template <int OUT_BF16, int ACT, int ROPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pp4_sk(
-    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wp, const float* __restrict__ bias, const float* res, int64_t ldr,
+    const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ Wp, const float* __restrict__ bias, const float* res, int64_t ldr,
     void* Cv, int64_t ldc, int M, int N, int K, int tiles_m, int TS, int nk, int dp_panels, int total_units, f32x4* partial, int* flags,
     int* status, int epoch, QkvRope qr, PpScale sc, int PG, int tiles_n) {
     pp_sk_body<OUT_BF16, ACT, ROPE, 4, 0, 1>(A, lda, Wp, bias, res, ldr, Cv, ldc, M, N, K, tiles_m, TS, nk, dp_panels, total_units, partial, flags,
@@ -933,7 +933,7 @@ int reserve_lds(Kern k, std::atomic<uint64_t>& done) {
 }
 
 template <int OUT_BF16, int ACT, int NF>
-int launch(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+int launch(const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
            int M, int N, int K, hipStream_t st) {
     static std::atomic<uint64_t> attr_set{0};
     if (int rc = reserve_lds(gemm_pp<OUT_BF16, ACT, NF>, attr_set)) return rc;
@@ -952,7 +952,7 @@ int pp_teams(int64_t M) {
 }
 
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
-int launch_sk(const bf16_t* A, int64_t lda, const bf16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+int launch_sk(const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
               int M, int N, int K, void* ws, hipStream_t st, const QkvRope& qr, PpScale sc = PpScale{nullptr, nullptr}) {
     static std::atomic<uint64_t> attr_set{0}, attr_set4{0};
     constexpr bool can4 = NF == 4 && !F8;
@@ -1065,9 +1065,9 @@ bool gemm_pp_dp_profitable(int64_t M, int64_t N, int64_t K) { return gemm_pp_dp_
 
 int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias, const float* res, int64_t ldr, void* C,
                    int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, void* ws, hipStream_t st) {
-    const bf16_t* a = (const bf16_t*)A;
-    const bf16_t* w = (const bf16_t*)Wp;
-    const int ob = out_dtype == RV_BF16;
+    const op16_t* a = (const op16_t*)A;
+    const op16_t* w = (const op16_t*)Wp;
+    const int ob = out_dtype == RV_OP16;
     const bool sk = ws && gemm_pp_sk_supported(1, M, N, K);
     const bool nf3 = sk && act != RV_ACT_SILU_MUL && gemm_pp_sk_plan(M, N, K, false) == 3;
     int rc;
@@ -1110,9 +1110,9 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st) {
     int rc = gemm_pp_sk_plan(M, N, K, false) == 3
-                 ? launch_sk<0, RV_ACT_NONE, 1, 3>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
+                 ? launch_sk<0, RV_ACT_NONE, 1, 3>((const op16_t*)A, lda, (const op16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
                                                    (int)K, ws, st, r)
-                 : launch_sk<0, RV_ACT_NONE, 1, 4>((const bf16_t*)A, lda, (const bf16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
+                 : launch_sk<0, RV_ACT_NONE, 1, 4>((const op16_t*)A, lda, (const op16_t*)Wp, nullptr, nullptr, 0, nullptr, 0, (int)M, (int)N,
                                                    (int)K, ws, st, r);
     if (rc) return rc;
     RV_CHECK_LAUNCH("gemm_pp_qkv_rope");
@@ -1135,8 +1135,8 @@ bool gemm_pp_fp8_supported(int64_t M, int64_t N, int64_t K, bool gated, bool rop
 }
 int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, const float* sw, const float* res, int64_t ldr, void* C,
                 int64_t ldc, int out_dtype, int act, int64_t M, int64_t N, int64_t K, const QkvRope* r, void* ws, hipStream_t st) {
-    const bf16_t* a = (const bf16_t*)A8;
-    const bf16_t* w = (const bf16_t*)W8p;
+    const op16_t* a = (const op16_t*)A8;
+    const op16_t* w = (const op16_t*)W8p;
     const PpScale sc{sa, sw};
     const int m = (int)M, n = (int)N, k2 = (int)(K / 2);
     const int64_t lda2 = lda / 2;
@@ -1145,11 +1145,11 @@ int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, c
         rc = gemm_pp_sk_plan(M, N, K / 2, false) == 3
                  ? launch_sk<0, RV_ACT_NONE, 1, 3, 1>(a, lda2, w, nullptr, nullptr, 0, nullptr, 0, m, n, k2, ws, st, *r, sc)
                  : launch_sk<0, RV_ACT_NONE, 1, 4, 1>(a, lda2, w, nullptr, nullptr, 0, nullptr, 0, m, n, k2, ws, st, *r, sc);
-    } else if (act == RV_ACT_SILU_MUL && out_dtype == RV_BF16) {
+    } else if (act == RV_ACT_SILU_MUL && out_dtype == RV_OP16) {
         rc = launch_sk<1, RV_ACT_SILU_MUL, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
     } else if (act == RV_ACT_NONE && out_dtype == RV_F32) {
         rc = launch_sk<0, RV_ACT_NONE, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
-    } else if (act == RV_ACT_NONE && out_dtype == RV_BF16) {
+    } else if (act == RV_ACT_NONE && out_dtype == RV_OP16) {
         rc = launch_sk<1, RV_ACT_NONE, 0, 4, 1>(a, lda2, w, nullptr, res, ldr, C, ldc, m, n, k2, ws, st, QkvRope{}, sc);
     } else {
         rv_set_error("gemm_pp_fp8: unsupported epilogue (act %d, out dtype %d)", act, out_dtype);

@@ -104,17 +104,6 @@ template <int MB, int WP = 1> struct RowsCfg {
     static constexpr int DW = WP == 2 ? 8 : 4, LPS = WP == 2 ? 2 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2;
 };
 typedef unsigned int rs_w8 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 rs_fp8x8(unsigned lo, unsigned hi) {     // = gemm.hip fp8x8_to_bf16x8 (exact: e4m3 has 3 mantissa bits)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-    union { bf16x8 v; unsigned u[4]; } r;
-    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
-    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
-    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
-    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
-    return r.v;
-}
 
 // Round 4: the rows' sums of squares of a consumed fused RMSNorm.  Every workgroup needs all <= 144 rows' sums: MB x 256 per-block
 // partials of 16 rows each (36.8k floats at 9 row blocks).  Rounds 2 - 3 loaded them as 144 conditional four-byte loads per thread
@@ -223,13 +212,13 @@ __device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wa
             const f32x4 t = cf[i];
             const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
             const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
-            const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
-            if (sec == 0) *(u32x2*)((bf16_t*)qr.q16 + (int64_t)b * D + hd0 + tile * 16 + kg * 4) = o;
-            else *(u32x2*)((bf16_t*)qr.kc + (((int64_t)b * qr.H + head) * qr.Smax + pos) * 128 + pc) = o;
+            const u32x2 o = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
+            if (sec == 0) *(u32x2*)((op16_t*)qr.q16 + (int64_t)b * D + hd0 + tile * 16 + kg * 4) = o;
+            else *(u32x2*)((op16_t*)qr.kc + (((int64_t)b * qr.H + head) * qr.Smax + pos) * 128 + pc) = o;
         } else {
-            bf16_t* dst = (bf16_t*)qr.vtc + ((int64_t)b * qr.H + head) * 128 * qr.Smax + rv_vt_index(pc, pos);
+            op16_t* dst = (op16_t*)qr.vtc + ((int64_t)b * qr.H + head) * 128 * qr.Smax + rv_vt_index(pc, pos);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[r * 8] = f32_to_bf16(v[r]);
+            for (int r = 0; r < 4; ++r) dst[r * 8] = f32_to_op16(v[r]);
         }
     }
 }
@@ -244,7 +233,7 @@ __device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wa
 // the slab ring.  One raw s_barrier per stage hands slab g to the consumers and the slot of slab g - 1 back to the producer.
 template <int MB, int VPW, int FIN, int WP = 1>
 __global__ __attribute__((amdgpu_flat_work_group_size(RS_THREADS, RS_THREADS), amdgpu_waves_per_eu(RowsCfg<MB>::WPE, RowsCfg<MB>::WPE))) void
-rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
+rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
             const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm, QkvRope qr) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     constexpr int S = 8 / VPW, LOG = VPW == 8 ? 3 : VPW == 4 ? 2 : VPW == 2 ? 1 : 0;
@@ -281,7 +270,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
         };
         auto issue = [&](int g) {
             const int kb = next_kb();
-            const bf16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
+            const op16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
             char* dst = rs_smem + (g % DX) * SLAB;
 #pragma unroll
             for (int i = 0; i < XL; ++i) glds16(xs + i * 512, dst + i * 1024);
@@ -299,8 +288,8 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs issued past the end must not outlive the ring's reuse below
     } else {
         // ---------------- consumers: weight fragments of stage g in ring slot g % DW (static: the loop is unrolled by DW) ----------------
-        const bf16_t* wp = W + (int64_t)ntile * (K >> 5) * (WP == 2 ? 256 : 512) + lane * 8;   // (fp8: half the bytes per tile)
-        typename std::conditional<WP == 2, rs_w8, bf16x8>::type wf[DW][LPS];
+        const op16_t* wp = W + (int64_t)ntile * (K >> 5) * (WP == 2 ? 256 : 512) + lane * 8;   // (fp8: half the bytes per tile)
+        typename std::conditional<WP == 2, rs_w8, op16x8>::type wf[DW][LPS];
         int li = 0, lc = 0;     // next stage to issue
         int ci = 0, cc = 0;     // stage being computed
 #define RS_ISSUE_W(slot)                                                                                                             \
@@ -310,7 +299,7 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
             kb_ = sp * VPW + li + 8 * lc;                                                                                            \
             if (++lc == vcount(li)) { lc = 0; ++li; }                                                                                \
         }                                                                                                                            \
-        const bf16_t* ws_ = kb_ >= 0 ? ((RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048)) : X + lane * 8; \
+        const op16_t* ws_ = kb_ >= 0 ? ((RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048)) : X + lane * 8; \
         _Pragma("unroll") for (int j_ = 0; j_ < LPS; ++j_)                                                                          \
             wf[slot][j_] = __builtin_nontemporal_load((const typename std::remove_reference<decltype(wf[0][0])>::type*)(ws_ + j_ * 512)); \
     } while (0)
@@ -338,16 +327,16 @@ rows_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* _
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            bf16x8 wj;
-                            if constexpr (WP == 2) wj = rs_fp8x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
+                            op16x8 wj;
+                            if constexpr (WP == 2) wj = fp8x8_to_op16x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
+                                const op16x8 xf = *(const op16x8*)(xs + (j * MB + mb) * 1024);
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
-                                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
+                                    acc[mb] = rv_mfma16(wj, xf, acc[mb]);
                                 }
                             }
                         }
@@ -504,7 +493,7 @@ constexpr int RS_MAXIT = 8;   // items per workgroup at most
 // (A separate kernel: folded into rows_kernel, the item bookkeeping cost the 5-row-block S = 2 variant 8 spilled VGPRs per stage.)
 template <int MB, int VPW, int FIN, int WP = 1>
 __global__ __attribute__((amdgpu_flat_work_group_size(RS_THREADS, RS_THREADS), amdgpu_waves_per_eu(RowsCfg<MB>::WPE, RowsCfg<MB>::WPE))) void
-rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
+rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* __restrict__ planes, const float* __restrict__ bias,
             const float* res, int64_t ldr, void* Cv, int64_t ldc, int M, int N, int K, GemvNorm nrm, QkvRope qr) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     constexpr int S = 8 / VPW, LOG = VPW == 8 ? 3 : VPW == 4 ? 2 : VPW == 2 ? 1 : 0;
@@ -544,7 +533,7 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
                 }
                 if (++pp == Tp) { pp = 0; pi = 0; ++pn; }
             }
-            const bf16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
+            const op16_t* xs = X + (kb >= 0 ? (int64_t)kb * (MB * 2048) : 0) + lane * 8;
             char* dst = rs_smem + (g % DX) * SLAB;
 #pragma unroll
             for (int i = 0; i < XL; ++i) glds16(xs + i * 512, dst + i * 1024);
@@ -564,12 +553,12 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
         // ---------------- consumers: weight fragments of slot g in ring slot g % DW = (slot in the item) % DW: a compile-time constant ----------------
         const int64_t tile_stride = (int64_t)(K >> 5) * (WP == 2 ? 256 : 512);     // elements of one 16-column tile (fp8: half the bytes)
         const int64_t item_stride = (int64_t)(G / S) * RS_W * tile_stride;         // the next item of this workgroup: column group + G / S
-        const bf16_t* wp = W + ((int)blockIdx.x / S * RS_W + wave) * tile_stride + lane * 8;     // this wave's tile of the item being ISSUED
-        typename std::conditional<WP == 2, rs_w8, bf16x8>::type wf[DW][LPS];
+        const op16_t* wp = W + ((int)blockIdx.x / S * RS_W + wave) * tile_stride + lane * 8;     // this wave's tile of the item being ISSUED
+        typename std::conditional<WP == 2, rs_w8, op16x8>::type wf[DW][LPS];
         int li = 0, lc = 0, lp = 0, ln = 0;     // next slot to issue: (virtual wave, k-block in it, slot in the item, item)
 #define RS_ISSUE_W(slot)                                                                                                             \
     do {                                                                                                                             \
-        const bf16_t* ws_ = X + lane * 8;                                                                                            \
+        const op16_t* ws_ = X + lane * 8;                                                                                            \
         if (ln < n_it) {                                                                                                             \
             if (lp < T) {                                                                                                            \
                 const int kb_ = sp * VPW + li + 8 * lc;                                                                              \
@@ -606,16 +595,16 @@ rows_kernel_p(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, float*
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            bf16x8 wj;
-                            if constexpr (WP == 2) wj = rs_fp8x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
+                            op16x8 wj;
+                            if constexpr (WP == 2) wj = fp8x8_to_op16x8(wf[u][j >> 1][(j & 1) * 2], wf[u][j >> 1][(j & 1) * 2 + 1]);
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const bf16x8 xf = *(const bf16x8*)(xs + (j * MB + mb) * 1024);
+                                const op16x8 xf = *(const op16x8*)(xs + (j * MB + mb) * 1024);
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
-                                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wj, xf, acc[mb], 0, 0, 0);
+                                    acc[mb] = rv_mfma16(wj, xf, acc[mb]);
                                 }
                             }
                         }
@@ -795,7 +784,7 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
 
 #define RS_KERNEL (PERS ? rows_kernel_p<MB, VPW, FIN, WP> : rows_kernel<MB, VPW, FIN, WP>)
 template <int MB, int VPW, int FIN, int WP, int PERS>
-int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
+int rows_launch(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * (2048 + 64) : 0);      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
     // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
@@ -830,7 +819,7 @@ int rows_launch(const bf16_t* X, const bf16_t* W, const float* bias, const float
 }
 #undef RS_KERNEL
 template <int MB, int FIN, int WP>
-int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
+int rows_by_split(int S, const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                   const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
     // more items than resident workgroups (and a real split): the persistent grid with deferred hand-overs
     // (5 row blocks: only the S = 4 instantiation of the persistent kernel is spill-free - S = 2 needs 8 more VGPRs than three waves per SIMD have)
@@ -846,7 +835,7 @@ int rows_by_split(int S, const bf16_t* X, const bf16_t* W, const float* bias, co
 #undef RS_LAUNCH
 }
 template <int FIN, int WP>
-int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
+int rows_by_mb(int MBp, int S, const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N,
                int K, const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
 #if RS_PART & 2
     return MBp == 8 ? rows_by_split<8, FIN, WP>(S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, qr, st)
@@ -857,13 +846,13 @@ int rows_by_mb(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bi
 #endif
 }
 template <int WP>
-int rows_by_fin(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype,
+int rows_by_fin(int MBp, int S, const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype,
                 int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st) {
     const QkvRope q0{};
     if (qr) return rows_by_mb<3, WP>(MBp, S, X, W, nullptr, nullptr, 0, nullptr, 0, M, N, K, nrm, *qr, st);
     if (act == RV_ACT_SILU_MUL) return rows_by_mb<1, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
     if (N >= 16384 && out_dtype == RV_F32) return rows_by_mb<2, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
-    if (N < 16384 && out_dtype == RV_BF16) return rows_by_mb<4, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
+    if (N < 16384 && out_dtype == RV_OP16) return rows_by_mb<4, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
     if (N < 16384) return rows_by_mb<0, WP>(MBp, S, X, W, bias, res, ldr, C, ldc, M, N, K, nrm, q0, st);
     rv_set_error("gemm_rows: bf16 output with N >= 16384 is not instantiated");
     return RV_ERR_ARG;
@@ -875,14 +864,14 @@ int rows_by_fin(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* b
 // 8 / 9 row-block instantiations.  Part 0 (this file itself) also holds the entry points.
 #define RS_PART_FN_(n) gemm_rows_part##n
 #define RS_PART_FN(n) RS_PART_FN_(n)
-int RS_PART_FN(RS_PART)(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
+int RS_PART_FN(RS_PART)(int MBp, int S, const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc,
                         int out_dtype, int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st) {
     return rows_by_fin<(RS_PART & 1) ? 2 : 1>(MBp, S, X, W, bias, res, ldr, C, ldc, out_dtype, act, M, N, K, nrm, qr, st);
 }
 
 #if RS_PART == 0
 #define RS_PART_DECL(n)                                                                                                                      \
-    int gemm_rows_part##n(int MBp, int S, const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, \
+    int gemm_rows_part##n(int MBp, int S, const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, \
                           int out_dtype, int act, int M, int N, int K, const GemvNorm& nrm, const QkvRope* qr, hipStream_t st)
 RS_PART_DECL(1);
 RS_PART_DECL(2);
@@ -894,7 +883,7 @@ extern "C" size_t rv_gemm_rows_ws_bytes(void) { return gemm_rows_ws_bytes(); }
 
 // X: 33 .. 144 fragment-packed rows (nrm.x_packed row blocks); nrm.planes: zero-initialised workspace of gemm_rows_ws_bytes().
 // qr != nullptr: the fused q/k/v + RoPE epilogue.  w_layout 1: bf16 fragment-packed W; 2: FP8 fragment-packed W + nrm.w_scale.
-int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
+int gemm_rows(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
               int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout) {
     RV_CHECK_ARG(w_layout == 1 || (w_layout == 2 && nrm.w_scale), "gemm_rows: bf16 (1) or fp8 + per-row scales (2) fragment-packed weights");
     RV_CHECK_ARG(M > 32 && M <= RV_ROWS_MAX && nrm.x_packed == rv_xp_blocks(M) && nrm.planes && nrm.arrive,
@@ -902,7 +891,7 @@ int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* 
     RV_CHECK_ARG(N / 64 <= RV_ROWS_COUNTERS / 4, "gemm_rows: too many column groups");
     RV_CHECK_ARG(N % 64 == 0 && K % 128 == 0 && K >= 1024 && N <= 32768, "gemm_rows: N %% 64, K %% 128, K >= 1024, N <= 32768");
     RV_CHECK_ARG(act == RV_ACT_NONE || act == RV_ACT_SILU_MUL, "gemm_rows: no activation or SILU_MUL");
-    RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_BF16, "gemm_rows: SILU_MUL writes bf16");
+    RV_CHECK_ARG(act != RV_ACT_SILU_MUL || out_dtype == RV_OP16, "gemm_rows: SILU_MUL writes bf16");
     const int MBp = nrm.x_packed, S = rows_splits(N, MBp);
     RV_CHECK_ARG((size_t)S * (N / 16) * MBp * 1024 <= gemm_rows_ws_bytes(), "gemm_rows: %d partial planes of N = %d do not fit the plane workspace", S, N);
     auto* part = MBp >= 8 ? (w_layout == 2 ? gemm_rows_part3 : gemm_rows_part2) : (w_layout == 2 ? gemm_rows_part1 : gemm_rows_part0);
@@ -923,7 +912,7 @@ extern "C" int rv_gemm_rows(const void* Xp, const void* Wp, const float* w_scale
     nrm.planes = (float*)planes;
     nrm.arrive = arrive;
     const int ldc = act == RV_ACT_SILU_MUL ? N / 2 : N;
-    return gemm_rows((const bf16_t*)Xp, (const bf16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr,
+    return gemm_rows((const op16_t*)Xp, (const op16_t*)Wp, nullptr, nullptr, 0, C, ldc, out_dtype, act, M, N, K, (hipStream_t)stream, nrm, nullptr,
                      w_scale ? 2 : 1);
 }
 #endif   // RS_PART == 0

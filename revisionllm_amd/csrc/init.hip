@@ -22,7 +22,7 @@ __global__ void init_hash_kernel(T* dst, int64_t n, uint64_t key, float step, fl
         const int v = (int)(h >> 40) - (1 << 23);
         const float w = hash_value(v, step, base);
         if (sizeof(T) == 2)
-            dst[i] = (T)f32_to_bf16(w);
+            dst[i] = (T)f32_to_op16(w);
         else
             dst[i] = (T)w;
     }
@@ -39,14 +39,14 @@ __global__ void init_hash_kernel<float>(float* dst, int64_t n, uint64_t key, flo
 
 extern "C" int rv_init_hash(void* dst, int dtype, int64_t n, uint64_t key, float step, float base, void* stream) {
     RV_CHECK_ARG(dst && n >= 0, "rv_init_hash: bad arguments");
-    RV_CHECK_ARG(dtype == RV_F32 || dtype == RV_BF16, "rv_init_hash: dtype must be f32 or bf16");
+    RV_CHECK_ARG(dtype == RV_F32 || dtype == RV_OP16, "rv_init_hash: dtype must be f32 or bf16");
     if (n == 0) return RV_OK;
     const int threads = 256;
     const int blocks = (int)(cdiv(n, threads) < 8192 ? cdiv(n, threads) : 8192);
     if (dtype == RV_F32)
         hipLaunchKernelGGL(init_hash_kernel<float>, dim3(blocks), dim3(threads), 0, as_stream(stream), (float*)dst, n, key, step, base);
     else
-        hipLaunchKernelGGL(init_hash_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, as_stream(stream), (bf16_t*)dst, n, key, step, base);
+        hipLaunchKernelGGL(init_hash_kernel<op16_t>, dim3(blocks), dim3(threads), 0, as_stream(stream), (op16_t*)dst, n, key, step, base);
     RV_CHECK_LAUNCH("rv_init_hash");
     return RV_OK;
 }

@@ -128,29 +128,29 @@ static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m,
         // inlines into, and a rotated value must not depend on which kernel (or how many rows) produced it
         const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
         const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
-        const u32x2 o = u32x2{pack_bf16x2(a0, b0), pack_bf16x2(a1, b1)};
+        const u32x2 o = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
         if (sec == 0) {
             if constexpr ((RS_PROBE_K_ & 1024) != 0) return;
             if constexpr (QSPLIT) {
-                bf16_t* dst = (bf16_t*)q.q16 + (int64_t)mrow * q.q_ld + hd;
+                op16_t* dst = (op16_t*)q.q16 + (int64_t)mrow * q.q_ld + hd;
                 *(u32x2*)dst = o;
-                *(u32x2*)(dst + q.q_lo) = u32x2{pack_bf16x2_lo(a0, b0), pack_bf16x2_lo(a1, b1)};
+                *(u32x2*)(dst + q.q_lo) = u32x2{pack_op16x2_lo(a0, b0), pack_op16x2_lo(a1, b1)};
             } else {
-                *(u32x2*)((bf16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
+                *(u32x2*)((op16_t*)q.q16 + (int64_t)mrow * D + hd) = o;
             }
         } else {
             if constexpr ((RS_PROBE_K_ & 512) != 0) return;
             const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
             for (int bb = b0_; bb < b1_; ++bb)
-                *(u32x2*)((bf16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
+                *(u32x2*)((op16_t*)q.kc + (((int64_t)bb * q.H + head) * q.Smax + pos) * 128 + p) = o;
         }
     } else {
         if constexpr ((RS_PROBE_K_ & 256) != 0) return;
         const int b0_ = (prefix ? 0 : b) + goff, b1_ = (prefix ? q.B : b + 1) + goff;
         for (int bb = b0_; bb < b1_; ++bb) {
-            bf16_t* dst = (bf16_t*)q.vtc + ((int64_t)bb * q.H + head) * 128 * q.Smax + rv_vt_index(p, pos);
+            op16_t* dst = (op16_t*)q.vtc + ((int64_t)bb * q.H + head) * 128 * q.Smax + rv_vt_index(p, pos);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[r * 8] = f32_to_bf16(v[r]);
+            for (int r = 0; r < 4; ++r) dst[r * 8] = f32_to_op16(v[r]);
         }
     }
 }
@@ -192,7 +192,7 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
 int gemv_blocks(int act, int64_t N);
-int gemm_rows(const bf16_t* X, const bf16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
+int gemm_rows(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
               int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 144 fragment-packed rows
 size_t gemm_rows_ws_bytes();   // partial planes of the 33 .. 144-row decode kernel (any LLM shape up to N = 32768)  // workgroups the decode kernel launches for an N-row weight (= producer partial rows)
 // A-resident kernel for short-K many-row problems (gemm_arows.hip): a workgroup keeps its block of A rows in LDS and walks N

@@ -10,7 +10,7 @@ namespace {
 template <int NV>  // d = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y32,
-                                                        bf16_t* __restrict__ y16, bf16_t* __restrict__ yp16,
+                                                        op16_t* __restrict__ y16, op16_t* __restrict__ yp16,
                                                         const float* __restrict__ pos, int64_t period, int64_t rows, int64_t gap) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
@@ -46,10 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
         if (y32) *(f32x4*)(y32 + orow * D + c) = y;
-        if (y16) *(u32x2*)(y16 + orow * D + c) = u32x2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        if (y16) *(u32x2*)(y16 + orow * D + c) = u32x2{pack_op16x2(y[0], y[1]), pack_op16x2(y[2], y[3])};
         if (yp16) {
             const f32x4 p = *(const f32x4*)(pr + c);
-            *(u32x2*)(yp16 + orow * D + c) = u32x2{pack_bf16x2(y[0] + p[0], y[1] + p[1]), pack_bf16x2(y[2] + p[2], y[3] + p[3])};
+            *(u32x2*)(yp16 + orow * D + c) = u32x2{pack_op16x2(y[0] + p[0], y[1] + p[1]), pack_op16x2(y[2] + p[2], y[3] + p[3])};
         }
     }
 }
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // up front (decode calls have a handful of rows, so the kernel is pure latency); NV == 0: generic two-pass loop ----
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
-                                                      const float* __restrict__ w, bf16_t* __restrict__ y, int64_t rows,
+                                                      const float* __restrict__ w, op16_t* __restrict__ y, int64_t rows,
                                                       int d, float eps, int packed, const int* __restrict__ row_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         for (int i = 0; i < NV; ++i) {
             const int c = i * 256 + lane * 4;
             *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
-                u32x2{pack_bf16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)), pack_bf16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
+                u32x2{pack_op16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)), pack_op16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
         }
     } else {
         float s = 0.f;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         for (int c = lane * 4; c < d; c += 256) {
             const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
             *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
-                u32x2{pack_bf16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_bf16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
+                u32x2{pack_op16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_op16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
         }
     }
 }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // ---- parity precision: RMSNorm whose output is the split pair [hi | lo] (row stride 2 * d), one wave per row, two passes;
 // and the plain split of an f32 matrix (the gated MLP activation computed in f32) ----
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* __restrict__ x, int64_t x_row_stride, const float* __restrict__ w,
-                                                            bf16_t* __restrict__ y, int64_t rows, int d, float eps, int packed,
+                                                            op16_t* __restrict__ y, int64_t rows, int d, float eps, int packed,
                                                             const int* __restrict__ row_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* __restr
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     const float r = rsqrtf(wave_sum(s) / (float)d + eps);
-    bf16_t* yr = y + row * 2 * d;
+    op16_t* yr = y + row * 2 * d;
     for (int c = lane * 4; c < d; c += 256) {
         const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
         const float o0 = ww[0] * (v[0] * r), o1 = ww[1] * (v[1] * r), o2 = ww[2] * (v[2] * r), o3 = ww[3] * (v[3] * r);
-        *(u32x2*)(packed ? y + rv_xp_index((int)row, c, packed) : yr + c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
-        *(u32x2*)(packed ? y + rv_xp_index((int)row, d + c, packed) : yr + d + c) = u32x2{pack_bf16x2_lo(o0, o1), pack_bf16x2_lo(o2, o3)};
+        *(u32x2*)(packed ? y + rv_xp_index((int)row, c, packed) : yr + c) = u32x2{pack_op16x2(o0, o1), pack_op16x2(o2, o3)};
+        *(u32x2*)(packed ? y + rv_xp_index((int)row, d + c, packed) : yr + d + c) = u32x2{pack_op16x2_lo(o0, o1), pack_op16x2_lo(o2, o3)};
     }
 }
 // f32 q/k/v rows -> RoPE + Q (split pair) + K / V^T cache append: one thread per 4 consecutive columns, the store rules of the fused epilogue
@@ -128,15 +128,15 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const float* __rest
     const f32x4 v = *(const f32x4*)(qkv + (int64_t)m * ld + n);
     qkv_rope_store_t<true>(qr, m, n, v, qkv_rope_coeffs(qr, m, n));
 }
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t rows, int n) {
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, op16_t* __restrict__ y, int64_t rows, int n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= rows * n) return;
     const int64_t row = i / n;
     const int c = (int)(i - row * n);
     const f32x4 v = *(const f32x4*)(x + row * ldx + c);
-    bf16_t* yr = y + row * 2 * n;
-    *(u32x2*)(yr + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *(u32x2*)(yr + n + c) = u32x2{pack_bf16x2_lo(v[0], v[1]), pack_bf16x2_lo(v[2], v[3])};
+    op16_t* yr = y + row * 2 * n;
+    *(u32x2*)(yr + c) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+    *(u32x2*)(yr + n + c) = u32x2{pack_op16x2_lo(v[0], v[1]), pack_op16x2_lo(v[2], v[3])};
 }
 
 // ---- per-row FP8 (e4m3fn, OCP) quantisation of bf16 activations for the FP8 prefill GEMMs: one wave per row;
@@ -147,27 +147,27 @@ __device__ __forceinline__ uint32_t fp8x4(float a, float b, float c, float d) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
 }
-__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const op16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
                                                              int64_t ldq, float* __restrict__ scale, int64_t rows, int K) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + row * ldx;
+    const op16_t* xr = x + row * ldx;
     uint8_t* qr = q + row * ldq;
     constexpr int NV = 8;              // rows up to 8 * 512 = 4096 stay in registers; longer ones are read twice
-    bf16x8 v[NV];
+    op16x8 v[NV];
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane * 8 + i * 512;
-        v[i] = c < K ? *(const bf16x8*)(xr + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        v[i] = c < K ? *(const op16x8*)(xr + c) : op16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)v[i][e])));
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(op16_to_f32((op16_t)v[i][e])));
     }
     for (int c = lane * 8 + NV * 512; c < K; c += 512) {
-        const bf16x8 t = *(const bf16x8*)(xr + c);
+        const op16x8 t = *(const op16x8*)(xr + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)t[e])));
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(op16_to_f32((op16_t)t[e])));
     }
     amax = wave_max(amax);
     const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
@@ -179,14 +179,14 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
         if (c >= K) break;
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)v[i][e]) * inv;
+        for (int e = 0; e < 8; ++e) f[e] = op16_to_f32((op16_t)v[i][e]) * inv;
         *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
     }
     for (int c = lane * 8 + NV * 512; c < K; c += 512) {
-        const bf16x8 t = *(const bf16x8*)(xr + c);
+        const op16x8 t = *(const op16x8*)(xr + c);
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((bf16_t)t[e]) * inv;
+        for (int e = 0; e < 8; ++e) f[e] = op16_to_f32((op16_t)t[e]) * inv;
         *(u32x2*)(qr + c) = u32x2{fp8x4(f[0], f[1], f[2], f[3]), fp8x4(f[4], f[5], f[6], f[7])};
     }
 }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const float* __restr
         const f32x4 ww = *(const f32x4*)(w + i * 256 + lane * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[i][e] = bf16_to_f32(f32_to_bf16(ww[e] * (v[i][e] * r)));   // the value the bf16 path hands to its GEMM
+            v[i][e] = op16_to_f32(f32_to_op16(ww[e] * (v[i][e] * r)));   // the value the bf16 path hands to its GEMM
             amax = fmaxf(amax, fabsf(v[i][e]));
         }
     }
@@ -239,25 +239,25 @@ __global__ void sine_pos_kernel(float* __restrict__ pos, int T, int d) {
 
 // ---- adapter row assembly -------------------------------------------------------------------------
 // frames: x bf16 [N*T,768] -> v32 (f32), vp16 = bf16(x + pos[t])           (text->video layer input)
-__global__ void frames_in_kernel(const bf16_t* __restrict__ x, const float* __restrict__ pos, float* __restrict__ v32,
-                                 bf16_t* __restrict__ vp16, int64_t rows, int T, int d) {
+__global__ void frames_in_kernel(const op16_t* __restrict__ x, const float* __restrict__ pos, float* __restrict__ v32,
+                                 op16_t* __restrict__ vp16, int64_t rows, int T, int d) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= rows * d) return;
     const int64_t row = i / d;
     const int c = (int)(i % d);
     const u32x2 raw = *(const u32x2*)(x + i);
-    const float f0 = __uint_as_float(raw[0] << 16), f1 = __uint_as_float(raw[0] & 0xffff0000u);
-    const float f2 = __uint_as_float(raw[1] << 16), f3 = __uint_as_float(raw[1] & 0xffff0000u);
+    const f32x4 f = op16x4_to_f32(raw);
+    const float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
     *(f32x4*)(v32 + i) = f32x4{f0, f1, f2, f3};
     const f32x4 p = *(const f32x4*)(pos + (row % T) * d + c);
-    *(u32x2*)(vp16 + i) = u32x2{pack_bf16x2(f0 + p[0], f1 + p[1]), pack_bf16x2(f2 + p[2], f3 + p[3])};
+    *(u32x2*)(vp16 + i) = u32x2{pack_op16x2(f0 + p[0], f1 + p[1]), pack_op16x2(f2 + p[2], f3 + p[3])};
 }
 
 // X = [cls ; frames] per sequence: src is either bf16 features (src16) or f32 frames (src32), [N,T,768];
 // writes x32, x16 = bf16(X), xp16 = bf16(X + pm[row]) with pm [T+1,768] (row 0 = cls_pos).
-__global__ void build_x_kernel(const bf16_t* __restrict__ src16, const float* __restrict__ src32,
+__global__ void build_x_kernel(const op16_t* __restrict__ src16, const float* __restrict__ src32,
                                const float* __restrict__ cls, const float* __restrict__ pm, float* __restrict__ x32,
-                               bf16_t* __restrict__ x16, bf16_t* __restrict__ xp16, int64_t N, int T, int d) {
+                               op16_t* __restrict__ x16, op16_t* __restrict__ xp16, int64_t N, int T, int d) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= N * (T + 1) * d) return;
     const int64_t row = i / d;
@@ -271,19 +271,18 @@ __global__ void build_x_kernel(const bf16_t* __restrict__ src16, const float* __
         v = *(const f32x4*)(src32 + (n * T + (t - 1)) * d + c);
     } else {
         const u32x2 raw = *(const u32x2*)(src16 + (n * T + (t - 1)) * d + c);
-        v = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
-                  __uint_as_float(raw[1] & 0xffff0000u)};
+        v = op16x4_to_f32(raw);
     }
     *(f32x4*)(x32 + i) = v;
-    *(u32x2*)(x16 + i) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)(x16 + i) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
     const f32x4 p = *(const f32x4*)(pm + (int64_t)t * d + c);
-    *(u32x2*)(xp16 + i) = u32x2{pack_bf16x2(v[0] + p[0], v[1] + p[1]), pack_bf16x2(v[2] + p[2], v[3] + p[3])};
+    *(u32x2*)(xp16 + i) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
 }
 
 // the CLS rows of X = [cls ; frames] alone (row n * (T + 1) of x32 / x16 / xp16): the frame rows were written in place by the last
 // text->video LayerNorm (layernorm_kernel, gap = T)
-__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pm, float* __restrict__ x32, bf16_t* __restrict__ x16,
-                                bf16_t* __restrict__ xp16, int64_t N, int T, int d) {
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pm, float* __restrict__ x32, op16_t* __restrict__ x16,
+                                op16_t* __restrict__ xp16, int64_t N, int T, int d) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= N * d) return;
     const int64_t n = i / d;
@@ -291,8 +290,8 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     const int64_t o = n * (T + 1) * d + c;
     const f32x4 v = *(const f32x4*)(cls + c), p = *(const f32x4*)(pm + c);
     *(f32x4*)(x32 + o) = v;
-    *(u32x2*)(x16 + o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *(u32x2*)(xp16 + o) = u32x2{pack_bf16x2(v[0] + p[0], v[1] + p[1]), pack_bf16x2(v[2] + p[2], v[3] + p[3])};
+    *(u32x2*)(x16 + o) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+    *(u32x2*)(xp16 + o) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
 }
 
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
@@ -303,22 +302,22 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 // ---- V [Nb, L, H*DH] bf16 (row stride ld) -> V^T [Nb, H, DH, Lpad] bf16, zero padded to Lpad ----
 // (DH = 512 - the 4096-d cross_attn ClipEncoder - takes its head in four 128-column slices, blockIdx.y = head * 4 + slice: the LDS tile stays 16 KiB)
 template <int DH>
-__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, int64_t ld, bf16_t* __restrict__ vt,
+__global__ __launch_bounds__(256) void transpose_v_kernel(const op16_t* __restrict__ v, int64_t ld, op16_t* __restrict__ vt,
                                                           int L, int Lpad, int H) {
     constexpr int DC = DH > 128 ? 128 : DH;          // columns of the head handled by one workgroup
     constexpr int NS = DH / DC;
-    __shared__ bf16_t tile[64][DC + 2];
+    __shared__ op16_t tile[64][DC + 2];
     const int l0 = blockIdx.x * 64, h = blockIdx.y / NS, d0 = (blockIdx.y % NS) * DC;
     const int64_t nb = blockIdx.z;
     for (int i = threadIdx.x; i < 64 * (DC / 2); i += 256) {
         const int r = i / (DC / 2), c2 = i % (DC / 2);
         uint32_t val = 0;
         if (l0 + r < L) val = *(const uint32_t*)(v + (nb * L + l0 + r) * ld + h * DH + d0 + c2 * 2);
-        tile[r][c2 * 2] = (bf16_t)(val & 0xffff);
-        tile[r][c2 * 2 + 1] = (bf16_t)(val >> 16);
+        tile[r][c2 * 2] = (op16_t)(val & 0xffff);
+        tile[r][c2 * 2 + 1] = (op16_t)(val >> 16);
     }
     __syncthreads();
-    bf16_t* o = vt + ((nb * H + h) * DH + d0) * (int64_t)Lpad;
+    op16_t* o = vt + ((nb * H + h) * DH + d0) * (int64_t)Lpad;
     for (int i = threadIdx.x; i < DC * 32; i += 256) {
         const int d = i / 32, l2 = i % 32;
         if (l0 + l2 * 2 < Lpad) {
@@ -353,17 +352,16 @@ __global__ void rope_table_rows_kernel(float2* __restrict__ cs, const int* __res
 }
 
 // ---- embedding gather + video-row splice -> f32 residual stream ----
-__global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __restrict__ map, const bf16_t* __restrict__ embed,
+__global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __restrict__ map, const op16_t* __restrict__ embed,
                                                            const float* __restrict__ video, float* __restrict__ h, int D) {
     const int64_t r = blockIdx.x;
     const int src = map[r];
     float* o = h + r * D;
     if (src >= 0) {
-        const bf16_t* e = embed + (int64_t)src * D;
+        const op16_t* e = embed + (int64_t)src * D;
         for (int c = threadIdx.x * 4; c < D; c += 1024) {
             const u32x2 raw = *(const u32x2*)(e + c);
-            *(f32x4*)(o + c) = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
-                                     __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+            *(f32x4*)(o + c) = op16x4_to_f32(raw);
         }
     } else {
         const float* v = video + (int64_t)(-(src + 1)) * D;
@@ -380,15 +378,15 @@ int k_layernorm(const float* x, const float* w, const float* b, float* y32, void
     if (rows == 0) return RV_OK;
     const unsigned blocks = (unsigned)cdiv(rows, 4);
     if (d == 768)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
     else if (d == 4096)
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
     else if (d == 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (bf16_t*)y16, (bf16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
     else {
         rv_set_error("layernorm: unsupported width %d (256, 512, 768, 1024, 4096)", d);
         return RV_ERR_ARG;
@@ -403,11 +401,11 @@ int k_rmsnorm(const float* x, int64_t x_row_stride, const float* w, void* y16, i
     if (rows == 0) return RV_OK;
     const dim3 grid((unsigned)cdiv(rows, 4));
     if (d == 4096)
-        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, x, x_row_stride, w, (op16_t*)y16, rows, d, eps, out_packed, row_idx);
     else if (d == 512)
-        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, st, x, x_row_stride, w, (op16_t*)y16, rows, d, eps, out_packed, row_idx);
     else
-        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
+        hipLaunchKernelGGL(rmsnorm_kernel<0>, grid, dim3(256), 0, st, x, x_row_stride, w, (op16_t*)y16, rows, d, eps, out_packed, row_idx);
     RV_CHECK_LAUNCH("rmsnorm");
     return RV_OK;
 }
@@ -416,7 +414,7 @@ int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* 
     RV_CHECK_ARG(x && w && y16 && d % 4 == 0 && x_row_stride % 4 == 0, "rmsnorm_split: bad arguments");
     RV_CHECK_ARG(!out_packed || (rows <= 16 * out_packed && d % 32 == 0), "rmsnorm_split: the packed decode layout holds <= 16 rows per block");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (bf16_t*)y16, rows, d, eps, out_packed, row_idx);
+    hipLaunchKernelGGL(rmsnorm_split_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, x, x_row_stride, w, (op16_t*)y16, rows, d, eps, out_packed, row_idx);
     RV_CHECK_LAUNCH("rmsnorm_split");
     return RV_OK;
 }
@@ -432,7 +430,7 @@ int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t 
 int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hipStream_t st) {
     RV_CHECK_ARG(x && y16 && n % 4 == 0 && ldx % 4 == 0, "split_bf16: bad arguments");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdiv(rows * n / 4, 256)), dim3(256), 0, st, x, ldx, (bf16_t*)y16, rows, n);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdiv(rows * n / 4, 256)), dim3(256), 0, st, x, ldx, (op16_t*)y16, rows, n);
     RV_CHECK_LAUNCH("split_bf16");
     return RV_OK;
 }
@@ -440,7 +438,7 @@ int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hi
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st) {
     RV_CHECK_ARG(x16 && q8 && scale && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "quant_rows_fp8: K, ldx, ldq must be multiples of 8");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x16, ldx, (uint8_t*)q8, ldq,
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, (const op16_t*)x16, ldx, (uint8_t*)q8, ldq,
                        scale, rows, K);
     RV_CHECK_LAUNCH("quant_rows_fp8");
     return RV_OK;
@@ -464,22 +462,22 @@ int k_sine_pos(float* pos, int T, int d, hipStream_t st) {
 }
 
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st) {
-    hipLaunchKernelGGL(frames_in_kernel, dim3((unsigned)cdiv(rows * d / 4, 256)), dim3(256), 0, st, (const bf16_t*)x16, pos, v32,
-                       (bf16_t*)vp16, rows, T, d);
+    hipLaunchKernelGGL(frames_in_kernel, dim3((unsigned)cdiv(rows * d / 4, 256)), dim3(256), 0, st, (const op16_t*)x16, pos, v32,
+                       (op16_t*)vp16, rows, T, d);
     RV_CHECK_LAUNCH("frames_in");
     return RV_OK;
 }
 
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
               int64_t N, int T, int d, hipStream_t st) {
-    hipLaunchKernelGGL(build_x_kernel, dim3((unsigned)cdiv(N * (T + 1) * d / 4, 256)), dim3(256), 0, st, (const bf16_t*)src16,
-                       src32, cls, pm, x32, (bf16_t*)x16, (bf16_t*)xp16, N, T, d);
+    hipLaunchKernelGGL(build_x_kernel, dim3((unsigned)cdiv(N * (T + 1) * d / 4, 256)), dim3(256), 0, st, (const op16_t*)src16,
+                       src32, cls, pm, x32, (op16_t*)x16, (op16_t*)xp16, N, T, d);
     RV_CHECK_LAUNCH("build_x");
     return RV_OK;
 }
 
 int k_cls_rows(const float* cls, const float* pm, float* x32, void* x16, void* xp16, int64_t N, int T, int d, hipStream_t st) {
-    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)cdiv(N * d / 4, 256)), dim3(256), 0, st, cls, pm, x32, (bf16_t*)x16, (bf16_t*)xp16, N, T, d);
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)cdiv(N * d / 4, 256)), dim3(256), 0, st, cls, pm, x32, (op16_t*)x16, (op16_t*)xp16, N, T, d);
     RV_CHECK_LAUNCH("cls_rows");
     return RV_OK;
 }
@@ -494,11 +492,11 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
     RV_CHECK_ARG(Lpad % 2 == 0 && Lpad >= L, "transpose_v: bad Lpad");
     dim3 grid((unsigned)cdiv(Lpad, 64), (unsigned)H, (unsigned)Nb);
     if (dh == 96)
-        hipLaunchKernelGGL(transpose_v_kernel<96>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+        hipLaunchKernelGGL(transpose_v_kernel<96>, grid, dim3(256), 0, st, (const op16_t*)v, ld, (op16_t*)vt, L, Lpad, H);
     else if (dh == 128)
-        hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+        hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, st, (const op16_t*)v, ld, (op16_t*)vt, L, Lpad, H);
     else if (dh == 512)
-        hipLaunchKernelGGL(transpose_v_kernel<512>, dim3(grid.x, grid.y * 4, grid.z), dim3(256), 0, st, (const bf16_t*)v, ld, (bf16_t*)vt, L, Lpad, H);
+        hipLaunchKernelGGL(transpose_v_kernel<512>, dim3(grid.x, grid.y * 4, grid.z), dim3(256), 0, st, (const op16_t*)v, ld, (op16_t*)vt, L, Lpad, H);
     else {
         rv_set_error("transpose_v: head dim %d unsupported", dh);
         return RV_ERR_ARG;
@@ -520,7 +518,7 @@ int k_rope_table_rows(float* cs, const int* row_pos, int rows, int dh, float the
 }
 
 int k_splice_embed(const int32_t* map, const void* embed, const float* video, float* h, int64_t rows, int D, hipStream_t st) {
-    hipLaunchKernelGGL(splice_embed_kernel, dim3((unsigned)rows), dim3(256), 0, st, map, (const bf16_t*)embed, video, h, D);
+    hipLaunchKernelGGL(splice_embed_kernel, dim3((unsigned)rows), dim3(256), 0, st, map, (const op16_t*)embed, video, h, D);
     RV_CHECK_LAUNCH("splice_embed");
     return RV_OK;
 }

@@ -487,7 +487,7 @@ __device__ __forceinline__ float ld(const T* p);
 template <>
 __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <>
-__device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float ld<op16_t>(const op16_t* p) { return op16_to_f32(*p); }
 
 // one block (1024 threads) per segment: column norms over frames, sims[t] = <f_t / norm, q>, sum of the k largest
 // (k <= 0: mean).  Phase 1 splits the frames over 4 thread groups per column block to keep ~T/4 loads per thread.
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(1024) void topk_cosine_kernel(const T* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto load = [&](const T* p, float (&v)[VEC]) {
         if constexpr (sizeof(T) == 2) {
-            const bf16x8 r = *(const bf16x8*)p;
+            const op16x8 r = *(const op16x8*)p;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = bf16_to_f32((bf16_t)r[e]);
+            for (int e = 0; e < VEC; ++e) v[e] = op16_to_f32((op16_t)r[e]);
         } else {
             const f32x4 r = *(const f32x4*)p;
 #pragma unroll
@@ -697,20 +697,20 @@ extern "C" int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32
 extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_cls, int32_t n, int32_t T, int32_t d, int32_t k,
                               float* out, void* stream) {
     RV_CHECK_ARG(feat && q_cls && out && n > 0 && T > 0 && d > 0, "rv_topk_cosine: bad arguments");
-    RV_CHECK_ARG(feat_dtype == RV_BF16 || feat_dtype == RV_F32, "rv_topk_cosine: dtype must be f32 or bf16");
-    const int vec = feat_dtype == RV_BF16 ? 8 : 4;
+    RV_CHECK_ARG(feat_dtype == RV_OP16 || feat_dtype == RV_F32, "rv_topk_cosine: dtype must be f32 or bf16");
+    const int vec = feat_dtype == RV_OP16 ? 8 : 4;
     const int chunks = d / vec, groups = chunks > 0 && chunks <= 1024 ? 1024 / chunks : 0;
     const size_t sm_fast = ((size_t)(groups + 1) * d + T) * sizeof(float);
     if (d % vec == 0 && groups > 0 && sm_fast <= 64 * 1024) {
-        if (feat_dtype == RV_BF16)
-            hipLaunchKernelGGL(topk_cosine_kernel<bf16_t>, dim3(n), dim3(1024), sm_fast, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+        if (feat_dtype == RV_OP16)
+            hipLaunchKernelGGL(topk_cosine_kernel<op16_t>, dim3(n), dim3(1024), sm_fast, as_stream(stream), (const op16_t*)feat, q_cls, T, d, k, out);
         else
             hipLaunchKernelGGL(topk_cosine_kernel<float>, dim3(n), dim3(1024), sm_fast, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
     } else {
         RV_CHECK_ARG((size_t)(5 * d + T) * 4 <= 64 * 1024, "rv_topk_cosine: 5*d + T too large for LDS");
         const size_t sm = (size_t)(5 * d + T) * sizeof(float);
-        if (feat_dtype == RV_BF16)
-            hipLaunchKernelGGL(topk_cosine_kernel_generic<bf16_t>, dim3(n), dim3(1024), sm, as_stream(stream), (const bf16_t*)feat, q_cls, T, d, k, out);
+        if (feat_dtype == RV_OP16)
+            hipLaunchKernelGGL(topk_cosine_kernel_generic<op16_t>, dim3(n), dim3(1024), sm, as_stream(stream), (const op16_t*)feat, q_cls, T, d, k, out);
         else
             hipLaunchKernelGGL(topk_cosine_kernel_generic<float>, dim3(n), dim3(1024), sm, as_stream(stream), (const float*)feat, q_cls, T, d, k, out);
     }
@@ -721,13 +721,13 @@ extern "C" int rv_topk_cosine(const void* feat, int feat_dtype, const float* q_c
 extern "C" int rv_topk_pool(const void* video, int dtype, const float* text, int32_t Nv, int32_t T, int32_t d, int32_t Nt, int32_t k,
                             float* out, int32_t* out_idx, void* stream) {
     RV_CHECK_ARG(video && text && out && Nv > 0 && T > 0 && d > 0 && Nt > 0, "rv_topk_pool: bad arguments");
-    RV_CHECK_ARG(dtype == RV_BF16 || dtype == RV_F32, "rv_topk_pool: dtype must be f32 or bf16");
+    RV_CHECK_ARG(dtype == RV_OP16 || dtype == RV_F32, "rv_topk_pool: dtype must be f32 or bf16");
     RV_CHECK_ARG(k >= 1 && k <= 64 && k <= T, "rv_topk_pool: k=%d must be in [1, min(64, T=%d)]", k, T);
     RV_CHECK_ARG(Nt <= 65535, "rv_topk_pool: at most 65535 texts per launch");
     const size_t sm = (size_t)(d + T) * sizeof(float);
     RV_CHECK_ARG(sm + 64 * sizeof(int) <= 64 * 1024, "rv_topk_pool: d + T too large for LDS (dynamic %zu B + 256 B static)", sm);
-    if (dtype == RV_BF16)
-        hipLaunchKernelGGL(topk_pool_kernel<bf16_t>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const bf16_t*)video, text, T, d, Nt, k, out, out_idx);
+    if (dtype == RV_OP16)
+        hipLaunchKernelGGL(topk_pool_kernel<op16_t>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const op16_t*)video, text, T, d, Nt, k, out, out_idx);
     else
         hipLaunchKernelGGL(topk_pool_kernel<float>, dim3(Nv, Nt), dim3(256), sm, as_stream(stream), (const float*)video, text, T, d, Nt, k, out, out_idx);
     RV_CHECK_LAUNCH("rv_topk_pool");

@@ -22,7 +22,7 @@ def _pad_k(t, mult=128):
 
 class ClipTowers:
     def __init__(self, embed_dim=768, image_res=224, patch=14, v_width=1024, v_layers=24, ctx=77, vocab=49408, t_width=768,
-                 t_layers=12, t_heads=None, device="cuda:0"):
+                 t_layers=12, t_heads=None, device="cuda:0", op_dtype=None):
         self.cfg = dict(embed_dim=embed_dim, image_res=image_res, patch=patch, v_width=v_width, v_layers=v_layers, ctx=ctx,
                         vocab=vocab, t_width=t_width, t_layers=t_layers)
         self.v_heads = v_width // 64                      # clip/model.py:268
@@ -30,7 +30,8 @@ class ClipTowers:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise hip.HipLibraryError("ClipTowers runs on the HIP kernels only (no CPU path)")
-        hip.lib()
+        self.op_dtype = hip.op_dtype(op_dtype)      # the library flavour the towers run on (fp16 by default)
+        hip.lib(self.op_dtype)
         self.w = {}
 
     # ---- weights ---------------------------------------------------------------------------------------------------
@@ -38,13 +39,13 @@ class ClipTowers:
         dev = self.device
         t = t.to(dev)
         if name.endswith((".in_proj_weight", ".out_proj.weight", ".c_fc.weight", ".c_proj.weight")):
-            self.w[name] = ops.pack_fragments(t.to(torch.bfloat16).contiguous())
+            self.w[name] = ops.pack_fragments(t.to(self.op_dtype).contiguous())
         elif name == "visual.conv1.weight":                # [W,3,p,p] -> [W, 3*p*p] padded in K
-            self.w[name] = ops.pack_fragments(_pad_k(t.reshape(t.shape[0], -1)).to(torch.bfloat16).contiguous())
+            self.w[name] = ops.pack_fragments(_pad_k(t.reshape(t.shape[0], -1)).to(self.op_dtype).contiguous())
         elif name in ("visual.proj", "text_projection"):   # x @ P  ->  rows of P^T
-            self.w[name] = ops.pack_fragments(t.t().to(torch.bfloat16).contiguous())
+            self.w[name] = ops.pack_fragments(t.t().to(self.op_dtype).contiguous())
         elif name == "token_embedding.weight":
-            self.w[name] = t.to(torch.bfloat16).contiguous()
+            self.w[name] = t.to(self.op_dtype).contiguous()
         else:                                              # biases, LayerNorm affine, embeddings
             self.w[name] = t.float().contiguous()
 
@@ -68,11 +69,11 @@ class ClipTowers:
     # ---- shared transformer block (clip/model.py:167-190) -------------------------------------------------------------
     def _block(self, x, p, n, L, heads, causal):
         w, W = self.w, x.shape[1]
-        _, xn, _ = ops.layernorm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], want=("bf16",))
+        _, xn, _ = ops.layernorm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], want=("op16",), op_dtype=self.op_dtype)
         qkv = ops.gemm(xn, w[p + "attn.in_proj_weight"], bias=w[p + "attn.in_proj_bias"], w_packed=True).view(n, L, 3, heads, W // heads)
         a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=causal).view(n * L, W)
         x = ops.gemm(a, w[p + "attn.out_proj.weight"], bias=w[p + "attn.out_proj.bias"], residual=x, out_dtype=torch.float32, w_packed=True)
-        _, xn, _ = ops.layernorm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], want=("bf16",))
+        _, xn, _ = ops.layernorm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], want=("op16",), op_dtype=self.op_dtype)
         h = ops.gemm(xn, w[p + "mlp.c_fc.weight"], bias=w[p + "mlp.c_fc.bias"], act=hip.RV_ACT_QUICK_GELU, w_packed=True)
         return ops.gemm(h, w[p + "mlp.c_proj.weight"], bias=w[p + "mlp.c_proj.bias"], residual=x, out_dtype=torch.float32, w_packed=True)
 
@@ -88,14 +89,14 @@ class ClipTowers:
         x = img.to(self.device, torch.float32)
         # stride = kernel convolution == GEMM over unfolded patches: rows (frame, gy, gx), columns (channel, py, px)
         patches = x.view(n, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(n * g * g, 3 * p * p)
-        tokens = ops.gemm(_pad_k(patches).to(torch.bfloat16), w["visual.conv1.weight"], out_dtype=torch.float32, w_packed=True)
+        tokens = ops.gemm(_pad_k(patches).to(self.op_dtype), w["visual.conv1.weight"], out_dtype=torch.float32, w_packed=True)
         L = g * g + 1
         x = torch.cat([w["visual.class_embedding"].expand(n, 1, W), tokens.view(n, g * g, W)], 1) + w["visual.positional_embedding"]
-        x, _, _ = ops.layernorm(x.view(n * L, W).contiguous(), w["visual.ln_pre.weight"], w["visual.ln_pre.bias"], want=("f32",))
+        x, _, _ = ops.layernorm(x.view(n * L, W).contiguous(), w["visual.ln_pre.weight"], w["visual.ln_pre.bias"], want=("f32",), op_dtype=self.op_dtype)
         for l in range(c["v_layers"]):
             x = self._block(x, f"visual.transformer.resblocks.{l}.", n, L, self.v_heads, False)
         cls = x.view(n, L, W)[:, 0].contiguous()
-        _, cls16, _ = ops.layernorm(cls, w["visual.ln_post.weight"], w["visual.ln_post.bias"], want=("bf16",))
+        _, cls16, _ = ops.layernorm(cls, w["visual.ln_post.weight"], w["visual.ln_post.bias"], want=("op16",), op_dtype=self.op_dtype)
         return ops.gemm(cls16, w["visual.proj"], out_dtype=torch.float32, w_packed=True)
 
     @torch.no_grad()
@@ -109,6 +110,6 @@ class ClipTowers:
         x = (w["token_embedding.weight"][tok].float() + w["positional_embedding"]).view(n * L, W).contiguous()
         for l in range(c["t_layers"]):
             x = self._block(x, f"transformer.resblocks.{l}.", n, L, self.t_heads, True)
-        hid, hid16, _ = ops.layernorm(x, w["ln_final.weight"], w["ln_final.bias"], want=("f32", "bf16"))
+        hid, hid16, _ = ops.layernorm(x, w["ln_final.weight"], w["ln_final.bias"], want=("f32", "op16"), op_dtype=self.op_dtype)
         eot = hid16.view(n, L, W)[torch.arange(n, device=self.device), tok.argmax(-1)].contiguous()
         return dict(last_hidden_state=hid.view(n, L, W), pooler_output=ops.gemm(eot, w["text_projection"], out_dtype=torch.float32, w_packed=True))

@@ -91,7 +91,9 @@ class WindowStager:
     copy: a buffer is overwritten only after that copy has completed, so the video of query i+1 (or i+depth-1) can be staged
     while query i's copy is still in flight."""
 
-    def __init__(self, device="cuda:0", depth=2):
+    def __init__(self, device="cuda:0", depth=2, op_dtype=None):
+        from .. import hip
+        self.op_dtype = hip.op_dtype(op_dtype)     # the engine's operand type (fp16 by default; the reference casts to its model dtype)
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
         self._slots = [{"buf": None, "event": None} for _ in range(max(1, depth))]
@@ -108,7 +110,7 @@ class WindowStager:
         if slot["event"] is not None:
             slot["event"].synchronize()          # the previous copy out of this buffer has finished reading it
         if slot["buf"] is None or slot["buf"].numel() < n:
-            slot["buf"] = torch.empty(n, dtype=torch.bfloat16).pin_memory()     # (its predecessor is idle: waited above)
+            slot["buf"] = torch.empty(n, dtype=self.op_dtype).pin_memory()     # (its predecessor is idle: waited above)
         host = slot["buf"][:n].view(W, F, features.shape[1])
         src = torch.from_numpy(np.ascontiguousarray(features))
         host.copy_(src[torch.from_numpy(frame_idx.astype(np.int64))])

@@ -19,13 +19,12 @@ def _dev_f32(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-def _dev_bf16(t, device):
-    return t.to(device=device, dtype=torch.bfloat16).contiguous()
-
-
-def _dev_packed(t, device):
-    """bf16 on the device in the fragment-packed GEMM layout."""
-    return ops.pack_fragments(_dev_bf16(t, device))
+def _dev16(t, device, dtype):
+    """A tensor as 16-bit operands of ``dtype`` on the device.  fp16 from wider types: values beyond +-65504 saturate (like the kernels' own
+    conversions) instead of becoming inf."""
+    if dtype == torch.float16 and t.dtype != torch.float16:
+        t = t.to(device=device, dtype=torch.float32).clamp(-65504.0, 65504.0)
+    return t.to(device=device, dtype=dtype).contiguous()
 
 
 class PersistGate:
@@ -63,10 +62,14 @@ class PersistGate:
 
 class Engine:
     def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, adapter_text=True, device="cuda:0", adapter_dim=768,
-                 adapter_heads=8, adapter_ff=2048, adapter_layers=2, gate=None):
+                 adapter_heads=8, adapter_ff=2048, adapter_layers=2, gate=None, op_dtype=None):
+        """``op_dtype``: "f16" / "bf16" (or the torch dtype): the 16-bit operand type of weights, activation copies and KV caches = which build of
+        the library this engine calls (hip.py; default: the process default, fp16)."""
         if not torch.cuda.is_available():
             raise hip.HipLibraryError("no GPU visible: revisionllm_amd runs only on the HIP device path")
-        self.lib = hip.lib()
+        self.flavour = hip.flavour_of(op_dtype)
+        self.op_dtype = hip.op_dtype(self.flavour)
+        self.lib = hip.lib(self.flavour)
         self.shape = shape
         self.device = torch.device(device)
         self.adapter_text = bool(adapter_text)
@@ -101,6 +104,13 @@ class Engine:
         return int(v.value)
 
     # ---- weights -------------------------------------------------------------------------------
+    def _dev16(self, t):
+        return _dev16(t, self.device, self.op_dtype)
+
+    def _dev_packed(self, t):
+        """16-bit operands on the device in the fragment-packed GEMM layout."""
+        return ops.pack_fragments(self._dev16(t))
+
     def bind(self, name, t):
         assert t.is_cuda and t.is_contiguous()
         self._keep[name] = t
@@ -144,22 +154,22 @@ class Engine:
         self.parity = bool(parity)
         self.fp8_decode = bool(fp8_decode)
         self.fp8_prefill = bool(fp8_prefill)
-        self.bind("llm.embed", _dev_bf16(get("model.embed_tokens.weight"), dev))
+        self.bind("llm.embed", self._dev16(get("model.embed_tokens.weight")))
         # the lm_head's K-duplicated copy is bound in EVERY precision (+ 0.26 GB): the lm_head input is always a split pair (option lm_head_split)
-        self._bind_matrix("llm.lm_head", _dev_bf16(get("lm_head.weight"), dev), fp8_decode, parity=True)
+        self._bind_matrix("llm.lm_head", self._dev16(get("lm_head.weight")), fp8_decode, parity=True)
         self.bind("llm.norm", _dev_f32(get("model.norm.weight"), dev))
         for i in range(s.layers):
             p = f"model.layers.{i}."
-            q, k, v = (_dev_bf16(get(p + f"self_attn.{n}_proj.weight"), dev) for n in "qkv")
+            q, k, v = (self._dev16(get(p + f"self_attn.{n}_proj.weight")) for n in "qkv")
             q, k = pair_interleave_heads(q, s.heads), pair_interleave_heads(k, s.heads)
             self._bind_matrix(f"llm.L{i}.wqkv", torch.cat([q, k, v], dim=0).contiguous(), fp8_decode, fp8_prefill, parity)
             del q, k, v
-            self._bind_matrix(f"llm.L{i}.wo", _dev_bf16(get(p + "self_attn.o_proj.weight"), dev), fp8_decode, fp8_prefill, parity)
-            g = _dev_bf16(get(p + "mlp.gate_proj.weight"), dev)
-            u = _dev_bf16(get(p + "mlp.up_proj.weight"), dev)
+            self._bind_matrix(f"llm.L{i}.wo", self._dev16(get(p + "self_attn.o_proj.weight")), fp8_decode, fp8_prefill, parity)
+            g = self._dev16(get(p + "mlp.gate_proj.weight"))
+            u = self._dev16(get(p + "mlp.up_proj.weight"))
             self._bind_matrix(f"llm.L{i}.wgu", pack_gate_up(g, u), fp8_decode, fp8_prefill, parity)
             del g, u
-            self._bind_matrix(f"llm.L{i}.wdown", _dev_bf16(get(p + "mlp.down_proj.weight"), dev), fp8_decode, fp8_prefill, parity)
+            self._bind_matrix(f"llm.L{i}.wdown", self._dev16(get(p + "mlp.down_proj.weight")), fp8_decode, fp8_prefill, parity)
             self.bind(f"llm.L{i}.norm1", _dev_f32(get(p + "input_layernorm.weight"), dev))
             self.bind(f"llm.L{i}.norm2", _dev_f32(get(p + "post_attention_layernorm.weight"), dev))
         self.has_llm = True
@@ -172,21 +182,21 @@ class Engine:
         self.bind("adp.cls_pos", _dev_f32(get("global_rep_pos"), dev))
         if self.adapter_dim == self.shape.hidden and self.adapter_dim != 768:
             # the hidden-wide `cross_attn` ClipEncoder (transformer.py:65-67,86): no output projector (nn.Identity), a text projector in front
-            self.txt_proj = (_dev_packed(get("text_mm_projector.weight"), dev), _dev_f32(get("text_mm_projector.bias"), dev))
+            self.txt_proj = (self._dev_packed(get("text_mm_projector.weight")), _dev_f32(get("text_mm_projector.bias"), dev))
         else:
-            self.bind("adp.proj_w", _dev_packed(get("mm_projector.weight"), dev))
+            self.bind("adp.proj_w", self._dev_packed(get("mm_projector.weight")))
             self.bind("adp.proj_b", _dev_f32(get("mm_projector.bias"), dev))
         stacks = ([("t2v_encoder", "t2v")] if self.adapter_text else []) + [("encoder", "enc")]
         for ref, tag in stacks:
             for l in range(self.adapter_layers):
                 r, o = f"{ref}.layers.{l}.", f"adp.{tag}.{l}."
-                self.bind(o + "w_in", _dev_packed(get(r + "self_attn.in_proj_weight"), dev))
+                self.bind(o + "w_in", self._dev_packed(get(r + "self_attn.in_proj_weight")))
                 self.bind(o + "b_in", _dev_f32(get(r + "self_attn.in_proj_bias"), dev))
-                self.bind(o + "w_out", _dev_packed(get(r + "self_attn.out_proj.weight"), dev))
+                self.bind(o + "w_out", self._dev_packed(get(r + "self_attn.out_proj.weight")))
                 self.bind(o + "b_out", _dev_f32(get(r + "self_attn.out_proj.bias"), dev))
-                self.bind(o + "w1", _dev_packed(get(r + "linear1.weight"), dev))
+                self.bind(o + "w1", self._dev_packed(get(r + "linear1.weight")))
                 self.bind(o + "b1", _dev_f32(get(r + "linear1.bias"), dev))
-                self.bind(o + "w2", _dev_packed(get(r + "linear2.weight"), dev))
+                self.bind(o + "w2", self._dev_packed(get(r + "linear2.weight")))
                 self.bind(o + "b2", _dev_f32(get(r + "linear2.bias"), dev))
                 for n in ("1", "2"):
                     self.bind(o + f"ln{n}_w", _dev_f32(get(r + f"norm{n}.weight"), dev))
@@ -198,9 +208,9 @@ class Engine:
         if self.adapter_dim != 768:
             # next to a hidden-wide cross_attn ClipEncoder the Linear(768 -> hidden) projector runs IN FRONT of the encoder
             # (vtimellm_arch.py:125 then :127-144); rv_project_dense is tied to the context's adapter width, so it goes through rv_gemm
-            self.frame_proj = (_dev_packed(get("weight"), self.device), _dev_f32(get("bias"), self.device))
+            self.frame_proj = (self._dev_packed(get("weight")), _dev_f32(get("bias"), self.device))
         else:
-            self.bind("proj.w", _dev_packed(get("weight"), self.device))
+            self.bind("proj.w", self._dev_packed(get("weight")))
             self.bind("proj.b", _dev_f32(get("bias"), self.device))
         self.has_linear = True
         self._loaded()
@@ -278,7 +288,7 @@ class Engine:
     def project_dense(self, x, out_dtype=torch.float32):
         """nn.Linear(768, D) on [..., 768] bf16 -> [..., D]."""
         lead = x.shape[:-1]
-        x2 = _dev_bf16(x, self.device).reshape(-1, x.shape[-1])
+        x2 = self._dev16(x).reshape(-1, x.shape[-1])
         y = torch.empty(x2.shape[0], self.shape.hidden, dtype=out_dtype, device=self.device)
         hip.check(self.lib.rv_project_dense(self._ctx, hip.ptr(x2), hip.ptr(y), hip.dtype_code(y), x2.shape[0], hip.stream()),
                   "rv_project_dense")
@@ -287,18 +297,18 @@ class Engine:
     def clip_encoder(self, x, txt=None, txt_mask=None, feature="cls"):
         """x [N,T,768]; txt [Nq,Lq,768], txt_mask [Nq,Lq] (1 = valid) -> f32 [N,D] ('cls') or [N,T+1,D] ('all')."""
         N, T, _ = x.shape
-        x = _dev_bf16(x, self.device)
+        x = self._dev16(x)
         wide = self.adapter_dim != 768           # the hidden-wide cross_attn ClipEncoder: frames and text are projected to its width first
         if wide:
             if getattr(self, "frame_proj", None) is None or getattr(self, "txt_proj", None) is None:
                 raise hip.HipLibraryError("the cross_attn ClipEncoder needs the Linear projector (load_linear_projector) and its text projector bound")
-            x = ops.gemm(x.reshape(N * T, -1), self.frame_proj[0], bias=self.frame_proj[1], out_dtype=torch.bfloat16, w_packed=True,
+            x = ops.gemm(x.reshape(N * T, -1), self.frame_proj[0], bias=self.frame_proj[1], out_dtype=self.op_dtype, w_packed=True,
                          ctx=self).view(N, T, self.adapter_dim)
         if self.adapter_text:
-            txt = _dev_bf16(txt, self.device)
+            txt = self._dev16(txt)
             Nq, Lq = txt.shape[0], txt.shape[1]
             if wide:
-                txt = ops.gemm(txt.reshape(Nq * Lq, -1), self.txt_proj[0], bias=self.txt_proj[1], out_dtype=torch.bfloat16, w_packed=True,
+                txt = ops.gemm(txt.reshape(Nq * Lq, -1), self.txt_proj[0], bias=self.txt_proj[1], out_dtype=self.op_dtype, w_packed=True,
                                ctx=self).view(Nq, Lq, self.adapter_dim)
             m = ops.h2d((txt_mask != 0).to(torch.uint8), self.device).contiguous()
         else:
@@ -330,7 +340,7 @@ class Engine:
         t = self._ws.get(key) if reuse else None
         if t is None:
             nbytes = self.lib.rv_kv_bytes(self._ctx, B, Smax)
-            t = torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device)
+            t = torch.zeros(nbytes // 2, dtype=self.op_dtype, device=self.device)
             if reuse:
                 for k_ in [k_ for k_ in self._ws if isinstance(k_, tuple) and k_[0] == "kv" and k_[1] == self.slot][:-3]:
                     del self._ws[k_]   # keep the pool small
@@ -399,7 +409,7 @@ class Engine:
         """One cache tensor for ``rows`` sequences ([L, rows, H, Smax, 128] + its V^T twin), zero-initialised."""
         Smax = (Smax + 31) // 32 * 32
         nbytes = self.lib.rv_kv_bytes(self._ctx, rows, Smax)
-        return torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device), Smax
+        return torch.zeros(nbytes // 2, dtype=self.op_dtype, device=self.device), Smax
 
     def llm_prefill_pool(self, h, B, P0, kv, kv_rows, kv_row0, Smax, logits=None):
         """Prefill of B sequences into rows kv_row0.. of a pool: h f32 [P0 + B*S, D] (shared prefix first; P0 = 0: [B*S, D])."""

@@ -144,7 +144,7 @@ def _prepare(args, store, stager, dev, id_, data):
         features = features[np.linspace(0, features.shape[0] - 1, args.num_frames, dtype=np.int32)]
     frame_idx = window_features(features, args)
     windows = stager.stage_windows(features, frame_idx).wait()
-    qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(torch.bfloat16) if query_feats is not None else None
+    qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(getattr(model, "dtype", torch.float32)) if query_feats is not None else None
     qc = torch.from_numpy(np.asarray(query_cls)).to(dev).float() if query_cls is not None else None
     duration = data["movie_duration"] if "movie_duration" in data else data["duration"]
     return dict(movie=movie, windows=windows, qf=qf, qc=qc, sentence=_sentence(data), timestamps=data["timestamps"], duration=duration)
@@ -166,7 +166,7 @@ def eval(args, tokenizer=None, model=None):  # noqa: A001 - the reference's name
         tokenizer, model, _ = load_pretrained_model(args, args.stage2, args.stage3, load_ckp=args.load_ckp)
         model = model.bfloat16().cuda()
     store = FeatureStore(args.feat_folder, q_feat_dir=args.q_feat_dir, vis_feat_storage="npy" if args.vis_feat_storage == "pth" else args.vis_feat_storage)
-    stager = WindowStager(model.device)
+    stager = WindowStager(model.device, op_dtype=getattr(model, "dtype", None))
     done = set(done_query_ids(prediction_path))
     items = split_items(load_items(args.data_path), args.split, args.total_split)
     print("batch: ", args.batch)

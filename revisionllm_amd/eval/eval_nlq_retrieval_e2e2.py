@@ -179,7 +179,7 @@ def eval(args, tokenizer=None, model=None):  # noqa: A001 - the reference's name
         tokenizer, model, _ = load_pretrained_model(args, args.stage2, args.stage3, load_ckp=args.load_ckp)
         model = model.bfloat16().cuda()
     store = FeatureStore(args.feat_folder, q_feat_dir=args.q_feat_dir, vis_feat_storage="npy" if args.vis_feat_storage == "pth" else args.vis_feat_storage)
-    stager = WindowStager(model.device)
+    stager = WindowStager(model.device, op_dtype=getattr(model, "dtype", None))
     done = set(done_query_ids(prediction_path))
     items = split_items(load_items(args.data_path), args.split, args.total_split)
     batch = args.batch
@@ -210,7 +210,7 @@ def eval(args, tokenizer=None, model=None):  # noqa: A001 - the reference's name
                 grounding_windows = list(range(frame_idx.shape[0]))
             staged = stager.stage_windows(features, frame_idx)
             dev = model.device
-            qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(torch.bfloat16) if query_feats is not None else None
+            qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(getattr(model, "dtype", torch.float32)) if query_feats is not None else None
             qc = torch.from_numpy(np.asarray(query_cls)).to(dev).float() if query_cls is not None else None
             windows = staged.wait()
             timestamps = data["timestamps"]
@@ -278,7 +278,7 @@ def _eval_in_flight(args, tokenizer, model, store, stager, items, done, groundin
             else:
                 grounding_windows = list(range(frame_idx.shape[0]))
             windows = stager.stage_windows(features, frame_idx).wait()
-            qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(torch.bfloat16)
+            qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(getattr(model, "dtype", torch.float32))
             qc = torch.from_numpy(np.asarray(query_cls)).to(dev).float()
             sentence = data["sentence"].strip().lower() if "sentence" in data else data["query"].strip(".?").lower()
             if "sentence" in data and sentence.endswith("."):

@@ -19,7 +19,7 @@ def _topk_pooling(text_embeds, video_embeds, k):
             raise HipLibraryError("_topk_pooling runs on the HIP device path only (no GPU visible)")
         dev = torch.device("cuda", torch.cuda.current_device())
         video_embeds = ops.h2d(video_embeds, dev)
-    if video_embeds.dtype not in (torch.bfloat16, torch.float32):
+    if video_embeds.dtype not in (torch.float16, torch.bfloat16, torch.float32):
         video_embeds = video_embeds.float()
     text = text_embeds.to(video_embeds.device).float()
     return ops.topk_pool(text, video_embeds, k).to(device=home, dtype=dt)

@@ -10,15 +10,21 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# REVISION_HIP_LIB: load another build of the same ABI (A/B kernel measurements); default is the in-tree library.
-LIB_PATH = os.environ.get("REVISION_HIP_LIB") or os.path.join(_HERE, "librevision_hip.so")
+# The library exists in two operand FLAVOURS with one ABI (include/revision_hip.h "dtypes"): fp16 operands (the default: the checkpoints'
+# own storage type, 11 significand bits) and bf16 operands (the reference's GPU dtype).  An Engine is built for one flavour and calls that
+# library; the functional wrappers in ops.py pick the library from the dtype of the 16-bit tensors they are handed.
+# REVISION_HIP_LIB / REVISION_HIP_LIB_BF16: load another build of the same ABI (A/B kernel measurements); default: the in-tree libraries.
+LIB_PATHS = {"f16": os.environ.get("REVISION_HIP_LIB") or os.path.join(_HERE, "librevision_hip.so"),
+             "bf16": os.environ.get("REVISION_HIP_LIB_BF16") or os.path.join(_HERE, "librevision_hip_bf16.so")}
+LIB_PATH = LIB_PATHS["f16"]
+OP_DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
 
-RV_F32, RV_BF16, RV_I32, RV_I64, RV_U8 = 0, 1, 2, 3, 4
+RV_F32, RV_BF16, RV_I32, RV_I64, RV_U8, RV_F16 = 0, 1, 2, 3, 4, 5
 RV_ACT_NONE, RV_ACT_RELU, RV_ACT_SILU_MUL, RV_ACT_QUICK_GELU = 0, 1, 2, 3
 RV_FEAT_CLS, RV_FEAT_ALL = 0, 2
 TOPK_CAP = 64
 
-_DT = {torch.float32: RV_F32, torch.bfloat16: RV_BF16, torch.int32: RV_I32, torch.int64: RV_I64, torch.uint8: RV_U8}
+_DT = {torch.float32: RV_F32, torch.bfloat16: RV_BF16, torch.float16: RV_F16, torch.int32: RV_I32, torch.int64: RV_I64, torch.uint8: RV_U8}
 
 
 class RvConfig(C.Structure):
@@ -32,13 +38,50 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
+_flavour = os.environ.get("REVISION_OP_DTYPE", "f16")
+if _flavour not in OP_DTYPES:
+    raise ValueError(f"REVISION_OP_DTYPE={_flavour!r}: expected one of {sorted(OP_DTYPES)}")
+
+
+def flavour():
+    """The process-wide DEFAULT flavour ("f16" unless REVISION_OP_DTYPE / set_flavour say otherwise): what an Engine built without an
+    explicit ``op_dtype`` and the wrappers without a 16-bit input tensor use."""
+    return _flavour
+
+
+def set_flavour(f):
+    global _flavour
+    f = flavour_of(f)
+    prev, _flavour = _flavour, f
+    return prev
+
+
+def flavour_of(x):
+    """"f16" / "bf16" from a flavour name, a torch dtype or a tensor (None -> the default flavour)."""
+    if x is None:
+        return _flavour
+    if isinstance(x, str):
+        if x not in OP_DTYPES:
+            raise ValueError(f"unknown operand flavour {x!r}")
+        return x
+    dt = x.dtype if torch.is_tensor(x) else x
+    for k, v in OP_DTYPES.items():
+        if v == dt:
+            return k
+    raise HipLibraryError(f"{dt} is not an operand type of librevision_hip (fp16 or bf16)")
+
+
+def op_dtype(f=None):
+    """torch dtype of a flavour's 16-bit operands."""
+    return OP_DTYPES[flavour_of(f)]
 
 _p, _i32, _i64, _f, _sz, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
 #: every symbol include/revision_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rv_abi_version": (C.c_int, []),
+    "rv_operand_dtype": (C.c_int, []),
     "rv_last_error": (C.c_int, [C.c_char_p, _sz]),
     "rv_ctx_create": (C.c_int, [C.POINTER(RvConfig), C.POINTER(_p)]),
     "rv_ctx_destroy": (None, [_p]),
@@ -81,29 +124,39 @@ SIGNATURES = {
 }
 
 
-def lib():
-    """Load (once) and return the ctypes handle; raises HipLibraryError when the extension is missing."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(f=None):
+    """Load (once) and return the ctypes handle of a flavour's library (f: flavour name, torch dtype, tensor or None = the default
+    flavour); raises HipLibraryError when the extension is missing."""
+    f = flavour_of(f)
+    h = _libs.get(f)
+    if h is None:
+        path = LIB_PATHS[f]
+        if not os.path.exists(path):
             raise HipLibraryError(
-                f"{LIB_PATH} not found: build it with `python -m revisionllm_amd.build` (hipcc, gfx950). "
+                f"{path} not found: build it with `python -m revisionllm_amd.build` (hipcc, gfx950). "
                 "revisionllm_amd has no CPU fallback.")
         try:
-            h = C.CDLL(LIB_PATH)
+            h = C.CDLL(path)
         except OSError as e:
-            raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+            raise HipLibraryError(f"cannot load {path}: {e}") from e
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        _lib = h
-    return _lib
+        if h.rv_operand_dtype() != _DT[OP_DTYPES[f]]:
+            raise HipLibraryError(f"{path} is not the {f} build of the library (rv_operand_dtype() = {h.rv_operand_dtype()})")
+        _libs[f] = h
+    return h
 
 
 def last_error():
+    """The calling thread's last error message (of whichever loaded library has one)."""
     buf = C.create_string_buffer(512)
-    lib().rv_last_error(buf, 512)
-    return buf.value.decode()
+    msgs = []
+    for h in _libs.values():
+        h.rv_last_error(buf, 512)
+        if buf.value:
+            msgs.append(buf.value.decode())
+    return " | ".join(msgs)
 
 
 def check(rc, what):
@@ -116,35 +169,43 @@ OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8
 
 class Options:
     """Owner of an OPTIONS-ONLY ``rv_ctx`` (``rv_ctx_create(NULL, ...)``): tunables for the building-block entry points that take
-    an optional context (``rv_gemm``, ``rv_gemm_fp8``, ``rv_sample``).  ``Options(gemm_tile_variant=6)``; pass it as ``ctx=``."""
+    an optional context (``rv_gemm``, ``rv_gemm_fp8``, ``rv_sample``).  ``Options(gemm_tile_variant=6)``; pass it as ``ctx=``.
+    A context belongs to ONE library: ``flavour`` (default: the process default) names it."""
 
-    def __init__(self, **kw):
+    def __init__(self, flavour=None, **kw):
+        self.flavour = flavour_of(flavour)
+        self.lib = lib(self.flavour)
         self._ctx = C.c_void_p()
-        check(lib().rv_ctx_create(None, C.byref(self._ctx)), "rv_ctx_create(options)")
+        check(self.lib.rv_ctx_create(None, C.byref(self._ctx)), "rv_ctx_create(options)")
         for k, v in kw.items():
             self.set(k, v)
 
     def set(self, key, value):
-        check(lib().rv_ctx_set_option(self._ctx, key.encode(), int(value)), f"rv_ctx_set_option({key})")
+        check(self.lib.rv_ctx_set_option(self._ctx, key.encode(), int(value)), f"rv_ctx_set_option({key})")
         return self
 
     def get(self, key):
         v = _i64()
-        check(lib().rv_ctx_get_option(self._ctx, key.encode(), C.byref(v)), f"rv_ctx_get_option({key})")
+        check(self.lib.rv_ctx_get_option(self._ctx, key.encode(), C.byref(v)), f"rv_ctx_get_option({key})")
         return int(v.value)
 
     def __del__(self):
         try:
             if self._ctx and self._ctx.value:
-                lib().rv_ctx_destroy(self._ctx)
+                self.lib.rv_ctx_destroy(self._ctx)
                 self._ctx = C.c_void_p()
         except Exception:
             pass
 
 
-def ctx_ptr(ctx):
-    """``rv_ctx*`` of an ``Options`` / ``Engine`` (or None -> NULL: the library's default tunables)."""
-    return None if ctx is None else ctx._ctx
+def ctx_ptr(ctx, f=None):
+    """``rv_ctx*`` of an ``Options`` / ``Engine`` (or None -> NULL: the library's default tunables).  ``f``: the flavour of the library
+    about to be called - a context of the other library is refused."""
+    if ctx is None:
+        return None
+    if f is not None and ctx.flavour != flavour_of(f):
+        raise HipLibraryError(f"a {ctx.flavour} context was passed to a {flavour_of(f)} call")
+    return ctx._ctx
 
 
 def ptr(t):

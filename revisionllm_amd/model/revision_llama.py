@@ -117,8 +117,9 @@ class _Inner:
 class ReVisionLlamaForCausalLM:
     """Drop-in for ``VTimeLLMLlamaForCausalLM`` on the inference path."""
 
-    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, device="cuda:0", max_sequence_length=None, engine=None):
-        """``engine``: an existing ``Engine`` to share (its LLM weights, workspaces and options): a second model object with
+    def __init__(self, shape: synth.LlamaShape = synth.VICUNA_7B, device="cuda:0", max_sequence_length=None, engine=None, op_dtype=None):
+        """``op_dtype``: "f16" (default) / "bf16": the 16-bit operand type of the engine this model creates (ignored with ``engine=``).
+        ``engine``: an existing ``Engine`` to share (its LLM weights, workspaces and options): a second model object with
         another adapter topology - e.g. the dense Linear projector next to the hierarchy ClipEncoder - then costs no second copy
         of the 13.5 GB of LLM weights."""
         self.shape = shape
@@ -132,14 +133,15 @@ class ReVisionLlamaForCausalLM:
         self.engine = engine
         self.model = _Inner(self)
         self.scores_mode = "processed"  # what transformers>=4.39 returns; "raw" = the override's intent (vtimellm_llama.py:321)
-        self.dtype = torch.bfloat16
+        self.op_flavour = engine.flavour if engine is not None else hip.flavour_of(op_dtype)
+        self.dtype = hip.op_dtype(self.op_flavour)
         self.uniform_fn = None  # optional (step, B) -> uniforms hook for reproducible sampling through inference()
         self.after_prefill = None  # optional () -> None hook called between the prefill and the decode loop of generate()
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _ensure_engine(self, adapter_text=None, adapter_dim=768):
         if self.engine is None:
-            self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device, adapter_dim=adapter_dim)
+            self.engine = Engine(self.shape, adapter_text=bool(adapter_text), device=self._device, adapter_dim=adapter_dim, op_dtype=self.op_flavour)
         elif adapter_text is not None and (bool(adapter_text) != self.engine.adapter_text or adapter_dim != self.engine.adapter_dim):
             raise RuntimeError("the engine's ClipEncoder topology (text-conditioned layers on / off, width) differs from this model's")
         return self.engine
@@ -167,7 +169,7 @@ class ReVisionLlamaForCausalLM:
         return self
 
     def to(self, *args, **kwargs):
-        """Weights live in HBM as bf16 with fp32 accumulation / residual stream; dtype moves are accepted and ignored.
+        """Weights live in HBM as 16-bit operands (fp16 by default, ``op_dtype``) with fp32 accumulation / residual stream; dtype moves are accepted and ignored.
         NOTE (differs from the reference): ``scores`` / ``logits`` returned by ``generate`` are float32 whatever dtype was
         asked for here (the reference returns them in the model dtype, bf16 on the GPU)."""
         return self

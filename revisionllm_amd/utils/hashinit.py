@@ -62,6 +62,22 @@ def round_bf16(x: np.ndarray) -> np.ndarray:
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
+def round_f16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> fp16 -> fp32, saturating at +-65504 like the kernels' conversions (values stay fp32)."""
+    return np.clip(np.ascontiguousarray(x, dtype=np.float32), -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+
+
+def round_op(x, op):
+    """Round to an operand type's grid: ``op`` False / None (no rounding), True or "bf16", "f16"."""
+    if op is None or op is False:
+        return x
+    if op is True or op == "bf16":
+        return round_bf16(x)
+    if op == "f16":
+        return round_f16(x)
+    raise ValueError(f"unknown operand type {op!r}")
+
+
 def amplitude_pieces(a, shape):
     """``a`` is a float (one amplitude for the whole tensor) or a list of (row_end, amplitude) pieces over the leading dimension
     (row_end None = to the end): -> [(first element, element count, amplitude)] over the flat index.  The pieces share ONE hash
@@ -88,4 +104,4 @@ def make_tensor(name, shape, seed, a, base=0.0, bf16=False):
     for e0, cnt, amp in amplitude_pieces(a, shape):
         w[e0:e0 + cnt] = hash_uniform(cnt, key, amp, base, offset=e0)
     w = w.reshape(shape)
-    return round_bf16(w) if bf16 else w
+    return round_op(w, bf16)

@@ -165,8 +165,8 @@ def linear_projector_spec(d=768, hidden=4096):
 
 
 def build_numpy(spec, seed: int, prefix: str = "", bf16: bool = False):
-    """Materialise a spec on the host -> {prefix+name: fp32 ndarray}.  ``bf16=True`` rounds every value
-    to a bf16-representable fp32 (what the device holds when the engine stores bf16)."""
+    """Materialise a spec on the host -> {prefix+name: fp32 ndarray}.  ``bf16=True`` (or "bf16") rounds every value
+    to a bf16-representable fp32, ``bf16="f16"`` to an fp16-representable one (what the device holds in that operand flavour)."""
     return {prefix + n: hashinit.make_tensor(prefix + n, shp, seed, a, base, bf16) for n, shp, a, base in spec}
 
 

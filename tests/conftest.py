@@ -10,6 +10,36 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# GPU test modules that run in BOTH operand flavours of the library (fp16 = the default build, bf16); every other module runs in the default
+# flavour only.  REVISION_TEST_FLAVOURS=f16 | bf16 | f16,bf16 overrides the list for every GPU module (a quick single-flavour run).
+DUAL_FLAVOUR_MODULES = {"test_gpu_kernels", "test_gpu_merged_decode", "test_gpu_full_depth_conditioned", "test_gpu_configs_verified"}
+
+
+def pytest_generate_tests(metafunc):
+    if "op_flavour" not in metafunc.fixturenames or not metafunc.module.__name__.split(".")[-1].startswith("test_gpu"):
+        return
+    forced = os.environ.get("REVISION_TEST_FLAVOURS")
+    if forced:
+        flavours = [f.strip() for f in forced.split(",") if f.strip()]
+    else:
+        flavours = ["f16", "bf16"] if metafunc.module.__name__.split(".")[-1] in DUAL_FLAVOUR_MODULES else ["f16"]
+    metafunc.parametrize("op_flavour", flavours, indirect=True, scope="module")
+
+
+@pytest.fixture(autouse=True, scope="module")
+def op_flavour(request):
+    """Sets the process default operand flavour (hip.set_flavour) for the tests of a module; module-scoped fixtures that build engines take
+    this fixture as an argument so that they are rebuilt per flavour."""
+    f = getattr(request, "param", None)
+    if f is None:
+        yield None
+        return
+    from revisionllm_amd import hip
+    prev = hip.set_flavour(f)
+    yield f
+    hip.set_flavour(prev)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -248,10 +248,11 @@ def g7_scores(M):
          cos_stage1_mean=torch.einsum("bd,d->b", pf, qc).mean())
 
 
-def big_model(M, shape, args, seed=SEED, cond=None):
+def big_model(M, shape, args, seed=SEED, cond=None, w_round=True):
     """Reference model at full size, filled tensor by tensor (never two copies of the 27 GB in memory).  MATRICES take
-    bf16-representable values (what the device holds), vectors stay fp32: both sides then hold identical weights and the
-    comparison isolates the arithmetic."""
+    bf16-representable values (what the bf16 build holds on the device; ``w_round=True``), vectors stay fp32: both sides then hold
+    identical weights and the comparison isolates the arithmetic.  ``w_round="f16"`` (G8d): matrices take fp16-representable values
+    that are NOT bf16-representable - what a real Vicuna checkpoint holds (builder.py:22 loads fp16, e2e2.py:185 widens to fp32)."""
     L = M["llama"]
     cfg = L.VTimeLLMConfig(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
                            num_attention_heads=shape.heads, num_key_value_heads=shape.heads, vocab_size=shape.vocab,
@@ -273,7 +274,7 @@ def big_model(M, shape, args, seed=SEED, cond=None):
             continue
         shp, a, base = table[k]
         assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
-        sd[k].copy_(T(hashinit.make_tensor(k, shp, seed, a, base, bf16=len(shp) > 1)))
+        sd[k].copy_(T(hashinit.make_tensor(k, shp, seed, a, base, bf16=w_round if len(shp) > 1 else False)))
     # initialize_vision_modules creates the adapter AFTER the constructor's .eval(): without this its Dropout(0.1) layers stay in
     # training mode (builder.py:42 has the same order; there PeftModel.from_pretrained(is_trainable=False) ends with model.eval())
     return model.eval()
@@ -353,7 +354,18 @@ def g8c_full_7b(M):
         g8c_windows(M)
 
 
-def g8_full_7b(M, cond=None):
+def g8d_full_7b(M):
+    """G8c as the reference REALLY runs it on the CPU: weight matrices fp16-representable and NOT
+    bf16-representable (an fp16 checkpoint widened to fp32: builder.py:22 + e2e2.py:185), features / query features fp32 and un-rounded.
+    G8c gives both sides bf16-representable matrices and features, so the build's own weight / feature STORAGE rounding is outside every
+    error measured against it; against G8d it is inside (bf16 build: rounds both; fp16 build: holds the matrices exactly, rounds the
+    features to 11 bits).  Same conditioning, prompt geometry, uniforms, recorded quantities and file layout as G8c."""
+    g8_full_7b(M, cond=synth.CONDITIONED, tag="g8d", w_round="f16", in_round=False)
+    if int(os.environ.get("G8_LAYERS", "32")) == 32:
+        g8c_windows(M, name="g8d")
+
+
+def g8_full_7b(M, cond=None, tag=None, w_round=True, in_round=True):
     """The stage-2 recursion of ONE query at full depth through the reference itself: random-init Vicuna-7B (32 layers, fp32,
     CPU), hierarchy ClipEncoder, W = batch = 100 windows x 256 frames, the 7 calls of e2e2.py:337-386 in its own loop order
     (randperm, repeat_interleave, inference() with its production generate kwargs; max_new_tokens patched 1024 -> 8 and EOS
@@ -369,20 +381,20 @@ def g8_full_7b(M, cond=None):
     shape = synth.VICUNA_7B if n_layers == 32 else synth.LlamaShape(layers=n_layers)
     name = "g8_full_7b" if n_layers == 32 else "g8_dry_%dL" % n_layers
     if cond is not None:
-        name = name.replace("g8_", "g8c_")
+        name = name.replace("g8_", (tag or "g8c") + "_")
     G, W, batch, Tn, Lq = 8, 100, 100, 256, 16
     seed = SEED
     t0 = time.time()
-    m = big_model(M, shape, ns(), seed, cond)
+    m = big_model(M, shape, ns(), seed, cond, w_round=w_round)
     draw = _InverseCdfDraw(hash_uniforms("g8c.uniforms", (7, G), seed)) if cond is not None else None
     hidden = {}
     print("g8: model filled in %.0f s" % (time.time() - t0))
     m.generation_config.eos_token_id = None
     m.generation_config.top_k, m.generation_config.top_p = 50, 1.0
     tok = synth.FakeTokenizer(vocab=shape.vocab)
-    features = T(synth.features("g8.feat", (W, Tn, 768), seed, bf16=True))
-    query_feats = T(synth.features("g8.q", (Lq, 768), seed, bf16=True))
-    query_cls = T(synth.features("g8.qcls", (768,), seed, bf16=True))
+    features = T(synth.features("g8.feat", (W, Tn, 768), seed, bf16=in_round))
+    query_feats = T(synth.features("g8.q", (Lq, 768), seed, bf16=in_round))
+    query_cls = T(synth.features("g8.qcls", (768,), seed, bf16=in_round))
     sentence = "a man opens the door of a red car"
     if cond is not None:
         # G8c: the 20-word sentence of bench.py -> P = 72 prompt ids, S = 171, 32 shared prefix ids: the prefill passes then have the
@@ -540,8 +552,9 @@ def g8_full_7b(M, cond=None):
         json.dump({"answers": rec["answers"], "sentence": sentence, "G": G, "W": W, "batch": batch, "T": Tn, "Lq": Lq,
                    "bf16_leg_error": bf["error"],
                    "conditioning": None if cond is None else {k: getattr(cond, k) for k in cond.__dataclass_fields__},
-                   "note": "weights: synth specs, seed %d, matrices rounded to bf16-representable fp32, vectors fp32; features "
-                           "bf16-representable; sampling: torch.manual_seed(%d) before the loop%s"
+                   "weights_rounded_to": "bf16" if w_round is True else w_round, "inputs_rounded_to": "bf16" if in_round is True else (in_round or "fp32 (un-rounded)"),
+                   "note": "weights: synth specs, seed %d, matrices rounded to the grid named in weights_rounded_to, vectors fp32; features "
+                           "as named in inputs_rounded_to; sampling: torch.manual_seed(%d) before the loop%s"
                            % (seed, seed, "" if cond is None else "; the multinomial draw = inverse-CDF walk over the reference's probs with the "
                                                                      "stored uniforms [call, step]")}, f, indent=1)
 
@@ -890,9 +903,9 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8d=g8d_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense)
     for k, fn in groups.items():
-        if (only and k not in only) or (not only and k in ("g8", "g8c", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
+        if (only and k not in only) or (not only and k in ("g8", "g8c", "g8d", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue
         fn(M)
     with open(os.path.join(HERE, "meta.json"), "w") as f:

@@ -9,6 +9,25 @@ from revisionllm_amd.utils import synth
 SEED = 1234  # must match tests/golden/make_goldens.py
 
 
+def fl():
+    """The operand flavour under test ("f16" / "bf16"): the conftest fixture ``op_flavour`` sets it per test (hip.set_flavour)."""
+    from revisionllm_amd import hip
+    return hip.flavour()
+
+
+def op():
+    """torch dtype of the flavour under test."""
+    from revisionllm_amd import hip
+    return hip.op_dtype()
+
+
+def tol(bf16_tol, f16_tol=None):
+    """A tolerance by flavour: fp16 operands carry 3 more significand bits than bf16 (measured on the kernel tests: errors 7 - 9 x smaller,
+    gpurun_out/err_{f16,bf16}.log of round 5), so a bound set for the bf16 kernels is asserted 6 x tighter for the fp16 ones - again ~2.5 x what
+    was measured - unless a measured value says otherwise (``f16_tol``)."""
+    return bf16_tol if fl() == "bf16" else (f16_tol if f16_tol is not None else bf16_tol / 6)
+
+
 def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 

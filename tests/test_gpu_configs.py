@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats, rel_err
+from helpers import SEED, T, feats, fl, op, rel_err, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def _args(**kw):
 
 
 @pytest.fixture(scope="module")
-def llm_7b():
+def llm_7b(op_flavour):
     """One engine with the 7B LLM + the hierarchy ClipEncoder + the dense projector; model objects of the three topologies share it."""
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
@@ -54,12 +54,12 @@ def test_stage1_dense_one_layer_vs_oracle(B):
     m.engine.init_synthetic(seed=SEED, llm=True, clip=False, linear=True)
     m.generation_config.eos_token_id = None
     ids = T(synth.synthetic_prompt_ids(72, 40, SEED, vocab=shape.vocab))[None].repeat(B, 1)
-    feat = feats("s1d.feat", (B, 256, 768), bf16=True)
+    feat = feats("s1d.feat", (B, 256, 768), bf16=fl())
     out = m.generate(ids, images=feat, do_sample=False, max_new_tokens=3, output_logits=True, return_dict_in_generate=True)
     assert out["sequences"].shape == (B, 72 + 3)
-    w16, w32 = synth.build_numpy(synth.llama_spec(shape), SEED, bf16=True), synth.build_numpy(synth.llama_spec(shape), SEED)
+    w16, w32 = synth.build_numpy(synth.llama_spec(shape), SEED, bf16=fl()), synth.build_numpy(synth.llama_spec(shape), SEED)
     w = {k: T(w32[k] if "norm" in k else w16[k]) for k in w16}
-    a16 = synth.build_numpy(synth.linear_projector_spec(), SEED, prefix="model.mm_projector.", bf16=True)
+    a16 = synth.build_numpy(synth.linear_projector_spec(), SEED, prefix="model.mm_projector.", bf16=fl())
     a32 = synth.build_numpy(synth.linear_projector_spec(), SEED, prefix="model.mm_projector.")
     wa = {k[len("model.mm_projector."):]: T(a16[k] if a16[k].ndim > 1 else a32[k]) for k in a16}
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
@@ -76,7 +76,7 @@ def test_stage1_dense_full_depth_properties(llm_7b):
     from revisionllm_amd.utils import synth
     m = llm_7b.dense
     ids = T(synth.synthetic_prompt_ids(72, 40, 5))[None]
-    feat = feats("s1d.full", (4, 256, 768), bf16=True).to(torch.bfloat16).cuda()
+    feat = feats("s1d.full", (4, 256, 768), bf16=fl()).to(op()).cuda()
     kw = dict(do_sample=False, max_new_tokens=3, output_logits=True, return_dict_in_generate=True)
     four = m.generate(ids.repeat(4, 1), images=feat, **kw)
     assert four["sequences"].shape == (4, 75)
@@ -106,8 +106,8 @@ def test_stage1_sparse_end_to_end_7b(llm_7b):
     and two windows in one batch give each window's own logits."""
     from revisionllm_amd.utils import synth
     m, eng = llm_7b.sparse, llm_7b.eng
-    x = feats("s1s.x", (2, 1024, 768), bf16=True).to(torch.bfloat16).cuda()
-    q = (feats("s1s.q", (2, 16, 768), bf16=True).to(torch.bfloat16).cuda(), torch.ones(2, 16))
+    x = feats("s1s.x", (2, 1024, 768), bf16=fl()).to(op()).cuda()
+    q = (feats("s1s.q", (2, 16, 768), bf16=fl()).to(op()).cuda(), torch.ones(2, 16))
     ids = T(synth.synthetic_prompt_ids(72, 40, 5))[None]
     rows, per = m.encode_images(x, q)
     assert per == 1 and rows.shape == (2, 4096)
@@ -134,8 +134,8 @@ def test_stage2_long_33_at_7b(llm_7b):
     m = llm_7b.hier
     tok = synth.FakeTokenizer()
     W = batch = 33
-    feat = ops.init_hash_(torch.empty(W, 256, 768, dtype=torch.bfloat16, device="cuda:0"), "s33.feat", 5, synth.SQRT3)
-    qf = ops.init_hash_(torch.empty(16, 768, dtype=torch.bfloat16, device="cuda:0"), "s33.q", 5, synth.SQRT3)
+    feat = ops.init_hash_(torch.empty(W, 256, 768, dtype=op(), device="cuda:0"), "s33.feat", 5, synth.SQRT3)
+    qf = ops.init_hash_(torch.empty(16, 768, dtype=op(), device="cuda:0"), "s33.q", 5, synth.SQRT3)
     qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device="cuda:0"), "s33.qc", 5, synth.SQRT3)
     plan = stage2.plan_groups(W, batch)
     assert [(e - s) * z for z, s, e in plan] == [32] * 8 + [33]          # 5 + 3 + 1 calls
@@ -183,8 +183,8 @@ def test_eos_lagging_flag_equals_per_step_sync():
     m.generation_config.eos_token_id, m.generation_config.pad_token_id = 2, 0
     B, P = 3, 40
     ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None].repeat(B, 1)
-    feat = feats("eos.feat", (B, 6, 16, 768), bf16=True)
-    q = (feats("eos.q", (B, 5, 768), bf16=True), torch.ones(B, 5))
+    feat = feats("eos.feat", (B, 6, 16, 768), bf16=fl())
+    q = (feats("eos.q", (B, 5, 768), bf16=fl()), torch.ones(B, 5))
     # rows emit EOS at steps 1, 3 and 3 -> the loop must stop after step 3 (4 new tokens), row 0 pads from step 2 on
     forced = torch.tensor([[7, 9, 11], [2, 12, 13], [5, 14, 15], [6, 2, 2], [8, 9, 10], [8, 9, 10], [8, 9, 10], [8, 9, 10]])
     kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=8, forced_tokens=forced, output_scores=True,
@@ -222,8 +222,8 @@ def test_eos_generates_interleave_on_two_streams():
     tok = synth.FakeTokenizer(vocab=synth.TINY.vocab)
     st = parallel.HipStages(m, tok)
     W, batch = 13, 8
-    feat = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qfs = [feats(f"il.q{i}", (5 + i, 768), bf16=True).to(torch.bfloat16).cuda() for i in range(3)]
+    feat = feats("s2.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qfs = [feats(f"il.q{i}", (5 + i, 768), bf16=fl()).to(op()).cuda() for i in range(3)]
     qc = feats("s2.qc", (768,)).cuda()
     plan = stage2.plan_groups(W, batch)
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
@@ -251,8 +251,8 @@ def test_second_generate_on_a_busy_slot_is_refused():
     m = _tiny_model()
     m.generation_config.eos_token_id = 2
     ids = torch.randint(3, 200, (2, 24))
-    feat = feats("busy.feat", (2, 6, 16, 768), bf16=True)
-    q = (feats("busy.q", (2, 5, 768), bf16=True), torch.ones(2, 5))
+    feat = feats("busy.feat", (2, 6, 16, 768), bf16=fl())
+    q = (feats("busy.q", (2, 5, 768), bf16=fl()), torch.ones(2, 5))
     kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=8, return_dict_in_generate=True)
     first = m.generate_steps(ids, **kw)
     ev = next(first)                       # runs the prefill and the first steps, then asks for a flag

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats, rel_err
+from helpers import SEED, T, feats, fl, op, rel_err, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -43,11 +43,11 @@ def test_topk_pooling_contract(as_revisionllm, golden):
     cos = torch.einsum("bd,d->b", pooled[:, 0], qc.cuda())
     assert rel_err(cos.cpu(), g["cos_stage2"]) < 1e-5
     # several videos x several texts, bf16 features (what the GPU drivers hold, e2e2.py:303), k up to the frame count
-    vid = feats("tp.vid", (5, 37, 768), bf16=True)
+    vid = feats("tp.vid", (5, 37, 768), bf16=fl())
     txt = feats("tp.txt", (3, 768))
     for k in (1, 3, 37):
         y = _topk_pooling(txt.cuda(), vid.bfloat16().cuda(), k)
-        assert y.dtype == torch.bfloat16 and y.shape == (5, 3, 768)
+        assert y.dtype == op() and y.shape == (5, 3, 768)
         ref = scores.topk_pooling(txt, vid, k)
         assert rel_err(y.float().cpu(), ref) < 8e-3                        # one bf16 rounding of the pooled sum
     from revisionllm_amd import ops
@@ -113,9 +113,9 @@ def test_reference_stage2_loop_through_the_aliased_names(as_revisionllm):
     real = model.generate
     model.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
     W, batch = 13, 8
-    features = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    query_feats = feats("s2.q", (5, 768), bf16=True).to(torch.bfloat16).cuda()
-    query_cls_feats = feats("s2.qc", (768,), bf16=True).to(torch.bfloat16).cuda()
+    features = feats("s2.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    query_feats = feats("s2.q", (5, 768), bf16=fl()).to(op()).cuda()
+    query_cls_feats = feats("s2.qc", (768,), bf16=fl()).to(op()).cuda()
     plan = stage2.plan_groups(W, batch)
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
     args = SimpleNamespace(batch=batch, q_feat_dir="x", single=True)
@@ -194,7 +194,7 @@ def test_window_stager_back_to_back_videos():
     for v in vids:
         _, idx = stage2.cut_windows(v.shape[0], num_frames=250)
         staged.append(st.stage_windows(v, idx))
-        want.append(torch.from_numpy(v.astype(np.float32))[torch.from_numpy(idx.astype(np.int64))].to(torch.bfloat16))
+        want.append(torch.from_numpy(v.astype(np.float32))[torch.from_numpy(idx.astype(np.int64))].to(op()))
     assert st._slots[0]["buf"] is not None and st._slots[1]["buf"] is not None and len(st._slots) == 2
     side = torch.cuda.Stream("cuda:0")
     for s, w in zip(staged, want):
@@ -202,7 +202,7 @@ def test_window_stager_back_to_back_videos():
             t = s.wait(side)
             got = t.clone()
         side.synchronize()
-        assert got.dtype == torch.bfloat16 and got.shape == w.shape and torch.equal(got.cpu(), w)
+        assert got.dtype == op() and got.shape == w.shape and torch.equal(got.cpu(), w)
     dev, ev = st.stage_windows(vids[0], stage2.cut_windows(9000, num_frames=250)[1])     # tuple form
     ev.synchronize()
     assert torch.equal(dev.cpu(), want[0])

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, clip_weights, feats
+from helpers import SEED, T, clip_weights, feats, fl, op, tol
 from test_gpu_full_depth_conditioned import ROOT, _hier_args, _inputs, _metrics, _model, _rel, _run_calls, g8c  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -33,7 +33,7 @@ def _oracle_weights(eng, cond):
     w = {}
     for name, shp, _a, _b in spec:
         t = get(name)
-        w[name] = t.to(torch.bfloat16).float() if len(shp) > 1 else t
+        w[name] = t.to(op()).float() if len(shp) > 1 else t
     return w
 
 
@@ -82,11 +82,11 @@ def test_error_budget_of_the_entropy_scores(g8c):
         with torch.device("cuda"):
             w = _oracle_weights(eng, synth.CONDITIONED)
             # fp32 adapter rows of all 100 windows (oracle), and the HIP adapter's rows of the same windows
-            wa = clip_weights(bf16=True, prefix="model.mm_projector.")
+            wa = clip_weights(bf16=fl(), prefix="model.mm_projector.")
             wa32 = clip_weights(bf16=False, prefix="model.mm_projector.")
             wa = {k: (v if v.dim() > 1 else wa32[k]).cuda() for k, v in wa.items()}
-            feat = feats("g8.feat", (meta["W"], meta["T"], 768), bf16=True).cuda()
-            qf = feats("g8.q", (meta["Lq"], 768), bf16=True).cuda()
+            feat = feats("g8.feat", (meta["W"], meta["T"], 768), bf16=fl()).cuda()
+            qf = feats("g8.q", (meta["Lq"], 768), bf16=fl()).cuda()
             ones = torch.ones(1, meta["Lq"])
             rows32 = torch.cat([o_adapter.encode_images(feat[i:i + 20][None], wa, (qf[None], ones), hierarchy=True)[0] for i in range(0, meta["W"], 20)])
             rows_hip = eng.clip_encoder(r.features, r.qf[None], torch.ones(1, meta["Lq"]), "cls")

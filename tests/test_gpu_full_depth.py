@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats
+from helpers import SEED, T, feats, fl, op, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def g8_run(golden):
+def g8_run(golden, op_flavour):
     """One pass over the 7 calls, reference mode (one generate per call, adapter inside the call), teacher-forced on the
     reference's sampled tokens."""
     from revisionllm_amd import ops
@@ -40,9 +40,9 @@ def g8_run(golden):
     m.engine.init_synthetic(seed=SEED, llm=True, clip=True)
     m.generation_config.eos_token_id = None
     W, Tn, Lq, G = meta["W"], meta["T"], meta["Lq"], meta["G"]
-    features = feats("g8.feat", (W, Tn, 768), bf16=True).to(torch.bfloat16).cuda()
-    qf = feats("g8.q", (Lq, 768), bf16=True).to(torch.bfloat16).cuda()
-    qc = feats("g8.qcls", (768,), bf16=True).cuda()
+    features = feats("g8.feat", (W, Tn, 768), bf16=fl()).to(op()).cuda()
+    qf = feats("g8.q", (Lq, 768), bf16=fl()).to(op()).cuda()
+    qc = feats("g8.qcls", (768,), bf16=fl()).cuda()
     ids = T(g["prompt_ids"])[None]
     perms = [T(p) for key in ("perms_z4", "perms_z2", "perms_z1") for p in g[key]]
     calls = []

@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats
+from helpers import SEED, T, feats, fl, op, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -55,9 +55,9 @@ def _model():
 
 def _inputs(g, meta):
     W, Tn, Lq = meta["W"], meta["T"], meta["Lq"]
-    features = feats("g8.feat", (W, Tn, 768), bf16=True).to(torch.bfloat16).cuda()
-    qf = feats("g8.q", (Lq, 768), bf16=True).to(torch.bfloat16).cuda()
-    qc = feats("g8.qcls", (768,), bf16=True).cuda()
+    features = feats("g8.feat", (W, Tn, 768), bf16=fl()).to(op()).cuda()
+    qf = feats("g8.q", (Lq, 768), bf16=fl()).to(op()).cuda()
+    qc = feats("g8.qcls", (768,), bf16=fl()).cuda()
     ids = T(g["prompt_ids"])[None]
     perms = [T(p) for key in ("perms_z4", "perms_z2", "perms_z1") for p in g[key]]
     return features, qf, qc, ids, perms
@@ -103,7 +103,7 @@ def _metrics(calls, g):
 
 
 @pytest.fixture(scope="module")
-def g8c(golden):
+def g8c(golden, op_flavour):
     g = golden.npz("g8c_full_7b")
     meta = golden.json("g8c_text")
     m = _model()
@@ -217,7 +217,7 @@ def _layer_weights_cpu(eng, l, cond):
     p = f"model.layers.{l}."
     w = {}
     for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
-        w[p + n + ".weight"] = get(p + n + ".weight").to(torch.bfloat16).float().cpu()
+        w[p + n + ".weight"] = get(p + n + ".weight").to(op()).float().cpu()
     for n in ("input_layernorm", "post_attention_layernorm"):
         w[p + n + ".weight"] = get(p + n + ".weight").cpu()
     return w
@@ -240,14 +240,14 @@ def test_conditioned_every_layer_teacher_forced(g8c):
     # ---- call 0 of the recursion: zoom 4, windows 0..24 in the recorded permutation, each presented 4 times ----
     z, start = int(g["zooms"][0]), int(g["starts"][0])
     b = meta["batch"] // z
-    feat = feats("g8.feat", (meta["W"], meta["T"], 768), bf16=True)[start:start + b][r.perms[0]].repeat_interleave(z, 0)
-    qf = feats("g8.q", (meta["Lq"], 768), bf16=True)
-    wa = clip_weights(bf16=True, prefix="model.mm_projector.")
+    feat = feats("g8.feat", (meta["W"], meta["T"], 768), bf16=fl())[start:start + b][r.perms[0]].repeat_interleave(z, 0)
+    qf = feats("g8.q", (meta["Lq"], 768), bf16=fl())
+    wa = clip_weights(bf16=fl(), prefix="model.mm_projector.")
     wa32 = clip_weights(bf16=False, prefix="model.mm_projector.")
     wa = {k: (v if v.dim() > 1 else wa32[k]) for k, v in wa.items()}
     rows = o_adapter.encode_images(feat[None], wa, (qf[None], torch.ones(1, meta["Lq"])), hierarchy=True)
     get = eng._synth_get(synth.llama_spec(eng.shape, cond=cond), SEED, "")
-    embed = get("model.embed_tokens.weight").to(torch.bfloat16).float().cpu()
+    embed = get("model.embed_tokens.weight").to(op()).float().cpu()
     h, mask, pos, _ = o_splice.splice(r.ids, list(rows), embed)
     S, D = h.shape[1], h.shape[2]
     tok1 = int(g["tokens"][0, 0])
@@ -312,7 +312,7 @@ def test_conditioned_parity_detects_a_broken_layer(g8c, fault):
     if fault == "rope_pairing_layer17":
         l = 17
         p = f"model.layers.{l}."
-        q, k, v = (get(p + f"self_attn.{n}_proj.weight").to(torch.bfloat16) for n in "qkv")
+        q, k, v = (get(p + f"self_attn.{n}_proj.weight").to(op()) for n in "qkv")
         good = eng.weight(f"llm.L{l}.wqkv")
         from revisionllm_amd import ops
         eng.bind(f"llm.L{l}.wqkv", ops.pack_fragments(torch.cat([q, eng_mod.pair_interleave_heads(k, eng.shape.heads), v], 0).contiguous()))
@@ -397,7 +397,7 @@ def test_conditioned_fp8_llm_path_through_the_headline_pipeline(g8c):
 
 
 @pytest.fixture(scope="module")
-def parity_model():
+def parity_model(op_flavour):
     """The same conditioned 7B weights with the K-duplicated copies bound and the engine switched to the PARITY precision."""
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
@@ -469,7 +469,7 @@ def test_parity_precision_through_the_140_row_pipeline(g8c, parity_model):
 
 
 @pytest.fixture(scope="module")
-def fp8_model():
+def fp8_model(op_flavour):
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
     m = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device="cuda:0")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, feats, rel_err
+from helpers import SEED, T, feats, fl, op, rel_err, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -19,11 +19,11 @@ def test_weight_streaming_kernel_17_to_32_rows(M, N, K, act):
     from revisionllm_amd import hip, ops
     dev = "cuda:0"
     g = torch.Generator().manual_seed(M * 7 + N)
-    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(op()).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(op()).to(dev)
     wp = ops.pack_fragments(w)
     res = torch.randn(M, N // 2 if act == 2 else N, generator=g).to(dev) if act == 0 else None
-    od = torch.bfloat16 if act == 2 else torch.float32
+    od = op() if act == 2 else torch.float32
     y = ops.gemm(a, wp, residual=res, out_dtype=od, act=act, w_packed=True)
     lo = ops.gemm(a[:16], wp, residual=None if res is None else res[:16], out_dtype=od, act=act, w_packed=True)
     hi = ops.gemm(a[16:], wp, residual=None if res is None else res[16:], out_dtype=od, act=act, w_packed=True)
@@ -209,8 +209,8 @@ def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams
     tok = synth.FakeTokenizer(vocab=synth.TINY.vocab)
     st = parallel.HipStages(m, tok)
     W, batch = 13, 8
-    feat = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qfs = [feats(f"ms.q{i}", (5 + i % 3, 768), bf16=True).to(torch.bfloat16).cuda() for i in range(n_passes)]
+    feat = feats("s2.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qfs = [feats(f"ms.q{i}", (5 + i % 3, 768), bf16=fl()).to(op()).cuda() for i in range(n_passes)]
     qc = feats("s2.qc", (768,)).cuda()
     plan = stage2.plan_groups(W, batch)                      # 4 + 2 + 2 calls -> generates of 8 rows (same row count per level here)
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
@@ -261,8 +261,8 @@ def test_ragged_generate_of_a_33_window_recursion_equals_the_two_generate_form()
     W, batch, n = 33, 33, 4
     plan = stage2.plan_groups(W, batch)
     assert len(plan) == 9
-    feat = feats("rg.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qfs = [feats(f"rg.q{i}", (5 + i % 3, 768), bf16=True).to(torch.bfloat16).cuda() for i in range(n)]
+    feat = feats("rg.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qfs = [feats(f"rg.q{i}", (5 + i % 3, 768), bf16=fl()).to(op()).cuda() for i in range(n)]
     qc = feats("rg.qc", (768,)).cuda()
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(2), W=W)
     unis = [torch.rand(6, len(plan), generator=torch.Generator().manual_seed(20 + i)) for i in range(n)]
@@ -309,8 +309,8 @@ def test_decode_server_with_eos_equals_classic_loop(pools):
                    torch.tensor([[2], [9], [9], [9], [9], [9]])]                                                         # ends at step 0
     for i, forced in enumerate(forced_sets):
         B = forced.shape[1]
-        feat = feats(f"eoss.feat{i}", (B, 6, 16, 768), bf16=True)
-        q = (feats(f"eoss.q{i}", (B, 5, 768), bf16=True), torch.ones(B, 5))
+        feat = feats(f"eoss.feat{i}", (B, 6, 16, 768), bf16=fl())
+        q = (feats(f"eoss.q{i}", (B, 5, 768), bf16=fl()), torch.ones(B, 5))
         kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=6, forced_tokens=forced, return_dict_in_generate=True,
                   uniforms=torch.full((6, B), 0.5))
         cases.append((ids.repeat(B, 1), kw, m.generate(ids.repeat(B, 1), **kw)))
@@ -340,8 +340,8 @@ def test_one_row_generates_in_flight_share_prefill_passes_and_decode_steps(parit
     ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
     cases = []
     for i in range(6):
-        feat = feats(f"s1row.feat{i}", (1, 6, 16, 768), bf16=True)
-        q = (feats(f"s1row.q{i}", (1, 5, 768), bf16=True), torch.ones(1, 5))
+        feat = feats(f"s1row.feat{i}", (1, 6, 16, 768), bf16=fl())
+        q = (feats(f"s1row.q{i}", (1, 5, 768), bf16=fl()), torch.ones(1, 5))
         kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=5, return_dict_in_generate=True,
                   uniforms=torch.rand(5, 1, generator=torch.Generator().manual_seed(100 + i)))
         cases.append((kw, m.generate(ids, **kw)))
@@ -370,8 +370,8 @@ def test_eos_job_running_all_its_steps_keeps_its_last_column():
     cases = []
     for i, steps in enumerate((G, G, 3)):           # two full-length generates and a short one that joins later
         B = 2
-        feat = feats(f"eosg.feat{i}", (B, 6, 16, 768), bf16=True)
-        q = (feats(f"eosg.q{i}", (B, 5, 768), bf16=True), torch.ones(B, 5))
+        feat = feats(f"eosg.feat{i}", (B, 6, 16, 768), bf16=fl())
+        q = (feats(f"eosg.q{i}", (B, 5, 768), bf16=fl()), torch.ones(B, 5))
         forced = torch.full((steps, B), 9 + i)
         kw = dict(images=feat, query_feats=q, do_sample=True, temperature=0.05, max_new_tokens=steps, forced_tokens=forced, return_dict_in_generate=True,
                   uniforms=torch.full((steps, B), 0.5))
@@ -405,8 +405,8 @@ def test_a_failing_generate_fails_alone_and_gives_its_rows_back():
     streams = [torch.cuda.Stream("cuda:0") for _ in range(4)]
 
     def make(i, sampling_t):
-        feat = feats(f"fail.feat{i}", (2, 6, 16, 768), bf16=True)
-        q = (feats(f"fail.q{i}", (2, 5, 768), bf16=True), torch.ones(2, 5))
+        feat = feats(f"fail.feat{i}", (2, 6, 16, 768), bf16=fl())
+        q = (feats(f"fail.q{i}", (2, 5, 768), bf16=fl()), torch.ones(2, 5))
         return dict(images=feat, query_feats=q, do_sample=True, temperature=sampling_t, max_new_tokens=4, return_dict_in_generate=True,
                     uniforms=torch.full((4, 2), 0.5))
     kws = [make(0, 0.05), make(1, 0.7), make(2, 0.05), make(3, 0.05)]            # generate 1 asks for other sampling settings: join() raises
@@ -466,7 +466,7 @@ def test_fp8_decode_weights_in_wide_merged_steps_7b_layer(R):
             assert torch.equal(got[s_][7 * i:7 * i + 7], want), (i, s_)
     # (b) the oracle with the same fake-quantised decode weights (prefill on the bf16 weights), generates 0 and n - 1
     w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), SEED).items()}
-    w = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}
+    w = {k: (v.to(op()).float() if v.dim() == 2 else v) for k, v in w.items()}
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w8 = llama.fp8_decode_weights(w, cfg)
     for i in (0, n - 1):
@@ -498,8 +498,8 @@ def test_handoff_status_travels_as_one_snapshot_and_still_raises():
     P = 40
     from revisionllm_amd.utils import synth
     ids = T(synth.synthetic_prompt_ids(P, 20, SEED, vocab=synth.TINY.vocab))[None]
-    feat = feats("status.feat", (1, 6, 16, 768), bf16=True)
-    q = (feats("status.q", (1, 5, 768), bf16=True), torch.ones(1, 5))
+    feat = feats("status.feat", (1, 6, 16, 768), bf16=fl())
+    q = (feats("status.q", (1, 5, 768), bf16=fl()), torch.ones(1, 5))
     m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=3)       # workspaces exist now
     snap = eng.handoff_status_async()
     assert snap is not None and len(snap[0]) == snap[1].numel() >= 1

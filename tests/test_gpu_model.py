@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEED, T, clip_weights, feats, rel_err
+from helpers import SEED, T, clip_weights, feats, fl, op, rel_err, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -36,11 +36,11 @@ def _model(shape, args, seed=SEED):
 
 def _oracle_weights(shape, clip, text=True):
     from revisionllm_amd.utils import synth
-    w16 = synth.build_numpy(synth.llama_spec(shape), SEED, bf16=True)
+    w16 = synth.build_numpy(synth.llama_spec(shape), SEED, bf16=fl())
     w32 = synth.build_numpy(synth.llama_spec(shape), SEED)
     w = {k: T(w32[k] if "norm" in k else w16[k]) for k in w16}
     spec = synth.clip_encoder_spec(hidden=shape.hidden, text=text) if clip else synth.linear_projector_spec(hidden=shape.hidden)
-    a16 = synth.build_numpy(spec, SEED, prefix="model.mm_projector.", bf16=True)
+    a16 = synth.build_numpy(spec, SEED, prefix="model.mm_projector.", bf16=fl())
     a32 = synth.build_numpy(spec, SEED, prefix="model.mm_projector.")
     wa = {k[len("model.mm_projector."):]: T(a16[k] if a16[k].ndim > 1 else a32[k]) for k in a16}
     return w, wa
@@ -71,8 +71,8 @@ def test_generate_vs_reference_golden_and_oracle(golden, tag):
     # vs the oracle on identical weights (inputs rounded to bf16 on both sides)
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w, wa = _oracle_weights(shape, clip)
-    fb = feat.to(torch.bfloat16).float()
-    qb = (q[0].to(torch.bfloat16).float(), q[1]) if q is not None else None
+    fb = feat.to(op()).float()
+    qb = (q[0].to(op()).float(), q[1]) if q is not None else None
     o = sampling.generate(ids, fb, qb, w, wa, cfg, adapter_kw=dict(clip_adapter=clip, hierarchy=clip), max_new_tokens=6,
                           eos_token_id=-1, forced_tokens=forced)
     want = torch.stack(o["logits"])
@@ -107,7 +107,7 @@ def test_fp8_decode_weights_vs_oracle_with_the_same_quantisation():
     got = torch.stack(m.generate(ids, **kw)["logits"]).cpu()
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w, wa = _oracle_weights(shape, True)
-    fb, qb = feat.to(torch.bfloat16).float(), (q[0].to(torch.bfloat16).float(), q[1])
+    fb, qb = feat.to(op()).float(), (q[0].to(op()).float(), q[1])
     ok = dict(adapter_kw=dict(clip_adapter=True, hierarchy=True), max_new_tokens=5, eos_token_id=-1, forced_tokens=forced)
     want8 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, w_llm_decode=llama.fp8_decode_weights(w, cfg), **ok)["logits"])
     want16 = torch.stack(sampling.generate(ids, fb, qb, w, wa, cfg, **ok)["logits"])
@@ -136,8 +136,8 @@ def test_sampling_scores_and_entropy_vs_oracle():
     m = _model(shape, _args())
     m.generation_config.top_k, m.generation_config.top_p = 50, 0.6
     ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None].repeat(2, 1)
-    feat = feats("smp.feat", (2, 10, 16, 768), bf16=True)
-    q = (feats("smp.q", (2, 5, 768), bf16=True), torch.tensor([[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]], dtype=torch.float32))
+    feat = feats("smp.feat", (2, 10, 16, 768), bf16=fl())
+    q = (feats("smp.q", (2, 5, 768), bf16=fl()), torch.tensor([[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]], dtype=torch.float32))
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w, wa = _oracle_weights(shape, True)
     u = torch.full((5, 2), 0.37)
@@ -168,8 +168,8 @@ def test_inference_api_end_to_end():
     m = _model(shape, _args())
     tok = synth.FakeTokenizer(vocab=shape.vocab)
     m.generation_config.eos_token_id = 2
-    feat = feats("inf.feat", (1, 12, 32, 768), bf16=True).to(torch.bfloat16).cuda()
-    q = (feats("inf.q", (1, 6, 768), bf16=True).to(torch.bfloat16).cuda(), torch.ones(1, 6).cuda())
+    feat = feats("inf.feat", (1, 12, 32, 768), bf16=fl()).to(op()).cuda()
+    q = (feats("inf.q", (1, 6, 768), bf16=fl()).to(op()).cuda(), torch.ones(1, 6).cuda())
     m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
     import revisionllm_amd.inference as inf
     real = m.generate
@@ -186,7 +186,7 @@ def test_inference_api_end_to_end():
     md.uniform_fn = m.uniform_fn
     reald = md.generate
     md.generate = lambda *a, **kw: reald(*a, **{**kw, "max_new_tokens": 4})
-    outs = inference_stage1(md, feats("inf.d", (3, 24, 768), bf16=True).cuda(), "<video>\nDuring which frames can we see a man?", tok)
+    outs = inference_stage1(md, feats("inf.d", (3, 24, 768), bf16=fl()).cuda(), "<video>\nDuring which frames can we see a man?", tok)
     assert len(outs) == 3 and all(isinstance(o, str) for o in outs)
 
 
@@ -196,8 +196,8 @@ def test_shared_prefix_prefill_is_exact():
     shape = synth.TINY
     m = _model(shape, _args())
     ids = T(synth.synthetic_prompt_ids(60, 33, SEED, vocab=shape.vocab))[None].repeat(3, 1)
-    feat = feats("sp.feat", (3, 7, 16, 768), bf16=True)
-    q = (feats("sp.q", (3, 4, 768), bf16=True), torch.ones(3, 4))
+    feat = feats("sp.feat", (3, 7, 16, 768), bf16=fl())
+    q = (feats("sp.q", (3, 4, 768), bf16=fl()), torch.ones(3, 4))
     kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
     a = m.generate(ids, share_prefix=True, **kw)
     b = m.generate(ids, share_prefix=False, **kw)
@@ -213,8 +213,8 @@ def test_kv_cache_growth_matches_oracle():
     shape = synth.TINY
     m = _model(shape, _args())
     ids = T(synth.synthetic_prompt_ids(30, 10, SEED, vocab=shape.vocab))[None]
-    feat = feats("kv.feat", (1, 5, 16, 768), bf16=True)
-    q = (feats("kv.q", (1, 4, 768), bf16=True), torch.ones(1, 4))
+    feat = feats("kv.feat", (1, 5, 16, 768), bf16=fl())
+    q = (feats("kv.q", (1, 4, 768), bf16=fl()), torch.ones(1, 4))
     G = 70
     out = m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=G, return_dict_in_generate=True, output_logits=True)
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
@@ -234,8 +234,8 @@ def test_stage2_batched_equals_reference_mode():
     m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
     tok = synth.FakeTokenizer(vocab=shape.vocab)
     W, batch = 13, 8
-    feat = feats("s2.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qf = feats("s2.q", (5, 768), bf16=True).to(torch.bfloat16).cuda()
+    feat = feats("s2.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qf = feats("s2.q", (5, 768), bf16=fl()).to(op()).cuda()
     qc = feats("s2.qc", (768,)).cuda()
     plan = stage2.plan_groups(W, batch)
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(1))
@@ -288,8 +288,8 @@ def test_load_pretrained_model_with_lora_checkpoint(tmp_path, monkeypatch):
     m = m.bfloat16().cuda()
     m.generation_config.eos_token_id = None
     ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None]
-    feat = feats("ld.feat", (1, 6, 16, 768), bf16=True)
-    q = (feats("ld.q", (1, 4, 768), bf16=True), torch.ones(1, 4))
+    feat = feats("ld.feat", (1, 6, 16, 768), bf16=fl())
+    q = (feats("ld.q", (1, 4, 768), bf16=fl()), torch.ones(1, 4))
     out = m.generate(ids, images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
     # oracle: merge in fp32 from the fp16 base (as the builder does), then round to bf16 like the engine
     w = {k: v.float() for k, v in base.items()}
@@ -299,8 +299,8 @@ def test_load_pretrained_model_with_lora_checkpoint(tmp_path, monkeypatch):
             A = lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_A.weight"]
             Bm = lw[f"base_model.model.model.layers.{i}.self_attn.{proj}.lora_B.weight"]
             w[n] = (w[n] + (alpha / r) * (Bm @ A)).to(torch.float16).float()
-    w = {k: (v if "norm" in k else v.to(torch.bfloat16).float()) for k, v in w.items()}
-    wa = {k[len("base_model.model.model.mm_projector."):]: (T(v) if v.ndim == 1 else T(v).to(torch.bfloat16).float()) for k, v in clip.items()}
+    w = {k: (v if "norm" in k else v.to(op()).float()) for k, v in w.items()}
+    wa = {k[len("base_model.model.model.mm_projector."):]: (T(v) if v.ndim == 1 else T(v).to(op()).float()) for k, v in clip.items()}
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), max_new_tokens=3, eos_token_id=-1,
                           forced_tokens=out["sequences"][:, ids.shape[1]:].t().cpu())
@@ -316,7 +316,7 @@ def test_stage1_driver_runs():
     real = m.generate
     m.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
     tok = synth.FakeTokenizer(vocab=shape.vocab)
-    feat = feats("s1.feat", (5, 24, 768), bf16=True).to(torch.bfloat16).cuda()
+    feat = feats("s1.feat", (5, 24, 768), bf16=fl()).to(op()).cuda()
     answers, info = stage1.run_query(m, tok, feat, None, feats("s1.qc", (768,)).cuda(), "a man", (10.0, 20.0), 600.0, batch=2,
                                      num_frames=24)
     assert len(answers) == 5 and set(info) == {"iou", "scores"} and len(info["iou"]) == len(info["scores"])
@@ -332,8 +332,8 @@ def test_stage2_ragged_levels_and_33_window_plan():
     m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
     tok = synth.FakeTokenizer(vocab=shape.vocab)
     W, batch = 9, 7
-    feat = feats("s2r.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qf = feats("s2r.q", (5, 768), bf16=True).to(torch.bfloat16).cuda()
+    feat = feats("s2r.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qf = feats("s2r.q", (5, 768), bf16=fl()).to(op()).cuda()
     qc = feats("s2r.qc", (768,)).cuda()
     plan = stage2.plan_groups(W, batch)
     assert sorted({(e - s) * z for z, s, e in plan}) == [4, 6, 7]
@@ -360,19 +360,19 @@ def test_sparse_adapter_1024_frames():
     from helpers import clip_weights
     eng = engine.Engine(synth.LlamaShape(layers=0), adapter_text=True, device="cuda:0")
     eng.init_synthetic(seed=SEED, llm=False, clip=True, clip_prefix="mm_projector.")
-    w, w32 = clip_weights(text=True, bf16=True), clip_weights(text=True, bf16=False)
+    w, w32 = clip_weights(text=True, bf16=fl()), clip_weights(text=True, bf16=False)
     for k_ in w:
         if w[k_].dim() == 1:
             w[k_] = w32[k_]
-    x = feats("ce1024.x", (1, 1024, 768), bf16=True)
-    txt = feats("ce1024.txt", (1, 16, 768), bf16=True)
+    x = feats("ce1024.x", (1, 1024, 768), bf16=fl())
+    txt = feats("ce1024.txt", (1, 16, 768), bf16=fl())
     y = eng.clip_encoder(x, txt, torch.ones(1, 16), "cls")
     ref = adapter.clip_encoder(x, w, txt, torch.ones(1, 16), True, "cls", False)[:, 0]
     assert rel_err(y.cpu(), ref) < 1e-2
 
 
 @pytest.fixture(scope="module")
-def model_7b():
+def model_7b(op_flavour):
     from revisionllm_amd.utils import synth
     m = _model(synth.VICUNA_7B, _args(), seed=3)
     return m
@@ -388,8 +388,8 @@ def test_full_size_properties_7b(model_7b):
     m = model_7b
     eng = m.engine
     dev = eng.device
-    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
-    qf = ops.init_hash_(torch.empty(1, 16, 768, dtype=torch.bfloat16, device=dev), "fs.q", 3, synth.SQRT3)
+    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=op(), device=dev), "fs.feat", 3, synth.SQRT3)
+    qf = ops.init_hash_(torch.empty(1, 16, 768, dtype=op(), device=dev), "fs.q", 3, synth.SQRT3)
     ones = torch.ones(1, 16)
     cls = eng.clip_encoder(feat, qf, ones, "cls")
     assert torch.isfinite(cls).all() and cls.shape == (100, 4096)
@@ -437,9 +437,9 @@ def test_recursions_in_flight_on_two_streams_match_sequential(model_7b):
     dev = m.engine.device
     tok = synth.FakeTokenizer()
     st = parallel.HipStages(m, tok)
-    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=torch.bfloat16, device=dev), "fs.feat", 3, synth.SQRT3)
+    feat = ops.init_hash_(torch.empty(100, 256, 768, dtype=op(), device=dev), "fs.feat", 3, synth.SQRT3)
     qcs = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), "fs.qc", 3, synth.SQRT3)
-    qfs = [ops.init_hash_(torch.empty(12 + i, 768, dtype=torch.bfloat16, device=dev), f"fs.q{i}", 3, synth.SQRT3) for i in range(3)]
+    qfs = [ops.init_hash_(torch.empty(12 + i, 768, dtype=op(), device=dev), f"fs.q{i}", 3, synth.SQRT3) for i in range(3)]
     plan = stage2.plan_groups(100, 100)
     perms = stage2.make_perms(plan, torch.Generator().manual_seed(5))
     uni = torch.rand(6, len(plan), generator=torch.Generator().manual_seed(6))
@@ -550,12 +550,12 @@ def test_fp8_prefill_vs_oracle_with_the_same_quantisation():
         del eng, kv
         torch.cuda.empty_cache()
     w = {k: T(v) for k, v in synth.build_numpy(synth.llama_spec(shape), 1).items()}
-    w = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}      # the engine binds bf16 matrices
+    w = {k: (v.to(op()).float() if v.dim() == 2 else v) for k, v in w.items()}      # the engine binds bf16 matrices
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     emb = torch.stack([torch.cat([h0[:P0], h0[P0 + b * (S - P0):P0 + (b + 1) * (S - P0)]]) for b in range(B)])
     w8 = llama.fp8_decode_weights(w, cfg)
     w8["lm_head.weight"] = w["lm_head.weight"]                                               # prefill lm_head stays bf16
-    want8 = llama.forward(emb, w8, cfg, last_only=True, act_quant=llama.fp8_act_rows)[:, 0]
+    want8 = llama.forward(emb, w8, cfg, last_only=True, act_quant=lambda t: llama.fp8_act_rows(t, op()))[:, 0]
     want8w = llama.forward(emb, w8, cfg, last_only=True)[:, 0]                                # weights quantised, activations not
     want16 = llama.forward(emb, w, cfg, last_only=True)[:, 0]
     e8, e8w, e16 = rel_err(logits["fp8"], want8), rel_err(logits["fp8"], want8w), rel_err(logits["fp8"], want16)
@@ -577,8 +577,8 @@ def test_multi_query_batching_on_device():
     m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
     tok = synth.FakeTokenizer(vocab=shape.vocab)
     W, batch = 13, 8
-    feat = feats("mq.feat", (W, 16, 768), bf16=True).to(torch.bfloat16).cuda()
-    qs = [(feats(f"mq.q{i}", (5, 768), bf16=True).to(torch.bfloat16).cuda(), feats(f"mq.qc{i}", (768,)).cuda(),
+    feat = feats("mq.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qs = [(feats(f"mq.q{i}", (5, 768), bf16=fl()).to(op()).cuda(), feats(f"mq.qc{i}", (768,)).cuda(),
            "a man is walking his dog across the street near the old park" + (" today" if i else " again")) for i in range(2)]
     plan = stage2.plan_groups(W, batch)
     perms = [stage2.make_perms(plan, torch.Generator().manual_seed(i)) for i in range(2)]
@@ -607,8 +607,8 @@ def test_chapters_cross_attn_variant(tmp_path):
     m.generation_config.eos_token_id = None
     assert m.get_model().cross_attn is m.get_model().mm_projector
     ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None]
-    feat = feats("ch.feat", (1, 6, 16, 768), bf16=True)
-    q = (feats("ch.q", (1, 4, 768), bf16=True), torch.ones(1, 4))
+    feat = feats("ch.feat", (1, 6, 16, 768), bf16=fl())
+    q = (feats("ch.q", (1, 4, 768), bf16=fl()), torch.ones(1, 4))
     kw = dict(images=feat, query_feats=q, do_sample=False, max_new_tokens=3, return_dict_in_generate=True, output_logits=True)
     assert torch.equal(torch.stack(m.generate(ids, **kw)["logits"]), torch.stack(ref.generate(ids, **kw)["logits"]))
     with pytest.raises(NotImplementedError):
@@ -683,12 +683,12 @@ def test_alternate_adapter_feature_with_iteration_step(hierarchy):
     g = torch.Generator().manual_seed(5)
     ln_w, ln_b = 1 + 0.1 * torch.randn(shape.hidden, generator=g), 0.1 * torch.randn(shape.hidden, generator=g)
     m.get_model().load_alternate_layer_norm(ln_w, ln_b)
-    w = clip_weights(hidden=shape.hidden, bf16=True, prefix="model.mm_projector.")
+    w = clip_weights(hidden=shape.hidden, bf16=fl(), prefix="model.mm_projector.")
     w32 = clip_weights(hidden=shape.hidden, bf16=False, prefix="model.mm_projector.")
     w = {k: (v if v.dim() > 1 else w32[k]) for k, v in w.items()}
-    q = (feats("alt.q", (2, 6, 768), bf16=True), torch.ones(2, 6))
-    flat = feats("alt.x", (2, 24, 768), bf16=True)                     # [b, t, d]
-    hier = feats("alt.xh", (2, 5, 24, 768), bf16=True)                 # [b, v, t, d]
+    q = (feats("alt.q", (2, 6, 768), bf16=fl()), torch.ones(2, 6))
+    flat = feats("alt.x", (2, 24, 768), bf16=fl())                     # [b, t, d]
+    hier = feats("alt.xh", (2, 5, 24, 768), bf16=fl())                 # [b, v, t, d]
     for it in (0, 1, 2, 3):
         images = hier if (hierarchy and it % 2 == 0) else flat
         rows, rps = m.encode_images(images, q, it)
@@ -718,7 +718,7 @@ def test_parity_precision_closes_the_llm_gemm_operand_roundings():
     m.engine.init_synthetic(seed=SEED, llm=True, clip=False, linear=True, parity=True)
     m.generation_config.eos_token_id = None
     ids = T(synth.synthetic_prompt_ids(24, 9, SEED, vocab=shape.vocab))[None].repeat(2, 1)
-    feat = feats("par.dense", (2, 24, 768), bf16=True)
+    feat = feats("par.dense", (2, 24, 768), bf16=fl())
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w, wa = _oracle_weights(shape, False)
     o = sampling.generate(ids, feat, None, w, wa, cfg, adapter_kw=dict(clip_adapter=False, hierarchy=False), max_new_tokens=6, eos_token_id=-1)
@@ -763,7 +763,7 @@ def test_cross_attn_dense_clip_encoder_vs_reference_golden_and_oracle(golden, te
     assert m.get_model().cross_attn_dense and m.engine.adapter_dim == 4096
     src, txt = feats("g14.src", (2, 16, 768)), feats("g14.txt", (2, 7, 768))
     mt = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]], dtype=torch.float32)
-    rows, rps = m.encode_images(src[:, None].to(torch.bfloat16), (txt.to(torch.bfloat16), mt))      # hierarchy: [b, v = 1, t, d]
+    rows, rps = m.encode_images(src[:, None].to(op()), (txt.to(op()), mt))      # hierarchy: [b, v = 1, t, d]
     assert rps == 1 and rows.shape == (2, 4096)
     g = golden.npz("g14_cross_attn_dense")[f"text{int(text)}_cls"][:, 0]
     e_ref = rel_err(rows.cpu(), g)
@@ -772,13 +772,13 @@ def test_cross_attn_dense_clip_encoder_vs_reference_golden_and_oracle(golden, te
         out = {}
         for k, v in d32.items():
             t = T(v)
-            out[k[len(pref):]] = t.to(torch.bfloat16).float() if t.dim() == 2 else t
+            out[k[len(pref):]] = t.to(op()).float() if t.dim() == 2 else t
         return out
-    y = adapter.encode_images_cross_attn(src.to(torch.bfloat16).float(), dev_w(lin32, "g14.mm_projector."), dev_w(ca32, "g14.cross_attn."),
-                                         (txt.to(torch.bfloat16).float(), mt), clip_adapter_text=text, feature="cls", hierarchy=False)[:, 0]
+    y = adapter.encode_images_cross_attn(src.to(op()).float(), dev_w(lin32, "g14.mm_projector."), dev_w(ca32, "g14.cross_attn."),
+                                         (txt.to(op()).float(), mt), clip_adapter_text=text, feature="cls", hierarchy=False)[:, 0]
     e_or = rel_err(rows.cpu(), y)
     print(f"\n[cross_attn dense, text={text}] rel err vs the reference's modules (fp32 weights) {e_ref:.3e}, vs the oracle on bf16 weights {e_or:.3e}")
     assert e_or < 6e-3 and e_ref < 8e-3          # (measured 2.4e-3 / 3.3e-3)
     # the 'all rows' form agrees with the CLS form on the CLS row
-    yall = m.engine.clip_encoder(src.to(torch.bfloat16), txt.to(torch.bfloat16), mt, "all")
+    yall = m.engine.clip_encoder(src.to(op()), txt.to(op()), mt, "all")
     assert yall.shape == (2, 17, 4096) and rel_err(yall[:, 0].cpu(), rows.cpu()) < 1e-2

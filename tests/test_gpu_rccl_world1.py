@@ -14,7 +14,7 @@ import time
 import pytest
 import torch
 
-from helpers import SEED
+from helpers import SEED, fl, op, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -42,8 +42,8 @@ def test_rccl_all_gathers_next_to_persistent_prefill_gemms(monkeypatch):
     W, Tn, Lq, G, copies = 100, 256, 16, 6, 8
     sets = []
     for k in range(copies):
-        feat = ops.init_hash_(torch.empty(W, Tn, 768, dtype=torch.bfloat16, device=dev), f"rccl1.feat{k}", SEED, synth.SQRT3)
-        qf = ops.init_hash_(torch.empty(Lq, 768, dtype=torch.bfloat16, device=dev), f"rccl1.q{k}", SEED, synth.SQRT3)
+        feat = ops.init_hash_(torch.empty(W, Tn, 768, dtype=op(), device=dev), f"rccl1.feat{k}", SEED, synth.SQRT3)
+        qf = ops.init_hash_(torch.empty(Lq, 768, dtype=op(), device=dev), f"rccl1.q{k}", SEED, synth.SQRT3)
         qc = ops.init_hash_(torch.empty(768, dtype=torch.float32, device=dev), f"rccl1.qc{k}", SEED, synth.SQRT3)
         g = torch.Generator().manual_seed(1000 + k)
         sets.append((feat, qf, qc, stage2.make_perms(stage2.plan_groups(W, 100), g, W=W)))

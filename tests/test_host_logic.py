@@ -145,31 +145,37 @@ def test_loader_key_rules_against_the_reference_loader(golden, tmp_path):
 
 
 def test_abi_exports_every_declared_symbol():
-    """include/revision_hip.h <-> the built library <-> the ctypes table must agree (loads on CPU, no compute)."""
+    """include/revision_hip.h <-> BOTH builds of the library (fp16 / bf16 operands) <-> the ctypes table must agree (loads on CPU, no compute)."""
     header = open(os.path.join(ROOT, "include", "revision_hip.h")).read()
     declared = set(re.findall(r"\b(rv_[a-z0-9_]+)\s*\(", header))
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
-    if not os.path.exists(hip.LIB_PATH):
+    if not all(os.path.exists(p) for p in hip.LIB_PATHS.values()):
         from revisionllm_amd import build
         build.build_library()
-    h = ctypes.CDLL(hip.LIB_PATH)
-    for name in declared:
-        assert hasattr(h, name), name
-    # ... and the reverse: the library exports no C symbol of its own that the header does not declare
     import subprocess
-    nm = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r"\b[TW] (rv_[a-z0-9_]+)$", nm, flags=re.M))
-    assert exported == declared, exported ^ declared
-    assert hip.lib().rv_abi_version() == 3
-    # argument validation runs on the host before any launch
-    assert hip.lib().rv_gemm(None, None, 0, None, 0, 0, None, None, 0, None, 0, 1, 0, 4, 4, 64, None, 0, None) < 0
-    assert "null operand" in hip.last_error()
+    for flavour, path in hip.LIB_PATHS.items():
+        h = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(h, name), (flavour, name)
+        # ... and the reverse: the library exports NOTHING that the header does not declare (-fvisibility=hidden + csrc/exports.map)
+        nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r"\b[A-Za-z] ([A-Za-z_][A-Za-z0-9_$.@]*)$", nm, flags=re.M))
+        assert exported == declared, (flavour, exported ^ declared)
+        lib = hip.lib(flavour)
+        assert lib.rv_abi_version() == 4
+        assert lib.rv_operand_dtype() == {"f16": hip.RV_F16, "bf16": hip.RV_BF16}[flavour]
+        # argument validation runs on the host before any launch
+        assert lib.rv_gemm(None, None, 0, None, 0, 0, None, None, 0, None, 0, lib.rv_operand_dtype(), 0, 4, 4, 64, None, 0, None) < 0
+        assert "null operand" in hip.last_error()
+        # a library refuses the OTHER flavour's dtype code (a bf16 tensor is never read as fp16 bits)
+        other = hip.RV_BF16 if flavour == "f16" else hip.RV_F16
+        assert lib.rv_init_hash(ctypes.c_void_p(64), other, 16, 0, 1.0, 0.0, None) < 0
 
 
 def test_product_has_no_cpu_fallback():
     from revisionllm_amd import ops
     with pytest.raises(hip.HipLibraryError, match="no CPU path|device tensors"):
-        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+        ops.gemm(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(4, 64, dtype=torch.float16))
     if not torch.cuda.is_available():
         from revisionllm_amd.engine import Engine
         with pytest.raises(hip.HipLibraryError, match="no GPU"):

@@ -464,7 +464,7 @@ def test_eval_driver_resume_and_error_handling(tmp_path, monkeypatch):
     calls = []
 
     class FakeStager:
-        def __init__(self, device):
+        def __init__(self, device, op_dtype=None):
             pass
 
         def stage_windows(self, features, frame_idx):
