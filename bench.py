@@ -104,6 +104,9 @@ def parse():
                    help="untimed steps run as part of the set-up, before the W warm-up steps (a fresh box starts at idle clocks; ~0.5 s)")
     p.add_argument("--host-profile", action="store_true",
                    help="measurement knob: cProfile the host side of the timed region and print the top entries to stderr (the line's value then includes the profiler's overhead)")
+    p.add_argument("--op-dtype", default=None, choices=["f16", "bf16"],
+                   help="operand flavour of the library (default: the package default, fp16 - the build that meets the north star's 1e-3; bf16 = the "
+                        "reference's own GPU dtype).  At N = 1 the other flavour is timed as an extra leg after the headline.")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the extra legs timed AFTER the headline")
@@ -134,13 +137,14 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     from revisionllm_amd import hip, ops
     eng, s = model.engine, model.shape
     dev = eng.device
+    OP = eng.op_dtype
     legs = {}
     # (1) prefill gate/up GEMM + SiLU*mul epilogue: [M,4096] x [22016,4096]^T  (MFMA-bound); M = the rows of one prefill pass of the timed
     #     region: prefill_groups steps' prefills ride together (serve.DecodeServer, rv_llm_prefill_pool_groups)
     M = M * prefill_groups
-    x = torch.randn(M, s.hidden, device=dev).to(torch.bfloat16)
+    x = torch.randn(M, s.hidden, device=dev).to(OP)
     w = eng.weight("llm.L0.wgu")
-    out = torch.empty(M, s.inter, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(M, s.inter, dtype=OP, device=dev)
     ms = event_time_ms(lambda: ops.gemm(x, w, act=hip.RV_ACT_SILU_MUL, out=out, w_packed=True, ctx=eng), 20)
     flops = 2.0 * M * s.hidden * 2 * s.inter
     # M <= 8192 rows: the persistent 256x256x64 ping-pong kernel (one 512-thread workgroup per CU), whole panels + stream-K tail
@@ -157,8 +161,8 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     state = {"i": 0}
     nbytes = 2.0 * s.hidden * 2 * s.inter
     if dec_rows <= 32:
-        xs = torch.randn(dec_rows, s.hidden, device=dev).to(torch.bfloat16)
-        outs = torch.empty(dec_rows, s.inter, dtype=torch.bfloat16, device=dev)
+        xs = torch.randn(dec_rows, s.hidden, device=dev).to(OP)
+        outs = torch.empty(dec_rows, s.inter, dtype=OP, device=dev)
 
         def gemv():
             ops.gemm(xs, ws[state["i"] % len(ws)], act=hip.RV_ACT_SILU_MUL, out=outs, w_packed=True, ctx=eng)
@@ -166,16 +170,16 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
         kname = "gemv_stream<2,1,2,1,0,3,2,4>" if dec_rows > 16 else "gemv_stream<2,1,2,1,0,2,1,8>"
         gthreads = (2 * s.inter // 32) * (256 if dec_rows > 16 else 512)
     else:
-        f = hip.lib().rv_gemm_rows
+        f = eng.lib.rv_gemm_rows
         mbp = ops.xp_blocks(dec_rows)
-        xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(torch.bfloat16)          # fragment-packed rows (any values: timing)
-        outs = torch.empty(mbp * 16 * s.inter, dtype=torch.bfloat16, device=dev)
+        xs = (torch.randn(mbp * 16 * s.hidden, device=dev) * 0.1).to(OP)          # fragment-packed rows (any values: timing)
+        outs = torch.empty(mbp * 16 * s.inter, dtype=OP, device=dev)
         planes = torch.zeros(40 << 20, dtype=torch.uint8, device=dev)
         arrive = torch.zeros(4096, dtype=torch.int32, device=dev)
 
         def gemv():
             rc = f(hip.ptr(xs), hip.ptr(ws[state["i"] % len(ws)]), None, hip.ptr(outs), dec_rows, 2 * s.inter, s.hidden, hip.ptr(planes), hip.ptr(arrive),
-                   hip.RV_ACT_SILU_MUL, hip.RV_BF16, hip.stream())
+                   hip.RV_ACT_SILU_MUL, hip.dtype_code(outs), hip.stream())
             assert rc == 0, hip.last_error()
             state["i"] += 1
         # what rows_splits / rows_by_split (gemm_rows.hip) pick for this shape (344 column groups): 4 row blocks: one workgroup per group;
@@ -213,17 +217,17 @@ def roofline_legs(model, n_calls, M, dec_rows=None, prefill_groups=1):
     #     Kernel: the A-resident GEMM (gemm_arows.hip): rows resident in LDS, A read once, C written once
     if "proj.w" not in eng._keep:
         eng.init_synthetic(seed=0, llm=False, clip=False, linear=True)
-    xf = torch.randn(100 * 256, 768, device=dev).to(torch.bfloat16)
-    ms = event_time_ms(lambda: eng.project_dense(xf, torch.bfloat16), 20)
+    xf = torch.randn(100 * 256, 768, device=dev).to(OP)
+    ms = event_time_ms(lambda: eng.project_dense(xf, OP), 20)
     nbytes = xf.numel() * 2 + 100 * 256 * s.hidden * 2
     legs["dense_projector_scan"] = dict(kernel="gemm_arows_kernel<1,0,7,2>", bound="hbm", ms=ms, achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", algorithmic=nbytes, grid_threads=cus * 512,
                                         tflops=2.0 * 100 * 256 * 768 * s.hidden / ms / 1e9)
     # (4) the adapter's widest K = 768 GEMM (FFN-1 + ReLU over 100 x 257 rows), MFMA-bound
-    xa = torch.randn(100 * 257, 768, device=dev).to(torch.bfloat16)
+    xa = torch.randn(100 * 257, 768, device=dev).to(OP)
     if "adp.enc.0.w1" in eng._keep:
         w1, b1 = eng.weight("adp.enc.0.w1"), eng.weight("adp.enc.0.b1")
-        oa = torch.empty(xa.shape[0], w1.shape[0], dtype=torch.bfloat16, device=dev)
+        oa = torch.empty(xa.shape[0], w1.shape[0], dtype=OP, device=dev)
         ms = event_time_ms(lambda: ops.gemm(xa, w1, bias=b1, act=hip.RV_ACT_RELU, out=oa, w_packed=True, ctx=eng), 20)
         fl = 2.0 * xa.shape[0] * 768 * w1.shape[0]
         legs["adapter_ffn1_gemm"] = dict(kernel="gemm_arows_kernel<1,1,7,2>", bound="mfma", ms=ms, achieved=fl / ms / 1e9, peak=MFMA_BF16_PEAK_TF,
@@ -408,6 +412,11 @@ def main():
         d.update(kw)
         return SimpleNamespace(**d)
 
+    from revisionllm_amd import hip
+    if args.op_dtype:
+        hip.set_flavour(args.op_dtype)
+    OP = hip.op_dtype()             # torch dtype of the 16-bit operands (features, weights, activation copies, KV caches)
+    DT = {"f16": "fp16", "bf16": "bf16"}[hip.flavour()]     # the line's `dtype`: the arithmetic type of the GEMM / attention operands (f32 accumulation, f32 residual stream)
     model = ReVisionLlamaForCausalLM(synth.VICUNA_7B, device=dev)
     model.get_model().initialize_vision_modules(hier_args())
     eng = model.engine
@@ -464,9 +473,9 @@ def main():
         tag = "" if k == 0 else f".s{k}"
         plan_ = stage2.plan_groups(W_, batch_)
         g = torch.Generator().manual_seed(args.seed * 100003 + k * 17 + (rank * 7919 if per_rank else 0))
-        feats_ = [hashed((Wl_, Tn, 768), torch.bfloat16, f"bench.feat{i if nq > 1 else ''}{'' if W_ == W else W_}.r{rank}{tag}") for i in range(nq)]
+        feats_ = [hashed((Wl_, Tn, 768), OP, f"bench.feat{i if nq > 1 else ''}{'' if W_ == W else W_}.r{rank}{tag}") for i in range(nq)]
         sent = SENTENCE if k == 0 else SENTENCE.replace("kitchen", f"kitchen{k}").replace("newspaper", f"newspaper{k}")
-        qs = [(hashed((args.lq, 768), torch.bfloat16, f"bench.q{i if nq > 1 else ''}{qtag}{tag}"),
+        qs = [(hashed((args.lq, 768), OP, f"bench.q{i if nq > 1 else ''}{qtag}{tag}"),
                hashed((768,), torch.float32, f"bench.qcls{i if nq > 1 else ''}{qtag}{tag}"), sent) for i in range(nq)]
         return {"qs": qs, "perms": [stage2.make_perms(plan_, g, W=W_) for _ in range(nq)], "feats": feats_ if nq > 1 else feats_[0]}
 
@@ -586,7 +595,7 @@ def main():
             frames = 1024
             qfeat = (qf[None], torch.ones(1, args.lq))
         m1.generation_config.eos_token_id = None
-        x = ops.init_hash_(torch.empty(1, frames, 768, dtype=torch.bfloat16, device=dev), f"bench.s1.{kind}", args.seed, synth.SQRT3)
+        x = ops.init_hash_(torch.empty(1, frames, 768, dtype=OP, device=dev), f"bench.s1.{kind}", args.seed, synth.SQRT3)
         ids = _prompt_ids("<video>\n" + "During which frames can we see {}?".format(SENTENCE), tok, 1)[0]
         gkw = dict(images=x, query_feats=qfeat, do_sample=True, temperature=0.05, max_new_tokens=G, return_dict_in_generate=True)
 
@@ -605,7 +614,7 @@ def main():
             # every window in flight is its OWN window (32 distinct ones, window i of a step group = set i); the adapter of a group of
             # windows runs as ONE call over [group, frames, 768] - the reference's stage-1 driver hands inference() a batch of windows
             # too (eval_nlq_negative.py:281-298) - and each window then decodes as its own one-row generate through the server
-            xs = ops.init_hash_(torch.empty(NB, frames, 768, dtype=torch.bfloat16, device=dev), f"bench.s1.{kind}.windows", args.seed, synth.SQRT3)
+            xs = ops.init_hash_(torch.empty(NB, frames, 768, dtype=OP, device=dev), f"bench.s1.{kind}.windows", args.seed, synth.SQRT3)
             enc_stream = torch.cuda.Stream(dev)
             gkw1 = {k_: v_ for k_, v_ in gkw.items() if k_ not in ("images", "query_feats")}
 
@@ -691,10 +700,10 @@ def main():
             extra[name] = {"value": W * nq * args.steps / t, "unit": "segments/s",
                            "ms_per_step": t / args.steps * 1e3, "recursions_per_step": nq,
                            "batch": f"{nq} videos x {W} windows, one query each" if nq > 1 else f"1 video x {W} windows",
-                           "decode_weights": "fp8 e4m3fn, per-row scale (same pools and merged steps as the headline)" if fp8 else "bf16",
-                           "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else "bf16"}
+                           "decode_weights": "fp8 e4m3fn, per-row scale (same pools and merged steps as the headline)" if fp8 else DT,
+                           "prefill_gemms": "fp8 x fp8 MFMA (e4m3fn weights per-row scale, activations quantised per row on the fly)" if fp8p else DT}
             if par:
-                extra[name].update(decode_weights="bf16", prefill_gemms="bf16 x 2: split operands [hi | lo] against K-duplicated weights",
+                extra[name].update(decode_weights=DT, prefill_gemms=DT + " x 2: split operands [hi | lo] against K-duplicated weights",
                                    precision="PARITY (rv_ctx_set_option precision = 1): every GEMM operand and Q carry 16 mantissa bits; the mode in which "
                                              "1/max_entropy, 1/mean_entropy meet 1e-3 against the fp32 reference (tests/test_gpu_full_depth_conditioned.py); "
                                              "unfused decode steps through the generic kernels")
@@ -811,7 +820,7 @@ def main():
                 entry = {"value": n1 / t, "unit": "segments/s", "ms_per_step": t / n1 * 1e3, "steps": n1, "warmup": n1 // 2, "config": cfg1,
                          "prefill_flops": 2.0 * S1 * 6.476e9 + 2.6e5 * S1 * S1 + 2.6e8}
                 if kind == "stage1_sparse":      # adapter alone: SURVEY 8d: 46.9 GFLOP per 1024-frame segment (MFMA-bound)
-                    x1 = ops.init_hash_(torch.empty(32, 1024, 768, dtype=torch.bfloat16, device=dev), "bench.s1.a", args.seed, synth.SQRT3)
+                    x1 = ops.init_hash_(torch.empty(32, 1024, 768, dtype=OP, device=dev), "bench.s1.a", args.seed, synth.SQRT3)
                     q32 = qf[None].expand(32, -1, -1).contiguous()
                     ms32 = event_time_ms(lambda: eng.clip_encoder(x1, q32, torch.ones(32, args.lq), "cls"), 5)
                     ms1 = event_time_ms(lambda: eng.clip_encoder(x1[:1], qf[None], torch.ones(1, args.lq), "cls"), 10)
@@ -951,7 +960,7 @@ def main():
             "metric": METRIC,
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "bf16 (fp8 e4m3 LLM weights / prefill GEMMs: extra measurement)" if (args.fp8_decode or args.fp8_prefill) else "bf16", "data": "synthetic",
+            "dtype": DT + " (fp8 e4m3 LLM weights / prefill GEMMs: extra measurement)" if (args.fp8_decode or args.fp8_prefill) else DT, "data": "synthetic",
             "config": {"workload": args.workload, "windows_per_gpu": Wl, "windows_total": W * (world if by_query else 1), "frames": Tn, "clip_dim": 768, "query_tokens": args.lq,
                        "inputs": ("every step in flight has its OWN video, query (tokens, CLS feature, sentence ids) and window permutations: %d distinct "
                                   "input sets, step k uses set k mod %d" % (n_sets, n_sets) if n_sets > 1 else

@@ -291,7 +291,9 @@ int rv_llm_decode_rows(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos,
  *   (inference.py:36 repeats one prompt per batch row; the 7 calls of a stage-2 recursion share "system prompt + USER: <video>").  The decode
  *   attention then reads the key blocks inside that prefix from the sibling's cache rows: the rows of one (generate, head) run on one XCD and hit
  *   its L2 instead of fetching identical copies from HBM (15 % of the K / V bytes of a 140-row step).  The hint cannot change a result - the
- *   bytes read are the same - only a wrong hint can; 0 (= row 0, length 0) means "nothing shared".  Smax <= 65535. */
+ *   bytes read are the same - only a wrong hint can; 0 (= row 0, length 0) means "nothing shared".  Contract of a word: sibling < R, 0 <= len < 32768
+ *   (the word is an int32) and len <= row_pos[r] + 1; a word that violates it is IGNORED by the kernel (the row reads its own cache), never followed out
+ *   of bounds.  Smax <= 65535. */
 int rv_llm_decode_rows_shared(rv_ctx* ctx, float* h, int32_t R, const int32_t* row_pos, const int32_t* row_share, void* kv, int32_t Smax,
                               float* logits, void* ws, size_t ws_bytes, void* stream);
 

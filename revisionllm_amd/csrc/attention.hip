@@ -59,6 +59,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         const int sv = a.row_share[b];
         const int srow = sv & 0xffff;
         share_len = sv >> 16;
+        // a word that names a row outside the batch or a prefix longer than the cache is IGNORED (the row reads its own cache: always correct),
+        // never followed out of bounds; rv_llm_decode_rows_shared documents the contract
+        if (srow >= a.B || share_len < 0 || share_len > Lk) share_len = 0;
         share_k = (int64_t)(srow - kb_) * a.k_bs;
         share_v = (int64_t)(srow - kb_) * a.vt_bs;
     }

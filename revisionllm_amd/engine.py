@@ -155,7 +155,7 @@ class Engine:
         self.fp8_decode = bool(fp8_decode)
         self.fp8_prefill = bool(fp8_prefill)
         self.bind("llm.embed", self._dev16(get("model.embed_tokens.weight")))
-        # the lm_head's K-duplicated copy is bound in EVERY precision (+ 0.26 GB): the lm_head input is always a split pair (option lm_head_split)
+        # the lm_head's K-duplicated copy is bound in EVERY precision (2 x V x D x 2 B = + 0.52 GB for 32000 x 4096): the lm_head input is always a split pair (option lm_head_split; 0 = single-operand lm_head input, the p2 copy then goes unused)
         self._bind_matrix("llm.lm_head", self._dev16(get("lm_head.weight")), fp8_decode, parity=True)
         self.bind("llm.norm", _dev_f32(get("model.norm.weight"), dev))
         for i in range(s.layers):
@@ -216,27 +216,35 @@ class Engine:
         self._loaded()
 
     # ---- synthetic weights generated on the device (bench / smoke / tests) -----------------------
-    def _synth_get(self, spec, seed, prefix):
+    def _synth_get(self, spec, seed, prefix, grid=None):
         table = {n: (shp, a, base) for n, shp, a, base in spec}
+        grid_dt = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[grid]
 
         def get(name):
             shp, a, base = table[name]
             t = torch.empty(shp, dtype=torch.float32, device=self.device)
-            return ops.init_hash_(t, prefix + name, seed, a, base)
+            ops.init_hash_(t, prefix + name, seed, a, base)
+            if grid_dt is not None and len(shp) > 1:      # matrices of a "checkpoint" stored in that type (vectors stay fp32, as in the goldens)
+                t = t.to(grid_dt).float()
+            return t
         return get
 
     def init_synthetic(self, seed=0, llm=True, clip=True, linear=False, llm_prefix="", clip_prefix="model.mm_projector.",
-                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False, cond=None, parity=False):
+                       linear_prefix="model.mm_projector.", fp8_decode=False, fp8_prefill=False, cond=None, parity=False, grid=None):
         """Random-init weights of the reference's shapes, bit-identical to ``synth.build_numpy`` on the host.
-        ``cond``: a ``synth.Conditioning`` (the well-conditioned LLM amplitudes of golden G8c); None = plain N(0, 0.02)."""
+        ``cond``: a ``synth.Conditioning`` (the well-conditioned LLM amplitudes of golden G8c); None = plain N(0, 0.02).
+        ``grid``: None = the hash stream's fp32 values converted straight to this engine's operand type (``build_numpy(bf16=<flavour>)`` on
+        the host); "bf16" / "f16" = the matrices of a CHECKPOINT stored in that type (``build_numpy(bf16=grid)``), which this engine then
+        converts to its operand type: exact when the operand type is at least as fine (an fp16 engine holds a bf16-grid matrix exactly up
+        to fp16's subnormal range), rounded otherwise (a bf16 engine rounds an fp16 checkpoint - golden G8d measures that term)."""
         if llm:
-            self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill, parity=parity)
+            self.load_llm(self._synth_get(synth.llama_spec(self.shape, cond=cond), seed, llm_prefix, grid), fp8_decode=fp8_decode, fp8_prefill=fp8_prefill, parity=parity)
         if clip:
             self.load_clip_adapter(self._synth_get(synth.clip_encoder_spec(hidden=self.shape.hidden, text=self.adapter_text,
                                                                            cross_attn=self.adapter_dim != 768), seed,
-                                                   clip_prefix))
+                                                   clip_prefix, grid))
         if linear:
-            self.load_linear_projector(self._synth_get(synth.linear_projector_spec(hidden=self.shape.hidden), seed, linear_prefix))
+            self.load_linear_projector(self._synth_get(synth.linear_projector_spec(hidden=self.shape.hidden), seed, linear_prefix, grid))
         return self
 
     # ---- workspaces ------------------------------------------------------------------------------

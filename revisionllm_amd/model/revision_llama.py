@@ -339,10 +339,18 @@ class ReVisionLlamaForCausalLM:
             # Samples with different numbers of video rows (the 9 calls of a 33-window recursion: 8 x 32 and 1 x 33): one generate of
             # right-padded sequences - under causal attention a valid position never sees a later (pad) one, so every row's tokens are what
             # its own generate would produce.  Only through a DecodeServer (rows decode at their own positions there anyway).
-            if server is None or attention_mask is not None or output_scores or output_logits or self.after_prefill is not None:
-                raise NotImplementedError("ragged generates (different numbers of video rows per sample) run through a serve.DecodeServer only, "
-                                          "without output_scores / output_logits / attention_mask")
+            if attention_mask is not None:
+                raise NotImplementedError("ragged generates (different numbers of video rows per sample) do not take an attention_mask")
             row_map, lens = self.build_row_map_ragged(input_ids, rows_per_sample, pad if pad is not None else 0)
+            ragged_ok = (server is not None and getattr(server, "prefill_batch", 1) > 1 and not output_scores and not output_logits
+                         and self.after_prefill is None and max_new_tokens >= 1 and server.fits(row_map.shape[1], max_new_tokens, row_map.shape[0]))
+            if not ragged_ok:
+                # no DecodeServer pass can take the padded batch (no server, pool rows / Smax / gmax too small, scores asked for): the samples run as
+                # equal-geometry sub-batches through the ordinary path - what the drivers did before ragged generates existed
+                return (yield from self._generate_split_by_rows(input_ids, video_rows, rows_per_sample, uniforms, forced_tokens, pad,
+                                                                dict(do_sample=do_sample, temperature=temperature, max_new_tokens=max_new_tokens, output_scores=output_scores,
+                                                                     return_dict_in_generate=return_dict_in_generate, output_logits=output_logits, top_k=top_k, top_p=top_p,
+                                                                     share_prefix=share_prefix, eos_lookahead=eos_lookahead, server=server, new_tokens_only=new_tokens_only)))
         else:
             if isinstance(rows_per_sample, (list, tuple)):
                 rows_per_sample = int(rows_per_sample[0]) if len(rows_per_sample) else 0
@@ -366,7 +374,12 @@ class ReVisionLlamaForCausalLM:
                 if not job.finished:        # an exception here or in a task this one was pumped from, or the task was cancelled
                     server.abandon(job)
         if lens is not None:
-            raise NotImplementedError("ragged generate: the DecodeServer had no room for it (pool rows / Smax / gmax too small)")
+            # a non-blocking server whose pools are momentarily full: the same fallback - equal-geometry sub-batches (each decodes in the pool if
+            # it finds room, alone otherwise), so whether a recursion completes never depends on pool occupancy
+            return (yield from self._generate_split_by_rows(input_ids, video_rows, rows_per_sample, uniforms, forced_tokens, pad,
+                                                            dict(do_sample=do_sample, temperature=temperature, max_new_tokens=max_new_tokens, output_scores=output_scores,
+                                                                 return_dict_in_generate=return_dict_in_generate, output_logits=output_logits, top_k=top_k, top_p=top_p,
+                                                                 share_prefix=share_prefix, eos_lookahead=eos_lookahead, server=server, new_tokens_only=new_tokens_only)))
         # A generate that decodes alone owns its engine slot's KV cache and workspace from its prefill to its last step.  Under a cooperative
         # scheduler (it yields at the EOS flag polls) a second generate started on the SAME slot meanwhile would be handed the same recycled
         # cache and overwrite it: refuse loudly - every call in flight needs its own slot (sched.Task(..., slot=i); engine.slot).
@@ -381,6 +394,39 @@ class ReVisionLlamaForCausalLM:
                                                     eos, pad, eos_lookahead))
         finally:
             eng.slots_in_flight.discard(slot)
+
+    def _generate_split_by_rows(self, input_ids, video_rows, rows_per_sample, uniforms, forced_tokens, pad, kw):
+        """A batch whose samples present different numbers of video rows, run as one ``generate_steps`` per row count (sample order kept inside a
+        sub-batch) and merged back into batch order.  Sub-batches that stop at different steps (EOS) are right-padded with the pad id / zeros."""
+        counts = [int(r) for r in rows_per_sample]
+        starts = [0]
+        for r in counts:
+            starts.append(starts[-1] + r)
+        if kw.get("output_scores") or kw.get("output_logits"):
+            raise NotImplementedError("ragged generates return no per-step scores / logits: call generate per equal-geometry group for those")
+        parts = []
+        for r in sorted(set(counts)):
+            sel = [i for i, c in enumerate(counts) if c == r]
+            rows = torch.cat([video_rows[starts[i]:starts[i + 1]] for i in sel], 0) if video_rows is not None else None
+            out = yield from self.generate_steps(input_ids[sel], video_rows=rows, rows_per_sample=r,
+                                                 uniforms=None if uniforms is None else uniforms[:, sel],
+                                                 forced_tokens=None if forced_tokens is None else forced_tokens[:, sel], **dict(kw, return_dict_in_generate=True))
+            parts.append((sel, out))
+        B = len(counts)
+        merged = GenerateOutput()
+        for key in ("sequences", "new_tokens", "entropy", "entropy_raw"):
+            vals = [(sel, out.get(key)) for sel, out in parts]
+            if any(v is None for _, v in vals):
+                continue
+            width = max(v.shape[1] for _, v in vals)
+            fill = (pad if pad is not None else 0) if key in ("sequences", "new_tokens") else 0
+            full = torch.full((B, width), fill, dtype=vals[0][1].dtype, device=vals[0][1].device)
+            for sel, v in vals:
+                full[torch.as_tensor(sel, device=full.device), :v.shape[1]] = v
+            merged[key] = full
+        if not kw.get("return_dict_in_generate"):
+            return merged["sequences"]
+        return merged
 
     def _generate_in_pool(self, server, job, eng, dev, input_ids, row_map, video_rows, B, S, P0, do_sample, temperature, top_k, top_p,
                           max_new_tokens, uniforms, forced_tokens, return_dict_in_generate, lens=None, new_tokens_only=False):
@@ -400,6 +446,11 @@ class ReVisionLlamaForCausalLM:
             h, p0 = eng.splice_embed(row_map, video_rows).view(B * S, -1), 0
         if lens is not None and not batched:
             raise NotImplementedError("ragged generates need a DecodeServer with prefill_batch > 1 (its prefill passes carry the per-sequence last rows)")
+        if do_sample and uniforms is None:
+            # drawn BEFORE the prefill is submitted: the ticket / ``ready`` event chain recorded behind it then covers the rand kernel, and the
+            # pool stream's copy of the whole [steps, B] block at join time (gated by ``ready`` only) can never run ahead of it
+            uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
+                        else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
         if batched:      # the server batches the waiting prefills of identical geometry into one pass (its own stream, FIFO)
             ticket = server.submit_prefill(job, h, B, p0, lens)
             from .. import sched
@@ -410,9 +461,6 @@ class ReVisionLlamaForCausalLM:
         else:
             first = eng.llm_prefill_pool(h, B, p0, pool.kv, pool.R, job.r0, pool.Smax)
             ready = None
-        if do_sample and uniforms is None:
-            uniforms = (torch.rand(max_new_tokens, B, device=dev) if self.uniform_fn is None
-                        else torch.stack([self.uniform_fn(s_, B).to(dev).float() for s_ in range(max_new_tokens)]))
         if ready is None:
             ready = torch.cuda.Event()
             ready.record()

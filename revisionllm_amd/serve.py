@@ -156,7 +156,8 @@ class DecodePool:
                 self.uni_all[:min(steps, self.G), r] = uniforms[:min(steps, self.G)].to(torch.float32)
             # the rows of this generate were prefilled with a shared prompt prefix of `shared_prefix` positions (bit-identical K / V in all of
             # them): their decode attention reads it from the generate's first row
-            self.share[r] = (job.r0 | (int(shared_prefix) << 16)) if (shared_prefix > 0 and job.B > 1 and self.Smax <= 65535) else 0
+            # (the word is sibling | len << 16 in an int32: a prefix of 32768 positions or more does not fit - such a generate simply does not share)
+            self.share[r] = (job.r0 | (int(shared_prefix) << 16)) if (0 < shared_prefix < 32768 and job.B > 1 and job.r0 <= 0xffff) else 0
         first_logits.record_stream(self.stream)
         job.joined = True
         self.pending -= 1
