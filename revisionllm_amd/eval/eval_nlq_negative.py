@@ -144,7 +144,7 @@ def _prepare(args, store, stager, dev, id_, data):
         features = features[np.linspace(0, features.shape[0] - 1, args.num_frames, dtype=np.int32)]
     frame_idx = window_features(features, args)
     windows = stager.stage_windows(features, frame_idx).wait()
-    qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(getattr(model, "dtype", torch.float32)) if query_feats is not None else None
+    qf = torch.from_numpy(np.asarray(query_feats)).to(dev).to(getattr(stager, "op_dtype", torch.float32)) if query_feats is not None else None
     qc = torch.from_numpy(np.asarray(query_cls)).to(dev).float() if query_cls is not None else None
     duration = data["movie_duration"] if "movie_duration" in data else data["duration"]
     return dict(movie=movie, windows=windows, qf=qf, qc=qc, sentence=_sentence(data), timestamps=data["timestamps"], duration=duration)
