@@ -1,0 +1,35 @@
+"""The stage-2 adapter alone (ClipEncoder, text-conditioned, CLS out) on one recursion's input, N times: for `rocprofv3 --kernel-trace --stats`
+(per-kernel time of the adapter when nothing else runs) and a HIP-event wall time.   python tools/adapter_prof.py [N] [f16|bf16]"""
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from revisionllm_amd import hip  # noqa: E402
+if len(sys.argv) > 2:
+    hip.set_flavour(sys.argv[2])
+from revisionllm_amd.model import ReVisionLlamaForCausalLM  # noqa: E402
+from revisionllm_amd.utils import synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device("cuda:0")
+m = ReVisionLlamaForCausalLM(synth.LlamaShape(layers=1), device=dev)
+m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=True, cross_attn=False, clip_adapter_text=True, clip_adapter_feature="cls", hierarchy=True,
+                                                        adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
+m.engine.init_synthetic(seed=0, llm=False, clip=True)
+eng = m.engine
+feats = torch.randn(100, 256, 768, device=dev).to(hip.op_dtype())
+qf = torch.randn(1, 16, 768, device=dev).to(hip.op_dtype())
+mask = torch.ones(1, 16)
+for _ in range(5):
+    eng.clip_encoder(feats, qf, mask, "cls")
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+a.record()
+for _ in range(n):
+    eng.clip_encoder(feats, qf, mask, "cls")
+b.record()
+torch.cuda.synchronize()
+print(f"adapter (100 windows x 256 frames, {hip.flavour()} operands): {a.elapsed_time(b) / n:.3f} ms per recursion over {n} runs")
