@@ -117,6 +117,10 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *   "lm_head_split"      1 (default) = the lm_head input is the split pair [hi | lo] (bf16(x), bf16(x - hi)) over the K-duplicated lm_head whenever
  *                        "llm.lm_head.p2" is bound (its bf16 rounding alone owns two thirds of the bf16 path's distance from the fp32 reference on the
  *                        entropy scores, profiles/r4_error_budget.json); 0 = bf16 lm_head input.  Not used with the FP8 decode weights.
+ *   "last_block_rows"    1 (default) = a prefill that returns logits runs the LAST block's o / MLP projections (and the head) on the last row of every
+ *                        sequence only - nothing reads that block's other output rows (its K / V are cached before); they go through the few-row
+ *                        weight-streaming kernels (<= 32 sequences per pass, >= 128 rows).  0 = every row through every block (rounds 1 - 4).  Logits
+ *                        differ in the last bits between the two settings (other summation order in that block's projections).
  *   "precision"          0 (default) = bf16 GEMM operands; 1 = PARITY precision of the LLM forward (every rv_llm_* entry point): every GEMM
  *                        operand (the outputs of the two RMSNorms, the attention output, silu(gate) * up, the lm_head input) is the split pair
  *                        [hi | lo] = (bf16(x), bf16(x - hi)) - 16 mantissa bits - multiplied with K-duplicated weight copies on the unchanged
@@ -302,10 +306,13 @@ int rv_llm_decode_rows_shared(rv_ctx* ctx, float* h, int32_t R, const int32_t* r
  * do_sample == 0), plus the entropy of the processed and of the raw distribution
  * (vtimellm_llama.py:312-338; funs_get_feature_X.py:131-132).  logits f32 [B,V].
  * out_topk_idx i32 / out_topk_val f32 [B,top_k_cap]: kept candidates in descending order (processed
- * scores), n_keep i32 [B].  top_k <= 64. */
+ * scores), n_keep i32 [B].  top_k in [1, 64], or 0 = NO top-k filter (HF: `top_k` None / 0 - TopKLogitsWarper is not instantiated; what a
+ * checkpoint's generation_config.json may ask for: inference.py:45-59 passes no top_k, so the config's value rules): every token is a candidate,
+ * only top-p trims; no candidate list is produced then (out_topk_* = -1 / -inf, n_keep = the number kept) and the kept set is
+ * {processed score >= out_threshold[b]}.  out_threshold f32 [B] (optional, may be NULL): the smallest processed score the filters keep. */
 int rv_sample(const rv_ctx* ctx /* optional: tunables */, const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
               int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
-              int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream);
+              int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, float* out_threshold, void* stream);
 /* get_entropy_statistics (funs_get_feature_X.py:120-146): logits f32 [B,G,V] -> [B,4] = max,min,mean,std. */
 int rv_entropy_stats(const float* logits, int32_t B, int32_t G, int32_t V, float* out, void* stream);
 /* Stage-2 cosine score (eval_nlq_retrieval_e2e2.py:380-386): feat bf16/f32 [n,T,768]; per segment:

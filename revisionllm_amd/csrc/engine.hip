@@ -309,6 +309,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "gemm_mhalf") return &o.gemm_mhalf;
     if (k == "precision") return &o.precision;
     if (k == "lm_head_split") return &o.lm_head_split;
+    if (k == "last_block_rows") return &o.last_block_rows;
     return nullptr;
 }
 }  // namespace
@@ -598,6 +599,10 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.planes = w.planes;
     consume.arrive = w.arrive;
     if (l1 < 0 || l1 > g.layers) l1 = g.layers;
+    // (see the last block below) a prefill whose head is asked for, on the plain 16-bit path, with few sequences and enough rows PER PREFILL to matter
+    // (Mg, not M: whether a prefill takes this path must not depend on how many prefills share its pass)
+    const bool tail_block = logits && l1 == g.layers && !par && !p8 && !fuse_norm && !row_pos && (S > 1 || P0 > 0) && c->opt.last_block_rows &&
+                            (int64_t)G * B <= 32 && Mg >= 128 && (size_t)M * F * 2 >= (((size_t)G * B * D * 4 + 255) & ~(size_t)255) + (size_t)G * B * F * 2;
     for (int l = l0; l < l1; ++l) {
         const LlmLayer& L = c->layers[l];
         op16_t* kc = kbase + l * per_layer;
@@ -710,6 +715,26 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                 a.q_lo = qlo;
                 blocked_vt(a);
                 RV_TRY(k_attention(a, st));
+            }
+            if (tail_block && l == g.layers - 1) {
+                // The LAST block of a prefill with a head: behind its attention nothing reads the block's output rows but the last row of every
+                // sequence (its K / V are in the cache already; logits come from the last positions).  o / norm / gate-up / down and the head run on
+                // those G x B rows alone, through the few-row weight-streaming kernels: 0.98 ms of 4096-row GEMMs per pass -> 0.07 ms.
+                const int64_t nr = (int64_t)G * B;
+                op16_t* a_last = w.q16;                                   // (Q is dead behind the attention)
+                float* h_last = (float*)w.act16;                          // (the gated-activation buffer is free until gate/up)
+                op16_t* act_last = (op16_t*)((char*)w.act16 + (((size_t)nr * D * 4 + 255) & ~(size_t)255));
+                RV_TRY(k_gather_last_rows(w.a16, h, last_rows, nr, (int)Mg, P0, B, S, a_last, h_last, (int)D, st));
+                RV_TRY(rv_gemm_impl(a_last, D, L.wo, D, 1, nullptr, h_last, D, h_last, D, RV_F32, RV_ACT_NONE, nr, D, D, w.sk, w.sk_bytes, st, nullptr));
+                RV_TRY(k_rmsnorm(h_last, D, L.norm2, w.xn16, nr, (int)D, g.rms_eps, st));
+                RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, act_last, F, RV_OP16, RV_ACT_SILU_MUL, nr, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
+                RV_TRY(rv_gemm_impl(act_last, F, L.wdown, F, 1, nullptr, h_last, D, h_last, D, RV_F32, RV_ACT_NONE, nr, D, F, w.sk, w.sk_bytes, st, nullptr));
+                if (c->lm_head2 && c->opt.lm_head_split) {
+                    RV_TRY(k_rmsnorm_split(h_last, D, c->final_norm, w.xl16, nr, (int)D, g.rms_eps, st));
+                    return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, nr, V, 2 * D, w.sk, w.sk_bytes, st);
+                }
+                RV_TRY(k_rmsnorm(h_last, D, c->final_norm, w.xl16, nr, (int)D, g.rms_eps, st));
+                return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, nr, V, D, w.sk, w.sk_bytes, st);
             }
             if (par) {
                 RV_TRY(rv_gemm_impl(w.a16, 2 * D, L.wo2, 2 * D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, 2 * D, w.sk, w.sk_bytes, st, nullptr));

@@ -19,6 +19,8 @@ struct RvOpts {
     int rows_spread = 0;        // 33 .. 144-row decode kernel: launches with at most this many workgroups take a CU each (0: never)
     int rows_fill = 240;        // 33 .. 144-row decode kernel: split K until a launch has at least this many workgroups (<= 8 ways)
     int lm_head_split = 1;      // LLM forward: the lm_head input is the split pair [hi | lo] over the K-duplicated lm_head whenever "llm.lm_head.p2" is bound (0: bf16 lm_head input, the round-3 arithmetic)
+    int last_block_rows = 1;    // LLM prefill with a head (logits asked for): 1 = behind its attention the LAST block runs o / MLP on the last row of every sequence only
+                                // (nothing reads the other rows' outputs of that block: its K / V are in the cache already); 0 = all rows (rounds 1 - 4)
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };
@@ -228,6 +230,8 @@ int k_rmsnorm_split(const float* x, int64_t x_row_stride, const float* w, void* 
 int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hipStream_t st);   // f32 [rows, n] -> bf16 [rows, 2 * n]
 // f32 q/k/v [M, 3D] (row stride ld; q / k rows pair-interleaved like the fused epilogue's) -> RoPE, Q as the split pair (qr.q_ld, qr.q_lo), K / V^T cache append
 int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t M, int64_t D, hipStream_t st);
+// output row i = gi * B + b of a_out (16-bit) / h_out (f32) <- input row idx[i], or gi * Mg + P0 + b * S + S - 1 with idx == nullptr
+int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t rows, int Mg, int P0, int B, int S, void* a_out, float* h_out, int D, hipStream_t st);
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,

@@ -327,6 +327,19 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const op16_t* __restri
     }
 }
 
+// ---- the LAST rows of G x B sequences, gathered out of a prefill batch: output row i = gi * B + b <- input row idx[i] (ragged sequences) or
+// gi * Mg + P0 + b * S + S - 1.  Copies the 16-bit row of `a` and the f32 row of `h` (llm_forward_impl: the last block runs its o / MLP
+// projections and the head on these rows only).
+__global__ __launch_bounds__(256) void gather_last_rows_kernel(const op16_t* __restrict__ a, const float* __restrict__ h, const int* __restrict__ idx,
+                                                               int Mg, int P0, int B, int S, op16_t* __restrict__ a_out, float* __restrict__ h_out, int D) {
+    const int i = blockIdx.x;
+    const int64_t r = idx ? (int64_t)idx[i] : (int64_t)(i / B) * Mg + P0 + (int64_t)(i % B) * S + S - 1;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        *(u32x2*)(a_out + (int64_t)i * D + c) = *(const u32x2*)(a + r * D + c);
+        *(f32x4*)(h_out + (int64_t)i * D + c) = *(const f32x4*)(h + r * D + c);
+    }
+}
+
 // ---- RoPE (cos, sin) table; the rotation itself and the KV-cache append live in the fused QKV epilogue (gemm.hip) ----
 // cs: (cos, sin) table [S][dh/2] for positions pos0..pos0+S-1, built once per forward (shared by all layers).
 __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int dh, float theta) {
@@ -502,6 +515,13 @@ int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lp
         return RV_ERR_ARG;
     }
     RV_CHECK_LAUNCH("transpose_v");
+    return RV_OK;
+}
+
+int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t rows, int Mg, int P0, int B, int S, void* a_out, float* h_out, int D, hipStream_t st) {
+    RV_CHECK_ARG(a16 && h && a_out && h_out && rows > 0 && D % 4 == 0, "gather_last_rows: bad arguments");
+    hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const op16_t*)a16, h, idx, Mg, P0, B, S, (op16_t*)a_out, h_out, D);
+    RV_CHECK_LAUNCH("gather_last_rows");
     return RV_OK;
 }
 

@@ -48,6 +48,21 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return t;
 }
 
+__device__ __forceinline__ unsigned block_max_u32(unsigned v, unsigned* shu) {  // shu: 16 words; all threads get the result
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
+        v = w > v ? w : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shu[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned t = 0u;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) t = shu[w] > t ? shu[w] : t;
+    return t;
+}
+
 // K-th largest of the block's keys, ONE key per thread, 4 bits per round and one barrier per round: five ballots give lane
 // c < 16 of every wave the number of its wave's matching keys whose digit is c; the 16 x 16 wave histograms meet in LDS
 // (double-buffered by round parity), every wave adds them up and suffix-scans them redundantly, so the choice of the digit
@@ -122,8 +137,9 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
                                                      int do_sample, float temperature, int top_k, float top_p,
                                                      int32_t* __restrict__ out_tok, float* __restrict__ out_hp,
                                                      float* __restrict__ out_hr, int32_t* __restrict__ out_idx,
-                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nkeep, int variant) {
+                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nkeep, float* __restrict__ out_thr, int variant) {
     __shared__ float sh[16];
+    __shared__ unsigned shu[16];
     __shared__ float topv[KCAP];
     __shared__ int topi[KCAP];
     __shared__ float e[KCAP];
@@ -174,6 +190,134 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
     const float inv_t = do_sample ? 1.0f / temperature : 1.0f;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) v[j] = tid + j * TPB < V ? v[j] * inv_t : -INFINITY;
+    if (do_sample && top_k == 0) {
+        // ---- top_k = 0: HF's "filter disabled" (TopKLogitsWarper is not instantiated) - every token is a candidate, only top-p trims.  No list of
+        // candidates can hold V entries, so nothing is sorted: the two places where the reference's order matters (the ascending cumulative
+        // sum of TopPLogitsWarper, the inverse-CDF walk in descending order) are answered by a 32-round binary descent over the order-preserving
+        // integer keys, each round one block-wide sum of the probabilities on one side of the candidate key.  Sums run in the block's
+        // reduction order, not sequentially: a draw whose uniform sits within rounding of a CDF step may differ from the oracle's (as for the
+        // K <= 64 path, tests keep uniforms away from the steps).
+        unsigned key[ITEMS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned u = __float_as_uint(v[j]);
+            key[j] = tid + j * TPB < V ? ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) : 0u;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = block_max(mx, sh);
+        float ex[ITEMS];
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            ex[j] = expf(v[j] - mx);
+            z += ex[j];
+        }
+        z = block_sum(z, sh);
+        unsigned kmax = 0u;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) kmax = key[j] > kmax ? key[j] : kmax;
+        kmax = block_max_u32(kmax, shu);                         // the largest key: never removed (HF keeps at least one token)
+        // top-p: remove the ascending prefix whose inclusive cumulative probability stays <= 1 - top_p; keep from key `cut` on
+        unsigned cut = 0u;
+        if (top_p < 1.0f) {
+            const float t = (1.0f - top_p) * z;                 // compare un-normalised sums
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned c2 = cut | (1u << bit);
+                float below = 0.f;
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) below += key[j] < c2 ? ex[j] : 0.f;
+                below = block_sum(below, sh);
+                if (below <= t && c2 <= kmax) cut = c2;
+            }
+        }
+        float z2 = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool kept = key[j] >= cut && tid + j * TPB < V;
+            z2 += kept ? ex[j] : 0.f;
+            cnt += kept ? 1.f : 0.f;
+        }
+        z2 = block_sum(z2, sh);
+        const int n_keep = (int)(block_sum(cnt, sh) + 0.5f);
+        const float iz2 = 1.0f / z2;
+        float hsum = 0.f, thr = INFINITY;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (key[j] >= cut && tid + j * TPB < V) {
+                const float p = ex[j] * iz2;
+                hsum += p * logf(p + 1e-10f);
+                thr = fminf(thr, v[j]);
+            }
+        }
+        const float hp = -block_sum(hsum, sh);
+        thr = -block_max(-thr, sh);                              // the smallest kept processed score
+        // draw: the token whose descending inclusive cumulative probability first exceeds u = the largest key c with sum_{kept, key >= c} p > u
+        const float u = (uniforms ? uniforms[b] : 0.f) * z2;
+        unsigned pick = cut;                                      // (rounding left no such key: the last kept token)
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned c2 = pick | (1u << bit);            // (>= cut: bits are only added)
+            float at_or_above = 0.f;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) at_or_above += key[j] >= c2 ? ex[j] : 0.f;
+            at_or_above = block_sum(at_or_above, sh);
+            if (at_or_above > u) pick = c2;
+        }
+        // `pick` is an existing kept key (the sum above is a step function of the key) unless rounding left no key with a sum above u: then the
+        // LAST kept token (the smallest kept key) is taken, as the oracle's clamp does.  Ties share a key: the reference orders them by index -
+        // the n-th of them with n = how many whole tied probabilities fit between the sum above the tie and u
+        float above = 0.f, tie_e = 0.f, ties = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) ties += (tid + j * TPB < V && key[j] == pick && key[j] >= cut) ? 1.f : 0.f;
+        int n_ties = (int)(block_sum(ties, sh) + 0.5f);
+        if (n_ties == 0) {
+            unsigned lowest = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (tid + j * TPB < V && key[j] >= cut) lowest = key[j] < lowest ? key[j] : lowest;
+            pick = ~block_max_u32(~lowest, shu);
+            ties = 0.f;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) ties += (tid + j * TPB < V && key[j] == pick) ? 1.f : 0.f;
+            n_ties = (int)(block_sum(ties, sh) + 0.5f);
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool kept = key[j] >= cut && tid + j * TPB < V;
+            above += (kept && key[j] > pick) ? ex[j] : 0.f;
+            if (kept && key[j] == pick) tie_e = ex[j];
+        }
+        above = block_sum(above, sh);
+        tie_e = block_max(tie_e, sh);
+        int nth = 0;
+        if (n_ties > 1 && tie_e > 0.f) {
+            nth = (int)floorf((u - above) / tie_e);
+            nth = nth < 0 ? 0 : (nth > n_ties - 1 ? n_ties - 1 : nth);
+        }
+        // the nth smallest index among the tokens whose key == pick: nth + 1 block-wide minimum searches (nth = 0 unless scores tie exactly)
+        int last = -1, chosen = -1;
+        for (int r = 0; r <= nth; ++r) {
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int i = tid + j * TPB;
+                if (i < V && key[j] == pick && key[j] >= cut && i > last) best = i < best ? i : best;
+            }
+            best = -(int)block_max((float)(-best), sh);           // indices < 2^24: exact in fp32
+            chosen = last = best;
+        }
+        if (tid == 0) {
+            out_tok[b] = chosen >= 0 && chosen < V ? chosen : 0;
+            out_hp[b] = hp;
+            out_nkeep[b] = n_keep;
+            if (out_thr) out_thr[b] = thr;
+        }
+        if (tid < KCAP && out_idx && out_val) {                   // no candidate list in this mode: the kept set is {score >= out_threshold}
+            out_idx[b * KCAP + tid] = -1;
+            out_val[b * KCAP + tid] = -INFINITY;
+        }
+        return;
+    }
     const int K = do_sample ? top_k : 1;
     // ---- top-K selection: radix select on order-preserving integer keys (2 bits per round, pure register counting +
     // one block reduction per round), then the <= K survivors are rank-sorted by (score desc, index asc).
@@ -385,6 +529,7 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
             out_tok[b] = topi[0];
             out_hp[b] = h_raw;
             out_nkeep[b] = 0;
+            if (out_thr) out_thr[b] = -INFINITY;
         }
         if (tid < KCAP && out_idx && out_val) {
             out_idx[b * KCAP + tid] = -1;
@@ -441,6 +586,7 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         out_tok[b] = topi[pos];
         out_hp[b] = -hp;
         out_nkeep[b] = keep;
+        if (out_thr) out_thr[b] = topv[keep - 1];       // the smallest kept processed score
 #ifdef RV_SAMPLE_PROBE
         tp[4] = wall_clock64();
         for (int q = 1; q < 5; ++q) out_val[b * KCAP + 59 + q] = (float)(tp[q] - tp[q - 1]);
@@ -670,17 +816,17 @@ __global__ __launch_bounds__(256) void topk_pool_kernel(const T* __restrict__ vi
 
 extern "C" int rv_sample(const rv_ctx* ctx, const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
                          int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
-                         int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, void* stream) {
+                         int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, float* out_threshold, void* stream) {
     RvOptScope scope(rv_ctx_opts(ctx));
     RV_CHECK_ARG(logits && out_tokens && out_entropy_proc && out_entropy_raw && out_nkeep, "rv_sample: null output");
     RV_CHECK_ARG(B > 0 && V > 0 && V <= TPB * ITEMS, "rv_sample: V=%d exceeds %d", V, TPB * ITEMS);
     if (do_sample) {
-        RV_CHECK_ARG(top_k >= 1 && top_k <= KCAP, "rv_sample: top_k=%d must be in [1,%d] when sampling", top_k, KCAP);
+        RV_CHECK_ARG(top_k >= 0 && top_k <= KCAP, "rv_sample: top_k=%d must be 0 (no top-k filter) or in [1,%d] when sampling", top_k, KCAP);
         RV_CHECK_ARG(temperature > 0.f && top_p > 0.f, "rv_sample: temperature and top_p must be positive");
         RV_CHECK_ARG(out_topk_idx && out_topk_val, "rv_sample: candidate outputs required when sampling");
     }
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(TPB), 0, as_stream(stream), logits, V, uniforms, do_sample, temperature, top_k,
-                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep, rv_cur_opts().sample_variant);
+                       top_p, out_tokens, out_entropy_proc, out_entropy_raw, out_topk_idx, out_topk_val, out_nkeep, out_threshold, rv_cur_opts().sample_variant);
     RV_CHECK_LAUNCH("rv_sample");
     return RV_OK;
 }

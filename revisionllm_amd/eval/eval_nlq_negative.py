@@ -74,6 +74,9 @@ def parse_args(argv=None):
     p.add_argument("--plus_baseline", type=_bool, default=False)
     # build-defined additions
     p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--op_dtype", default=None, choices=["f16", "bf16"],
+                   help="build-defined: operand type of the HIP library (default f16: fp16 operands, the checkpoints' own storage type, scores within 1e-3 of the "
+                        "reference's fp32 CPU path; bf16: the reference's GPU dtype)")
     p.add_argument("--in_flight", type=int, default=1,
                    help="queries processed concurrently: > 1 runs them as scheduler tasks on their own HIP streams; their window batches prefill in "
                         "the DecodeServer's batched passes and decode in its merged steps (what bench.py's stage-1 workloads time); 1 = the reference's loop")

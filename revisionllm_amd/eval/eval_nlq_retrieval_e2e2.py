@@ -83,6 +83,9 @@ def parse_args(argv=None):
     p.add_argument("--mode", type=str, default="batched", choices=["batched", "reference"],
                    help="batched: results-preserving restructuring (default); reference: one inference() per (level, group) as the reference loops")
     p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--op_dtype", default=None, choices=["f16", "bf16"],
+                   help="build-defined: operand type of the HIP library (default f16: fp16 operands, the checkpoints' own storage type, scores within 1e-3 of the "
+                        "reference's fp32 CPU path; bf16: the reference's GPU dtype)")
     p.add_argument("--in_flight", type=int, default=1,
                    help="queries processed concurrently (batched mode): > 1 runs them as scheduler tasks on their own HIP streams whose LLM prefills "
                         "ride up to four to a pass and whose decode steps are merged (serve.DecodeServer: two KV pools filled and stepped in turn) - "

@@ -117,7 +117,7 @@ SIGNATURES = {
     "rv_llm_prefill_pool_groups_ragged": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p, _p, _sz, _p]),
     "rv_llm_decode_rows": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p, _sz, _p]),
     "rv_llm_decode_rows_shared": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i32, _p, _p, _sz, _p]),
-    "rv_sample": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "rv_sample": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _f, _i32, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "rv_entropy_stats": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "rv_topk_cosine": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "rv_topk_pool": (C.c_int, [_p, C.c_int, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
@@ -164,7 +164,7 @@ def check(rc, what):
         raise HipLibraryError(f"{what} failed (status {rc}): {last_error()}")
 
 
-OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant", "rows_fill", "rows_spread", "rows_persistent", "rows_single", "gemm_waves", "gemm_mhalf", "precision", "lm_head_split")
+OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant", "rows_fill", "rows_spread", "rows_persistent", "rows_single", "gemm_waves", "gemm_mhalf", "precision", "lm_head_split", "last_block_rows")
 
 
 class Options:

@@ -122,7 +122,9 @@ def load_pretrained_model(args, stage2=None, stage3=None, load_ckp=False):
     tokenizer = AutoTokenizer.from_pretrained(model_base, use_fast=False)
     with open(os.path.join(model_base, "config.json")) as f:
         cfg = json.load(f)
-    model = ReVisionLlamaForCausalLM(shape_from_config(cfg), max_sequence_length=cfg.get("max_sequence_length"))
+    # build-defined: args.op_dtype = "f16" (default: the checkpoints' own storage type - builder.py:22 loads them with torch_dtype=float16 -
+    # held exactly; segment scores within 1e-3 of the reference's fp32 CPU path) or "bf16" (the reference's GPU dtype, e2e2.py:181-185)
+    model = ReVisionLlamaForCausalLM(shape_from_config(cfg), max_sequence_length=cfg.get("max_sequence_length"), op_dtype=getattr(args, "op_dtype", None))
     model.fp8_prefill = bool(getattr(args, "fp8_prefill", False))  # build-defined opt-in: FP8 x FP8 prefill GEMMs
     model.fp8_decode = bool(getattr(args, "fp8_decode", False))   # build-defined opt-in: FP8 copies of the LLM weights for decode steps
     model.parity = bool(getattr(args, "parity", False))           # build-defined opt-in: K-duplicated copies for the parity precision (engine option precision = 1)

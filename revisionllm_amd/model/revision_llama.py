@@ -318,6 +318,7 @@ class ReVisionLlamaForCausalLM:
         gc = self.generation_config
         temperature = gc.temperature if temperature is None else temperature
         top_k = gc.top_k if top_k is None else top_k
+        top_k = 0 if top_k is None else int(top_k)      # HF: None / 0 = no top-k filter (the sampling kernel's top_k = 0 path)
         top_p = gc.top_p if top_p is None else top_p
         max_new_tokens = 20 if max_new_tokens is None else max_new_tokens
         eos, pad = gc.eos_token_id, gc.pad_token_id
@@ -523,7 +524,12 @@ class ReVisionLlamaForCausalLM:
             ent_r.append(o["entropy_raw"])
             if output_logits or (output_scores and (not do_sample or self.scores_mode == "raw")):
                 raw_steps.append(logits.clone())
-            if output_scores and do_sample and self.scores_mode == "processed":
+            if output_scores and do_sample and self.scores_mode == "processed" and not top_k:
+                # no top-k filter (top_k = 0 / None): there is no candidate list - the processed scores are logits / T with everything below the
+                # kernel's top-p threshold at -inf
+                sc = logits / temperature
+                score_steps.append(sc.masked_fill(sc < o["threshold"][:, None], float("-inf")))
+            elif output_scores and do_sample and self.scores_mode == "processed":
                 V = logits.shape[1]
                 sc = torch.full((B, V + 1), float("-inf"), device=dev)      # column V swallows the dropped candidates
                 keep = torch.arange(hip.TOPK_CAP, device=dev)[None] < o["n_keep"][:, None]

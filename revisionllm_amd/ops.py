@@ -252,18 +252,20 @@ def h2d(t, device, dtype=None):
 
 
 def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0, ctx=None):
-    """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B]).
-    (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""
+    """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B], threshold f32 [B]).
+    ``top_k`` in [1, 64], or 0 / None = no top-k filter (HF: filter disabled): no candidate list then - the kept set is {processed score >=
+    threshold}.  (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""
+    top_k = 0 if top_k is None else top_k
     B, V = logits.shape
     dev = logits.device
     o = dict(tokens=torch.empty(B, dtype=torch.int32, device=dev), entropy_proc=torch.empty(B, dtype=torch.float32, device=dev),
              entropy_raw=torch.empty(B, dtype=torch.float32, device=dev),
              topk_idx=torch.empty((B, hip.TOPK_CAP), dtype=torch.int32, device=dev),
              topk_val=torch.empty((B, hip.TOPK_CAP), dtype=torch.float32, device=dev),
-             n_keep=torch.empty(B, dtype=torch.int32, device=dev))
+             n_keep=torch.empty(B, dtype=torch.int32, device=dev), threshold=torch.empty(B, dtype=torch.float32, device=dev))
     hip.check((ctx.lib if ctx is not None else hip.lib()).rv_sample(hip.ctx_ptr(ctx), hip.ptr(_c(logits)), B, V, hip.ptr(uniforms), int(do_sample), float(temperature), int(top_k),
                                   float(top_p if top_p is not None else 1.0), hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
-                                  hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]),
+                                  hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]), hip.ptr(o["threshold"]),
                                   hip.stream()), "rv_sample")
     return o
 

@@ -12,7 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # GPU test modules that run in BOTH operand flavours of the library (fp16 = the default build, bf16); every other module runs in the default
 # flavour only.  REVISION_TEST_FLAVOURS=f16 | bf16 | f16,bf16 overrides the list for every GPU module (a quick single-flavour run).
-DUAL_FLAVOUR_MODULES = {"test_gpu_kernels", "test_gpu_merged_decode", "test_gpu_full_depth_conditioned", "test_gpu_configs_verified"}
+# (test_gpu_configs_verified runs the 7B fp32 oracle on the host cores for minutes: it checks the DEFAULT flavour at the north star's 1e-3; the bf16
+# build's 3e-3 on the same configurations was measured in round 4 - REVISION_TEST_FLAVOURS=bf16 repeats it)
+DUAL_FLAVOUR_MODULES = {"test_gpu_kernels", "test_gpu_merged_decode", "test_gpu_full_depth_conditioned"}
 
 
 def pytest_generate_tests(metafunc):
