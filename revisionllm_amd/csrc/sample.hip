@@ -254,12 +254,12 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         thr = -block_max(-thr, sh);                              // the smallest kept processed score
         // draw: the token whose descending inclusive cumulative probability first exceeds u = the largest key c with sum_{kept, key >= c} p > u
         const float u = (uniforms ? uniforms[b] : 0.f) * z2;
-        unsigned pick = cut;                                      // (rounding left no such key: the last kept token)
+        unsigned pick = 0u;                                        // greedy from the top bit: the largest c whose kept mass at or above c exceeds u
         for (int bit = 31; bit >= 0; --bit) {
-            const unsigned c2 = pick | (1u << bit);            // (>= cut: bits are only added)
+            const unsigned c2 = pick | (1u << bit);
             float at_or_above = 0.f;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) at_or_above += key[j] >= c2 ? ex[j] : 0.f;
+            for (int j = 0; j < ITEMS; ++j) at_or_above += (key[j] >= c2 && key[j] >= cut) ? ex[j] : 0.f;
             at_or_above = block_sum(at_or_above, sh);
             if (at_or_above > u) pick = c2;
         }

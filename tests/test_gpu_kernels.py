@@ -524,17 +524,21 @@ def test_sample_without_a_top_k_filter(dev):
         # the ascending cumulative sum of TopPLogitsWarper is a sequential f32 sum in the oracle and a tree of partial sums on the device: a
         # token whose inclusive sum lands within rounding of 1 - top_p may fall on either side - at most one token of difference per row
         nk = o["n_keep"].cpu().long()
-        assert ((nk - keep).abs() <= 1).all(), (temp, p, nk.tolist(), keep.tolist())
+        # (row 5 holds exactly tied scores: the reference's unstable ascending sort removes an arbitrary part of a tie group that straddles the cut,
+        # the kernel keeps the whole group - compared on the rows with distinct scores)
+        assert ((nk - keep).abs()[:5] <= 1).all(), (temp, p, nk.tolist(), keep.tolist())
+        assert nk[5] >= keep[5]
         same = nk == keep
         thr = torch.where(torch.isfinite(sc), sc, torch.full_like(sc, float("inf"))).amin(-1)
         assert torch.allclose(o["threshold"].cpu()[same], thr[same], rtol=1e-6)
         ent = scores.entropy_statistics(sc[:, None])[:, 0]
         assert torch.allclose(o["entropy_proc"].cpu()[same], ent[same], rtol=2e-4, atol=1e-5)
-        # the draw: the oracle's token wherever its uniform is not within 1e-4 of a step of the descending CDF
+        # the draw: the oracle's token wherever its uniform is not within 2e-6 of a step of the descending CDF (f32 sums in another order; a flat
+        # row's steps are 3e-5 wide)
         pr = torch.softmax(sc.double(), -1)
         srt = torch.sort(pr, descending=True, stable=True, dim=-1)
         cum = srt.values.cumsum(-1)
-        safe = ((cum - u[:, None].double()).abs().amin(-1) > 1e-4) & same
+        safe = ((cum - u[:, None].double()).abs().amin(-1) > 2e-6) & same
         tok = sampling.select_token(sc, u)
         assert (o["tokens"].cpu().long()[safe] == tok[safe]).all(), (temp, p)
         assert safe.sum() >= 4

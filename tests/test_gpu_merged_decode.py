@@ -293,6 +293,47 @@ def test_ragged_generate_of_a_33_window_recursion_equals_the_two_generate_form()
             assert rel_err(b[k], a[k]) < 1e-5 and rel_err(c[k], a[k]) < 1e-5, k
 
 
+def test_ragged_generate_that_no_pool_can_take_falls_back_to_equal_geometry_groups():
+    """whether a recursion completes must not depend on the DecodeServer's capacity.  The 9 calls of a 33-window recursion
+    form a ragged batch (8 x 32 + 1 x 33 video tokens); with a server whose pools hold only 8 rows (``fits`` is false for the padded batch), with a
+    server whose Smax is too short, and with no server at all, ``generate_steps`` runs them as equal-geometry sub-batches (the two-generate form
+    of round 3) instead of raising - same answers, entropies to 1e-5 of the ragged run through a server that CAN take it."""
+    from revisionllm_amd import parallel, sched, serve
+    from revisionllm_amd.eval import stage2
+    from revisionllm_amd.utils import synth
+    m = _tiny_model()
+    tok = synth.FakeTokenizer(vocab=synth.TINY.vocab)
+    st = parallel.HipStages(m, tok)
+    W = batch = 33
+    plan = stage2.plan_groups(W, batch)
+    feat = feats("rg.feat", (W, 16, 768), bf16=fl()).to(op()).cuda()
+    qf, qc = feats("rg.q0", (5, 768), bf16=fl()).to(op()).cuda(), feats("rg.qc", (768,)).cuda()
+    perms = stage2.make_perms(plan, torch.Generator().manual_seed(2), W=W)
+    uni = torch.rand(6, len(plan), generator=torch.Generator().manual_seed(20))
+    kw = dict(batch=batch, perms=[perms], max_new_tokens=6)
+
+    def through(server):
+        st.server = server
+        inter = sched.Interleaver(servers=[server] if server is not None else ())
+        task = inter.add(sched.Task(lambda t: parallel.launch_queries_sharded_steps(st, tok, feat, W, [(qf, qc, "query 0")], uniforms=uni, turn=t, **kw),
+                                    torch.cuda.Stream("cuda:0"), m.engine, 0))
+        rec = parallel.collect_queries(inter.finish(task))[0]
+        m.engine.slot = 0
+        st.server = None
+        return rec
+    roomy = serve.DecodeServer(m, rows=27, smax=160, gmax=16, pools=2, gang=True, prefill_batch=4)
+    want = through(roomy)
+    assert roomy.pf_tickets == 1                                                   # (one ragged generate)
+    small = serve.DecodeServer(m, rows=8, smax=160, gmax=16, pools=2, gang=True, prefill_batch=4)          # 9 rows do not fit 8
+    short = serve.DecodeServer(m, rows=27, smax=64, gmax=16, pools=2, gang=True, prefill_batch=4)          # S + G > Smax
+    for server in (small, short, None):
+        got = through(server)
+        assert got["answers"] == want["answers"] and got["starts"] == want["starts"] and got["score_cos"] == want["score_cos"]
+        for k in ("max_entropy", "mean_entropy"):
+            assert rel_err(got[k], want[k]) < 1e-5, k
+    assert small.pf_tickets == 2 and short.pf_tickets == 0       # two sub-batches through the pools, one after the other / nothing fits: both groups decode alone
+
+
 @pytest.mark.parametrize("pools", [1, 2])
 def test_decode_server_with_eos_equals_classic_loop(pools):
     """EOS in the merged path (``pools`` = 2: under the gang policy, the partly filled pool sealed when the scheduler runs dry): generates whose rows emit EOS at different steps (teacher-forced) leave the pool early; sequences and

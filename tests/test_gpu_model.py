@@ -186,9 +186,17 @@ def test_generate_with_the_top_k_filter_disabled():
     both = torch.isfinite(got_sc) & torch.isfinite(want_sc)
     assert (got_sc[both] - want_sc[both]).abs().max() < tol(1.2e-2) * torch.stack(o["logits"]).abs().max()
     assert torch.allclose(out["entropy"].cpu(), _entropy(want_sc).t(), rtol=tol(2e-2), atol=1e-4)
-    # free-running: the same uniforms draw the oracle's tokens (0.37 is far from every CDF step of these rows)
-    free = m.generate(ids, images=feat, query_feats=q, do_sample=True, max_new_tokens=4, return_dict_in_generate=True, uniforms=u)
-    assert torch.equal(free["sequences"].cpu(), o["sequences"])
+    # free-running: every token the kernel draws is the oracle's draw ON THE KERNEL'S OWN processed scores (with ~400 candidates a CDF step is
+    # 2.5e-3 wide: the logit error of 16-bit GEMMs moves a draw across a step now and then, so the oracle's own tokens are not the yardstick here)
+    free = m.generate(ids, images=feat, query_feats=q, do_sample=True, max_new_tokens=4, return_dict_in_generate=True, output_scores=True, uniforms=u)
+    fs = torch.stack(free["scores"]).cpu()
+    drawn = free["sequences"][:, ids.shape[1]:].t().cpu()
+    pr = torch.softmax(fs.double(), -1)
+    cum = torch.sort(pr, descending=True, stable=True, dim=-1).values.cumsum(-1)
+    safe = (cum - 0.37).abs().amin(-1) > 1e-5
+    for s_ in range(4):
+        want_tok = sampling.select_token(fs[s_], u[s_])
+        assert (drawn[s_][safe[s_]] == want_tok[safe[s_]]).all(), s_
 
 
 def test_inference_api_end_to_end():

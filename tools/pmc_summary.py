@@ -34,7 +34,7 @@ def sq_summary(sq_dir, grbm_dir, out_prefix, n_xcd=8, simds=1024):
     GRBM_GUI_ACTIVE counts GPU cycles summed over the XCDs.  mfma_util = MFMA busy cycles / (kernel cycles x SIMDs)."""
     import glob
     names = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
-             "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")
+             "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in (sq_dir, grbm_dir):
         for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
