@@ -345,6 +345,61 @@ def test_layernorm_rmsnorm_sinepos(dev):
         assert (p.cpu() - adapter.sine_pos_embed(Tn)).abs().max() < 2e-5
 
 
+def test_fp16_saturating_conversions_never_produce_inf(dev):
+    """The range guard of the fp16 build: activations of magnitude 1e4 - inside fp16's range - go through norms, GEMMs,
+    the gated epilogue and a whole Llama block without an inf or NaN, and still match the oracle; a GEMM OUTPUT beyond +-65504 stored as fp16 comes
+    out as +-65504 (saturated), never inf, while the same product with an f32 output is exact.  (The bf16 build has fp32's exponent range: skipped.)"""
+    if fl() != "f16":
+        pytest.skip("fp16 range guard")
+    from oracle import llama
+    from revisionllm_amd import hip, ops
+    from revisionllm_amd.utils import synth
+    # (1) planted 1e4-magnitude activations: RMSNorm, LayerNorm and a GEMM on them are finite and right
+    x = feats("sat.x", (40, 4096)) * 2
+    x[:, 7] = 1.0e4
+    x[3, 100:164] = -1.2e4
+    w = feats("sat.w", (4096,)) * 0.1 + 1
+    y = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+    assert torch.isfinite(y).all() and rel_err(y.float().cpu(), llama.rmsnorm(x, w, 1e-5)) < tol(BF16_TOL)
+    a = (feats("sat.a", (130, 512), bf16=fl()) * 1.0e4).clamp(-6.0e4, 6.0e4)          # |a| up to 1.7e4: representable, 3 x below the limit
+    wm = bf(feats("sat.wm", (64, 512), bf16=fl()) * (1.0 / math.sqrt(512))).float()
+    ref = a.to(op()).double() @ wm.double().t()                                          # |ref| ~ 1e4
+    y32 = ops.gemm(a.to(op()).to(dev), wm.to(op()).to(dev), out_dtype=torch.float32)
+    y16 = ops.gemm(a.to(op()).to(dev), wm.to(op()).to(dev), out_dtype=op())
+    assert rel_err(y32.cpu(), ref) < F32_TOL * 5 and torch.isfinite(y16).all() and rel_err(y16.float().cpu(), ref) < tol(BF16_TOL)
+    # (2) a product beyond the fp16 range: f32 output exact, fp16 output saturated at +-65504 (what an inf would have been), finite everywhere
+    big = torch.full((32, 512), 300.0)
+    big[1] = -300.0
+    wb = torch.full((48, 512), 1.0)
+    r32 = ops.gemm(big.to(op()).to(dev), wb.to(op()).to(dev), out_dtype=torch.float32)
+    r16 = ops.gemm(big.to(op()).to(dev), wb.to(op()).to(dev), out_dtype=op())
+    assert torch.equal(r32.cpu(), torch.full((32, 48), 153600.0) * torch.tensor([1.0, -1.0] + [1.0] * 30)[:, None])
+    assert torch.isfinite(r16).all() and torch.equal(r16.float().cpu(), r32.cpu().clamp(-65504.0, 65504.0))
+    # ... and through the gated epilogue silu(gate) * up (the one activation copy whose size follows the checkpoint): 300 * 512 = 1.5e5 per column
+    gu = ops.gemm(big.to(op()).to(dev), torch.ones(64, 512, dtype=op(), device=dev), act=hip.RV_ACT_SILU_MUL, w_packed=False)
+    assert torch.isfinite(gu).all() and float(gu.float().abs().max()) == 65504.0
+    # (3) a whole block of the tiny Llama on a residual stream with 1e4-magnitude "massive activations": finite, and the oracle's result
+    eng = _tiny_engine(dev)
+    shape = synth.TINY
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    wl = llama_weights(shape, bf16=fl())
+    w32 = llama_weights(shape, bf16=False)
+    for k_ in wl:
+        if "norm" in k_:
+            wl[k_] = w32[k_]
+    h = feats("sat.h", (2, 40, shape.hidden)) * 0.5
+    h[:, :, 11] = 1.0e4
+    h[1, 5, 200:232] = -8.0e3
+    pos = torch.arange(40)[None].expand(2, 40)
+    cos, sin = llama.rope_cos_sin(pos, cfg.head_dim, cfg.theta)
+    bias = llama._bias_from_mask(torch.ones(2, 40, dtype=torch.bool), 40, 0, h.dtype)
+    want = llama.decoder_layer(h, wl, 0, cfg, cos, sin, bias, llama.KVCache(cfg.layers))
+    kv, Smax = eng.new_kv(2, 64, reuse=False)
+    got = eng.llm_layers(h.clone().to(dev).contiguous(), 0, kv, Smax, 0, 1).cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max() / (want - h).abs().max()) < tol(1e-2)          # against what the block ADDED to the stream
+
+
 def _ref_attn(q, k, v, causal, pad, q_pos0, kv_div):
     B, Lq, H, dh = q.shape
     k = k.repeat_interleave(kv_div, 0)
