@@ -23,7 +23,7 @@ def _dev16(t, device, dtype):
     """A tensor as 16-bit operands of ``dtype`` on the device.  fp16 from wider types: values beyond +-65504 saturate (like the kernels' own
     conversions) instead of becoming inf."""
     if dtype == torch.float16 and t.dtype != torch.float16:
-        t = t.to(device=device, dtype=torch.float32).clamp(-65504.0, 65504.0)
+        t = t.to(device=device, dtype=torch.float32).clamp(-65504.0, 65504.0)      # (no host sync: an unconditional pass, only for inputs that are not fp16 already)
     return t.to(device=device, dtype=dtype).contiguous()
 
 

@@ -487,13 +487,13 @@ def test_parity_precision_meets_the_north_star_tolerance_per_call_and_batched(g8
     rec = stage2.run_query(m, synth.FakeTokenizer(), r.features, r.qf, r.qc, meta["sentence"], batch=meta["batch"], perms=r.perms,
                            mode="batched", max_new_tokens=meta["G"], uniforms=u)
     b_max, b_mean = _rel(rec["max_entropy"], g["inv_max"]), _rel(rec["mean_entropy"], g["inv_mean"])
-    report = {"precision": "parity", "tolerance": PARITY_TOL,
+    report = {"precision": "parity (split operands)", "operand_flavour": fl(), "tolerance": PARITY_TOL,
               "per_call_teacher_forced": {"inv_max": forced.e_max.tolist(), "inv_mean": forced.e_mean.tolist()},
               "per_call_free_running": {"inv_max": free.e_max.tolist(), "inv_mean": free.e_mean.tolist()},
               "batched_recursion": {"inv_max": b_max.tolist(), "inv_mean": b_mean.tolist()},
               "raw_logit_abs_err_over_answer_logit_std": {"max": float(forced.err.max() / forced.sd), "mean": float(forced.err.mean() / forced.sd)}}
     print("\n[G8c parity precision] " + json.dumps(report, indent=1))
-    with open(os.path.join(ROOT, "gpurun_out", "g8c_parity_precision.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "g8c_parity_precision_%s.json" % fl()), "w") as f:
         json.dump(report, f, indent=1)
     assert (free.tokens == g["tokens"]).all()
     assert forced.e_max.max() <= PARITY_TOL and forced.e_mean.max() <= PARITY_TOL
@@ -589,7 +589,7 @@ def test_conditioned_fp8_llm_path_free_running_proposals(g8c, fp8_model, copies,
     print("\n[G8c fp8 LLM path FREE-RUNNING] copies", copies, "pool rows", pool_rows, ": frames / iou / starts / zooms equal the reference's in every instance; "
           "words of the sampled answers equal: %.3f; answers that differ (call, fp8, reference): %s; worst rel err of the entropy scores %.3e"
           % (agree, sorted(differing), worst))
-    with open(os.path.join(ROOT, "gpurun_out", f"g8c_fp8_free_{pool_rows}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"g8c_fp8_free_{pool_rows}_{fl()}.json"), "w") as f:
         json.dump({"copies": copies, "pool_rows": pool_rows, "frames_iou_starts_zooms_equal": True, "answer_words_equal_fraction": agree,
                    "answers_that_differ": [list(d) for d in sorted(differing)], "worst_entropy_score_rel_err": worst}, f, indent=1)
     assert agree >= 0.9                                                          # (measured: one tail token of one call of seven)
