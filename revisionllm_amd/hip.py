@@ -161,7 +161,12 @@ def last_error():
 
 def check(rc, what):
     if rc != 0:
-        raise HipLibraryError(f"{what} failed (status {rc}): {last_error()}")
+        # the error string is per library and thread and is not cleared by later successes: with both builds loaded, prefer the message that names
+        # the entry point that just failed
+        msgs = last_error().split(" | ")
+        name = what.split("(")[0]
+        mine = [m for m in msgs if name in m]
+        raise HipLibraryError(f"{what} failed (status {rc}): {' | '.join(mine or msgs)}")
 
 
 OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant", "rows_fill", "rows_spread", "rows_persistent", "rows_single", "gemm_waves", "gemm_mhalf", "precision", "lm_head_split", "last_block_rows")
