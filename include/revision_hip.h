@@ -121,6 +121,10 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        sequence only - nothing reads that block's other output rows (its K / V are cached before); they go through the few-row
  *                        weight-streaming kernels (<= 32 sequences per pass, >= 128 rows).  0 = every row through every block (rounds 1 - 4).  Logits
  *                        differ in the last bits between the two settings (other summation order in that block's projections).
+ *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
+ *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the
+ *                        LayerNorm inputs are read as fp16, accumulation and statistics stay f32 (transformer.py:210-223,271-305 keep fp32 activations; the measured
+ *                        distance to the fp32 reference is in DESIGN section 4).  0 = the f32 stream.  Ignored by the bf16 build (always f32).
  *   "precision"          0 (default) = bf16 GEMM operands; 1 = PARITY precision of the LLM forward (every rv_llm_* entry point): every GEMM
  *                        operand (the outputs of the two RMSNorms, the attention output, silu(gate) * up, the lm_head input) is the split pair
  *                        [hi | lo] = (bf16(x), bf16(x - hi)) - 16 mantissa bits - multiplied with K-duplicated weight copies on the unchanged

@@ -105,6 +105,14 @@ __device__ __forceinline__ op16x8 fp8x8_to_op16x8(unsigned lo, unsigned hi) {
     return r.v;
 }
 
+// The residual operand of a GEMM epilogue: f32 rows (the LLM's residual stream; ldr = row stride in elements) or - ldr NEGATIVE - rows of 16-bit
+// operands with stride -ldr (the adapter's 16-bit residual stream in the fp16 build, engine.hip rv_clip_encoder).  The sign rides in the stride
+// every kernel already takes, so no kernel signature knows about it; rv_gemm_impl is where it is set (argument res16).
+__device__ __forceinline__ f32x4 rv_residual4(const float* res, int64_t ldr, int64_t m, int64_t n) {
+    if (ldr < 0) return op16x4_to_f32(*(const u32x2*)((const op16_t*)res + m * (-ldr) + n));
+    return *(const f32x4*)(res + m * ldr + n);
+}
+
 // split operands (parity precision): x = hi + lo with hi = op16(x), lo = op16(x - hi) (bf16: 16 significand bits; fp16: 22)
 __device__ __forceinline__ float op16_residual(float x) { return x - op16_to_f32(f32_to_op16(x)); }
 __device__ __forceinline__ uint32_t pack_op16x2_lo(float a, float b) { return pack_op16x2(op16_residual(a), op16_residual(b)); }

@@ -310,6 +310,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "precision") return &o.precision;
     if (k == "lm_head_split") return &o.lm_head_split;
     if (k == "last_block_rows") return &o.last_block_rows;
+    if (k == "adapter_stream16") return &o.adapter_stream16;
     return nullptr;
 }
 }  // namespace
@@ -380,6 +381,14 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
     const float scale = 1.0f / sqrtf((float)dh);
     const int64_t R0 = (int64_t)N * T, R1 = (int64_t)N * (T + 1);
 
+    // The encoder's residual stream.  Reference and bf16 build: fp32 in HBM (x32 / y32) next to the 16-bit copies the GEMMs read.  fp16 build with an
+    // output projector (round 5, option adapter_stream16): the stream IS those 16-bit copies - every sublayer output is stored as fp16 once (11
+    // significand bits: the rounding its consumer GEMMs apply anyway), the residual operand of the out-projection / FFN-2 epilogues is read as fp16
+    // (rv_gemm_impl res16) and LayerNorm reads fp16 rows.  The f32 round trips were 0.44 ms of the adapter's 1.87 ms (tools/ffn2_probe.py: FFN-2 131 us
+    // with its f32 output + residual, 89 us without); accumulation, LayerNorm statistics and the CLS-only last layer stay f32.
+    const bool s16 = RV_OP_F16 != 0 && c->adp_proj_w != nullptr && c->opt.adapter_stream16 != 0;
+    op16_t* xs16 = (op16_t*)w.x32;      // (the f32 buffers, re-used for the 16-bit stream: half their size is enough)
+    op16_t* ys16 = (op16_t*)w.y32;
     // position table: row 0 = learned CLS position, rows 1..T = sine embedding (transformer.py:109-116)
     RV_TRY(k_copy_f32(c->cls_pos, w.pm, d, st));
     RV_TRY(k_sine_pos(w.pm + d, T, (int)d, st));
@@ -390,7 +399,8 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         RV_CHECK_LAUNCH("invert_mask");
         float* v32 = w.x32;
         op16_t* vp16 = w.xp16;
-        RV_TRY(k_frames_in(x, w.pm + d, v32, vp16, R0, T, (int)d, st));
+        RV_TRY(k_frames_in(x, w.pm + d, s16 ? nullptr : v32, vp16, R0, T, (int)d, st));
+        const op16_t* vres16 = (const op16_t*)x;      // 16-bit stream: the first layer's residual is the input itself
         for (size_t l = 0; l < c->t2v.size(); ++l) {
             const AdapterLayer& L = c->t2v[l];
             op16_t* q16 = w.qk16;
@@ -401,6 +411,20 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
                        w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
             RV_TRY(k_attention(a, st));
+            if (s16) {
+                RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, (const float*)vres16, d, ys16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st, nullptr, 1));
+                RV_TRY(k_layernorm(nullptr, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st, 0, ys16));
+                RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
+                RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, (const float*)ys16, d, ys16, d, RV_OP16, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st, nullptr, 1));
+                if (l + 1 < c->t2v.size()) {
+                    RV_TRY(k_layernorm(nullptr, L.ln2_w, L.ln2_b, nullptr, xs16, vp16, w.pm + d, T, R0, (int)d, st, 0, ys16));
+                    vres16 = xs16;
+                } else {
+                    RV_TRY(k_layernorm(nullptr, L.ln2_w, L.ln2_b, nullptr, w.x16, w.xp16, w.pm + d, T, R0, (int)d, st, T, ys16));
+                    RV_TRY(k_cls_rows(c->cls_token, w.pm, nullptr, w.x16, w.xp16, N, T, (int)d, st));
+                }
+                continue;
+            }
             RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
@@ -416,7 +440,7 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             }
         }
     } else {
-        RV_TRY(k_build_x(x, nullptr, c->cls_token, w.pm, w.x32, w.x16, w.xp16, N, T, (int)d, st));
+        RV_TRY(k_build_x(x, nullptr, c->cls_token, w.pm, s16 ? nullptr : w.x32, w.x16, w.xp16, N, T, (int)d, st));
     }
 
     for (size_t l = 0; l < c->enc.size(); ++l) {
@@ -439,7 +463,15 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             AttnArgs a{qc16, d, d, kk16, d, (int64_t)(T + 1) * d, dh, w.vt16, (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, d,
                        nullptr, N, H, dh, 1, T + 1, 0, 0, 1, scale, 1};
             RV_TRY(k_attention(a, st));
-            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, sx, y0, d, RV_F32, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
+            const float* cls_res = w.x32;      // the CLS rows of the stream (row stride sx)
+            int64_t cls_ld = sx;
+            if (s16) {                          // 16-bit stream: the N CLS rows as f32 (this layer's few rows stay on the f32 path)
+                float* y3 = w.y32 + (int64_t)3 * N * d;
+                RV_TRY(k_rows_to_f32(w.x16, sx, y3, N, (int)d, st));
+                cls_res = y3;
+                cls_ld = d;
+            }
+            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, cls_res, cls_ld, y0, d, RV_F32, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, y1, d, y2, d, RV_F32, RV_ACT_NONE, N, d, ff, w.sk, w.sk_bytes, st));
@@ -455,6 +487,14 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
                    (int64_t)d * w.Lpad, (int64_t)dh * w.Lpad, w.Lpad, w.a16, d, (int64_t)(T + 1) * d, nullptr, N, H, dh, T + 1,
                    T + 1, 0, 0, 1, scale};
         RV_TRY(k_attention(a, st));
+        if (s16) {      // residual = x16 (the stream), sublayer outputs fp16, LayerNorm reads them
+            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, (const float*)w.x16, d, ys16, d, RV_OP16, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st, nullptr, 1));
+            RV_TRY(k_layernorm(nullptr, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R1, (int)d, st, 0, ys16));
+            RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));
+            RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, (const float*)w.x16, d, ys16, d, RV_OP16, RV_ACT_NONE, R1, d, ff, w.sk, w.sk_bytes, st, nullptr, 1));
+            RV_TRY(k_layernorm(nullptr, L.ln2_w, L.ln2_b, nullptr, w.x16, w.xp16, w.pm, T + 1, R1, (int)d, st, 0, ys16));
+            continue;
+        }
         RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, w.x32, d, w.y32, d, RV_F32, RV_ACT_NONE, R1, d, d, w.sk, w.sk_bytes, st));
         RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, w.x32, w.x16, nullptr, nullptr, 0, R1, (int)d, st));
         RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R1, ff, d, w.sk, w.sk_bytes, st));

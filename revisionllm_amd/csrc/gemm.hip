@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const op16_t* __restrict__ A, i
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) {
                     u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                     *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = p;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const op16_t* __restrict__ A
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
@@ -773,8 +773,13 @@ void launch_gemv(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, con
 
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm) {
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm, int res16) {
     RV_CHECK_ARG(A && W && C, "rv_gemm: null operand");
+    if (res16) {   // a residual of 16-bit operand rows: the tile kernels read it through rv_residual4 (common.h), told by a negative row stride
+        RV_CHECK_ARG(residual && M > 32 && !norm && w_layout <= 1 && ldr > 0 && ldr % 4 == 0, "rv_gemm: a 16-bit residual needs M > 32, bf16 / fp16 weights, ldr %% 4 == 0");
+        ldr = -ldr;
+        ws = nullptr;          // (output-tiled kernels: the stream-K hand-off epilogues are not exercised with it)
+    }
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
     RV_CHECK_ARG(K % 64 == 0, "rv_gemm: K=%lld must be a multiple of 64", (long long)K);

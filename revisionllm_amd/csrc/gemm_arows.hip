@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const op16_t* __restric
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + m * ldc + n) = v;
             }

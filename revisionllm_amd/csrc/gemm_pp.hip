@@ -519,7 +519,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
@@ -579,7 +579,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
-                if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+                if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
@@ -688,7 +688,7 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
-            if (res) v += *(const f32x4*)(res + (int64_t)m * ldr + n);
+            if (res) v += rv_residual4(res, ldr, m, n);
             if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
             else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
         }

@@ -21,6 +21,8 @@ struct RvOpts {
     int lm_head_split = 1;      // LLM forward: the lm_head input is the split pair [hi | lo] over the K-duplicated lm_head whenever "llm.lm_head.p2" is bound (0: bf16 lm_head input, the round-3 arithmetic)
     int last_block_rows = 1;    // LLM prefill with a head (logits asked for): 1 = behind its attention the LAST block runs o / MLP on the last row of every sequence only
                                 // (nothing reads the other rows' outputs of that block: its K / V are in the cache already); 0 = all rows (rounds 1 - 4)
+    int adapter_stream16 = 1;   // ClipEncoder, fp16 build with an output projector: the encoder's residual stream lives in HBM as 16-bit operands (the copies its GEMMs
+                                // read anyway) instead of f32 + 16-bit copies; 0 = the f32 stream (always so in the bf16 build)
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };
@@ -192,7 +194,7 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 // ws: optional zero-initialised stream-K workspace (>= gemm_pp_ws_bytes()); NULL -> output-tiled kernels only
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
-                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr);
+                 int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr, int res16 = 0);   // res16: `residual` points at 16-bit operand rows (M > 32 only)
 int gemv_blocks(int act, int64_t N);
 int gemm_rows(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
               int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 144 fragment-packed rows
@@ -218,7 +220,7 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap = 0);
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap = 0, const void* x_op16 = nullptr);   // x_op16: the input rows as 16-bit operands instead of f32 x
 int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);
@@ -237,6 +239,7 @@ int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,
               int64_t N, int T, int d, hipStream_t st);
 int k_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+int k_rows_to_f32(const void* src16, int64_t ld, float* dst, int64_t rows, int d, hipStream_t st);   // 16-bit operand rows (stride ld) -> contiguous f32 rows
 int k_cls_rows(const float* cls, const float* pm, float* x32, void* x16, void* xp16, int64_t N, int T, int d, hipStream_t st);   // row 0 of every [CLS ; frames] sequence
 int k_transpose_v(const void* v, int64_t ld, void* vt, int64_t Nb, int L, int Lpad, int H, int dh, hipStream_t st);
 int k_rope_table(float* cs, int S, int pos0, int dh, float theta, hipStream_t st);

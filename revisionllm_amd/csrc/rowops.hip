@@ -11,7 +11,8 @@ template <int NV>  // d = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y32,
                                                         op16_t* __restrict__ y16, op16_t* __restrict__ yp16,
-                                                        const float* __restrict__ pos, int64_t period, int64_t rows, int64_t gap) {
+                                                        const float* __restrict__ pos, int64_t period, int64_t rows, int64_t gap,
+                                                        const op16_t* __restrict__ x16in) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+        v[i] = x16in ? op16x4_to_f32(*(const u32x2*)(x16in + row * D + i * 256 + lane * 4)) : *(const f32x4*)(xr + i * 256 + lane * 4);
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) * (1.0f / D);
@@ -248,7 +249,7 @@ __global__ void frames_in_kernel(const op16_t* __restrict__ x, const float* __re
     const u32x2 raw = *(const u32x2*)(x + i);
     const f32x4 f = op16x4_to_f32(raw);
     const float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-    *(f32x4*)(v32 + i) = f32x4{f0, f1, f2, f3};
+    if (v32) *(f32x4*)(v32 + i) = f32x4{f0, f1, f2, f3};
     const f32x4 p = *(const f32x4*)(pos + (row % T) * d + c);
     *(u32x2*)(vp16 + i) = u32x2{pack_op16x2(f0 + p[0], f1 + p[1]), pack_op16x2(f2 + p[2], f3 + p[3])};
 }
@@ -273,7 +274,7 @@ __global__ void build_x_kernel(const op16_t* __restrict__ src16, const float* __
         const u32x2 raw = *(const u32x2*)(src16 + (n * T + (t - 1)) * d + c);
         v = op16x4_to_f32(raw);
     }
-    *(f32x4*)(x32 + i) = v;
+    if (x32) *(f32x4*)(x32 + i) = v;
     *(u32x2*)(x16 + i) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
     const f32x4 p = *(const f32x4*)(pm + (int64_t)t * d + c);
     *(u32x2*)(xp16 + i) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
@@ -289,9 +290,18 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     const int c = (int)(i % d);
     const int64_t o = n * (T + 1) * d + c;
     const f32x4 v = *(const f32x4*)(cls + c), p = *(const f32x4*)(pm + c);
-    *(f32x4*)(x32 + o) = v;
+    if (x32) *(f32x4*)(x32 + o) = v;
     *(u32x2*)(x16 + o) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
     *(u32x2*)(xp16 + o) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
+}
+
+// rows of 16-bit operands (row stride ld) -> contiguous f32 rows
+__global__ void rows_to_f32_kernel(const op16_t* __restrict__ src, int64_t ld, float* __restrict__ dst, int64_t rows, int d) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * d) return;
+    const int64_t r = i / d;
+    const int c = (int)(i % d);
+    *(f32x4*)(dst + i) = op16x4_to_f32(*(const u32x2*)(src + r * ld + c));
 }
 
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
@@ -385,21 +395,21 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __rest
 }  // namespace
 
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap) {
-    RV_CHECK_ARG(x && w && b && rows >= 0, "layernorm: bad arguments");
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap, const void* x_op16) {
+    RV_CHECK_ARG((x || x_op16) && w && b && rows >= 0, "layernorm: bad arguments");
     RV_CHECK_ARG(!yp16 || (pos && period > 0), "layernorm: y_pos needs pos table and period");
     if (rows == 0) return RV_OK;
     const unsigned blocks = (unsigned)cdiv(rows, 4);
     if (d == 768)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
     else if (d == 4096)
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
     else if (d == 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap);
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
     else {
         rv_set_error("layernorm: unsupported width %d (256, 512, 768, 1024, 4096)", d);
         return RV_ERR_ARG;
@@ -492,6 +502,12 @@ int k_build_x(const void* src16, const float* src32, const float* cls, const flo
 int k_cls_rows(const float* cls, const float* pm, float* x32, void* x16, void* xp16, int64_t N, int T, int d, hipStream_t st) {
     hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)cdiv(N * d / 4, 256)), dim3(256), 0, st, cls, pm, x32, (op16_t*)x16, (op16_t*)xp16, N, T, d);
     RV_CHECK_LAUNCH("cls_rows");
+    return RV_OK;
+}
+
+int k_rows_to_f32(const void* src16, int64_t ld, float* dst, int64_t rows, int d, hipStream_t st) {
+    hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)cdiv(rows * d / 4, 256)), dim3(256), 0, st, (const op16_t*)src16, ld, dst, rows, d);
+    RV_CHECK_LAUNCH("rows_to_f32");
     return RV_OK;
 }
 

