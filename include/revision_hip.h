@@ -119,7 +119,7 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        entropy scores, profiles/r4_error_budget.json); 0 = bf16 lm_head input.  Not used with the FP8 decode weights.
  *   "last_block_rows"    1 (default) = a prefill that returns logits runs the LAST block's o / MLP projections (and the head) on the last row of every
  *                        sequence only - nothing reads that block's other output rows (its K / V are cached before); they go through the few-row
- *                        weight-streaming kernels (<= 32 sequences per pass, >= 128 rows).  0 = every row through every block (rounds 1 - 4).  Logits
+ *                        weight-streaming kernels (<= 32 sequences per pass, sequences of >= 32 positions).  0 = every row through every block (rounds 1 - 4).  Logits
  *                        differ in the last bits between the two settings (other summation order in that block's projections).
  *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
  *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the

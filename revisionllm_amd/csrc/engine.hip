@@ -472,12 +472,14 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
                 cls_ld = d;
             }
             RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, cls_res, cls_ld, y0, d, RV_F32, RV_ACT_NONE, N, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st));
+            // (16-bit stream: y0 / y2 are read THROUGH the operand type and y1 - the FFN-2 residual - holds operand-representable values: the same values the
+            //  full-length form of this layer stores as fp16, so the CLS rows do not depend on which form ran)
+            RV_TRY(k_layernorm(y0, L.ln1_w, L.ln1_b, y1, w.x16, nullptr, nullptr, 0, N, (int)d, st, 0, nullptr, s16 ? 3 : 0));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, N, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, y1, d, y2, d, RV_F32, RV_ACT_NONE, N, d, ff, w.sk, w.sk_bytes, st));
             if (!c->adp_proj_w)      // identity projector: the CLS rows' last LayerNorm IS the output
                 return k_layernorm(y2, L.ln2_w, L.ln2_b, (float*)out, nullptr, nullptr, nullptr, 0, N, (int)d, st);
-            RV_TRY(k_layernorm(y2, L.ln2_w, L.ln2_b, nullptr, w.x16, nullptr, nullptr, 0, N, (int)d, st));
+            RV_TRY(k_layernorm(y2, L.ln2_w, L.ln2_b, nullptr, w.x16, nullptr, nullptr, 0, N, (int)d, st, 0, nullptr, s16 ? 1 : 0));
             return rv_gemm_impl(w.x16, d, c->adp_proj_w, d, 1, c->adp_proj_b, nullptr, 0, out, D, RV_F32, RV_ACT_NONE, N, D, d, w.sk, w.sk_bytes, st);
         }
         RV_TRY(rv_gemm_impl(w.xp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, w.qk16, 2 * d, RV_OP16, RV_ACT_NONE, R1, 2 * d, d, w.sk, w.sk_bytes, st));
@@ -639,10 +641,11 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.planes = w.planes;
     consume.arrive = w.arrive;
     if (l1 < 0 || l1 > g.layers) l1 = g.layers;
-    // (see the last block below) a prefill whose head is asked for, on the plain 16-bit path, with few sequences and enough rows PER PREFILL to matter
-    // (Mg, not M: whether a prefill takes this path must not depend on how many prefills share its pass)
+    // (see the last block below) a prefill whose head is asked for, on the plain 16-bit path, with few sequences of >= 32 positions.  The test is on the
+    // SEQUENCE length P0 + S: it must not depend on how many prefills share the pass, nor on whether the prompt prefix is shared (a recursion's calls
+    // run one by one in the reference mode and as one shared-prefix batch in the batched mode: both must take the same kernels)
     const bool tail_block = logits && l1 == g.layers && !par && !p8 && !fuse_norm && !row_pos && (S > 1 || P0 > 0) && c->opt.last_block_rows &&
-                            (int64_t)G * B <= 32 && Mg >= 128 && (size_t)M * F * 2 >= (((size_t)G * B * D * 4 + 255) & ~(size_t)255) + (size_t)G * B * F * 2;
+                            (int64_t)G * B <= 32 && (int64_t)P0 + S >= 32 && (size_t)M * F * 2 >= (((size_t)G * B * D * 4 + 255) & ~(size_t)255) + (size_t)G * B * F * 2;
     for (int l = l0; l < l1; ++l) {
         const LlmLayer& L = c->layers[l];
         op16_t* kc = kbase + l * per_layer;

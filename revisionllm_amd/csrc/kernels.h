@@ -220,7 +220,7 @@ int gemm_pp_launch(const void* A, int64_t lda, const void* Wp, const float* bias
 int gemm_pp_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t N, int64_t K, const QkvRope& r, void* ws,
                      hipStream_t st);
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap = 0, const void* x_op16 = nullptr);   // x_op16: the input rows as 16-bit operands instead of f32 x
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap = 0, const void* x_op16 = nullptr, int rnd = 0);   // rnd: see layernorm_kernel   // x_op16: the input rows as 16-bit operands instead of f32 x
 int k_rmsnorm_quant(const float* x, int64_t x_row_stride, const float* w, void* q8, float* scale, int64_t rows, int d, float eps,
                     hipStream_t st);
 int k_quant_rows_fp8(const void* x16, int64_t ldx, void* q8, int64_t ldq, float* scale, int64_t rows, int K, hipStream_t st);

@@ -12,7 +12,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ b, float* __restrict__ y32,
                                                         op16_t* __restrict__ y16, op16_t* __restrict__ yp16,
                                                         const float* __restrict__ pos, int64_t period, int64_t rows, int64_t gap,
-                                                        const op16_t* __restrict__ x16in) {
+                                                        const op16_t* __restrict__ x16in, int rnd) {
+    // rnd & 1: the f32 input is rounded through the operand type first (what reading a 16-bit copy of it would give); rnd & 2: the f32 output
+    // holds operand-representable values.  The CLS-only last layer of the adapter keeps its few rows in f32 buffers and uses both flags to stay
+    // VALUE-identical to the 16-bit-stream form of the same layer (engine.hip, adapter_stream16).
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -26,6 +29,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = x16in ? op16x4_to_f32(*(const u32x2*)(x16in + row * D + i * 256 + lane * 4)) : *(const f32x4*)(xr + i * 256 + lane * 4);
+        if (rnd & 1) v[i] = op16x4_to_f32(u32x2{pack_op16x2(v[i][0], v[i][1]), pack_op16x2(v[i][2], v[i][3])});
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) * (1.0f / D);
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
-        if (y32) *(f32x4*)(y32 + orow * D + c) = y;
+        if (y32) *(f32x4*)(y32 + orow * D + c) = (rnd & 2) ? op16x4_to_f32(u32x2{pack_op16x2(y[0], y[1]), pack_op16x2(y[2], y[3])}) : y;
         if (y16) *(u32x2*)(y16 + orow * D + c) = u32x2{pack_op16x2(y[0], y[1]), pack_op16x2(y[2], y[3])};
         if (yp16) {
             const f32x4 p = *(const f32x4*)(pr + c);
@@ -395,21 +399,21 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const int32_t* __rest
 }  // namespace
 
 int k_layernorm(const float* x, const float* w, const float* b, float* y32, void* y16, void* yp16, const float* pos,
-                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap, const void* x_op16) {
+                int64_t period, int64_t rows, int d, hipStream_t st, int64_t gap, const void* x_op16, int rnd) {
     RV_CHECK_ARG((x || x_op16) && w && b && rows >= 0, "layernorm: bad arguments");
     RV_CHECK_ARG(!yp16 || (pos && period > 0), "layernorm: y_pos needs pos table and period");
     if (rows == 0) return RV_OK;
     const unsigned blocks = (unsigned)cdiv(rows, 4);
     if (d == 768)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16, rnd);
     else if (d == 4096)
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16, rnd);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16, rnd);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16, rnd);
     else if (d == 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16);
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, b, y32, (op16_t*)y16, (op16_t*)yp16, pos, period, rows, gap, (const op16_t*)x_op16, rnd);
     else {
         rv_set_error("layernorm: unsupported width %d (256, 512, 768, 1024, 4096)", d);
         return RV_ERR_ARG;
