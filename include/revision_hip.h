@@ -121,6 +121,9 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        sequence only - nothing reads that block's other output rows (its K / V are cached before); they go through the few-row
  *                        weight-streaming kernels (<= 32 sequences per pass, sequences of >= 32 positions).  0 = every row through every block (rounds 1 - 4).  Logits
  *                        differ in the last bits between the two settings (other summation order in that block's projections).
+ *   "adapter_fold_t2v"   1 (default) = rv_clip_encoder, text -> video layers (transformer.py:271-305) whose queries have <= 32 text tokens: Q projection + cross-attention +
+ *                        output projection run as x.A1^T -> softmax -> P.A2^T with A1 / A2 folded from the text K / V rows per (layer, query) - the same function, other
+ *                        rounding points (q and the attention output are never rounded to 16 bits; A1 / A2 are).  0 = the three separate steps.
  *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
  *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the
  *                        LayerNorm inputs are read as fp16, accumulation and statistics stay f32 (transformer.py:210-223,271-305 keep fp32 activations; the measured

@@ -221,6 +221,8 @@ __global__ void invert_mask_kernel(const uint8_t* __restrict__ valid, uint8_t* _
 struct ClipWs {
     float *pm, *x32, *y32;
     op16_t *x16, *xp16, *qk16, *vv16, *vt16, *a16, *h16, *tk16, *tv16, *tvt16;
+    op16_t *fa1, *fa2;   // folded text -> video cross-attention: per query A1 [H * LK, d] and A2 [d, H * LK] (fragment-packed), LK <= 32 ...
+    float* fc1;          // ... and c1 [H * LK]
     uint8_t* pad;
     void* sk;  // stream-K GEMM workspace (flags must be zero: the engine's Python owner allocates it zeroed)
     size_t sk_bytes;
@@ -252,7 +254,10 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
     w.tv16 = (op16_t*)k.take((size_t)RT * d * 2);
     w.tvt16 = (op16_t*)k.take((size_t)(Nq > 0 ? Nq : 1) * d * w.Lqpad * 2);
     w.pad = (uint8_t*)k.take((size_t)RT);
-    (void)H;
+    const size_t nqf = (size_t)(Nq > 0 ? Nq : 1);
+    w.fa1 = (op16_t*)k.take(nqf * (size_t)H * 32 * d * 2);
+    w.fa2 = (op16_t*)k.take(nqf * (size_t)H * 32 * d * 2);
+    w.fc1 = (float*)k.take(nqf * (size_t)H * 32 * 4);
     w.bytes = k.off;
     return w;
 }
@@ -311,6 +316,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "lm_head_split") return &o.lm_head_split;
     if (k == "last_block_rows") return &o.last_block_rows;
     if (k == "adapter_stream16") return &o.adapter_stream16;
+    if (k == "adapter_fold_t2v") return &o.adapter_fold_t2v;
     return nullptr;
 }
 }  // namespace
@@ -386,7 +392,7 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
     // significand bits: the rounding its consumer GEMMs apply anyway), the residual operand of the out-projection / FFN-2 epilogues is read as fp16
     // (rv_gemm_impl res16) and LayerNorm reads fp16 rows.  The f32 round trips were 0.44 ms of the adapter's 1.87 ms (tools/ffn2_probe.py: FFN-2 131 us
     // with its f32 output + residual, 89 us without); accumulation, LayerNorm statistics and the CLS-only last layer stay f32.
-    const bool s16 = RV_OP_F16 != 0 && c->adp_proj_w != nullptr && c->opt.adapter_stream16 != 0;
+    const bool s16 = RV_OP_F16 != 0 && c->adp_proj_w != nullptr && c->opt.adapter_stream16 != 0 && (int64_t)N * T > 32;   // (> 32 rows: the tile kernels, which read a 16-bit residual)
     op16_t* xs16 = (op16_t*)w.x32;      // (the f32 buffers, re-used for the 16-bit stream: half their size is enough)
     op16_t* ys16 = (op16_t*)w.y32;
     // position table: row 0 = learned CLS position, rows 1..T = sine embedding (transformer.py:109-116)
@@ -404,15 +410,41 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         for (size_t l = 0; l < c->t2v.size(); ++l) {
             const AdapterLayer& L = c->t2v[l];
             op16_t* q16 = w.qk16;
-            RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
-            AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
-                       w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
-            RV_TRY(k_attention(a, st));
+            // Folded cross-attention (rowops.hip t2v_fold_kernel): all frame rows of a query attend to its <= 32 text tokens, so Q projection + attention +
+            // output projection = x . A1^T -> softmax -> P . A2^T: two skinny GEMMs (K = 768 -> N = H * LK; K = H * LK -> N = 768) instead of two 768 x 768 ones
+            // and two [rows, 768] round trips.  Per query: the rows of its N / Nq windows.
+            const int LK = Lq <= 16 ? 16 : 32;
+            const int64_t NK = (int64_t)H * LK, Rq = (int64_t)(N / Nq) * T;
+            const bool fold = c->opt.adapter_fold_t2v != 0 && Lq <= 32 && dh <= 128 && NK % 64 == 0 && Rq > 32;
+            if (fold) {
+                float* S32 = (float*)w.qk16;        // [R0, NK] f32 (the q / k buffer is free in this stage)
+                op16_t* P16 = w.a16;                // [R0, NK]
+                RV_TRY(k_t2v_fold(L.w_in, L.b_in, L.w_out, w.tk16, w.tv16, Nq, Lq, LK, H, dh, scale, w.fa1, w.fc1, w.fa2, st));
+                for (int qi = 0; qi < Nq; ++qi)
+                    RV_TRY(rv_gemm_impl(vp16 + qi * Rq * d, d, w.fa1 + qi * NK * d, d, 1, w.fc1 + qi * NK, nullptr, 0, S32 + qi * Rq * NK, NK, RV_F32, RV_ACT_NONE, Rq, NK, d,
+                                        w.sk, w.sk_bytes, st));
+                RV_TRY(k_t2v_softmax(S32, w.pad, P16, R0, H, LK, Lq, Rq, st));
+                for (int qi = 0; qi < Nq; ++qi) {
+                    const int64_t r0 = qi * Rq;
+                    if (s16)
+                        RV_TRY(rv_gemm_impl(P16 + r0 * NK, NK, w.fa2 + qi * NK * d, NK, 1, L.b_out, (const float*)(vres16 + r0 * d), d, ys16 + r0 * d, d, RV_OP16, RV_ACT_NONE, Rq, d,
+                                            NK, w.sk, w.sk_bytes, st, nullptr, 1));
+                    else
+                        RV_TRY(rv_gemm_impl(P16 + r0 * NK, NK, w.fa2 + qi * NK * d, NK, 1, L.b_out, v32 + r0 * d, d, w.y32 + r0 * d, d, RV_F32, RV_ACT_NONE, Rq, d, NK, w.sk,
+                                            w.sk_bytes, st));
+                }
+            } else {
+                RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
+                RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
+                AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
+                           w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
+                RV_TRY(k_attention(a, st));
+            }
             if (s16) {
-                RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, (const float*)vres16, d, ys16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st, nullptr, 1));
+                if (!fold)
+                    RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, (const float*)vres16, d, ys16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st, nullptr, 1));
                 RV_TRY(k_layernorm(nullptr, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st, 0, ys16));
                 RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
                 RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, (const float*)ys16, d, ys16, d, RV_OP16, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st, nullptr, 1));
@@ -425,7 +457,8 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
                 }
                 continue;
             }
-            RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
+            if (!fold)
+                RV_TRY(rv_gemm_impl(w.a16, d, L.w_out, d, 1, L.b_out, v32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
             RV_TRY(k_layernorm(w.y32, L.ln1_w, L.ln1_b, nullptr, w.x16, nullptr, nullptr, 0, R0, (int)d, st));
             RV_TRY(rv_gemm_impl(w.x16, d, L.w1, d, 1, L.b1, nullptr, 0, w.h16, ff, RV_OP16, RV_ACT_RELU, R0, ff, d, w.sk, w.sk_bytes, st));
             RV_TRY(rv_gemm_impl(w.h16, ff, L.w2, ff, 1, L.b2, w.y32, d, w.y32, d, RV_F32, RV_ACT_NONE, R0, d, ff, w.sk, w.sk_bytes, st));

@@ -23,6 +23,8 @@ struct RvOpts {
                                 // (nothing reads the other rows' outputs of that block: its K / V are in the cache already); 0 = all rows (rounds 1 - 4)
     int adapter_stream16 = 1;   // ClipEncoder, fp16 build with an output projector: the encoder's residual stream lives in HBM as 16-bit operands (the copies its GEMMs
                                 // read anyway) instead of f32 + 16-bit copies; 0 = the f32 stream (always so in the bf16 build)
+    int adapter_fold_t2v = 1;   // ClipEncoder text -> video layers with <= 32 text tokens: Q projection + cross-attention + output projection as two skinny GEMMs around a
+                                // softmax (rowops.hip t2v_fold_kernel); 0 = the three separate steps
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };
@@ -234,6 +236,10 @@ int k_split_bf16(const float* x, int64_t ldx, void* y16, int64_t rows, int n, hi
 int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t M, int64_t D, hipStream_t st);
 // output row i = gi * B + b of a_out (16-bit) / h_out (f32) <- input row idx[i], or gi * Mg + P0 + b * S + S - 1 with idx == nullptr
 int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t rows, int Mg, int P0, int B, int S, void* a_out, float* h_out, int D, hipStream_t st);
+// text -> video cross-attention folded into two skinny GEMMs (rowops.hip): A1p [Nq][H * LK, d] / A2p [Nq][d, H * LK] fragment-packed, c1 [Nq][H * LK]
+int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int Nq, int Lq, int LK, int H, int dh, float scale,
+               void* A1p, float* c1, void* A2p, hipStream_t st);
+int k_t2v_softmax(const float* S, const uint8_t* pad, void* P16, int64_t rows, int H, int LK, int Lq, int64_t rows_per_query, hipStream_t st);
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);
 int k_frames_in(const void* x16, const float* pos, float* v32, void* vp16, int64_t rows, int T, int d, hipStream_t st);
 int k_build_x(const void* src16, const float* src32, const float* cls, const float* pm, float* x32, void* x16, void* xp16,

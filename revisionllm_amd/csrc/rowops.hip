@@ -354,6 +354,83 @@ __global__ __launch_bounds__(256) void gather_last_rows_kernel(const op16_t* __r
     }
 }
 
+// ---- text -> video cross-attention, FOLDED (round 5).  In a T2V layer (adapter/transformer.py:271-305: nn.MultiheadAttention with query = frames + pos, key = value =
+// the query's <= 32 text tokens) every one of the N x T frame rows attends to the SAME few keys, so the three steps "Q projection, attention, output projection" - 60 GFLOP
+// and two [rows, 768] round trips per layer at 100 x 256 rows - collapse algebraically into two skinny GEMMs around a softmax:
+//     S[r, (h, j)] = scale * (q_r,h . k_j,h) = x_r . A1[(h, j), :] + c1[(h, j)]       A1[(h, j), k] = scale * sum_d K[j, h d] Wq[h d, k],  c1 = scale * bq_h . K[j, h]
+//     out[r, n]   = sum_(h, j) P[r, (h, j)] * A2[n, (h, j)] + bo[n]                   A2[n, (h, j)] = sum_d Wo[n, h d] V[j, h d]
+// with P = softmax over the valid keys j of head h.  A1 [H * LK, d] and A2 [d, H * LK] (LK = 16 or 32 key slots per head) are built here per (layer, query) from
+// the text K / V rows - 19 MFLOP - directly in the fragment-packed weight layout of the GEMM kernels; 2 x 5 GFLOP of GEMMs replace the 60.
+__device__ __forceinline__ int64_t rv_wp_index(int n, int k, int K) {      // element (n, k) of a fragment-packed [N, K] weight (ops.pack_fragments)
+    return ((((int64_t)(n >> 4) * (K >> 5) + (k >> 5)) * 64 + (n & 15) + 16 * ((k >> 3) & 3)) * 8) + (k & 7);
+}
+// grid (ceil(d / 256), H * LK, Nq); A1p / A2p: [Nq][H * LK * d] packed, c1: [Nq][H * LK]
+__global__ __launch_bounds__(256) void t2v_fold_kernel(const op16_t* __restrict__ wq_p, const float* __restrict__ bq, const op16_t* __restrict__ wo_p,
+                                                       const op16_t* __restrict__ tk, const op16_t* __restrict__ tv, int Lq, int LK, int H, int dh, int d, float scale,
+                                                       op16_t* __restrict__ A1p, float* __restrict__ c1, op16_t* __restrict__ A2p) {
+    const int k = blockIdx.x * 256 + threadIdx.x;          // a column of Wq (A1) / a row of Wo (A2)
+    const int hj = blockIdx.y, h = hj / LK, j = hj % LK, q = blockIdx.z;
+    const int NK = H * LK;
+    __shared__ float kr[128], vr[128];                      // the key / value row of (query, token j), head h
+    const bool valid = j < Lq;
+    for (int t = threadIdx.x; t < dh; t += 256) {
+        kr[t] = valid ? op16_to_f32(tk[((int64_t)q * Lq + j) * d + h * dh + t]) : 0.f;
+        vr[t] = valid ? op16_to_f32(tv[((int64_t)q * Lq + j) * d + h * dh + t]) : 0.f;
+    }
+    __syncthreads();
+    if (k < d) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int t = 0; t < dh; ++t) {
+            a1 += kr[t] * op16_to_f32(wq_p[rv_wp_index(h * dh + t, k, d)]);       // Wq[h dh + t, k]
+            a2 += vr[t] * op16_to_f32(wo_p[rv_wp_index(k, h * dh + t, d)]);       // Wo[k, h dh + t]   (k plays n here)
+        }
+        A1p[(int64_t)q * NK * d + rv_wp_index(hj, k, d)] = f32_to_op16(a1 * scale);
+        A2p[(int64_t)q * NK * d + rv_wp_index(k, hj, NK)] = f32_to_op16(a2);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {              // c1[(h, j)] = scale * bq_h . K[j, h]
+        float c = 0.f;
+        for (int t = threadIdx.x; t < dh; t += 64) c += kr[t] * bq[h * dh + t];
+        c = wave_sum(c);
+        if (threadIdx.x == 0) c1[(int64_t)q * NK + hj] = c * scale;
+    }
+}
+// P[r, (h, j)] = softmax_j (S[r, (h, j)]) over the keys j < Lq that are not padded (pad[q][j] == 1: ignore); one thread per (row, head) - its LK scores are 64 / 128
+// contiguous bytes, a wave's are one contiguous 4 / 8 KiB run: 16-byte loads and 8-byte stores; the other slots get 0
+template <int LK>
+__global__ __launch_bounds__(256) void t2v_softmax_kernel(const float* __restrict__ S, const uint8_t* __restrict__ pad, op16_t* __restrict__ P, int64_t rows, int H, int Lq,
+                                                          int64_t rows_per_query) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * H) return;
+    const int64_t r = i / H;
+    const uint8_t* pq = pad + (r / rows_per_query) * Lq;
+    unsigned valid = 0u;                                     // bit j: key j exists and is not padding
+    for (int j = 0; j < Lq; ++j) valid |= (pq[j] == 0 ? 1u : 0u) << j;
+    const f32x4* s4 = (const f32x4*)(S + i * LK);
+    f32x4 v[LK / 4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < LK / 4; ++c) {
+        v[c] = s4[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!((valid >> (c * 4 + e)) & 1u)) v[c][e] = -INFINITY;
+            mx = fmaxf(mx, v[c][e]);
+        }
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int c = 0; c < LK / 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[c][e] = mx == -INFINITY ? 0.f : __expf(v[c][e] - mx);      // (a query whose every token is padding: no key - all zeros)
+            z += v[c][e];
+        }
+    const float iz = z > 0.f ? 1.0f / z : 0.f;
+    u32x2* p2 = (u32x2*)(P + i * LK);
+#pragma unroll
+    for (int c = 0; c < LK / 4; ++c) p2[c] = u32x2{pack_op16x2(v[c][0] * iz, v[c][1] * iz), pack_op16x2(v[c][2] * iz, v[c][3] * iz)};
+}
+
 // ---- RoPE (cos, sin) table; the rotation itself and the KV-cache append live in the fused QKV epilogue (gemm.hip) ----
 // cs: (cos, sin) table [S][dh/2] for positions pos0..pos0+S-1, built once per forward (shared by all layers).
 __global__ void rope_table_kernel(float2* __restrict__ cs, int S, int pos0, int dh, float theta) {
@@ -542,6 +619,27 @@ int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t 
     RV_CHECK_ARG(a16 && h && a_out && h_out && rows > 0 && D % 4 == 0, "gather_last_rows: bad arguments");
     hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const op16_t*)a16, h, idx, Mg, P0, B, S, (op16_t*)a_out, h_out, D);
     RV_CHECK_LAUNCH("gather_last_rows");
+    return RV_OK;
+}
+
+int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int Nq, int Lq, int LK, int H, int dh, float scale,
+               void* A1p, float* c1, void* A2p, hipStream_t st) {
+    const int d = H * dh;
+    RV_CHECK_ARG(wq_p && bq && wo_p && tk16 && tv16 && A1p && c1 && A2p && Nq > 0 && Lq > 0 && Lq <= LK && (LK == 16 || LK == 32) && dh <= 128 && d % 32 == 0,
+                 "t2v_fold: bad arguments");
+    hipLaunchKernelGGL(t2v_fold_kernel, dim3((unsigned)cdiv(d, 256), (unsigned)(H * LK), (unsigned)Nq), dim3(256), 0, st, (const op16_t*)wq_p, bq, (const op16_t*)wo_p,
+                       (const op16_t*)tk16, (const op16_t*)tv16, Lq, LK, H, dh, d, scale, (op16_t*)A1p, c1, (op16_t*)A2p);
+    RV_CHECK_LAUNCH("t2v_fold");
+    return RV_OK;
+}
+
+int k_t2v_softmax(const float* S, const uint8_t* pad, void* P16, int64_t rows, int H, int LK, int Lq, int64_t rows_per_query, hipStream_t st) {
+    RV_CHECK_ARG(S && pad && P16 && rows > 0 && (LK == 16 || LK == 32) && Lq <= LK && rows_per_query > 0, "t2v_softmax: bad arguments");
+    if (LK == 16)
+        hipLaunchKernelGGL(t2v_softmax_kernel<16>, dim3((unsigned)cdiv(rows * H, 256)), dim3(256), 0, st, S, pad, (op16_t*)P16, rows, H, Lq, rows_per_query);
+    else
+        hipLaunchKernelGGL(t2v_softmax_kernel<32>, dim3((unsigned)cdiv(rows * H, 256)), dim3(256), 0, st, S, pad, (op16_t*)P16, rows, H, Lq, rows_per_query);
+    RV_CHECK_LAUNCH("t2v_softmax");
     return RV_OK;
 }
 
