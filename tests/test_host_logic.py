@@ -172,6 +172,40 @@ def test_abi_exports_every_declared_symbol():
         assert lib.rv_init_hash(ctypes.c_void_p(64), other, 16, 0, 1.0, 0.0, None) < 0
 
 
+def test_operand_flavour_plumbing_on_the_host():
+    """The two builds behind one Python surface (hip.py): flavour names / dtypes, the process default and its override, per-library option contexts that are
+    refused by the other library, the unknown-option error naming the entry point, and the host-side rounding grids the fixtures use."""
+    import numpy as np
+    from revisionllm_amd.utils import hashinit
+    assert hip.flavour_of("f16") == hip.flavour_of(torch.float16) == hip.flavour_of(torch.zeros(2, dtype=torch.float16)) == "f16"
+    assert hip.flavour_of(torch.bfloat16) == "bf16" and hip.op_dtype("bf16") is torch.bfloat16 and hip.op_dtype("f16") is torch.float16
+    with pytest.raises(hip.HipLibraryError):
+        hip.flavour_of(torch.float32)
+    with pytest.raises(ValueError):
+        hip.flavour_of("fp8")
+    prev = hip.set_flavour("bf16")
+    try:
+        assert hip.flavour() == "bf16" and hip.op_dtype() is torch.bfloat16 and hip.flavour_of(None) == "bf16"
+    finally:
+        hip.set_flavour(prev)
+    assert hip.flavour() == prev
+    for f in ("f16", "bf16"):
+        o = hip.Options(flavour=f, gemm_tile_variant=6, last_block_rows=0, adapter_stream16=0, adapter_fold_t2v=0)
+        assert o.flavour == f and o.get("gemm_tile_variant") == 6 and o.get("last_block_rows") == 0 and o.get("adapter_fold_t2v") == 0
+        assert hip.ctx_ptr(o, f) is o._ctx and hip.ctx_ptr(None, f) is None
+        with pytest.raises(hip.HipLibraryError, match="context"):
+            hip.ctx_ptr(o, "bf16" if f == "f16" else "f16")
+        with pytest.raises(hip.HipLibraryError, match="unknown option"):
+            o.set("no_such_option", 1)
+    for k in hip.OPTION_KEYS:                       # every documented key exists in both libraries
+        assert hip.Options(flavour="f16").get(k) == hip.Options(flavour="bf16").get(k)
+    x = np.array([1.0 + 2.0 ** -9, 1.0 + 2.0 ** -12, 70000.0, -1e9, 3e-8], dtype=np.float32)
+    assert hashinit.round_op(x, None) is x and np.array_equal(hashinit.round_op(x, True), hashinit.round_bf16(x))
+    f16 = hashinit.round_op(x, "f16")
+    assert f16[0] == np.float32(1.0 + 2.0 ** -9) and f16[1] == 1.0 and f16[2] == 65504.0 and f16[3] == -65504.0      # 11 bits kept; saturated, never inf
+    assert hashinit.round_op(x, "bf16")[0] == 1.0                                                                       # 8 bits: the same value rounds away
+
+
 def test_product_has_no_cpu_fallback():
     from revisionllm_amd import ops
     with pytest.raises(hip.HipLibraryError, match="no CPU path|device tensors"):
