@@ -66,6 +66,9 @@
 #ifndef RS_PART
 #define RS_PART 0
 #endif
+#ifndef RS_DW_BIG
+#define RS_DW_BIG 4            // weight ring depth at 8 / 9 row blocks (probe builds: tools/rows_ab.sh)
+#endif
 
 namespace {
 
@@ -101,7 +104,7 @@ constexpr int RS_THREADS = (RS_W + 1) * 64;
 // (GemvNorm::w_scale).  A 128-k stage is then 2 loads of 1 KiB per consumer wave instead of 4: the ring is twice as many STAGES deep for
 // the same registers (and the same bytes in flight).
 template <int MB, int WP = 1> struct RowsCfg {
-    static constexpr int DW = WP == 2 ? 8 : 4, LPS = WP == 2 ? 2 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2;
+    static constexpr int DW = WP == 2 ? 8 : (MB >= 8 ? RS_DW_BIG : 4), LPS = WP == 2 ? 2 : 4, DX = MB == 4 ? 4 : 3, WPE = MB <= 5 ? 3 : 2;
 };
 typedef unsigned int rs_w8 __attribute__((ext_vector_type(4)));
 
@@ -223,6 +226,36 @@ __device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wa
     }
 }
 
+// Round 5.  With 8 / 9 row blocks a CU holds ONE workgroup: one consumer wave per SIMD, nothing to hide a wave's LDS latency but its own
+// instruction stream - and the compiler's schedule of a stage was "two fragment reads, wait, two MFMAs" eighteen times over (it sinks the 36
+// reads to their uses to save registers): every pair paid a full LDS round trip, a stage took the SUM of its LDS time (4 waves x 36 KiB = 1152
+// cycles) and its MFMA time (36 x 32 cycles) instead of the larger of the two.  The stage's order is now prescribed: RS_PF fragment reads ahead of
+// the MFMA that consumes the oldest (a rotating window of RS_PF x 4 registers; the compiler still inserts the exact lgkmcnt waits).
+// Measured (same box, isolated 140-row steps, alternating libraries): 8.26 / 8.27 -> 8.04 / 8.10 ms and 8.42 / 8.36 -> 8.16 / 8.28 ms per step
+// (112 rows: 7.39 / 7.34 -> 7.03 / 7.16) - 2 %, not the 2 x the cycle count promised: ds_read_b128 moves 256 B/clk (a stage's 144 KiB = 576
+// cycles, as long as its 36 MFMAs of 16 cycles), so a stage was never LDS- or MFMA-bound; what the launch waits for is its weight stream.
+// And a DEEPER weight ring at 9 row blocks (RS_DW_BIG = 6 / 8 with this window or a 4-fragment one: the registers are there at one workgroup
+// per CU) is slower again: 8.68 / 8.63 / 9.40 ms per step (the persistent form pads an item's 16 stages to the ring depth; 8 deep spills).
+#ifndef RS_PF_N
+#define RS_PF_N 8
+#endif
+constexpr int RS_PF = RS_PF_N;
+template <int MB, int WP>
+__device__ __forceinline__ void rows_stage_schedule() {
+#ifndef RS_NO_STAGE_SCHEDULE
+    if constexpr (MB >= 8 && !(RS_PROBE & 4)) {
+        constexpr int R = 4 * MB;                                         // fragment reads = MFMAs of a stage
+        __builtin_amdgcn_sched_group_barrier(0x100, RS_PF, 0);            // DS reads
+#pragma unroll
+        for (int i = 0; i < R - RS_PF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // ... one read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, RS_PF, 0);
+    }
+#endif
+}
+
 // FIN: 0 = f32 out, one tile per block (o / down projections: residual, next-norm prescale + sums of squares)
 //      1 = bf16 SILU(gate) * up, tile pairs (gate/up)        2 = f32 out, tile pairs (N >= 16384: lm_head)
 //      3 = fused q/k/v + RoPE epilogue                        4 = bf16 out, one tile per block
@@ -340,6 +373,7 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
                                 }
                             }
                         }
+                        rows_stage_schedule<MB, WP>();
                     }
                     if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
                         if constexpr (VPW > 1) {
@@ -608,6 +642,7 @@ rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float*
                                 }
                             }
                         }
+                        rows_stage_schedule<MB, WP>();
                         if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
                             if constexpr (VPW > 1) {
                                 bool placed = false;
