@@ -45,8 +45,16 @@
 // 56 MB of extra traffic next to 180 MB of weights (PMC: 241 MB per launch), which eats most of the second round's fixed cost.
 // 129 .. 144 rows (MB = 9: twenty 7-row generates in one step): 10.07 ms per step = 0.50 ms per generate (70 rows: 0.68, 112: 0.54).
 // (e) rows_single (8 / 9 row blocks): the fused QKV projection (192 column groups) runs UNSPLIT on 192 of the 256 CUs - 84 -> 64 us per launch at
-// 140 rows, step 10.06 -> 9.47 ms: at one workgroup per CU the four consumer waves each read the WHOLE slab (4 x 36 KiB per stage = 1150 LDS
-// cycles), so a launch is bound by LDS reads per stage rather than by how many CUs stream - fewer, longer workgroups without planes win.
+// 140 rows, step 10.06 -> 9.47 ms: fewer, longer workgroups without planes win.  (Round 3 put that down to LDS reads - "4 x 36 KiB per stage =
+// 1150 LDS cycles" - which counted ds_read_b128 at 128 B/clk; it moves 256: a stage's reads are 576 cycles, as long as its 36 MFMAs.)
+// (f) Round 5, the probes again at 140 rows (plain epilogues, back-to-back launches, us per launch for N = 12288 / 22016 at K = 4096; regular
+// 32.5 / 58.5): weights L1-hot 23.8 / 43.6; no barriers 33.3 / 63.7; no MFMAs 32.1 / 57.7; no slabs 30.0 / 55.8; hot + no barriers + no slabs
+// 21.1 / 37.9, ... + no MFMAs 14.0 / 27.1, ... + no LDS reads 19.1 / 36.2, all of them off 11.0 / 26.2.  So a stage of the bare loop costs ~460
+// cycles, its MFMAs add ~600 (they do NOT hide under the loop's own issue stream with one wave per SIMD) and its LDS reads ~100; with real
+// weights the stage takes 0.9 us whatever the ring depth (RS_DW_BIG = 5 / 6 / 8: N = 4096 shapes unchanged to the 0.1 us, the others slower by
+// their pad slots and spills) and whatever order the tiles' k-blocks are walked in (RS_PROBE & 8192: 58.5 -> 55.2, 32.9 -> 33.0): 16 KiB per CU
+// per 0.9 us = 4.4 TB/s marginal next to a fixed 8 (N = 4096) .. 17 us (gate/up) per launch.  What a launch at 9 row blocks pays for is the
+// memory system's rate at one workgroup per CU and its fixed cost, not the stage's arithmetic.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -60,6 +68,8 @@
 //   RS_PROBE & 2   no per-stage barrier: consumers and producer run free (slabs may be stale)
 //   RS_PROBE & 4   no MFMAs (the accumulators get one add per stage so that the loads stay live)
 //   RS_PROBE & 8   the producer stages no slabs at all
+//   RS_PROBE & 8192  every wave walks its tile's k-blocks from its own rotated start (sums in another order: is the weight stream camping on channels?)
+//   RS_PROBE & 4096  one activation fragment per stage instead of 4 * MB (the compiler hoists the read: no LDS traffic in the loop)
 #ifndef RS_PROBE
 #define RS_PROBE 0
 #endif
@@ -332,7 +342,7 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
             kb_ = sp * VPW + li + 8 * lc;                                                                                            \
             if (++lc == vcount(li)) { lc = 0; ++li; }                                                                                \
         }                                                                                                                            \
-        const op16_t* ws_ = kb_ >= 0 ? ((RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048)) : X + lane * 8; \
+        const op16_t* ws_ = kb_ >= 0 ? ((RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)((RS_PROBE & 8192) ? (kb_ + ((int)blockIdx.x * RS_W + wave) * 5) % nkb : kb_) * (WP == 2 ? 1024 : 2048)) : X + lane * 8; \
         _Pragma("unroll") for (int j_ = 0; j_ < LPS; ++j_)                                                                          \
             wf[slot][j_] = __builtin_nontemporal_load((const typename std::remove_reference<decltype(wf[0][0])>::type*)(ws_ + j_ * 512)); \
     } while (0)
@@ -365,7 +375,7 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const op16x8 xf = *(const op16x8*)(xs + (j * MB + mb) * 1024);
+                                const op16x8 xf = *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
@@ -596,7 +606,7 @@ rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float*
         if (ln < n_it) {                                                                                                             \
             if (lp < T) {                                                                                                            \
                 const int kb_ = sp * VPW + li + 8 * lc;                                                                              \
-                ws_ = (RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)kb_ * (WP == 2 ? 1024 : 2048);                 \
+                ws_ = (RS_PROBE & 1) ? W + lane * 8 + (kb_ & 1) * 2048 : wp + (int64_t)((RS_PROBE & 8192) ? (kb_ + ((int)blockIdx.x * RS_W + wave) * 5) % (K >> 7) : kb_) * (WP == 2 ? 1024 : 2048);                 \
                 if (++lc == vcount(li)) { lc = 0; ++li; }                                                                            \
             }                                                                                                                        \
             if (++lp == Tp) { lp = 0; li = 0; ++ln; wp += item_stride; }                                                             \
@@ -634,7 +644,7 @@ rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float*
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const op16x8 xf = *(const op16x8*)(xs + (j * MB + mb) * 1024);
+                                const op16x8 xf = *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
