@@ -316,7 +316,8 @@ int rv_llm_decode_rows_shared(rv_ctx* ctx, float* h, int32_t R, const int32_t* r
  * scores), n_keep i32 [B].  top_k in [1, 64], or 0 = NO top-k filter (HF: `top_k` None / 0 - TopKLogitsWarper is not instantiated; what a
  * checkpoint's generation_config.json may ask for: inference.py:45-59 passes no top_k, so the config's value rules): every token is a candidate,
  * only top-p trims; no candidate list is produced then (out_topk_* = -1 / -inf, n_keep = the number kept) and the kept set is
- * {processed score >= out_threshold[b]}.  out_threshold f32 [B] (optional, may be NULL): the smallest processed score the filters keep. */
+ * {processed score >= out_threshold[b]}.  top_k > 64 (wider than the list; >= V removes nothing) runs the same way: TopKLogitsWarper's rule - every score
+ * below the top_k-th largest one goes, a tie at that place stays whole - then top-p over what is left.  out_threshold f32 [B] (optional, may be NULL): the smallest processed score the filters keep. */
 int rv_sample(const rv_ctx* ctx /* optional: tunables */, const float* logits, int32_t B, int32_t V, const float* uniforms, int32_t do_sample, float temperature,
               int32_t top_k, float top_p, int32_t* out_tokens, float* out_entropy_proc, float* out_entropy_raw,
               int32_t* out_topk_idx, float* out_topk_val, int32_t* out_nkeep, float* out_threshold, void* stream);

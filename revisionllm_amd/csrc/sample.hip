@@ -190,7 +190,7 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
     const float inv_t = do_sample ? 1.0f / temperature : 1.0f;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) v[j] = tid + j * TPB < V ? v[j] * inv_t : -INFINITY;
-    if (do_sample && top_k == 0) {
+    if (do_sample && (top_k == 0 || top_k > KCAP)) {
         // ---- top_k = 0: HF's "filter disabled" (TopKLogitsWarper is not instantiated) - every token is a candidate, only top-p trims.  No list of
         // candidates can hold V entries, so nothing is sorted: the two places where the reference's order matters (the ascending cumulative
         // sum of TopPLogitsWarper, the inverse-CDF walk in descending order) are answered by a 32-round binary descent over the order-preserving
@@ -206,11 +206,25 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
             mx = fmaxf(mx, v[j]);
         }
         mx = block_max(mx, sh);
+        // top_k > KCAP (no list can hold the candidates either): TopKLogitsWarper removes every score BELOW the top_k-th largest one (a tie at that
+        // place stays whole) - the same descent, over counts: kcut = the largest key that at least top_k keys reach; what lies below it gets no mass
+        // and, through `cut` >= kcut, no part in anything that follows.  top_k >= V removes nothing (HF: min(top_k, V)).
+        unsigned kcut = 0u;
+        if (top_k > 0 && top_k < V) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned c2 = kcut | (1u << bit);
+                float reach = 0.f;
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) reach += key[j] >= c2 ? 1.f : 0.f;       // (padding keys are 0: never >= c2; counts <= 32768 are exact)
+                reach = block_sum(reach, sh);
+                if (reach >= (float)top_k) kcut = c2;
+            }
+        }
         float ex[ITEMS];
         float z = 0.f;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            ex[j] = expf(v[j] - mx);
+            ex[j] = key[j] >= kcut ? expf(v[j] - mx) : 0.f;
             z += ex[j];
         }
         z = block_sum(z, sh);
@@ -220,7 +234,8 @@ __global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ l
         kmax = block_max_u32(kmax, shu);                         // the largest key: never removed (HF keeps at least one token)
         // top-p: remove the ascending prefix whose inclusive cumulative probability stays <= 1 - top_p; keep from key `cut` on
         unsigned cut = 0u;
-        if (top_p < 1.0f) {
+        if (top_p >= 1.0f) cut = kcut;
+        else {               // (the keys below kcut carry no mass: the descent ends at or above it)
             const float t = (1.0f - top_p) * z;                 // compare un-normalised sums
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned c2 = cut | (1u << bit);
@@ -821,7 +836,7 @@ extern "C" int rv_sample(const rv_ctx* ctx, const float* logits, int32_t B, int3
     RV_CHECK_ARG(logits && out_tokens && out_entropy_proc && out_entropy_raw && out_nkeep, "rv_sample: null output");
     RV_CHECK_ARG(B > 0 && V > 0 && V <= TPB * ITEMS, "rv_sample: V=%d exceeds %d", V, TPB * ITEMS);
     if (do_sample) {
-        RV_CHECK_ARG(top_k >= 0 && top_k <= KCAP, "rv_sample: top_k=%d must be 0 (no top-k filter) or in [1,%d] when sampling", top_k, KCAP);
+        RV_CHECK_ARG(top_k >= 0, "rv_sample: top_k=%d must be 0 (no top-k filter) or positive when sampling", top_k);
         RV_CHECK_ARG(temperature > 0.f && top_p > 0.f, "rv_sample: temperature and top_p must be positive");
         RV_CHECK_ARG(out_topk_idx && out_topk_val, "rv_sample: candidate outputs required when sampling");
     }

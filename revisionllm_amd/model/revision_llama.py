@@ -524,9 +524,9 @@ class ReVisionLlamaForCausalLM:
             ent_r.append(o["entropy_raw"])
             if output_logits or (output_scores and (not do_sample or self.scores_mode == "raw")):
                 raw_steps.append(logits.clone())
-            if output_scores and do_sample and self.scores_mode == "processed" and not top_k:
-                # no top-k filter (top_k = 0 / None): there is no candidate list - the processed scores are logits / T with everything below the
-                # kernel's top-p threshold at -inf
+            if output_scores and do_sample and self.scores_mode == "processed" and (not top_k or top_k > hip.TOPK_CAP):
+                # no top-k filter (top_k = 0 / None) or one wider than the candidate list (top_k > 64): there is no list - the processed scores are
+                # logits / T with everything below the kernel's threshold (the smallest score the top-k and top-p filters keep) at -inf
                 sc = logits / temperature
                 score_steps.append(sc.masked_fill(sc < o["threshold"][:, None], float("-inf")))
             elif output_scores and do_sample and self.scores_mode == "processed":

@@ -253,7 +253,7 @@ def h2d(t, device, dtype=None):
 
 def sample(logits, uniforms=None, do_sample=False, temperature=1.0, top_k=50, top_p=1.0, ctx=None):
     """-> dict(tokens i32 [B], entropy_proc, entropy_raw f32 [B], topk_idx i32 [B,64], topk_val f32 [B,64], n_keep i32 [B], threshold f32 [B]).
-    ``top_k`` in [1, 64], or 0 / None = no top-k filter (HF: filter disabled): no candidate list then - the kept set is {processed score >=
+    ``top_k`` in [1, 64]; 0 / None = no top-k filter (HF: filter disabled) and ``top_k`` > 64 (kept by threshold: scores below the top_k-th largest go): no candidate list then - the kept set is {processed score >=
     threshold}.  (The kernel writes every output element, so the buffers are plain ``empty`` allocations.)"""
     top_k = 0 if top_k is None else top_k
     B, V = logits.shape

@@ -607,6 +607,49 @@ def test_sample_without_a_top_k_filter(dev):
         assert int(o["tokens"][0]) == want == int(sampling.select_token(sampling.process_logits(lt, 1.0, 0, 1.0), torch.tensor([uu]))[0]), (uu, int(o["tokens"][0]))
 
 
+def test_sample_with_a_top_k_wider_than_the_candidate_list(dev):
+    """top_k > 64 (HF allows any; the kernel's candidate list holds 64): TopKLogitsWarper by threshold - every score below the top_k-th largest goes, a
+    tie at that place stays whole - then top-p and the draw as in the unfiltered path.  Against the oracle's warper chain: kept counts (exact for
+    top_p = 1, ties included), threshold, processed entropy, drawn tokens; top_k >= V equals top_k = 0; top_k = 65 next to the list path's 64."""
+    from oracle import sampling, scores
+    from revisionllm_amd import ops
+    logits = feats("smpk.logits", (6, 32000)) * 1.3
+    logits[5] = (logits[5] * 2).round() / 2                      # many exactly tied scores: the k-th place lies inside a tie group
+    u = torch.tensor([0.0, 0.3, 0.55, 0.9, 0.999, 0.42])
+    for k in (65, 100, 1000, 31999):
+        for (temp, p) in ((1.0, 1.0), (0.7, 0.9), (2.0, 0.5)):
+            o = ops.sample(logits.to(dev), u.to(dev), True, temp, k, p)
+            sc = sampling.process_logits(logits, temp, k, p)
+            keep = torch.isfinite(sc).sum(-1)
+            nk = o["n_keep"].cpu().long()
+            if p >= 1.0:
+                assert torch.equal(nk, keep), (k, nk.tolist(), keep.tolist())        # a count, not a sum: exact, the tie group at the k-th place whole
+                assert nk[5] > k or k == 31999
+            else:
+                assert ((nk - keep).abs()[:5] <= 1).all(), (k, temp, p, nk.tolist(), keep.tolist())
+            same = nk == keep
+            thr = torch.where(torch.isfinite(sc), sc, torch.full_like(sc, float("inf"))).amin(-1)
+            assert torch.allclose(o["threshold"].cpu()[same], thr[same], rtol=1e-6)
+            ent = scores.entropy_statistics(sc[:, None])[:, 0]
+            assert torch.allclose(o["entropy_proc"].cpu()[same], ent[same], rtol=2e-4, atol=1e-5)
+            pr = torch.softmax(sc.double(), -1)
+            cum = torch.sort(pr, descending=True, stable=True, dim=-1).values.cumsum(-1)
+            safe = ((cum - u[:, None].double()).abs().amin(-1) > 2e-6) & same
+            tok = sampling.select_token(sc, u)
+            assert (o["tokens"].cpu().long()[safe] == tok[safe]).all(), (k, temp, p)
+            assert safe.sum() >= 4
+            assert (o["topk_idx"].cpu() == -1).all()
+    # top_k >= V removes nothing: the same outputs as top_k = 0, bit for bit
+    for k in (32000, 50000):
+        a, b = ops.sample(logits.to(dev), u.to(dev), True, 0.7, k, 0.9), ops.sample(logits.to(dev), u.to(dev), True, 0.7, 0, 0.9)
+        for name in a:
+            assert torch.equal(a[name].cpu(), b[name].cpu()), (k, name)
+    # 65 by threshold next to 64 from the list: one more candidate, below the list's last
+    a, b = ops.sample(logits[:5].to(dev), u[:5].to(dev), True, 0.05, 65, 1.0), ops.sample(logits[:5].to(dev), u[:5].to(dev), True, 0.05, 64, 1.0)
+    assert torch.equal(a["n_keep"].cpu(), b["n_keep"].cpu() + 1)
+    assert (a["threshold"] <= b["topk_val"][:, 63]).all()
+
+
 def test_sample_fast_path_equals_general_path(dev):
     """The compacted-candidate selection (default) and the general 16-round selection give identical outputs, bit for bit:
     decode-like rows, rows with ties across the k-th place (the fast path hands over), a nearly flat row (> 1024 candidates)."""

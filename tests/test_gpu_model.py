@@ -160,28 +160,32 @@ def test_sampling_scores_and_entropy_vs_oracle():
     assert torch.allclose(out["entropy"].cpu(), _entropy(got_sc).t(), rtol=1e-4, atol=1e-6)
 
 
-def test_generate_with_the_top_k_filter_disabled():
-    """A checkpoint whose generation_config.json disables top-k (``top_k`` None / 0; inference.py:45-59 passes no top_k, so the config rules):
-    generate() samples from the whole vocabulary (T = 1, top_p = 0.9), teacher-forced on the oracle's draws: processed ``scores`` = logits / T
-    with the nucleus complement at -inf - same support as the oracle's, same entropies."""
+@pytest.mark.parametrize("k,p", [(None, 0.9), (200, 1.0), (150, 0.95)])
+def test_generate_with_the_top_k_filter_disabled(k, p):
+    """A checkpoint whose generation_config.json disables top-k (``top_k`` None / 0; inference.py:45-59 passes no top_k, so the config rules) or
+    sets one wider than the kernel's candidate list (``top_k`` > 64): generate() samples from the whole vocabulary / the top_k best (T = 1, top_p as
+    given), teacher-forced on the oracle's draws: processed ``scores`` = logits / T with the filtered tokens at -inf - same support as the oracle's,
+    same entropies."""
     from oracle import llama, sampling
     from revisionllm_amd.utils import synth
     shape = synth.TINY
     m = _model(shape, _args())
-    m.generation_config.top_k, m.generation_config.top_p, m.generation_config.temperature = None, 0.9, 1.0
+    m.generation_config.top_k, m.generation_config.top_p, m.generation_config.temperature = k, p, 1.0
     ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None].repeat(2, 1)
     feat = feats("smp.feat", (2, 10, 16, 768), bf16=fl())
     q = (feats("smp.q", (2, 5, 768), bf16=fl()), torch.ones(2, 5))
     cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
     w, wa = _oracle_weights(shape, True)
     u = torch.full((4, 2), 0.37)
-    o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), do_sample=True, temperature=1.0, top_k=0, top_p=0.9, max_new_tokens=4,
+    o = sampling.generate(ids, feat, q, w, wa, cfg, adapter_kw=dict(hierarchy=True), do_sample=True, temperature=1.0, top_k=k or 0, top_p=p, max_new_tokens=4,
                           eos_token_id=-1, uniforms=u)
     forced = o["sequences"][:, ids.shape[1]:].t()
     out = m.generate(ids, images=feat, query_feats=q, do_sample=True, max_new_tokens=4, output_scores=True, return_dict_in_generate=True, uniforms=u,
                      forced_tokens=forced)
     got_sc, want_sc = torch.stack(out["scores"]).cpu(), torch.stack(o["scores"])
     assert torch.isfinite(want_sc).sum(-1).min() > 64                       # more candidates than any top-k list of the kernel holds
+    if k and p >= 1.0:
+        assert (torch.isfinite(got_sc).sum(-1) >= k).all() and (torch.isfinite(got_sc).sum(-1) <= k + 2).all()      # exactly k but for a tie / a near-tie at the k-th place
     assert (torch.isfinite(got_sc) == torch.isfinite(want_sc)).float().mean() > (0.999 if fl() == "f16" else 0.997)      # (tokens at the nucleus cut)
     both = torch.isfinite(got_sc) & torch.isfinite(want_sc)
     assert (got_sc[both] - want_sc[both]).abs().max() < tol(1.2e-2) * torch.stack(o["logits"]).abs().max()
