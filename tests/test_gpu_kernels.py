@@ -639,6 +639,18 @@ def test_sample_with_a_top_k_wider_than_the_candidate_list(dev):
             assert (o["tokens"].cpu().long()[safe] == tok[safe]).all(), (k, temp, p)
             assert safe.sum() >= 4
             assert (o["topk_idx"].cpu() == -1).all()
+    # short / ragged vocabularies (padding lanes must never count as candidates)
+    for V in (1024, 1500, 4099):
+        x = feats(f"smpk.v{V}", (4, V)) * 2.0
+        for k in (65, 100, V - 1):
+            o = ops.sample(x.to(dev), u[:4].to(dev), True, 0.8, k, 1.0)
+            sc = sampling.process_logits(x, 0.8, k, 1.0)
+            assert torch.equal(o["n_keep"].cpu().long(), torch.isfinite(sc).sum(-1)), (V, k)
+            assert torch.allclose(o["threshold"].cpu(), torch.where(torch.isfinite(sc), sc, torch.full_like(sc, float("inf"))).amin(-1), rtol=1e-6)
+            pr = torch.softmax(sc.double(), -1)
+            cum = torch.sort(pr, descending=True, stable=True, dim=-1).values.cumsum(-1)
+            safe = (cum - u[:4, None].double()).abs().amin(-1) > 2e-6
+            assert (o["tokens"].cpu().long()[safe] == sampling.select_token(sc, u[:4])[safe]).all() and safe.sum() >= 3, (V, k)
     # top_k >= V removes nothing: the same outputs as top_k = 0, bit for bit
     for k in (32000, 50000):
         a, b = ops.sample(logits.to(dev), u.to(dev), True, 0.7, k, 0.9), ops.sample(logits.to(dev), u.to(dev), True, 0.7, 0, 0.9)
