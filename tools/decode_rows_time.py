@@ -42,3 +42,20 @@ for R in rows:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print(f"{'fp8 ' if fp8 else ''}rows {R:2d}: {ms:.3f} ms/step  {wbytes / ms / 1e9:.2f} TB/s  {ms / R * 1e3:.1f} us/row", flush=True)
+    if "--graph" in sys.argv:
+        # the same step captured into ONE hipGraph (torch.cuda.graph on a side stream; the library launches on torch's current stream) and replayed:
+        # what is left of a step when the ~165 launches cost the host nothing and the device no front-end gaps
+        g = torch.cuda.CUDAGraph()
+        hg = h0.clone()
+        with torch.cuda.graph(g):
+            eng.llm_decode_rows(hg, pos, kv, sm, logits=logits, row_share=share)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(n):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        mg = e0.elapsed_time(e1) / n
+        print(f"rows {R:2d}: {mg:.3f} ms/step replayed as one hipGraph ({mg / ms:.3f} x the stream-launched step)", flush=True)
