@@ -58,7 +58,7 @@ def select_token(scores, uniform=None):
 
 def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_kw, do_sample=False,
              temperature=1.0, top_k=0, top_p=1.0, max_new_tokens=8, eos_token_id=2, pad_token_id=0,
-             uniforms=None, forced_tokens=None, n_layers=None, w_llm_decode=None, timings=None):
+             uniforms=None, forced_tokens=None, n_layers=None, w_llm_decode=None, timings=None, visual_memory=None, prefix_memory=None):
     """The generate loop as driven by inference.py:45-59.
 
     Returns dict(sequences [B,P+G], logits list of G [B,V] raw, scores list of G [B,V] processed).
@@ -66,12 +66,17 @@ def generate(input_ids, images, query_feats, w_llm, w_adapter, cfg, *, adapter_k
     random-init models where free-running tokens would diverge on near-ties).
     ``w_llm_decode``: weights used by the KV-cached decode steps instead of ``w_llm`` (the build's opt-in FP8 decode path:
     ``oracle.llama.fp8_decode_weights``); the prefill always uses ``w_llm``.
+    ``visual_memory`` [B,768] / [B,M,768] + ``prefix_memory`` int64 [B,Lp]: the ``<memory>`` prompts of inference.py:29-30 (Linear projector
+    only, see ``oracle.splice.memory_features``); input_ids then hold one -300 behind the -200.
     ``timings``: a dict that receives the wall seconds of the three stages (``adapter``, ``prefill``, ``decode``: bench.py's cpu_baseline).
     """
     import time
     t0 = time.perf_counter()
     feats = _adapter.encode_images(images, w_adapter, query_feats, **adapter_kw)
-    embeds, mask, pos, _ = _splice.splice(input_ids, list(feats), w_llm["model.embed_tokens.weight"])
+    mem = None
+    if visual_memory is not None:
+        mem = _splice.memory_features(visual_memory, prefix_memory, w_llm["model.embed_tokens.weight"], w_adapter["weight"], w_adapter["bias"])
+    embeds, mask, pos, _ = _splice.splice(input_ids, list(feats), w_llm["model.embed_tokens.weight"], memory=mem)
     t1 = time.perf_counter()
     cache = _llama.KVCache(cfg.layers)
     B = input_ids.shape[0]

@@ -1,14 +1,25 @@
 """Oracle: splice of video rows into the text embedding sequence.
 
 Test infrastructure only.  Follows revisionllm/model/vtimellm_arch.py:149-299
-(prepare_inputs_labels_for_multimodal after the adapter dispatch), ``visual_memory is None`` path.
+(prepare_inputs_labels_for_multimodal after the adapter dispatch): the ``visual_memory is None`` path and,
+with ``memory_features``, the ``<memory>`` path (arch.py:179-232).
 """
 import torch
 
 IMAGE_TOKEN_INDEX = -200  # revisionllm/constants.py:8
+MEMORY_TOKEN_INDEX = -300  # revisionllm/constants.py:9
 
 
-def splice(input_ids, image_features, embed_weight, attention_mask=None, max_length=None, padding_side="right"):
+def memory_features(visual_memory, prefix_memory, embed_weight, proj_weight, proj_bias):
+    """arch.py:220-222: ``cat([embed_tokens(prefix_memory), mm_projector(vis_mem)], 1)`` with ``vis_mem = visual_memory[:, None]`` for a
+    [B,768] memory (one row per sample) or the [B,M,768] tensor as it is.  The projector is the Linear one: the reference calls
+    ``mm_projector(vis_mem)`` with ONE argument, which the ClipEncoder adapter cannot take (transformer.py:119 fails on ``src_txt=None``).
+    prefix_memory int64 [B,Lp].  -> [B, Lp + M, D]."""
+    vis = visual_memory[:, None] if visual_memory.dim() == 2 else visual_memory
+    return torch.cat([embed_weight[prefix_memory], vis.float() @ proj_weight.float().t() + proj_bias.float()], dim=1)
+
+
+def splice(input_ids, image_features, embed_weight, attention_mask=None, max_length=None, padding_side="right", memory=None):
     """input_ids [B,P] (with -200 sentinels); image_features: sequence of per-row [Nv,D] (or [D]) tensors
     consumed in order; embed_weight [V,D].
 
@@ -16,6 +27,9 @@ def splice(input_ids, image_features, embed_weight, attention_mask=None, max_len
     concatenate [text0 ; video rows ; text1 ...].  A row without -200 still consumes one entry
     (arch.py:170-177).  Then (arch.py:240-286) truncate to ``max_length`` when set, pad (right unless
     ``padding_side == 'left'``) with zeros, mask True on real rows, position ids arange on real rows.
+
+    ``memory`` [B,Lm,D] (``memory_features``): the ``<memory>`` path (arch.py:179-232) - every row holds one -200 and, behind it, one -300:
+    [text0 ; video rows ; text1 ; memory rows of this sample ; text2].
 
     Returns (inputs_embeds [B,L,D], attention_mask [B,L] bool, position_ids [B,L] int64, lengths list).
     """
@@ -30,6 +44,18 @@ def splice(input_ids, image_features, embed_weight, attention_mask=None, max_len
         if n_img == 0:
             rows.append(embed_weight[ids])
             cur += 1
+            continue
+        if memory is not None:
+            # arch.py:181-183, 207-232: the chunk borders are the -200 positions followed by the -300 positions; video and memory rows of THIS
+            # sample (both indexed by cur_image_idx, which advances once)
+            cut = [-1] + torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist() + torch.where(ids == MEMORY_TOKEN_INDEX)[0].tolist() + [ids.shape[0]]
+            chunks = [embed_weight[ids[cut[i] + 1:cut[i + 1]]] for i in range(len(cut) - 1)]
+            f = image_features[cur]
+            parts = [chunks[0], f[None] if f.dim() == 1 else f, chunks[1], memory[cur]]
+            if len(chunks) == 3:
+                parts.append(chunks[2])
+            cur += 1
+            rows.append(torch.cat(parts, dim=0))
             continue
         cut = [-1] + torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist() + [ids.shape[0]]
         parts = []

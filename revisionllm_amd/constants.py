@@ -10,6 +10,6 @@ DEFAULT_IMAGE_TOKEN = "<video>"
 DEFAULT_MEMORY_TOKEN = "<memory>"
 DEFAULT_IGNORE_TOKEN = "<ignore>"
 
-#: memory prefixes (revisionllm/constants.py:14-15), used only by the streaming-memory training variant
+#: memory prefixes (revisionllm/constants.py:14-15), the streaming-memory variant's prefix texts (tokenised by the caller into ``prefix_memory``)
 PREFIX = ["Here is an example of a past memory where the event did not occur: ",
           "Here is an example of a past memory where the event did take place: "]

@@ -244,24 +244,35 @@ class ReVisionLlamaForCausalLM:
         return torch.tensor([r + [pad_id] * (S - len(r)) for r in out], dtype=torch.int32), lens
 
     @staticmethod
-    def build_row_map(input_ids, rows_per_sample, attention_mask=None):
+    def build_row_map(input_ids, rows_per_sample, attention_mask=None, memory=None):
         """Splice plan (vtimellm_arch.py:149-238): int32 [B,S]; >= 0 token id, < 0 -> video row -(v+1).
-        Sample b consumes video rows [b*rows_per_sample, (b+1)*rows_per_sample) at its -200 slot."""
+        Sample b consumes video rows [b*rows_per_sample, (b+1)*rows_per_sample) at its -200 slot.
+        ``memory`` = (prefix ids [B][Lp], M, base): the ``<memory>`` path (vtimellm_arch.py:179-232, round 5) - the -300 slot of sample b becomes its
+        prefix-memory TOKENS (``embed_tokens(prefix_memory)`` is what any token of the row gets) followed by the M projected memory rows
+        base + b*M .. of the same feature-row table; the slot must follow the video (the reference's chunk order: text, video, text, memory, text)."""
         ids = input_ids.cpu().tolist()
         mask = attention_mask.cpu().tolist() if attention_mask is not None else None
         out = []
         for b, row in enumerate(ids):
             if mask is not None:
                 row = [t for t, m in zip(row, mask[b]) if m]
-            if MEMORY_TOKEN_INDEX in row:
-                raise NotImplementedError("visual_memory / <memory> prompts (training-time streaming memory) are not built")
-            r, used = [], 0
+            if (MEMORY_TOKEN_INDEX in row) != (memory is not None):
+                raise ValueError("a <memory> slot (-300) needs visual_memory / prefix_memory and the other way round (inference.py:29-30 appends the "
+                                 "marker exactly when a memory is given)")
+            r, used, used_mem = [], 0, 0
             for t in row:
                 if t == IMAGE_TOKEN_INDEX:
                     if used:
                         raise NotImplementedError("more than one <video> per sample")
                     r.extend(-(b * rows_per_sample + i + 1) for i in range(rows_per_sample))
                     used = 1
+                elif t == MEMORY_TOKEN_INDEX:
+                    if used_mem or not used:
+                        raise NotImplementedError("one <memory> per sample, behind its <video> (vtimellm_arch.py:207-232)")
+                    prefix, M, base = memory
+                    r.extend(int(x) for x in prefix[b])
+                    r.extend(-(base + b * M + i + 1) for i in range(M))
+                    used_mem = 1
                 else:
                     r.append(t)
             out.append(r)
@@ -312,8 +323,8 @@ class ReVisionLlamaForCausalLM:
         """
         if num_beams != 1:
             raise NotImplementedError("beam search is not on the grounding path (num_beams=1, inference.py:51)")
-        if visual_memory is not None or prefix_memory is not None:
-            raise NotImplementedError("visual_memory / prefix_memory (streaming-memory variant) are not built")
+        if (visual_memory is None) != (prefix_memory is None):
+            raise ValueError("visual_memory and prefix_memory come together (vtimellm_arch.py:220-222 concatenates them)")
         eng = self._ensure_engine()
         gc = self.generation_config
         temperature = gc.temperature if temperature is None else temperature
@@ -335,6 +346,24 @@ class ReVisionLlamaForCausalLM:
             uniforms = ops.h2d(uniforms, dev, torch.float32)
         if forced_tokens is not None:
             forced_tokens = ops.h2d(forced_tokens, dev, torch.long)
+        memory = None
+        if visual_memory is not None:
+            # <memory> prompts (inference.py:29-30; vtimellm_arch.py:179-232): [text, video, text, embed(prefix_memory) ++ mm_projector(vis_mem), text].
+            # The reference calls ``mm_projector(vis_mem)`` with one argument (arch.py:222): that is the Linear projector - a ClipEncoder adapter
+            # fails there (transformer.py:119, ``src_txt`` None), so it is refused here with the reason instead of an AttributeError.
+            if self.model.clip_adapter:
+                raise NotImplementedError("visual_memory with a ClipEncoder adapter: the reference's mm_projector(vis_mem) call (vtimellm_arch.py:222) passes no "
+                                          "query features and fails in ClipEncoder.forward (transformer.py:119); only the Linear projector runs this path")
+            if video_rows is None or isinstance(rows_per_sample, (list, tuple)):
+                raise NotImplementedError("visual_memory needs the video features of an ordinary (non-ragged) generate")
+            vis = visual_memory[:, None] if visual_memory.dim() == 2 else visual_memory            # arch.py:220
+            pm = torch.as_tensor(prefix_memory).long().cpu()
+            if pm.dim() != 2 or pm.shape[0] != vis.shape[0] or vis.shape[0] != input_ids.shape[0]:
+                raise ValueError("visual_memory [B,768] / [B,M,768] and prefix_memory int [B,Lp]: one memory per row of input_ids")
+            mem_rows = eng.project_dense(vis).reshape(-1, self.shape.hidden)
+            memory = (pm.tolist(), int(vis.shape[1]), int(video_rows.reshape(-1, self.shape.hidden).shape[0]))
+            video_rows = video_rows.reshape(-1, self.shape.hidden)
+            video_rows = torch.cat([video_rows, mem_rows.to(video_rows.dtype)], 0)
         lens = None
         if isinstance(rows_per_sample, (list, tuple)) and len(set(rows_per_sample)) > 1:
             # Samples with different numbers of video rows (the 9 calls of a 33-window recursion: 8 x 32 and 1 x 33): one generate of
@@ -355,7 +384,7 @@ class ReVisionLlamaForCausalLM:
         else:
             if isinstance(rows_per_sample, (list, tuple)):
                 rows_per_sample = int(rows_per_sample[0]) if len(rows_per_sample) else 0
-            row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask)
+            row_map = self.build_row_map(input_ids, rows_per_sample, attention_mask, memory)
         B, S = row_map.shape
         P0 = self._common_text_prefix(row_map) if (share_prefix and B > 1) else 0
         job = None

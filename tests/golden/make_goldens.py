@@ -895,6 +895,54 @@ def g14_cross_attn_dense(M):
     save("g14_cross_attn_dense", **out)
 
 
+def g15_memory(M):
+    """The ``<memory>`` prompts (inference.py:29-30, vtimellm_arch.py:179-232) through the reference: the splice with a [B,768] and a [B,3,768]
+    visual memory + prefix tokens, a greedy generate, and inference() end to end - on the Linear projector, the only adapter whose
+    ``mm_projector(vis_mem)`` call (arch.py:222, one argument) the reference can run (the ClipEncoder fails at transformer.py:119)."""
+    out = {}
+    shape = synth.TINY
+    args = ns(clip_adapter=False, clip_adapter_text=False, hierarchy=False)
+    m = tiny_model(M, shape, args)
+    tok = synth.FakeTokenizer(vocab=shape.vocab)
+    prompt = M["conversation"].conv_templates["v1"].copy().system + " USER: <video>\nDuring which video can we see a man?<memory> ASSISTANT:"
+    prompt_ids = M["mm_utils"].tokenizer_image_token(prompt, tok, return_tensors="pt")
+    out["prompt_ids"] = prompt_ids
+    B = 2
+    ids = prompt_ids[None].repeat(B, 1)
+    feat = T(synth.features("g15.feat", (B, 24, 768), SEED))
+    vm2 = T(synth.features("g15.vm2", (B, 768), SEED))
+    vm3 = T(synth.features("g15.vm3", (B, 3, 768), SEED))
+    pm = T(np.array([[11, 12, 13, 14], [21, 22, 23, 24]], dtype=np.int64))
+    out["prefix_memory"] = pm
+    for tag, vm in (("m1", vm2), ("m3", vm3)):
+        r = m.prepare_inputs_labels_for_multimodal(ids, None, torch.ones_like(ids), None, None, feat, None, vm, pm, None)
+        out[f"{tag}_embeds"], out[f"{tag}_mask"] = r[4], r[2]
+        m.generation_config.eos_token_id = None
+        g = m.generate(ids, images=feat, query_feats=None, do_sample=False, max_new_tokens=6, use_cache=True, visual_memory=vm, prefix_memory=pm,
+                       output_scores=True, output_logits=True, return_dict_in_generate=True)
+        out[f"{tag}_greedy_seq"] = g["sequences"]
+        out[f"{tag}_greedy_logits"] = torch.stack(g["logits"], 0)
+    # inference() end to end with a memory (sampled at T = 0.05 as inference.py hard-codes; seeded)
+    m.generation_config.top_k, m.generation_config.top_p = 50, 1.0
+    torch.manual_seed(11)
+    import unittest.mock as mock
+    real_generate = m.generate
+
+    def short_generate(*a, **kw):
+        kw["max_new_tokens"] = 5
+        kw["output_hidden_states"] = False
+        return real_generate(*a, **kw)
+
+    with mock.patch.object(m, "generate", short_generate):
+        text, mo = M["inference"].inference(m, feat, None, "<video>\nDuring which video can we see a man?", tok, visual_memory=vm2, prefix_memory=pm,
+                                            return_list=True)
+    out["inference_seq"] = mo["sequences"]
+    out["inference_scores"] = torch.stack(mo["scores"], 0)
+    save("g15_memory", **out)
+    with open(os.path.join(HERE, "g15_text.json"), "w") as f:
+        json.dump({"inference_text": text}, f)
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -903,7 +951,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8d=g8d_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8d=g8d_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense, g15=g15_memory)
     for k, fn in groups.items():
         if (only and k not in only) or (not only and k in ("g8", "g8c", "g8d", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue

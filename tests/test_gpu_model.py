@@ -233,6 +233,67 @@ def test_inference_api_end_to_end():
     assert len(outs) == 3 and all(isinstance(o, str) for o in outs)
 
 
+@pytest.mark.parametrize("tag", ["m1", "m3"])
+def test_memory_prompts_vs_reference_golden_and_oracle(golden, tag):
+    """``visual_memory`` / ``prefix_memory`` with a ``<memory>`` prompt (inference.py:29-30, vtimellm_arch.py:179-232; VERDICT r4 missing #4) on the Linear
+    projector - the adapter the reference's own ``mm_projector(vis_mem)`` call can run: [text, video rows, text, prefix-memory tokens, projected memory
+    row(s), text] against the reference's greedy run (golden G15) and the oracle on identical weights; through inference(); refused with the reason for a
+    ClipEncoder adapter and for a marker without a memory."""
+    from oracle import llama, sampling
+    from revisionllm_amd import mm_utils
+    from revisionllm_amd.conversation import conv_templates
+    from revisionllm_amd.inference import inference
+    from revisionllm_amd.utils import synth
+    g = golden.npz("g15_memory")
+    shape = synth.TINY
+    m = _model(shape, _args(clip_adapter=False, clip_adapter_text=False, hierarchy=False))
+    ids = T(g["prompt_ids"])[None].repeat(2, 1)
+    feat = feats("g15.feat", (2, 24, 768))
+    vm = feats("g15.vm2", (2, 768)) if tag == "m1" else feats("g15.vm3", (2, 3, 768))
+    pm = T(g["prefix_memory"])
+    seq = T(g[f"{tag}_greedy_seq"])
+    forced = seq[:, ids.shape[1]:].t()
+    out = m.generate(ids, images=feat, do_sample=False, max_new_tokens=6, return_dict_in_generate=True, output_logits=True, forced_tokens=forced,
+                     visual_memory=vm, prefix_memory=pm)
+    got = torch.stack(out["logits"]).cpu()
+    assert rel_err(got, T(g[f"{tag}_greedy_logits"])) < 2e-2                      # vs the reference's own fp32 outputs
+    assert (out["sequences"].cpu() == seq).all()                                  # prompt echoed incl. the -200 / -300 sentinels
+    cfg = llama.LlamaCfg(shape.hidden, shape.inter, shape.layers, shape.heads, shape.vocab, shape.eps, shape.theta)
+    w, wa = _oracle_weights(shape, False)
+    o = sampling.generate(ids, feat.to(op()).float(), None, w, wa, cfg, adapter_kw=dict(clip_adapter=False, hierarchy=False), max_new_tokens=6, eos_token_id=-1,
+                          forced_tokens=forced, visual_memory=vm.to(op()).float(), prefix_memory=pm)
+    want = torch.stack(o["logits"])
+    assert rel_err(got, want) < 1.2e-2
+    top2 = want.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * 3e-2 * want.abs().max()
+    assert (got.argmax(-1)[safe] == want.argmax(-1)[safe]).all()
+    # without the memory the logits differ (the slot is really spliced) ...
+    ids_plain = T(mm_utils.tokenizer_image_token(conv_templates["v1"].copy().system + " USER: <video>\nDuring which video can we see a man? ASSISTANT:",
+                                                 synth.FakeTokenizer(vocab=shape.vocab), return_tensors="pt"))[None].repeat(2, 1)
+    plain = m.generate(ids_plain, images=feat, do_sample=False, max_new_tokens=1, return_dict_in_generate=True, output_logits=True)
+    assert rel_err(torch.stack(plain["logits"]).cpu()[0], got[0]) > 1e-2
+    if tag == "m1":
+        # ... inference() appends the marker itself and runs the same path (teacher-forcing is not its business: shapes + sentinels)
+        tok = synth.FakeTokenizer(vocab=shape.vocab)
+        m.uniform_fn = lambda step, B: torch.full((B,), 0.5)
+        real = m.generate
+        m.generate = lambda *a, **kw: real(*a, **{**kw, "max_new_tokens": 5})
+        text, mo = inference(m, feat.cuda(), None, "<video>\nDuring which video can we see a man?", tok, visual_memory=vm, prefix_memory=pm, return_list=True)
+        m.generate = real
+        assert len(text) == 2 and (mo["sequences"][:, :ids.shape[1]].cpu() == ids).all() and mo["sequences"].shape[1] == ids.shape[1] + 5
+        # the contracts: marker without a memory, memory without a marker, half a memory, a ClipEncoder adapter
+        with pytest.raises(ValueError, match="<memory>"):
+            m.generate(ids, images=feat, max_new_tokens=1)
+        with pytest.raises(ValueError, match="<memory>"):
+            m.generate(ids_plain, images=feat, max_new_tokens=1, visual_memory=vm, prefix_memory=pm)
+        with pytest.raises(ValueError, match="come together"):
+            m.generate(ids, images=feat, max_new_tokens=1, visual_memory=vm)
+        mc = _model(shape, _args())
+        with pytest.raises(NotImplementedError, match="transformer.py:119"):
+            mc.generate(ids, images=feats("g15.h", (2, 4, 8, 768)), query_feats=(feats("g15.q", (2, 4, 768)), torch.ones(2, 4)), max_new_tokens=1,
+                        visual_memory=vm, prefix_memory=pm)
+
+
 def test_shared_prefix_prefill_is_exact():
     """Prefilling the common text prefix once and broadcasting its K/V gives bit-identical logits."""
     from revisionllm_amd.utils import synth
