@@ -108,25 +108,49 @@ def merge_stage1_stage2(grounding_logs, retrieval_logs, retrieval_logs2=None, bu
     return merged, (sum(selected) / sum(total) if total else 0.0)
 
 
-def main(argv=None):
-    p = argparse.ArgumentParser()
-    p.add_argument("--grounding_path", default="checkpoints/stage1_dense")
-    p.add_argument("--retrieval_path", default="checkpoints/stage2_long_100")
-    p.add_argument("--retrieval_path2", default=None)
-    p.add_argument("--distributed_retrieval", type=int, default=16)
-    a = p.parse_args(argv)
-    g = load_predictions(a.grounding_path, a.distributed_retrieval)
-    r = load_predictions(a.retrieval_path, a.distributed_retrieval)
-    r2 = load_predictions(a.retrieval_path2, a.distributed_retrieval) if a.retrieval_path2 else None
-    merged, frac = merge_stage1_stage2(g, r, r2)
-    print(a.grounding_path)
-    print(frac)
-    metrics = grounding_metrics_stream(merged)
-    print("====================== Grounding ======================")
+def print_metrics(metrics):
     for k, v in (metrics or {}).items():
         print(f"{k}: {v:.2f}")
-    with open(os.path.join(a.grounding_path, "result_retrieval.txt"), "w+") as f:
-        json.dump(metrics, f)
+
+
+def main(argv=None, chapters=False):
+    """The scripts' ``__main__`` (metric_retrieval_forward.py:81-199; ``chapters=True``: metric_retrieval_forward_chapters.py - no second
+    retrieval run by default and the merge run twice, ``buffer`` -1 = stage-1 proposals as they are, then 0 = filtered by the retrieved windows).
+    Same argument surface, the same lines on stdout, ``result_retrieval.txt`` of the LAST buffer in ``--grounding_path``.  -> the last metrics.
+    (Not carried over: the chapters script also min-max normalises ``rl['info']['mean_entropy']`` in place - unused afterwards, and a division by
+    zero for a run with one retrieved window; ``--task captioning`` / ``--single False`` need the reference's captioning metrics / free-text
+    answers, SURVEY section 2 rows 13 - 15: refused.)"""
+    def _bool(v):                                   # the reference declares ``type=bool``: any non-empty string is True
+        return bool(v)
+    p = argparse.ArgumentParser()
+    p.add_argument("--grounding_path", type=str, default="/checkpoints/chapters_stage1_dense" if chapters else "checkpoints/stage1_dense")
+    p.add_argument("--retrieval_path", type=str, default="/checkpoints/chapters_stage2_long_100" if chapters else "checkpoints/stage2_long_100")
+    p.add_argument("--retrieval_path2", type=str, default=None if chapters else "checkpoints/stage2_long_33")
+    p.add_argument("--task", type=str, default="grounding", choices=["all", "grounding", "captioning"])
+    p.add_argument("--data_path", type=str, default="revisionllm/eval/data_example.json")
+    p.add_argument("--stream", type=_bool, default=True)
+    p.add_argument("--distributed_grounding", type=int, default=16)
+    p.add_argument("--distributed_retrieval", type=int, default=16)
+    p.add_argument("--single", type=_bool, default=True)
+    a = p.parse_args(argv)
+    if a.task != "grounding" or not a.single or not a.stream:
+        raise NotImplementedError("only the grounding metrics of the streamed, single-answer logs are built (--task grounding --stream True --single True: "
+                                  "what the MAD recipes run); captioning metrics are out of scope (SURVEY section 2)")
+    g = load_predictions(a.grounding_path, a.distributed_retrieval)
+    r = load_predictions(a.retrieval_path, a.distributed_retrieval)
+    r2 = load_predictions(a.retrieval_path2, a.distributed_retrieval) if a.retrieval_path2 is not None else None
+    metrics = None
+    for buffer in ((-1, 0) if chapters else (0,)):
+        print("buffer: ", buffer)
+        merged, frac = merge_stage1_stage2(g, r, r2, buffer)      # (in place, like the script: a later buffer sees the earlier one's filtering)
+        print(a.grounding_path)
+        print(frac)
+        print("====================== Grounding ======================")
+        print(f"Found {len(merged)} logs")
+        metrics = grounding_metrics_stream(merged)
+        print_metrics(metrics)
+        with open(os.path.join(a.grounding_path, "result_retrieval.txt"), "w+") as f:
+            json.dump(metrics, f)
     return metrics
 
 

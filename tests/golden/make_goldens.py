@@ -688,6 +688,15 @@ def g10_metrics(M):
             with open(os.path.join(td, "g", "result_retrieval.txt")) as f:
                 out[tag] = json.load(f)
             out[tag + "_selected_fraction"] = float(p.stdout.split("\n")[2])
+            out[tag + "_stdout"] = p.stdout.replace(td, "<td>").split("\n")
+        # the chapters variant (metric_retrieval_forward_chapters.py): ONE retrieval run, buffers -1 (no filter) and 0; the result file holds the last
+        script = os.path.join(ref_import.REF_ROOT, "revisionllm", "eval", "metric_retrieval_forward_chapters.py")
+        p = subprocess.run([sys.executable, script, "--grounding_path", os.path.join(td, "g"), "--retrieval_path", os.path.join(td, "r")],
+                           capture_output=True, text=True, cwd=td)
+        assert p.returncode == 0, p.stderr
+        with open(os.path.join(td, "g", "result_retrieval.txt")) as f:
+            out["chapters"] = json.load(f)
+        out["chapters_stdout"] = p.stdout.replace(td, "<td>").split("\n")
     with open(os.path.join(HERE, "g10_metrics.json"), "w") as f:
         json.dump({"grounding": g, "retrieval": r, "retrieval2": r2, "expected": out}, f)
     print("wrote g10_metrics.json", {k: (len(v) if isinstance(v, dict) else v) for k, v in out.items()})

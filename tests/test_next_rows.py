@@ -37,6 +37,44 @@ def test_f1_metric_merge_matches_reference_script(golden, tmp_path):
     assert json.load(open(tmp_path / "g" / "result_retrieval.txt"))["R1@0.5"] == pytest.approx(exp["R1@0.5"], abs=1e-9)
 
 
+def test_f1_metric_scripts_under_their_reference_names(golden, tmp_path, capsys):
+    """``metric_retrieval_forward`` and ``metric_retrieval_forward_chapters`` as modules of their own: the scripts' argument
+    surface and defaults, and - on the synthetic logs the reference scripts themselves were run on - the same stdout line for line (buffer, path,
+    selected fraction, header, log count, every metric) and the same ``result_retrieval.txt``; the chapters form runs the merge at buffer -1 and 0."""
+    import importlib
+    from revisionllm_amd.eval import metric_retrieval_forward as mrf, metric_retrieval_forward_chapters as mrfc
+    g = golden.json("g10_metrics")
+    td = str(tmp_path)
+    for name, logs in (("g", g["grounding"]), ("r", g["retrieval"]), ("r2", g["retrieval2"])):
+        os.makedirs(tmp_path / name)
+        with open(tmp_path / name / "predictions_streaming_0.txt", "w") as f:
+            for x in logs:
+                f.write(json.dumps(x) + "\n")
+    capsys.readouterr()
+    out = mrf.main(["--grounding_path", f"{td}/g", "--retrieval_path", f"{td}/r", "--retrieval_path2", f"{td}/r2"])
+    lines = capsys.readouterr().out.replace(td, "<td>").split("\n")
+    assert lines == g["expected"]["two_runs_stdout"]
+    assert out["R5@0.3"] == pytest.approx(g["expected"]["two_runs"]["R5@0.3"], abs=1e-9)
+    out = mrfc.main(["--grounding_path", f"{td}/g", "--retrieval_path", f"{td}/r"])
+    lines = capsys.readouterr().out.replace(td, "<td>").split("\n")
+    assert lines == g["expected"]["chapters_stdout"]
+    res = json.load(open(tmp_path / "g" / "result_retrieval.txt"))
+    assert set(res) == set(g["expected"]["chapters"])
+    for k, v in g["expected"]["chapters"].items():
+        assert res[k] == pytest.approx(v, abs=1e-9) and out[k] == pytest.approx(v, abs=1e-9), k
+    # defaults as the scripts declare them; what is not built says so
+    with pytest.raises(SystemExit):
+        mrf.main(["--task", "dense"])
+    with pytest.raises(NotImplementedError, match="captioning"):
+        mrf.main(["--task", "captioning"])
+    with pytest.raises(KeyError):                     # the default second run (checkpoints/stage2_long_33) is absent here: the reference's KeyError
+        mrf.main(["--grounding_path", f"{td}/g", "--retrieval_path", f"{td}/r"])
+    import revisionllm_amd
+    revisionllm_amd.install_as_revisionllm()
+    assert importlib.import_module("revisionllm.eval.metric_retrieval_forward").main is mrf.main
+    assert importlib.import_module("revisionllm.eval.metric_retrieval_forward_chapters").main is mrfc.main
+
+
 def test_f1_metrics_edge_cases():
     assert metrics.grounding_metrics_stream([]) is None
     m = metrics.grounding_metrics_stream([{"info": {"iou": [0.2, 0.8], "scores": [0.1, 0.9]}}, {"info": {"iou": [], "scores": []}}])
