@@ -52,8 +52,8 @@ SENTENCE = ("a person opens the door and walks into the kitchen while another pe
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)        # (the driver's flags: a bare `python bench.py` measures what BENCH_rNN.json holds; 90 s in all)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="stage2_long_100", choices=["stage2_long_100", "stage2_long_33", "stage1_dense", "stage1_sparse"],
                    help="BASELINE.json configuration timed as the line's value (default: the one the metric is quoted on)")
     p.add_argument("--scaling", default="queries", choices=["queries", "segments", "weak", "strong"],
