@@ -55,6 +55,15 @@
 // their pad slots and spills) and whatever order the tiles' k-blocks are walked in (RS_PROBE & 8192: 58.5 -> 55.2, 32.9 -> 33.0): 16 KiB per CU
 // per 0.9 us = 4.4 TB/s marginal next to a fixed 8 (N = 4096) .. 17 us (gate/up) per launch.  What a launch at 9 row blocks pays for is the
 // memory system's rate at one workgroup per CU and its fixed cost, not the stage's arithmetic.
+// (g) ... which the cycle stamps of one consumer wave then corrected (RS_PROBE & 16384, tools/rows_stamps.py; N = 12288, K = 4096, 140 rows, COLD weights, workgroup 8):
+// the wave never waits - neither for its weights (the ring's three stages cover the HBM latency) nor at the barrier (the s_memtime pair around each reads
+// its own ~112 cycles).  A stage is ~1300 cycles of the wave's OWN instruction stream: the 36 x (read, wait, MFMA) triples take 1010 .. 1170 (27 - 30 cycles
+// per MFMA; the MFMAs alone, RS_PROBE & 4096: 984; the reads alone: 552 = 256 B/clk for the CU's four waves), the loop / fold behind them ~200 (fold stages
+// + 500).  The compiler's read-2 / MFMA-2 order cost 1484: that was the 400 cycles the prescribed order removed.  Issuing a stage's first eight reads BEFORE
+// the next weight loads are set up (RS_EARLY_READS = 1, with or without pinning those loads to the head of the block): 1080 / 1088 vs 1168 under the stamps,
+// 8.15 - 8.26 vs 8.15 - 8.17 ms per step without - level, not kept as the default.  So the 9-row-block launches are MFMA-ISSUE-bound inside a stage (16 cycles per
+// MFMA would be the pipe's rate; this loop reaches 27, the prefill GEMM's main loop 23) and pay ~12 us per launch outside the stages (launch gap, cold first
+// weights, the exchange and the finish): 37 % of a QKV launch.  Eight row blocks (112 rows): 1012 cycles for 32 MFMAs.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -68,6 +77,8 @@
 //   RS_PROBE & 2   no per-stage barrier: consumers and producer run free (slabs may be stale)
 //   RS_PROBE & 4   no MFMAs (the accumulators get one add per stage so that the loads stay live)
 //   RS_PROBE & 8   the producer stages no slabs at all
+//   RS_PROBE & 16384 cycle stamps (s_memtime) of consumer wave 0 of workgroup 8 at four points of every stage of an UNSPLIT launch - before the weight
+//                    wait, behind it, behind the barrier, behind the last MFMA - left in the first 2 KiB of the planes workspace (tools/rows_stamps.py)
 //   RS_PROBE & 8192  every wave walks its tile's k-blocks from its own rotated start (sums in another order: is the weight stream camping on channels?)
 //   RS_PROBE & 4096  one activation fragment per stage instead of 4 * MB (the compiler hoists the read: no LDS traffic in the loop)
 #ifndef RS_PROBE
@@ -250,12 +261,19 @@ __device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wa
 #define RS_PF_N 8
 #endif
 constexpr int RS_PF = RS_PF_N;
+#ifndef RS_EARLY_READS
+#define RS_EARLY_READS 0      // 1: a stage's first RS_PF fragment reads are issued right behind the barrier, BEFORE the next stage's weight loads are set up
+#endif
+constexpr bool rows_early(int MB) { return RS_EARLY_READS && MB >= 8 && !(RS_PROBE & (4 | 4096)); }
 template <int MB, int WP>
 __device__ __forceinline__ void rows_stage_schedule() {
 #ifndef RS_NO_STAGE_SCHEDULE
     if constexpr (MB >= 8 && !(RS_PROBE & 4)) {
         constexpr int R = 4 * MB;                                         // fragment reads = MFMAs of a stage
-        __builtin_amdgcn_sched_group_barrier(0x100, RS_PF, 0);            // DS reads
+        if constexpr (!rows_early(MB)) __builtin_amdgcn_sched_group_barrier(0x100, RS_PF, 0);            // DS reads (early form: already issued)
+#ifdef RS_EARLY_PIN_VMEM
+        else __builtin_amdgcn_sched_group_barrier(0x020, WP == 2 ? 2 : 4, 0);                             // the next stage's weight loads stay at the head of the block
+#endif
 #pragma unroll
         for (int i = 0; i < R - RS_PF; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA ...
@@ -358,13 +376,36 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // published by the stage barriers; read in the finish, many barriers later
             }
         }
+        unsigned long long* stamps = (unsigned long long*)(rs_smem + DX * SLAB + MB * (2048 + 64));
+        const bool stamping = (RS_PROBE & 16384) && S == 1 && wave == 0 && blockIdx.x == 8;
+#define RS_STAMP(k_)                                                                       \
+    if constexpr (RS_PROBE & 16384) {                                                      \
+        if (stamping && g < 64) {                                                          \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (lane == 0) stamps[g * 4 + (k_)] = t_;                                      \
+        }                                                                                  \
+    }
+        if constexpr (RS_PROBE & 16384) {
+            if (stamping) {
+                for (int i = lane; i < 256; i += 64) stamps[i] = 0ull;
+            }
+        }
         for (int g0 = 0; g0 < T; g0 += DW) {
 #pragma unroll
             for (int u = 0; u < DW; ++u) {
                 const int g = g0 + u;
                 if (g < T) {
+                    RS_STAMP(0)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * LPS) : "memory");   // the weights of stage g have landed
+                    RS_STAMP(1)
                     if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();         // ... and its slab (producer)
+                    RS_STAMP(2)
+                    op16x8 pre[rows_early(MB) ? RS_PF : 1];
+                    if constexpr (rows_early(MB)) {
+                        const char* xs0 = rs_smem + (g % DX) * SLAB + lane * 16;
+#pragma unroll
+                        for (int i = 0; i < RS_PF; ++i) pre[i] = *(const op16x8*)(xs0 + i * 1024);
+                    }
                     RS_ISSUE_W((u + DW - 1) % DW);
                     {
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
@@ -375,7 +416,8 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const op16x8 xf = *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
+                                const op16x8 xf = (rows_early(MB) && j * MB + mb < RS_PF) ? pre[(j * MB + mb) % RS_PF]
+                                                                                           : *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
@@ -385,6 +427,7 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
                         }
                         rows_stage_schedule<MB, WP>();
                     }
+                    RS_STAMP(3)
                     if (++cc == vcount(ci)) {     // virtual wave ci is complete: fold it into the tree (binary-counter merge of adjacent subtrees)
                         if constexpr (VPW > 1) {
                             bool placed = false;
@@ -412,6 +455,13 @@ rows_kernel(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float* _
             }
         }
 #undef RS_ISSUE_W
+#undef RS_STAMP
+        if constexpr (RS_PROBE & 16384) {
+            if (stamping) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = lane; i < 256; i += 64) ((unsigned long long*)planes)[i] = stamps[i];
+            }
+        }
     }
     const unsigned plane = (unsigned)(N >> 4) * MB * 1024;   // bytes per split plane (S planes <= 36 MiB: 32-bit offsets)
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(planes, 0, 0x7ffffff0, 0x00020000);
@@ -634,6 +684,12 @@ rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float*
                 for (int u = 0; u < DW; ++u, ++g) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * LPS) : "memory");   // the weights of slot g have landed
                     if constexpr (!(RS_PROBE & 2)) __builtin_amdgcn_s_barrier();         // ... and its slab (producer)
+                    op16x8 pre[rows_early(MB) ? RS_PF : 1];
+                    if constexpr (rows_early(MB)) {       // (a pad slot reads its L2-hot dummy slab and uses nothing of it)
+                        const char* xs0 = rs_smem + (g % DX) * SLAB + lane * 16;
+#pragma unroll
+                        for (int i = 0; i < RS_PF; ++i) pre[i] = *(const op16x8*)(xs0 + i * 1024);
+                    }
                     RS_ISSUE_W((u + DW - 1) % DW);
                     if (s0 + u < T) {
                         const char* xs = rs_smem + (g % DX) * SLAB + lane * 16;
@@ -644,7 +700,8 @@ rows_kernel_p(const op16_t* __restrict__ X, const op16_t* __restrict__ W, float*
                             else wj = wf[u][j];
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) {
-                                const op16x8 xf = *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
+                                const op16x8 xf = (rows_early(MB) && j * MB + mb < RS_PF) ? pre[(j * MB + mb) % RS_PF]
+                                                                                           : *(const op16x8*)(xs + ((RS_PROBE & 4096) ? 0 : (j * MB + mb) * 1024));
                                 if constexpr (RS_PROBE & 4) {
                                     if (mb == 0) acc[0][0] += __builtin_bit_cast(f32x4, wj)[j & 3] + __builtin_bit_cast(f32x4, xf)[0];
                                 } else {
@@ -831,7 +888,8 @@ int rows_splits(int64_t N, int MBp) {   // workgroups per 64-column group: the s
 template <int MB, int VPW, int FIN, int WP, int PERS>
 int rows_launch(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int M, int N, int K,
                 const GemvNorm& nrm, const QkvRope& qr, hipStream_t st) {
-    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * (2048 + 64) : 0);      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
+    size_t lds = (size_t)RowsCfg<MB, WP>::DX * MB * 4096 + (rows_sumsq_at_head(MB) ? (size_t)MB * (2048 + 64) : 0)      // the slab ring (+ the rows' sums of squares [MB][32][16] f32)
+                 + ((RS_PROBE & 16384) ? 2048 : 0);
     // Spreading.  The dispatcher packs workgroups two to a CU (<= 5 row blocks): a launch of 256 workgroups (the o / down projections) then
     // occupies 128 of the 256 CUs (PMC: SQ_BUSY_CU_CYCLES = 0.50 of the launch).  A launch with no more workgroups than `rows_spread`
     // asks for more LDS than two workgroups can share, so each gets a CU of its own.
