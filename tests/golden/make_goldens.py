@@ -101,7 +101,8 @@ def g3_clip_encoder(M):
     save("g3_clip_encoder", **out)
 
 
-def tiny_model(M, shape, args, seed=SEED):
+def tiny_model(M, shape, args, seed=SEED, w_round=False, cond=None):
+    """``w_round``: the grid the MATRICES are rounded to (False = the hash stream's fp32 values; "f16" = an fp16 checkpoint widened to fp32)."""
     L = M["llama"]
     cfg = L.VTimeLLMConfig(hidden_size=shape.hidden, intermediate_size=shape.inter, num_hidden_layers=shape.layers,
                            num_attention_heads=shape.heads, num_key_value_heads=shape.heads, vocab_size=shape.vocab,
@@ -109,12 +110,18 @@ def tiny_model(M, shape, args, seed=SEED):
                            pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")
     model = L.VTimeLLMLlamaForCausalLM(cfg).eval()
     model.get_model().initialize_vision_modules(args)
-    w = synth.build_numpy(synth.llama_spec(shape), seed)
+    w = synth.build_numpy(synth.llama_spec(shape, cond=cond), seed)
     if args.clip_adapter:
         w.update(synth.build_numpy(synth.clip_encoder_spec(hidden=shape.hidden, text=args.clip_adapter_text), seed,
                                    prefix="model.mm_projector."))
     else:
         w.update(synth.build_numpy(synth.linear_projector_spec(hidden=shape.hidden), seed, prefix="model.mm_projector."))
+    if w_round:
+        wr = synth.build_numpy(synth.llama_spec(shape, cond=cond), seed, bf16=w_round)
+        if args.clip_adapter:
+            wr.update(synth.build_numpy(synth.clip_encoder_spec(hidden=shape.hidden, text=args.clip_adapter_text), seed,
+                                        prefix="model.mm_projector.", bf16=w_round))
+        w.update({k: v for k, v in wr.items() if v.ndim > 1})
     fill(model, w)
     return model.eval()
 
@@ -952,6 +959,82 @@ def g15_memory(M):
         json.dump({"inference_text": text}, f)
 
 
+
+def g16_stage2_loop(M):
+    """The reference's OWN ``eval()`` (eval_nlq_retrieval_e2e2.py:172-421: window cutting, the zoom loop :337-386, ``iou``, ``write_log``)
+    executed from the imported module on a TINY reference model, and its JSONL records kept as the fixture - the GPU test
+    (tests/test_gpu_dropin.py) runs the build's driver under the reference's module names on the same files and must reproduce these
+    records.  Nothing of the loop is restated here: ``eval(args)`` is CALLED.  What is swapped out around it (no arithmetic of the path):
+      * ``load_pretrained_model`` -> the tiny hash-seeded reference model (``tiny_model``; matrices on the fp16 grid = an fp16 checkpoint
+        widened by e2e2.py:185) and ``helpers.DigitTokenizer`` (no checkpoint / sentencepiece file exists here);
+      * ``lmdb.open`` (the query-feature store; liblmdb is absent) -> an object whose ``begin().get(key)`` returns the bytes of
+        ``qfeats/<id>.npz`` - the payload format e2e2.py:250-255 reads;
+      * ``model.generate``: ``max_new_tokens`` 1024 -> ``STAGE2_LOOP_G`` and ``torch.multinomial`` -> the recorded inverse-CDF walk (as in G8c),
+        so the build's sampling kernel runs free against the reference's tokens; ``torch.randperm`` is wrapped to RECORD the permutations."""
+    import io
+    import tempfile
+    import unittest.mock as mock
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import helpers
+    e2 = M["e2e2"]
+    shape, G = synth.TINY, helpers.STAGE2_LOOP_G
+    model = tiny_model(M, shape, ns(), w_round="f16", cond=synth.CONDITIONED)
+    model.generation_config.eos_token_id = None
+    model.generation_config.top_k, model.generation_config.top_p = 50, 1.0
+    tok = helpers.DigitTokenizer(vocab=shape.vocab)
+    with tempfile.TemporaryDirectory() as tmp:
+        files = helpers.stage2_loop_fixture_files(tmp)
+        n_calls = 64
+        draw = _InverseCdfDraw(hash_uniforms("g16.uniforms", (n_calls, G)))
+        real_generate = model.generate
+
+        def short_generate(*a, **kw):
+            kw["max_new_tokens"] = G
+            draw.step = 0
+            with mock.patch.object(torch, "multinomial", draw):
+                out = real_generate(*a, **kw)
+            assert draw.step == G
+            draw.call += 1
+            return out
+        model.generate = short_generate
+
+        class _Txn:
+            def get(self, key):
+                with open(os.path.join(files["q_feat_dir"], key.decode() + ".npz"), "rb") as f:
+                    return f.read()
+
+        class _Env:
+            def begin(self, buffers=True):
+                return _Txn()
+        perms, real_randperm = [], torch.randperm
+
+        def recording_randperm(n, *a, **kw):
+            p = real_randperm(n, *a, **kw)
+            perms.append(p.tolist())
+            return p
+        argv = ["eval"] + helpers.STAGE2_LOOP_ARGV + ["--data_path", files["data_path"], "--feat_folder", files["feat_folder"],
+                                                      "--q_feat_dir", files["q_feat_dir"], "--log_path", os.path.join(tmp, "out")]
+        with mock.patch.object(sys, "argv", argv):
+            args = e2.parse_args()
+        torch.manual_seed(SEED)
+        with mock.patch.object(e2, "load_pretrained_model", lambda *a, **kw: (tok, model, 2048)), \
+                mock.patch.object(e2.lmdb, "open", lambda *a, **kw: _Env(), create=True), \
+                mock.patch.object(torch, "randperm", recording_randperm):
+            e2.eval(args)
+        with open(os.path.join(tmp, "out", "predictions_streaming_0.txt")) as f:
+            records = [json.loads(line) for line in f]
+    assert len(records) == len(files["ann"]), "the reference's per-query handler swallowed an exception: %d of %d records" % (len(records), len(files["ann"]))
+    per_query = len(perms) // len(records)
+    assert draw.call == len(perms) and per_query * len(records) == len(perms)
+    with open(os.path.join(HERE, "g16_stage2_loop.json"), "w") as f:
+        json.dump({"records": records, "perms": [perms[i * per_query:(i + 1) * per_query] for i in range(len(records))],
+                   "uniforms": [[float(x) for x in row] for row in draw.u[:draw.call]], "G": G, "argv": helpers.STAGE2_LOOP_ARGV,
+                   "redraws": draw.redraws,
+                   "note": "records = the lines the reference's eval() wrote (e2e2.py:142-152,411-417); inputs: helpers.stage2_loop_fixture_files; "
+                           "model: synth.TINY with synth.CONDITIONED amplitudes, seed %d, matrices on the fp16 grid; draw = inverse-CDF walk with uniforms[call, step]" % SEED}, f, indent=1)
+    print("wrote g16_stage2_loop:", len(records), "records,", len(perms), "calls,", draw.redraws, "re-drawn uniforms;", records[0]["answer"][:4])
+
+
 def main():
     M = ref_import.install()
     for k, v in M.items():
@@ -960,7 +1043,7 @@ def main():
     import transformers
     only = set(sys.argv[1:])
     groups = dict(g1=g1_pos, g2=g2_layers, g3=g3_clip_encoder, g4=g4_splice, g5=g5_tiny_generate, g6=g6_7b_layer,
-                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8d=g8d_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense, g15=g15_memory)
+                  g7=g7_scores, g8=g8_full_7b, g8c=g8c_full_7b, g8d=g8d_full_7b, g8cw=g8c_windows, g9=g9_driver, g10=g10_metrics, g11=g11_clip_towers, g12=g12_clip_tokenizer, g13=g13_loader, g14=g14_cross_attn_dense, g15=g15_memory, g16=g16_stage2_loop)
     for k, fn in groups.items():
         if (only and k not in only) or (not only and k in ("g8", "g8c", "g8d", "g8cw")):   # g8 / g8c (27 GB, ~15 min) only on request
             continue

@@ -128,3 +128,35 @@ def loader_fixture_files(dirpath, seed=SEED):
                                                   **{"base_model.model.lm_head.weight": head}))
     put("lora_plain/non_lora_trainables.bin", {"model.mm_projector." + k: v for k, v in enc2.items()})
     return paths
+
+
+# ---- G16: the reference's own stage-2 eval() on a tiny model (make_goldens.py g16 runs the reference on the SAME files) ----
+STAGE2_LOOP_G = 5           # new tokens per call in fixture G16
+STAGE2_LOOP_ARGV = ["--batch", "8", "--vis_feat_storage", "npy", "--num_frames", "16", "--adapter_input_dim", "768"]
+
+
+class DigitTokenizer(synth.FakeTokenizer):
+    """Random-init models never emit digits: every answer decodes to "In video <n>." with n derived from the FIRST sampled token, so that
+    the drivers' answer -> window arithmetic runs on every call (fixture G16 and the drop-in test use the same rule on both sides)."""
+
+    def batch_decode(self, seqs, skip_special_tokens=True):
+        return ["In video %d." % (int(s[0]) % 40) for s in seqs]
+
+
+def stage2_loop_fixture_files(dirpath, seed=SEED):
+    """Inputs of fixture G16, hash-seeded: one 1900-frame movie stored as fp16 ``.npy`` (what the reference's feature folders hold: 15 windows
+    at the default 625-frame window / 125-frame step), three queries with fp32 token / CLS features (``.npz`` per query id: the payload of the
+    reference's text LMDB), a MAD-style annotation file.  -> dict(data_path, feat_folder, q_feat_dir, ann)."""
+    import json
+    feat_dir, q_dir = os.path.join(dirpath, "feats"), os.path.join(dirpath, "qfeats")
+    os.makedirs(feat_dir, exist_ok=True), os.makedirs(q_dir, exist_ok=True)
+    np.save(os.path.join(feat_dir, "movieA.npy"), synth.features("g16.movieA", (1900, 768), seed).astype(np.float16))
+    ann = {}
+    for i in range(3):
+        ann[f"q{i}"] = {"movie": "movieA", "sentence": f"A man opens door {i}.", "timestamps": [130.0 * i, 130.0 * i + 8], "movie_duration": 380.0}
+        np.savez_compressed(os.path.join(q_dir, f"q{i}.npz"), token_features=synth.features(f"g16.q{i}.tok", (5 + i, 768), seed),
+                            cls_features=synth.features(f"g16.q{i}.cls", (768,), seed))
+    data_path = os.path.join(dirpath, "ann.json")
+    with open(data_path, "w") as f:
+        json.dump(ann, f)
+    return dict(data_path=data_path, feat_folder=feat_dir, q_feat_dir=q_dir, ann=ann)
