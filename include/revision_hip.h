@@ -33,7 +33,8 @@
  *         librevision_hip_bf16.so  bf16 operands (RV_BF16; v_mfma_f32_16x16x32_bf16): the reference's own GPU dtype (e2e2.py:181-185), 8 bits.
  *     rv_operand_dtype() says which one a loaded library is; wherever this header says "bf16" for a buffer it means "the library's operand
  *     type".  A library REFUSES the other flavour's dtype code (rv_weights_bind, rv_init_hash, rv_gemm out_dtype, ...): a bf16 tensor can
- *     never be read as fp16 bits silently.  f32 -> fp16 conversions saturate at +-65504 (no inf is ever produced by a conversion).
+ *     never be read as fp16 bits silently.  f32 -> fp16 conversions saturate at +-65504 (no inf is ever produced by a conversion), a NaN
+ *     stays a NaN, and every saturation is COUNTED in the status buffer bound with rv_numeric_status_bind (option "saturated").
  */
 #ifndef REVISION_HIP_H
 #define REVISION_HIP_H
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 4
+#define RV_ABI_VERSION 5
 
 typedef enum { RV_OK = 0, RV_ERR_ARG = -1, RV_ERR_UNBOUND = -2, RV_ERR_HIP = -3, RV_ERR_WORKSPACE = -4 } rv_status;
 typedef enum { RV_F32 = 0, RV_BF16 = 1, RV_I32 = 2, RV_I64 = 3, RV_U8 = 4, RV_F16 = 5 } rv_dtype;
@@ -119,7 +120,7 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        entropy scores, profiles/r4_error_budget.json); 0 = bf16 lm_head input.  Not used with the FP8 decode weights.
  *   "last_block_rows"    1 (default) = a prefill that returns logits runs the LAST block's o / MLP projections (and the head) on the last row of every
  *                        sequence only - nothing reads that block's other output rows (its K / V are cached before); they go through the few-row
- *                        weight-streaming kernels (<= 32 sequences per pass, sequences of >= 32 positions).  0 = every row through every block (rounds 1 - 4).  Logits
+ *                        weight-streaming kernels, <= 32 of them at a time (sequences of >= 32 positions; whatever number of prefills shares the pass).  0 = every row through every block (rounds 1 - 4).  Logits
  *                        differ in the last bits between the two settings (other summation order in that block's projections).
  *   "adapter_fold_t2v"   1 (default) = rv_clip_encoder, text -> video layers (transformer.py:271-305) whose queries have <= 32 text tokens: Q projection + cross-attention +
  *                        output projection run as x.A1^T -> softmax -> P.A2^T with A1 / A2 folded from the text K / V rows per (layer, query) - the same function, other
@@ -134,9 +135,21 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        GEMM kernels; no norm fusion, no FP8.  Needs "llm.L{i}.{wqkv,wo,wgu,wdown}.p2" and "llm.lm_head.p2" bound
  *                        (RV_ERR_UNBOUND otherwise).  What it is for: the reference's fp32 segment scores to the north star's 1e-3
  *                        (vtimellm_llama.py:38-90 executed in fp32 on the CPU; funs_get_feature_X.py:120-146); ~2 x the prefill GEMM time.
+ *   "saturated"          (read; write 0 to reset) the sticky count of f32 -> fp16 stores that met a value outside +-65504 since the last reset - any kernel,
+ *                        any context of this library instance on the current device (rv_numeric_status_bind: one buffer per instance and device).  The
+ *                        reference's bf16 path cannot overflow (e2e2.py:182); this build's default operand type can, and then costs accuracy in that element
+ *                        instead of producing inf: this is how a caller learns that a checkpoint's activations left the fp16 range.  Reading or resetting
+ *                        waits for the device.  Always 0 in the bf16 flavour and when no buffer is bound.
  * Unknown keys / out-of-range values return RV_ERR_ARG. */
 int rv_ctx_set_option(rv_ctx* ctx, const char* key, int64_t value);
 int rv_ctx_get_option(const rv_ctx* ctx, const char* key, int64_t* value);
+/* Numeric status buffer (ABI v5): 4 x uint32 of caller-owned device memory, 16-byte aligned, zeroed by the caller.  Word 0 = saturated fp16 stores (see
+ * option "saturated"; one count per converted pair / quad that held an out-of-range element), words 1 - 3 reserved.  Every kernel of the library instance
+ * adds into it from then on (NULL unbinds: nothing is counted); callers that copy results to the host anyway read it with them instead of through the
+ * option (no extra wait).  The binding is per library instance and device, not per context: it is the one piece of device-side shared state
+ * (device code of different translation units cannot share a symbol without relocatable device code, so each keeps a copy of this pointer).
+ * No counterpart in the reference: torch raises / propagates inf on its own. */
+int rv_numeric_status_bind(uint32_t* status_dev);
 /* Bind a device tensor under a build-defined packed name (see DESIGN.md "weight layout").  Every bf16 MATRIX
  * except llm.embed is fragment-packed (rv_gemm w_layout 1); vectors are plain f32:
  *   llm.embed [V,D] bf16; llm.L{i}.wqkv [3D,D] bf16 (q;k;v rows; inside every head the q and k rows are

@@ -46,7 +46,7 @@ def build_library(force=False, verbose=False, flavours=("f16", "bf16")):
             src = os.path.join(CSRC, s)
             obj = os.path.join(OBJ, fl, s.replace(".hip", ".o"))
             if force or _stale(obj, [src] + hdrs):
-                jobs.append([hipcc] + FLAGS + [FLAVOURS[fl][1], "-c", src, "-o", obj])
+                jobs.append([hipcc] + FLAGS + [FLAVOURS[fl][1], "-DRV_TU=" + s.replace(".hip", ""), "-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

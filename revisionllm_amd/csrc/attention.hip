@@ -145,7 +145,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
         m_run = m_new;
         union { op16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2(p[2 * i], p[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2_bounded(p[2 * i], p[2 * i + 1]);
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running maximum moved for some row of this wave
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
-        *(u32x2*)(op + dt * 16) = u32x2{pack_op16x2(o[dt][0] * inv, o[dt][1] * inv), pack_op16x2(o[dt][2] * inv, o[dt][3] * inv)};
+        *(u32x2*)(op + dt * 16) = pack_op16x4(f32x4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv});
     if (a.out_lo) {
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
@@ -305,7 +305,7 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
             m_run[qt] = m_new;
             union { op16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2(pp[2 * i], pp[2 * i + 1]);
+            for (int i = 0; i < 4; ++i) pf.u[i] = pack_op16x2_bounded(pp[2 * i], pp[2 * i + 1]);
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) o[qt][dt] *= alpha;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
         op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)row * a.o_rs + h * DH + g * 4;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
-            *(u32x2*)(op + dt * 16) = u32x2{pack_op16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_op16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
+            *(u32x2*)(op + dt * 16) = pack_op16x4(f32x4{o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv});
     }
 }
 

@@ -50,18 +50,76 @@ void rv_set_error(const char* fmt, ...);
         }                                                                       \
     } while (0)
 
+// ---- numeric status: fp16 stores that saturated (fp16 flavour) -------------------------------------------------
+// rv_numeric_status_bind() hands the library a caller-owned device buffer of 4 uint32; word 0 counts f32 -> fp16 conversions that
+// met a value outside +-65504 (each count = one converted pair / quad that held at least one such element).  Device code cannot share a
+// symbol across translation units without relocatable device code, so every TU owns a copy of the POINTER (set by its registered
+// rv_tu_bind) and all of them add into the one buffer.  Null (never bound): nothing is counted.
+// (one NAMED variable per translation unit - build.py passes -DRV_TU=<file stem>: the HIP runtime registers device variables by name, and a
+// file-local symbol is not visible in the code object it looks the name up in)
+#ifndef RV_TU
+#define RV_TU standalone   // a lone `hipcc -c file.hip`; linking two such objects into one library needs distinct names (revisionllm_amd/build.py passes them)
+#endif
+#define RV_CAT2(a, b) a##b
+#define RV_CAT(a, b) RV_CAT2(a, b)
+#define rv_tu_numeric_ptr RV_CAT(rvd_numeric_ptr_, RV_TU)
+__device__ __attribute__((used, visibility("default"))) unsigned int* rv_tu_numeric_ptr = nullptr;
+struct RvTuNode {
+    RvTuNode* next;
+    int (*bind)(unsigned int*);
+};
+void rv_numeric_register(RvTuNode* n);   // error.hip: links the TU into the list rv_numeric_status_bind walks
+static int rv_tu_bind(unsigned int* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(rv_tu_numeric_ptr), &p, sizeof(p), 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+static RvTuNode rv_tu_node{nullptr, rv_tu_bind};
+__attribute__((constructor)) static void rv_tu_ctor() { rv_numeric_register(&rv_tu_node); }
+
 #if RV_OP_F16
 typedef _Float16 rv_half2 __attribute__((ext_vector_type(2)));
 typedef _Float16 rv_half8 __attribute__((ext_vector_type(8)));
+typedef unsigned short rv_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float op16_to_f32(op16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
-// round-to-nearest-even fp32 -> fp16, saturating: one v_med3_f32 in front of the conversion (a NaN comes out as -65504: med3 returns the
-// minimum of the other two operands; the residual stream and every statistic stay f32, where a NaN remains visible)
-__device__ __forceinline__ float op16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
-__device__ __forceinline__ op16_t f32_to_op16(float f) { return __builtin_bit_cast(op16_t, (_Float16)op16_sat(f)); }
-__device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
-    const rv_half2 h = {(_Float16)op16_sat(lo), (_Float16)op16_sat(hi)};
-    return __builtin_bit_cast(uint32_t, h);
+// round-to-nearest-even fp32 -> fp16 that SATURATES at +-65504, keeps a NaN a NaN and REPORTS a saturation (round 6; rounds 1 - 5 clamped
+// with v_med3_f32 in front of the conversion, which turned a NaN into -65504 and told nobody).  v_cvt_pk_f16_f32 yields +-inf for anything
+// beyond the range (and for an f32 inf): per 16-bit lane, (w | 0x8000) + 0x0400 is 0 exactly for +-inf (NaN: 1 .. 0x3ff, finite: >= 0x8400), so
+// m = sat(1 - that) is 1 in the lanes that overflowed and w - m turns 0x7c00 / 0xfc00 into 0x7bff / 0xfbff = +-65504.  Four packed integer ops
+// per pair; the report (rv_note_saturation) is a compare and a branch that is never taken on in-range data.
+// (the conversion is spelled as the instruction: a C cast lets the compiler contract "a * b + c, then round to fp16" into v_fma_mixlo_f16, which rounds ONCE -
+// closer to the real number but not the f32 value rounded to fp16 that every oracle, the host initialiser and the sibling kernels produce)
+__device__ __forceinline__ uint32_t rv_cvt_pk_f16(float lo, float hi) {
+    uint32_t w;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+    return w;
 }
+__device__ __forceinline__ uint32_t pack_op16x2_m(float lo, float hi, uint32_t& m_any) {
+    const uint32_t w = rv_cvt_pk_f16(lo, hi);
+    const rv_u16x2 y = __builtin_bit_cast(rv_u16x2, w | 0x80008000u) + (rv_u16x2){0x0400, 0x0400};
+    const rv_u16x2 m = __builtin_elementwise_sub_sat((rv_u16x2){1, 1}, y);
+    m_any |= __builtin_bit_cast(uint32_t, m);
+    return __builtin_bit_cast(uint32_t, (rv_u16x2)(__builtin_bit_cast(rv_u16x2, w) - m));
+}
+__device__ __forceinline__ void rv_note_saturation(uint32_t m_any) {
+    if (__builtin_expect(m_any != 0, 0)) {
+        unsigned int* p = rv_tu_numeric_ptr;
+        if (p) atomicAdd(p, 1u);
+    }
+}
+__device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
+    uint32_t m = 0;
+    const uint32_t w = pack_op16x2_m(lo, hi, m);
+    rv_note_saturation(m);
+    return w;
+}
+__device__ __forceinline__ u32x2 pack_op16x4(f32x4 v) {          // four consecutive outputs: one report for the quad
+    uint32_t m = 0;
+    const u32x2 w = {pack_op16x2_m(v[0], v[1], m), pack_op16x2_m(v[2], v[3], m)};
+    rv_note_saturation(m);
+    return w;
+}
+__device__ __forceinline__ op16_t f32_to_op16(float f) { return (op16_t)pack_op16x2(f, 0.f); }
+// values known to lie inside the fp16 range (softmax numerators <= 1 in the attention inner loops): the bare conversion (a NaN stays a NaN)
+__device__ __forceinline__ uint32_t pack_op16x2_bounded(float lo, float hi) { return rv_cvt_pk_f16(lo, hi); }
 __device__ __forceinline__ float op16x2_lo_f32(uint32_t w) { return (float)__builtin_bit_cast(rv_half2, w)[0]; }
 __device__ __forceinline__ float op16x2_hi_f32(uint32_t w) { return (float)__builtin_bit_cast(rv_half2, w)[1]; }
 __device__ __forceinline__ f32x4 rv_mfma16(op16x8 a, op16x8 b, f32x4 c) {
@@ -79,10 +137,13 @@ __device__ __forceinline__ op16_t f32_to_op16(float f) {
 __device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
     return (uint32_t)f32_to_op16(lo) | ((uint32_t)f32_to_op16(hi) << 16);
 }
+__device__ __forceinline__ u32x2 pack_op16x4(f32x4 v) { return u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])}; }
+__device__ __forceinline__ uint32_t pack_op16x2_bounded(float lo, float hi) { return pack_op16x2(lo, hi); }
 __device__ __forceinline__ float op16x2_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float op16x2_hi_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ f32x4 rv_mfma16(op16x8 a, op16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 #endif
+__device__ __forceinline__ u32x2 pack_op16x4(const float (&v)[4]) { return pack_op16x4(f32x4{v[0], v[1], v[2], v[3]}); }
 __device__ __forceinline__ f32x4 op16x4_to_f32(u32x2 raw) {
     return f32x4{op16x2_lo_f32(raw[0]), op16x2_hi_f32(raw[0]), op16x2_lo_f32(raw[1]), op16x2_hi_f32(raw[1])};
 }

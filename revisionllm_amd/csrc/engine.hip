@@ -321,8 +321,20 @@ int* option_slot(RvOpts& o, const char* key) {
 }
 }  // namespace
 
+unsigned int* rv_numeric_bound();   // error.hip
+
 extern "C" int rv_ctx_set_option(rv_ctx* c, const char* key, int64_t value) {
     RV_CHECK_ARG(c && key, "rv_ctx_set_option: null argument");
+    if (std::string(key) == "saturated") {       // reset the sticky count of the bound numeric status buffer (waits for the device)
+        RV_CHECK_ARG(value == 0, "rv_ctx_set_option: 'saturated' can only be reset to 0");
+        if (unsigned int* p = rv_numeric_bound()) {
+            if (hipDeviceSynchronize() != hipSuccess || hipMemset(p, 0, 16) != hipSuccess) {
+                rv_set_error("rv_ctx_set_option: resetting the numeric status failed: %s", hipGetErrorString(hipGetLastError()));
+                return RV_ERR_HIP;
+            }
+        }
+        return RV_OK;
+    }
     int* slot = option_slot(c->opt, key);
     RV_CHECK_ARG(slot, "rv_ctx_set_option: unknown option '%s'", key);
     const std::string k(key);
@@ -336,6 +348,18 @@ extern "C" int rv_ctx_set_option(rv_ctx* c, const char* key, int64_t value) {
 
 extern "C" int rv_ctx_get_option(const rv_ctx* c, const char* key, int64_t* value) {
     RV_CHECK_ARG(c && key && value, "rv_ctx_get_option: null argument");
+    if (std::string(key) == "saturated") {       // sticky count of fp16 stores that saturated (0 when no status buffer is bound); waits for the device
+        *value = 0;
+        if (unsigned int* p = rv_numeric_bound()) {
+            unsigned int n = 0;
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) {
+                rv_set_error("rv_ctx_get_option: reading the numeric status failed: %s", hipGetErrorString(hipGetLastError()));
+                return RV_ERR_HIP;
+            }
+            *value = n;
+        }
+        return RV_OK;
+    }
     const int* slot = option_slot(const_cast<rv_ctx*>(c)->opt, key);
     RV_CHECK_ARG(slot, "rv_ctx_get_option: unknown option '%s'", key);
     *value = *slot;
@@ -674,11 +698,11 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
     consume.planes = w.planes;
     consume.arrive = w.arrive;
     if (l1 < 0 || l1 > g.layers) l1 = g.layers;
-    // (see the last block below) a prefill whose head is asked for, on the plain 16-bit path, with few sequences of >= 32 positions.  The test is on the
+    // (see the last block below) a prefill whose head is asked for, on the plain 16-bit path, with sequences of >= 32 positions.  The test is on the
     // SEQUENCE length P0 + S: it must not depend on how many prefills share the pass, nor on whether the prompt prefix is shared (a recursion's calls
     // run one by one in the reference mode and as one shared-prefix batch in the batched mode: both must take the same kernels)
     const bool tail_block = logits && l1 == g.layers && !par && !p8 && !fuse_norm && !row_pos && (S > 1 || P0 > 0) && c->opt.last_block_rows &&
-                            (int64_t)G * B <= 32 && (int64_t)P0 + S >= 32 && (size_t)M * F * 2 >= (((size_t)G * B * D * 4 + 255) & ~(size_t)255) + (size_t)G * B * F * 2;
+                            (int64_t)P0 + S >= 32 && (size_t)M * F * 2 >= (((size_t)G * B * D * 4 + 255) & ~(size_t)255) + (size_t)G * B * F * 2;
     for (int l = l0; l < l1; ++l) {
         const LlmLayer& L = c->layers[l];
         op16_t* kc = kbase + l * per_layer;
@@ -801,16 +825,29 @@ int llm_forward_impl(rv_ctx* c, float* h, int B, int S, int pos0, int P0, void* 
                 float* h_last = (float*)w.act16;                          // (the gated-activation buffer is free until gate/up)
                 op16_t* act_last = (op16_t*)((char*)w.act16 + (((size_t)nr * D * 4 + 255) & ~(size_t)255));
                 RV_TRY(k_gather_last_rows(w.a16, h, last_rows, nr, (int)Mg, P0, B, S, a_last, h_last, (int)D, st));
-                RV_TRY(rv_gemm_impl(a_last, D, L.wo, D, 1, nullptr, h_last, D, h_last, D, RV_F32, RV_ACT_NONE, nr, D, D, w.sk, w.sk_bytes, st, nullptr));
-                RV_TRY(k_rmsnorm(h_last, D, L.norm2, w.xn16, nr, (int)D, g.rms_eps, st));
-                RV_TRY(rv_gemm_impl(w.xn16, D, L.wgu, D, 1, nullptr, nullptr, 0, act_last, F, RV_OP16, RV_ACT_SILU_MUL, nr, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
-                RV_TRY(rv_gemm_impl(act_last, F, L.wdown, F, 1, nullptr, h_last, D, h_last, D, RV_F32, RV_ACT_NONE, nr, D, F, w.sk, w.sk_bytes, st, nullptr));
-                if (c->lm_head2 && c->opt.lm_head_split) {
-                    RV_TRY(k_rmsnorm_split(h_last, D, c->final_norm, w.xl16, nr, (int)D, g.rms_eps, st));
-                    return rv_gemm_impl(w.xl16, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, nr, V, 2 * D, w.sk, w.sk_bytes, st);
+                // <= 32 rows at a time: the few-row kernels' rows are bit-identical whatever they are batched with, so a sequence's logits do not depend
+                // on how many prefills share the pass (5 x 7 = 35 rows used to fall back to the all-rows form: ADVICE r5)
+                const bool split = c->lm_head2 && c->opt.lm_head_split;
+                for (int64_t c0 = 0; c0 < nr; c0 += 32) {
+                    const int64_t n = nr - c0 < 32 ? nr - c0 : 32;
+                    op16_t* a_c = a_last + c0 * D;
+                    float* h_c = h_last + c0 * D;
+                    op16_t* act_c = act_last + c0 * F;
+                    op16_t* xn_c = w.xn16 + c0 * D;
+                    op16_t* xl_c = w.xl16 + c0 * D * (split ? 2 : 1);
+                    RV_TRY(rv_gemm_impl(a_c, D, L.wo, D, 1, nullptr, h_c, D, h_c, D, RV_F32, RV_ACT_NONE, n, D, D, w.sk, w.sk_bytes, st, nullptr));
+                    RV_TRY(k_rmsnorm(h_c, D, L.norm2, xn_c, n, (int)D, g.rms_eps, st));
+                    RV_TRY(rv_gemm_impl(xn_c, D, L.wgu, D, 1, nullptr, nullptr, 0, act_c, F, RV_OP16, RV_ACT_SILU_MUL, n, 2 * F, D, w.sk, w.sk_bytes, st, nullptr));
+                    RV_TRY(rv_gemm_impl(act_c, F, L.wdown, F, 1, nullptr, h_c, D, h_c, D, RV_F32, RV_ACT_NONE, n, D, F, w.sk, w.sk_bytes, st, nullptr));
+                    if (split) {
+                        RV_TRY(k_rmsnorm_split(h_c, D, c->final_norm, xl_c, n, (int)D, g.rms_eps, st));
+                        RV_TRY(rv_gemm_impl(xl_c, 2 * D, c->lm_head2, 2 * D, 1, nullptr, nullptr, 0, logits + c0 * V, V, RV_F32, RV_ACT_NONE, n, V, 2 * D, w.sk, w.sk_bytes, st));
+                    } else {
+                        RV_TRY(k_rmsnorm(h_c, D, c->final_norm, xl_c, n, (int)D, g.rms_eps, st));
+                        RV_TRY(rv_gemm_impl(xl_c, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits + c0 * V, V, RV_F32, RV_ACT_NONE, n, V, D, w.sk, w.sk_bytes, st));
+                    }
                 }
-                RV_TRY(k_rmsnorm(h_last, D, c->final_norm, w.xl16, nr, (int)D, g.rms_eps, st));
-                return rv_gemm_impl(w.xl16, D, c->lm_head, D, 1, nullptr, nullptr, 0, logits, V, RV_F32, RV_ACT_NONE, nr, V, D, w.sk, w.sk_bytes, st);
+                return RV_OK;
             }
             if (par) {
                 RV_TRY(rv_gemm_impl(w.a16, 2 * D, L.wo2, 2 * D, 1, nullptr, h, D, h, D, RV_F32, RV_ACT_NONE, M, D, 2 * D, w.sk, w.sk_bytes, st, nullptr));

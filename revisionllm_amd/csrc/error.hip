@@ -22,6 +22,27 @@ extern "C" int rv_last_error(char* buf, size_t n) {
     return RV_OK;
 }
 
+// ---- numeric status (common.h): every translation unit registers itself at load time; rv_numeric_status_bind points all of them at one
+// caller-owned device buffer.  The list is built by static constructors (no HIP call), walked under the caller's current device.
+static RvTuNode* g_numeric_head = nullptr;
+static unsigned int* g_numeric_ptr = nullptr;
+void rv_numeric_register(RvTuNode* n) {
+    n->next = g_numeric_head;
+    g_numeric_head = n;
+}
+unsigned int* rv_numeric_bound() { return g_numeric_ptr; }
+
+extern "C" int rv_numeric_status_bind(uint32_t* status_dev) {
+    RV_CHECK_ARG(((uintptr_t)status_dev & 15) == 0, "rv_numeric_status_bind: the buffer must be 16-byte aligned");
+    for (RvTuNode* n = g_numeric_head; n; n = n->next)
+        if (n->bind((unsigned int*)status_dev) != 0) {
+            rv_set_error("rv_numeric_status_bind: hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
+            return RV_ERR_HIP;
+        }
+    g_numeric_ptr = (unsigned int*)status_dev;
+    return RV_OK;
+}
+
 // ---- per-call option scope (see kernels.h) ----
 const RvOpts g_default_opts{};
 static thread_local const RvOpts* t_opts = nullptr;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const op16_t* __restrict__ A, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
                 if (OUT_BF16) {
-                    u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                    u32x2 p = pack_op16x4(v);
                     *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = p;
                 } else {
                     *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_tile(const op16_t* __restrict__ A, i
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
                 if (OUT_BF16) {
-                    u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                    u32x2 p = pack_op16x4(v);
                     *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = p;
                 } else {
                     *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                        *(u32x2*)(my + row * RS + ((ni >> 1) * 16 + kg * 4) * 2) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                        *(u32x2*)(my + row * RS + ((ni >> 1) * 16 + kg * 4) * 2) = pack_op16x4(v);
                     }
                 } else {
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                         }
-                        *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                        *(u32x2*)(my + row * RS + (ni * 16 + kg * 4) * 2) = pack_op16x4(v);
                     }
                 }
             }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const op16_t* __restrict__ A
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_tile_p5(const op16_t* __restrict__ A
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }

@@ -182,8 +182,9 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const op16_t* __restric
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = rv_act_apply<ACT>(v0[r]); v1[r] = rv_act_apply<ACT>(v1[r]); }
                     }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(pack_op16x2(v0[0], v0[1]), pack_op16x2(v1[0], v1[1]), false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(pack_op16x2(v0[2], v0[3]), pack_op16x2(v1[2], v1[3]), false, false);
+                    const u32x2 w0 = pack_op16x4(v0), w1 = pack_op16x4(v1);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
                     pend[mf] = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
                 pend_ptr = (op16_t*)Cv + (int64_t)(r0 + fr) * ldc + n0 + (kg & 1) * 16 + (kg >> 1) * 8;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_arows_kernel(const op16_t* __restric
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + m * ldc + n) = v;
             }
         }

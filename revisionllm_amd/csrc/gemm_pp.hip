@@ -455,7 +455,7 @@ __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const Q
         const f32x4 t = *(const f32x4*)(row.cs + (p0 + ni * 16));   // pairs (p >> 1) of p = p0 + ni * 16: (c0, s0, c1, s1) at cs + (p >> 1) * 2
         const float a0 = __fmaf_rn(v[ni][0], t[0], -__fmul_rn(v[ni][1], t[1])), b0 = __fmaf_rn(v[ni][1], t[0], __fmul_rn(v[ni][0], t[1]));
         const float a1 = __fmaf_rn(v[ni][2], t[2], -__fmul_rn(v[ni][3], t[3])), b1 = __fmaf_rn(v[ni][3], t[2], __fmul_rn(v[ni][2], t[3]));
-        o[ni] = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
+        o[ni] = pack_op16x4(f32x4{a0, b0, a1, b1});
     }
     if (sec == 0) {
         op16_t* dst = (op16_t*)qr.q16 + (int64_t)row.mrow * (qr.H * 128) + head * 128 + p0;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][0][r]) * acc[ni + 1][0][r];
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -520,7 +520,7 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -566,7 +566,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
         } else {
@@ -580,7 +580,7 @@ __device__ __forceinline__ void pp4_epilogue(const f32x4 (&acc)[8][8], const flo
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
-                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }
         }
@@ -676,7 +676,7 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(v0[r]) * v1[r];
-        if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+        if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
         else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
     } else {
 #pragma unroll
@@ -689,7 +689,7 @@ __device__ __forceinline__ void pp_epilogue_unit(f32x4 v0, f32x4 v1, int w, int 
                 for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
             }
             if (res) v += rv_residual4(res, ldr, m, n);
-            if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+            if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
             else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
         }
     }

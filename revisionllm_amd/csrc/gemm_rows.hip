@@ -236,7 +236,7 @@ __device__ __forceinline__ void rows_qkv_finish(const f32x4 (&sres)[PPW], int wa
             const f32x4 t = cf[i];
             const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
             const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
-            const u32x2 o = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
+            const u32x2 o = pack_op16x4(f32x4{a0, b0, a1, b1});
             if (sec == 0) *(u32x2*)((op16_t*)qr.q16 + (int64_t)b * D + hd0 + tile * 16 + kg * 4) = o;
             else *(u32x2*)((op16_t*)qr.kc + (((int64_t)b * qr.H + head) * qr.Smax + pos) * 128 + pc) = o;
         } else {

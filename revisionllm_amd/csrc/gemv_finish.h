@@ -61,7 +61,7 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gemv_silu(s[0][r]) * s[NT - 1][r];
         if (OUT_BF16) {
-            u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+            u32x2 p = pack_op16x4(v);
             *(u32x2*)((op16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, no, nrm.out_packed) : (int64_t)b * ldc + no)) = p;
         } else {
             *(f32x4*)((float*)Cv + (int64_t)b * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
             }
             if (res && !(RS_PROBE & 128)) v += one ? res_pre : *(const f32x4*)(res + (int64_t)b * ldr + n);
             if (OUT_BF16) {
-                u32x2 p = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+                u32x2 p = pack_op16x4(v);
                 *(u32x2*)((op16_t*)Cv + (nrm.out_packed ? rv_xp_index(b, n, nrm.out_packed) : (int64_t)b * ldc + n)) = p;
             } else {
                 *(f32x4*)((float*)Cv + (int64_t)b * ldc + n) = v;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void gemv_finish(f32x4 (&s)[NT], int mb, int fr, int 
             if (nrm.out_sumsq && !(RS_PROBE & 32)) {  // producer: RMSNorm pre-scaled activation for the next projection + sum of squares
                 const f32x4 wn = one ? wn_pre : *(const f32x4*)(nrm.w_next + n);
                 *(u32x2*)((op16_t*)nrm.xw_out + (nrm.out_packed ? rv_xp_index(b, n, nrm.out_packed) : (int64_t)b * N + n)) =
-                    u32x2{pack_op16x2(v[0] * wn[0], v[1] * wn[1]), pack_op16x2(v[2] * wn[2], v[3] * wn[3])};
+                    pack_op16x4(f32x4{v[0] * wn[0], v[1] * wn[1], v[2] * wn[2], v[3] * wn[3]});
                 // (explicit fma chain: the contraction hipcc picks for a*a + b*b + ... may differ between template instantiations,
                 //  and a row's sum must not depend on how many rows it is batched with)
                 sq = __fmaf_rn(v[3], v[3], __fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], __fmaf_rn(v[0], v[0], sq))));

@@ -134,7 +134,7 @@ static __device__ __forceinline__ void qkv_rope_store_t(const QkvRope& q, int m,
         // inlines into, and a rotated value must not depend on which kernel (or how many rows) produced it
         const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
         const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
-        const u32x2 o = u32x2{pack_op16x2(a0, b0), pack_op16x2(a1, b1)};
+        const u32x2 o = pack_op16x4(f32x4{a0, b0, a1, b1});
         if (sec == 0) {
             if constexpr ((RS_PROBE_K_ & 1024) != 0) return;
             if constexpr (QSPLIT) {

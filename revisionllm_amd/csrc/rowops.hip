@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = x16in ? op16x4_to_f32(*(const u32x2*)(x16in + row * D + i * 256 + lane * 4)) : *(const f32x4*)(xr + i * 256 + lane * 4);
-        if (rnd & 1) v[i] = op16x4_to_f32(u32x2{pack_op16x2(v[i][0], v[i][1]), pack_op16x2(v[i][2], v[i][3])});
+        if (rnd & 1) v[i] = op16x4_to_f32(pack_op16x4(f32x4{v[i][0], v[i][1], v[i][2], v[i][3]}));
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) * (1.0f / D);
@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
-        if (y32) *(f32x4*)(y32 + orow * D + c) = (rnd & 2) ? op16x4_to_f32(u32x2{pack_op16x2(y[0], y[1]), pack_op16x2(y[2], y[3])}) : y;
-        if (y16) *(u32x2*)(y16 + orow * D + c) = u32x2{pack_op16x2(y[0], y[1]), pack_op16x2(y[2], y[3])};
+        if (y32) *(f32x4*)(y32 + orow * D + c) = (rnd & 2) ? op16x4_to_f32(pack_op16x4(y)) : y;
+        if (y16) *(u32x2*)(y16 + orow * D + c) = pack_op16x4(y);
         if (yp16) {
             const f32x4 p = *(const f32x4*)(pr + c);
-            *(u32x2*)(yp16 + orow * D + c) = u32x2{pack_op16x2(y[0] + p[0], y[1] + p[1]), pack_op16x2(y[2] + p[2], y[3] + p[3])};
+            *(u32x2*)(yp16 + orow * D + c) = pack_op16x4(f32x4{y[0] + p[0], y[1] + p[1], y[2] + p[2], y[3] + p[3]});
         }
     }
 }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         for (int i = 0; i < NV; ++i) {
             const int c = i * 256 + lane * 4;
             *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
-                u32x2{pack_op16x2(ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r)), pack_op16x2(ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r))};
+                pack_op16x4(f32x4{ww[i][0] * (v[i][0] * r), ww[i][1] * (v[i][1] * r), ww[i][2] * (v[i][2] * r), ww[i][3] * (v[i][3] * r)});
         }
     } else {
         float s = 0.f;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         for (int c = lane * 4; c < d; c += 256) {
             const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
             *(u32x2*)(y + (packed ? rv_xp_index((int)row, c, packed) : row * d + c)) =
-                u32x2{pack_op16x2(ww[0] * (v[0] * r), ww[1] * (v[1] * r)), pack_op16x2(ww[2] * (v[2] * r), ww[3] * (v[3] * r))};
+                pack_op16x4(f32x4{ww[0] * (v[0] * r), ww[1] * (v[1] * r), ww[2] * (v[2] * r), ww[3] * (v[3] * r)});
         }
     }
 }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* __restr
     for (int c = lane * 4; c < d; c += 256) {
         const f32x4 v = *(const f32x4*)(xr + c), ww = *(const f32x4*)(w + c);
         const float o0 = ww[0] * (v[0] * r), o1 = ww[1] * (v[1] * r), o2 = ww[2] * (v[2] * r), o3 = ww[3] * (v[3] * r);
-        *(u32x2*)(packed ? y + rv_xp_index((int)row, c, packed) : yr + c) = u32x2{pack_op16x2(o0, o1), pack_op16x2(o2, o3)};
+        *(u32x2*)(packed ? y + rv_xp_index((int)row, c, packed) : yr + c) = pack_op16x4(f32x4{o0, o1, o2, o3});
         *(u32x2*)(packed ? y + rv_xp_index((int)row, d + c, packed) : yr + d + c) = u32x2{pack_op16x2_lo(o0, o1), pack_op16x2_lo(o2, o3)};
     }
 }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     const int c = (int)(i - row * n);
     const f32x4 v = *(const f32x4*)(x + row * ldx + c);
     op16_t* yr = y + row * 2 * n;
-    *(u32x2*)(yr + c) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+    *(u32x2*)(yr + c) = pack_op16x4(v);
     *(u32x2*)(yr + n + c) = u32x2{pack_op16x2_lo(v[0], v[1]), pack_op16x2_lo(v[2], v[3])};
 }
 
@@ -255,7 +255,7 @@ __global__ void frames_in_kernel(const op16_t* __restrict__ x, const float* __re
     const float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
     if (v32) *(f32x4*)(v32 + i) = f32x4{f0, f1, f2, f3};
     const f32x4 p = *(const f32x4*)(pos + (row % T) * d + c);
-    *(u32x2*)(vp16 + i) = u32x2{pack_op16x2(f0 + p[0], f1 + p[1]), pack_op16x2(f2 + p[2], f3 + p[3])};
+    *(u32x2*)(vp16 + i) = pack_op16x4(f32x4{f0 + p[0], f1 + p[1], f2 + p[2], f3 + p[3]});
 }
 
 // X = [cls ; frames] per sequence: src is either bf16 features (src16) or f32 frames (src32), [N,T,768];
@@ -279,9 +279,9 @@ __global__ void build_x_kernel(const op16_t* __restrict__ src16, const float* __
         v = op16x4_to_f32(raw);
     }
     if (x32) *(f32x4*)(x32 + i) = v;
-    *(u32x2*)(x16 + i) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+    *(u32x2*)(x16 + i) = pack_op16x4(v);
     const f32x4 p = *(const f32x4*)(pm + (int64_t)t * d + c);
-    *(u32x2*)(xp16 + i) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
+    *(u32x2*)(xp16 + i) = pack_op16x4(f32x4{v[0] + p[0], v[1] + p[1], v[2] + p[2], v[3] + p[3]});
 }
 
 // the CLS rows of X = [cls ; frames] alone (row n * (T + 1) of x32 / x16 / xp16): the frame rows were written in place by the last
@@ -295,8 +295,8 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     const int64_t o = n * (T + 1) * d + c;
     const f32x4 v = *(const f32x4*)(cls + c), p = *(const f32x4*)(pm + c);
     if (x32) *(f32x4*)(x32 + o) = v;
-    *(u32x2*)(x16 + o) = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
-    *(u32x2*)(xp16 + o) = u32x2{pack_op16x2(v[0] + p[0], v[1] + p[1]), pack_op16x2(v[2] + p[2], v[3] + p[3])};
+    *(u32x2*)(x16 + o) = pack_op16x4(v);
+    *(u32x2*)(xp16 + o) = pack_op16x4(f32x4{v[0] + p[0], v[1] + p[1], v[2] + p[2], v[3] + p[3]});
 }
 
 // rows of 16-bit operands (row stride ld) -> contiguous f32 rows
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void t2v_softmax_kernel(const float* __restric
     const float iz = z > 0.f ? 1.0f / z : 0.f;
     u32x2* p2 = (u32x2*)(P + i * LK);
 #pragma unroll
-    for (int c = 0; c < LK / 4; ++c) p2[c] = u32x2{pack_op16x2(v[c][0] * iz, v[c][1] * iz), pack_op16x2(v[c][2] * iz, v[c][3] * iz)};
+    for (int c = 0; c < LK / 4; ++c) p2[c] = pack_op16x4(f32x4{v[c][0] * iz, v[c][1] * iz, v[c][2] * iz, v[c][3] * iz});
 }
 
 // ---- RoPE (cos, sin) table; the rotation itself and the KV-cache append live in the fused QKV epilogue (gemm.hip) ----

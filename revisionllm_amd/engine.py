@@ -84,6 +84,11 @@ class Engine:
         self.slots_in_flight = set()   # slots whose generate (decoding alone) has started and not finished: see model.generate_steps
         self.gate = gate if gate is not None else PersistGate.for_device(self.device)
         self.has_llm = self.has_clip = self.has_linear = False
+        # fp16 stores that saturated (the reference's bf16 path cannot overflow; this build's default operand type can): the library counts them in
+        # a device word that travels with the hand-off status snapshots.  on_saturation: "warn" (once per new count), "raise" or "ignore"
+        self.numeric_status = hip.numeric_status(self.flavour, self.device)
+        self.on_saturation = "warn"
+        self.saturated_seen = 0
 
     def __del__(self):
         try:
@@ -256,9 +261,35 @@ class Engine:
             self._ws[key] = t
         return t
 
+    _NUMERIC_KEY = ("numeric", "saturated")
+
     def _status_words(self):
-        return [(key, ws[8188:8192].view(torch.int32)) for key, ws in list(self._ws.items())
-                if isinstance(key, tuple) and key[0] != "kv" and key[1] in ("llm", "clip") and ws.numel() >= 8192]
+        words = [(key, ws[8188:8192].view(torch.int32)) for key, ws in list(self._ws.items())
+                 if isinstance(key, tuple) and key[0] != "kv" and key[1] in ("llm", "clip") and ws.numel() >= 8192]
+        if words:       # the saturation count rides along (same copy, same event)
+            words.append((self._NUMERIC_KEY, self.numeric_status[:1]))
+        return words
+
+    def saturated(self, reset=False):
+        """Sticky count of f32 -> fp16 stores that met a value outside +-65504 (``rv_ctx_get_option("saturated")``; waits for the device).  Always 0
+        for a bf16 engine.  ``reset``: zero it afterwards."""
+        n = self.get_option("saturated")
+        if reset:
+            self.set_option("saturated", 0)
+            self.saturated_seen = 0
+        return n
+
+    def _note_saturation(self, count):
+        if count <= self.saturated_seen:
+            return
+        new, self.saturated_seen = count - self.saturated_seen, count
+        msg = (f"{new} fp16 store(s) saturated at +-65504 since the last check ({count} in total): activations of this checkpoint leave the fp16 range; "
+               "the affected elements lost accuracy (no inf was produced).  Use op_dtype='bf16' for the reference's exponent range.")
+        if self.on_saturation == "raise":
+            raise hip.HipLibraryError(msg)
+        if self.on_saturation == "warn":
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
     def handoff_status_async(self):
         """Snapshot of every workspace's hand-off status word, copied to pinned host memory on the CURRENT stream (no host wait): a pipeline
@@ -283,7 +314,10 @@ class Engine:
             keys, vals = [k for k, _ in words], torch.cat([w for _, w in words]).cpu()
         else:
             keys, vals = snapshot
-        bad = [(k, int(v)) for k, v in zip(keys, vals.tolist()) if v != 0]
+        bad = [(k, int(v)) for k, v in zip(keys, vals.tolist()) if v != 0 and k != self._NUMERIC_KEY]
+        sat = [int(v) & 0xffffffff for k, v in zip(keys, vals.tolist()) if k == self._NUMERIC_KEY]
+        if sat:
+            self._note_saturation(sat[0])
         if bad:
             for k, _ in bad:
                 ws = self._ws.get(k)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "rv_init_hash": (C.c_int, [_p, C.c_int, _i64, _u64, _f, _f, _p]),
     "rv_ctx_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
     "rv_ctx_get_option": (C.c_int, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "rv_numeric_status_bind": (C.c_int, [_p]),
     "rv_gemm_ws_bytes": (_sz, []),
     "rv_gemm_rows_ws_bytes": (_sz, []),
     "rv_gemm_rows": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, C.c_int, C.c_int, _p]),
@@ -146,6 +147,28 @@ def lib(f=None):
             raise HipLibraryError(f"{path} is not the {f} build of the library (rv_operand_dtype() = {h.rv_operand_dtype()})")
         _libs[f] = h
     return h
+
+
+_numeric = {}
+
+
+def numeric_status(f=None, device=None):
+    """The numeric status buffer of a flavour's library on a device (``rv_numeric_status_bind``): int32 [4] device tensor, word 0 = the sticky count of
+    f32 -> fp16 stores that saturated.  Created, zeroed and bound on first use (one per library instance and device; the library keeps the pointer, this
+    module keeps the tensor alive).  Reading it is an ordinary device -> host copy: pipelines that copy results out anyway take it along."""
+    f = flavour_of(f)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (f, dev.index)
+    t = _numeric.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)          # the zero fill is complete before any kernel can add to the buffer
+            check(lib(f).rv_numeric_status_bind(C.c_void_p(t.data_ptr())), "rv_numeric_status_bind")
+        _numeric[key] = t
+    return t
 
 
 def last_error():

@@ -125,6 +125,7 @@ def load_pretrained_model(args, stage2=None, stage3=None, load_ckp=False):
     # build-defined: args.op_dtype = "f16" (default: the checkpoints' own storage type - builder.py:22 loads them with torch_dtype=float16 -
     # held exactly; segment scores within 1e-3 of the reference's fp32 CPU path) or "bf16" (the reference's GPU dtype, e2e2.py:181-185)
     model = ReVisionLlamaForCausalLM(shape_from_config(cfg), max_sequence_length=cfg.get("max_sequence_length"), op_dtype=getattr(args, "op_dtype", None))
+    print(f"[revisionllm_amd] operand type: {str(model.dtype).replace('torch.', '')} (args.op_dtype = {getattr(args, 'op_dtype', None)!r}; f32 accumulation / residual stream)", flush=True)
     model.fp8_prefill = bool(getattr(args, "fp8_prefill", False))  # build-defined opt-in: FP8 x FP8 prefill GEMMs
     model.fp8_decode = bool(getattr(args, "fp8_decode", False))   # build-defined opt-in: FP8 copies of the LLM weights for decode steps
     model.parity = bool(getattr(args, "parity", False))           # build-defined opt-in: K-duplicated copies for the parity precision (engine option precision = 1)

@@ -8,6 +8,7 @@ adapter dispatch, building the splice map, the token loop, EOS bookkeeping and o
 """
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 
 from .. import hip, ops
@@ -159,11 +160,24 @@ class ReVisionLlamaForCausalLM:
     def cuda(self, device=None):
         return self
 
-    def bfloat16(self):
+    _dtype_note_done = False
+
+    def _dtype_request(self, what, asked):
+        """``model.bfloat16()`` / ``.half()`` / ``.to(dtype)`` keep the reference's call sites working (e2e2.py:181-185) but do NOT pick the arithmetic:
+        the operand type belongs to the library build this model was created for (``args.op_dtype`` / ``--op_dtype``; fp16 by default).  A request for
+        the OTHER 16-bit type is answered once per process with a note instead of silently."""
+        if asked is not None and asked != self.dtype and asked in (torch.float16, torch.bfloat16) and not ReVisionLlamaForCausalLM._dtype_note_done:
+            ReVisionLlamaForCausalLM._dtype_note_done = True
+            print(f"[revisionllm_amd] {what}: ignored - this model computes with {str(self.dtype).replace('torch.', '')} operands "
+                  f"(librevision_hip{'_bf16' if self.op_flavour == 'bf16' else ''}.so, f32 accumulation and residual stream); pass op_dtype="
+                  f"'{'bf16' if asked == torch.bfloat16 else 'f16'}' to load_pretrained_model's args (--op_dtype) to change the operand type", flush=True)
         return self
 
+    def bfloat16(self):
+        return self._dtype_request(".bfloat16()", torch.bfloat16)
+
     def half(self):
-        return self
+        return self._dtype_request(".half()", torch.float16)
 
     def float(self):
         return self
@@ -172,7 +186,8 @@ class ReVisionLlamaForCausalLM:
         """Weights live in HBM as 16-bit operands (fp16 by default, ``op_dtype``) with fp32 accumulation / residual stream; dtype moves are accepted and ignored.
         NOTE (differs from the reference): ``scores`` / ``logits`` returned by ``generate`` are float32 whatever dtype was
         asked for here (the reference returns them in the model dtype, bf16 on the GPU)."""
-        return self
+        asked = kwargs.get("dtype", next((a for a in args if isinstance(a, torch.dtype)), None))
+        return self._dtype_request(f".to({asked})", asked)
 
     # ---- adapter dispatch (vtimellm_arch.py:102-147) ---------------------------------------------
     def encode_images(self, images, query_feats, iteration_step=None):
@@ -556,7 +571,10 @@ class ReVisionLlamaForCausalLM:
             if output_scores and do_sample and self.scores_mode == "processed" and (not top_k or top_k > hip.TOPK_CAP):
                 # no top-k filter (top_k = 0 / None) or one wider than the candidate list (top_k > 64): there is no list - the processed scores are
                 # logits / T with everything below the kernel's threshold (the smallest score the top-k and top-p filters keep) at -inf
-                sc = logits / temperature
+                # - computed EXACTLY as the kernel computes them (sample.hip: v * (1.0f / temperature), both in f32): logits / T differs from that by
+                # one ulp for about one value in seven at T = 0.05, and a smallest kept score that lands one ulp BELOW the threshold would be masked
+                # although it was kept (with one kept token the whole row would turn -inf)
+                sc = logits * float(np.float32(1.0) / np.float32(temperature))
                 score_steps.append(sc.masked_fill(sc < o["threshold"][:, None], float("-inf")))
             elif output_scores and do_sample and self.scores_mode == "processed":
                 V = logits.shape[1]

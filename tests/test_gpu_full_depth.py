@@ -37,7 +37,8 @@ def g8_run(golden, op_flavour):
     m.get_model().initialize_vision_modules(SimpleNamespace(clip_adapter=True, cross_attn=False, pretrain_clip_adapter=None,
                                                             pretrain_mm_mlp_adapter=None, clip_adapter_text=True, clip_adapter_feature="cls",
                                                             hierarchy=True, adapter_input_dim=768))
-    m.engine.init_synthetic(seed=SEED, llm=True, clip=True, grid="bf16")      # the fixture's reference ran on bf16-representable matrices
+    # the fixture's reference ran on bf16-representable matrices; parity=True also binds the K-duplicated copies the split-operand precision multiplies with
+    m.engine.init_synthetic(seed=SEED, llm=True, clip=True, grid="bf16", parity=True)
     m.generation_config.eos_token_id = None
     W, Tn, Lq, G = meta["W"], meta["T"], meta["Lq"], meta["G"]
     features = feats("g8.feat", (W, Tn, 768), bf16="bf16").to(op()).cuda()
@@ -45,21 +46,31 @@ def g8_run(golden, op_flavour):
     qc = feats("g8.qcls", (768,), bf16="bf16").cuda()
     ids = T(g["prompt_ids"])[None]
     perms = [T(p) for key in ("perms_z4", "perms_z2", "perms_z1") for p in g[key]]
+    r = SimpleNamespace(g=g, meta=meta, model=m, features=features, qf=qf, qc=qc, perms=perms, ids=ids)
+    r.calls = _per_call(r)
+    r.cos = ops.topk_cosine(features, qc, 3).cpu()
+    return r
+
+
+def _per_call(r):
+    """The 7 calls one by one (reference mode), teacher-forced on the reference's tokens, in the engine's CURRENT precision."""
+    from revisionllm_amd import ops
+    g, meta, m = r.g, r.meta, r.model
+    Lq, G = meta["Lq"], meta["G"]
     calls = []
     for c, (z, start) in enumerate(zip(g["zooms"].tolist(), g["starts"].tolist())):
         b = meta["batch"] // z
-        feat = features[start:start + b][perms[c].cuda()]
+        feat = r.features[start:start + b][r.perms[c].cuda()]
         if z > 1:
             feat = feat.repeat_interleave(z, 0)
-        out = m.generate(ids, images=feat[None], query_feats=(qf[None], torch.ones(1, Lq)), do_sample=True, temperature=0.05, top_k=50,
+        out = m.generate(r.ids, images=feat[None], query_feats=(r.qf[None], torch.ones(1, Lq)), do_sample=True, temperature=0.05, top_k=50,
                          top_p=1.0, max_new_tokens=G, forced_tokens=T(g["tokens"][c])[:, None], output_scores=True, output_logits=True,
                          return_dict_in_generate=True)
         raw = torch.stack(out["logits"], 1)[0].cpu()            # [G, V]
         proc = torch.stack(out["scores"], 1)                      # [1, G, V] processed
         stats = ops.entropy_stats(proc)[0].cpu()
         calls.append(dict(raw=raw, proc=proc[0].cpu(), stats=stats))
-    cos = ops.topk_cosine(features, qc, 3).cpu()
-    return SimpleNamespace(g=g, meta=meta, calls=calls, cos=cos, model=m, features=features, qf=qf, qc=qc, perms=perms, ids=ids)
+    return calls
 
 
 def _rel(a, b):
@@ -118,6 +129,44 @@ def test_full_depth_scores_vs_reference(g8_run):
     # bf16 arithmetic through 32 random layers: no further from the fp32 reference than the reference's OWN bf16 path
     assert err.mean() <= 0.5 * err16.mean() and err.max() <= err16.max()            # measured: 0.28 x / 0.26 x
     assert np.median(e_max) <= 1.5 * np.median(b_max) + 1e-3 and np.median(e_mean) <= 1.5 * np.median(b_mean) + 1e-3
+
+
+def test_full_depth_g8_conditioning_and_the_parity_precision(g8_run, golden):
+    """What 1e-3 means on the benchmark's OWN weights.  G8 = plain N(0, 0.02) random-init Vicuna-7B, the weights bench.py times.
+    (a) tests/golden/g8_fp32_vs_fp64.json (make_goldens.py g8x: call 0 through the reference in fp32 and in float64): the reference's own fp32 scores are
+    determined to ~1e-4 - G8 IS a legitimate 1e-3 target for an arithmetic with enough bits; (b) the fixture's bf16 leg (the reference's own GPU arithmetic,
+    e2e2.py:182) misses it by 2 % - 258 %, the build's default fp16 operands by up to ~7 % (test above): on these weights the recursion amplifies an operand
+    rounding ~1000 x; (c) the build's PARITY precision (rv_ctx_set_option precision = 1: every GEMM operand a split pair, 22 significand bits in the fp16 build)
+    is run here on G8 and its element-wise distances are recorded in gpurun_out/g8_parity_precision1.json and asserted."""
+    r, g = g8_run, g8_run.g
+    fx = golden.json("g8_fp32_vs_fp64")
+    assert fx["g8"]["rerun_fp32"]["rel_to_recorded"] == [0.0, 0.0]                       # the float64 leg ran on exactly the recorded call
+    floor = max(fx["g8"]["fp32_vs_fp64"]["inv_max"], fx["g8"]["fp32_vs_fp64"]["inv_mean"])
+    assert floor < 1e-3                                                                   # the reference's fp32 determines these scores to better than the north star
+    eng = r.model.engine
+    eng.set_option("precision", 1)
+    try:
+        calls = _per_call(r)
+    finally:
+        eng.set_option("precision", 0)
+    st = np.stack([c["stats"].numpy() for c in calls])
+    e_max, e_mean = _rel(1 / st[:, 0], g["inv_max"]), _rel(1 / st[:, 2], g["inv_mean"])
+    st0 = np.stack([c["stats"].numpy() for c in r.calls])
+    d_max, d_mean = _rel(1 / st0[:, 0], g["inv_max"]), _rel(1 / st0[:, 2], g["inv_mean"])
+    b_max, b_mean = _rel(1 / g["bf16_stats"][:, 0], g["inv_max"]), _rel(1 / g["bf16_stats"][:, 2], g["inv_mean"])
+    report = {"fixture": "G8: plain N(0, 0.02) random-init Vicuna-7B (the weights bench.py times), 7 calls, teacher-forced", "operands": fl(),
+              "reference_fp32_vs_fp64_call0": fx["g8"]["fp32_vs_fp64"],
+              "inv_max_entropy_rel_err": {"precision_1_split_operands": e_max.tolist(), "default_precision": d_max.tolist(), "reference_bf16": b_max.tolist()},
+              "inv_mean_entropy_rel_err": {"precision_1_split_operands": e_mean.tolist(), "default_precision": d_mean.tolist(), "reference_bf16": b_mean.tolist()},
+              "north_star_tolerance": 1e-3}
+    print("\n[G8, parity precision] " + json.dumps(report, indent=1))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "g8_parity_precision1_%s.json" % fl()), "w") as f:
+        json.dump(report, f, indent=1)
+    assert np.isfinite(st[:, :3]).all()
+    # the split operands must pay off by an order of magnitude on the median call, and never be worse than the default precision
+    assert np.median(e_max) <= 0.2 * np.median(d_max) and np.median(e_mean) <= 0.2 * np.median(d_mean)
+    assert e_max.max() <= d_max.max() and e_mean.max() <= d_mean.max()
 
 
 def test_full_depth_batched_recursion_matches_per_call(g8_run):

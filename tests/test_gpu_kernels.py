@@ -32,7 +32,7 @@ def bf(x):
 
 def test_abi_version(dev):
     from revisionllm_amd import hip
-    assert hip.lib().rv_abi_version() == 4 and hip.lib().rv_operand_dtype() == hip.dtype_code(torch.empty(0, dtype=op()))
+    assert hip.lib().rv_abi_version() == 5 and hip.lib().rv_operand_dtype() == hip.dtype_code(torch.empty(0, dtype=op()))
 
 
 def test_init_hash_bit_exact(dev):
@@ -398,6 +398,84 @@ def test_fp16_saturating_conversions_never_produce_inf(dev):
     got = eng.llm_layers(h.clone().to(dev).contiguous(), 0, kv, Smax, 0, 1).cpu()
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max() / (want - h).abs().max()) < tol(1e-2)          # against what the block ADDED to the stream
+
+
+def test_fp16_saturation_is_reported(dev):
+    """VERDICT r5 #6 / ADVICE r5: the fp16 build's stores saturate instead of overflowing - and now SAY so, and a NaN stays a NaN.  (a) a GEMM row whose
+    products leave +-65504 comes out saturated, the library's sticky count (rv_numeric_status_bind / option "saturated") goes up, every other row is
+    bit-identical to the run without the planted row; a NaN planted in one input row yields NaN in that output row only (rounds 1 - 5: -65504);
+    (b) the same through the Llama engine in its prefill form and in BOTH decode forms (rv_llm_forward S = 1 and the merged rv_llm_decode_rows): a NaN
+    planted in one sequence's residual stream gives NaN logits for that sequence and bit-identical logits for the others; a 1e7 residual row (the fused
+    RMSNorm operand w * h of the decode kernels) is counted, warned about once by check_handoff_status, and leaves the other rows unchanged.
+    The bf16 build: NaN behaviour the same, the count stays 0."""
+    from revisionllm_amd import hip, ops
+    f16 = fl() == "f16"
+    status = hip.numeric_status(fl(), dev)
+    count = lambda: int(status[0].item()) & 0xffffffff
+    a = feats("satr.a", (48, 512), bf16=fl())
+    w = feats("satr.w", (64, 512), bf16=fl())
+    clean = ops.gemm(a.to(op()).to(dev), w.to(op()).to(dev), out_dtype=op())
+    c0 = count()
+    big = a.clone()
+    big[5] = 300.0 * torch.sign(w[0])                     # row 5 . w[0] = 300 * sum |w[0]| ~ 1.3e5
+    got = ops.gemm(big.to(op()).to(dev), w.to(op()).to(dev), out_dtype=op())
+    keep = torch.arange(48) != 5
+    assert torch.isfinite(got).all() and torch.equal(got[keep], clean[keep])
+    if f16:
+        assert float(got[5, 0]) == 65504.0 and count() > c0
+    else:
+        assert count() == c0 == 0
+    nan = a.clone()
+    nan[7, 33] = float("nan")
+    got = ops.gemm(nan.to(op()).to(dev), w.to(op()).to(dev), out_dtype=op())
+    keep = torch.arange(48) != 7
+    assert torch.isnan(got[7]).all() and torch.equal(got[keep], clean[keep])
+    # (b) the engine
+    eng = _tiny_engine(dev)
+    D = eng.shape.hidden
+    eng.on_saturation = "warn"
+    eng.saturated(reset=True)
+    h0 = feats("satr.h", (3, 24, D)) * 0.5
+
+    def prefill(h):
+        kv, Smax = eng.new_kv(3, 64, reuse=False)
+        return eng.llm_forward(h.clone().to(dev).contiguous(), 0, kv, Smax).clone(), kv, Smax
+    base, kv, Smax = prefill(h0)
+    hn = h0.clone()
+    hn[1, 9, 17] = float("nan")
+    got, _, _ = prefill(hn)
+    assert torch.isnan(got[1]).all() and torch.equal(got[[0, 2]], base[[0, 2]])
+    assert eng.saturated() == 0
+    h1 = feats("satr.h1", (3, 1, D)) * 0.5
+    for form in ("forward", "decode_rows"):
+        def step(h):
+            kv2 = kv.clone()
+            if form == "forward":
+                return eng.llm_forward(h.clone().to(dev).contiguous(), 24, kv2, Smax).clone()
+            return eng.llm_decode_rows(h[:, 0].clone().to(dev).contiguous(), torch.full((3,), 24, dtype=torch.int32, device=dev), kv2, Smax).clone()
+        base1 = step(h1)
+        assert torch.isfinite(base1).all() and eng.saturated() == 0
+        hn = h1.clone()
+        hn[2, 0, 5] = float("nan")
+        got = step(hn)
+        assert torch.isnan(got[2]).all() and torch.equal(got[:2], base1[:2]), form
+        hb = h1.clone()
+        hb[0, 0, 40:44] = 1.0e7                  # w_next * h of the fused-RMSNorm operand leaves the fp16 range in four elements of row 0
+        got = step(hb)
+        assert torch.isfinite(got).all() and torch.equal(got[1:], base1[1:]), form
+        if f16:
+            assert eng.saturated() > 0, form
+            eng.saturated_seen = 0
+            with pytest.warns(RuntimeWarning, match="saturated"):
+                eng.check_handoff_status()
+            eng.on_saturation = "raise"
+            eng.saturated_seen = 0
+            with pytest.raises(hip.HipLibraryError, match="saturated"):
+                eng.check_handoff_status()
+            eng.on_saturation = "warn"
+            assert eng.saturated(reset=True) > 0 and eng.saturated() == 0
+        else:
+            assert eng.saturated() == 0
 
 
 def _ref_attn(q, k, v, causal, pad, q_pos0, kv_div):

@@ -160,6 +160,39 @@ def test_sampling_scores_and_entropy_vs_oracle():
     assert torch.allclose(out["entropy"].cpu(), _entropy(got_sc).t(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("temperature", [0.05, 0.7])
+@pytest.mark.parametrize("k,p", [(0, 0.6), (100, 0.9), (100, 1.0)])
+def test_processed_scores_keep_every_token_the_kernel_kept(k, p, temperature):
+    """without a top-k list the processed ``scores`` are rebuilt from the kernel's threshold, so they must be computed as the kernel computes
+    them (logit * (1.0f / T) in f32, not logit / T: one ulp apart for one value in seven at T = 0.05): the number of finite scores of every row equals the
+    kernel's own kept count, the sampled token's score is finite, and no row is all -inf - also at the sharp T = 0.05 / top_p = 0.6 of inference.py:49-51
+    where a single token can be the whole kept set."""
+    from revisionllm_amd import ops
+    from revisionllm_amd.utils import synth
+    shape = synth.TINY
+    m = _model(shape, _args())
+    m.generation_config.top_k, m.generation_config.top_p, m.generation_config.temperature = k, p, temperature
+    ids = T(synth.synthetic_prompt_ids(40, 20, SEED, vocab=shape.vocab))[None].repeat(3, 1)
+    feat = feats("smp.feat", (3, 10, 16, 768), bf16=fl())
+    q = (feats("smp.q", (3, 5, 768), bf16=fl()), torch.ones(3, 5))
+    u = torch.tensor([[0.03, 0.5, 0.97]]).repeat(6, 1)
+    out = m.generate(ids, images=feat, query_feats=q, do_sample=True, temperature=temperature, max_new_tokens=6, output_scores=True, output_logits=True,
+                     return_dict_in_generate=True, uniforms=u)
+    sc, raw = torch.stack(out["scores"]), torch.stack(out["logits"])                     # [G,B,V]
+    tok = out["sequences"][:, ids.shape[1]:].t()
+    assert torch.isfinite(sc.gather(2, tok[..., None])).all()                            # what was drawn was kept
+    for s_ in range(sc.shape[0]):
+        o = ops.sample(raw[s_].contiguous(), u[s_].cuda(), True, temperature, k, p, ctx=m.engine)
+        assert torch.equal(torch.isfinite(sc[s_]).sum(-1).int(), o["n_keep"].int()), (s_, torch.isfinite(sc[s_]).sum(-1), o["n_keep"])
+        assert torch.equal(o["tokens"].long(), tok[s_])
+    # a scaled-up row: ONE token owns the nucleus - its score must survive the threshold compare
+    big = raw[0] * 40.0
+    o = ops.sample(big.contiguous(), u[0].cuda(), True, temperature, k, 0.6, ctx=m.engine)
+    scb = big * float(np.float32(1.0) / np.float32(temperature))
+    kept = (scb >= o["threshold"][:, None]).sum(-1)
+    assert torch.equal(kept.int(), o["n_keep"].int()) and (kept >= 1).all()
+
+
 @pytest.mark.parametrize("k,p", [(None, 0.9), (200, 1.0), (150, 0.95)])
 def test_generate_with_the_top_k_filter_disabled(k, p):
     """A checkpoint whose generation_config.json disables top-k (``top_k`` None / 0; inference.py:45-59 passes no top_k, so the config rules) or

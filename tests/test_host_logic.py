@@ -162,7 +162,7 @@ def test_abi_exports_every_declared_symbol():
         exported = set(re.findall(r"\b[A-Za-z] ([A-Za-z_][A-Za-z0-9_$.@]*)$", nm, flags=re.M))
         assert exported == declared, (flavour, exported ^ declared)
         lib = hip.lib(flavour)
-        assert lib.rv_abi_version() == 4
+        assert lib.rv_abi_version() == 5
         assert lib.rv_operand_dtype() == {"f16": hip.RV_F16, "bf16": hip.RV_BF16}[flavour]
         # argument validation runs on the host before any launch
         assert lib.rv_gemm(None, None, 0, None, 0, 0, None, None, 0, None, 0, lib.rv_operand_dtype(), 0, 4, 4, 64, None, 0, None) < 0

@@ -18,7 +18,7 @@ def main():
     o = ops.sample(logits, u, True, 0.05, 50, 1.0)
     lib, st = hip.lib(), hip.stream()
     args = (None, hip.ptr(logits), B, 32000, hip.ptr(u), 1, 0.05, 50, 1.0, hip.ptr(o["tokens"]), hip.ptr(o["entropy_proc"]),
-            hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]), st)
+            hip.ptr(o["entropy_raw"]), hip.ptr(o["topk_idx"]), hip.ptr(o["topk_val"]), hip.ptr(o["n_keep"]), hip.ptr(o["threshold"]), st)
     for _ in range(5):
         lib.rv_sample(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
