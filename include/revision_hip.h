@@ -125,6 +125,9 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *   "adapter_fold_t2v"   1 (default) = rv_clip_encoder, text -> video layers (transformer.py:271-305) whose queries have <= 32 text tokens: Q projection + cross-attention +
  *                        output projection run as x.A1^T -> softmax -> P.A2^T with A1 / A2 folded from the text K / V rows per (layer, query) - the same function, other
  *                        rounding points (q and the attention output are never rounded to 16 bits; A1 / A2 are).  0 = the three separate steps.
+ *   "attn_lds"           1 (default) = rv_attention / the ClipEncoder's and CLIP towers' self-attention with >= 96 keys and no mask (head width 64 / 96, not causal): a
+ *                        workgroup of 128 query rows stages every 32-key block of K / V^T in LDS once (LDS-DMA, double-buffered) instead of each wave fetching its own
+ *                        copy from L2 (transformer.py:193,210-223 at T = 256 / 1024).  0 = the per-wave form.  Rows are bit-identical either way.
  *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
  *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the
  *                        LayerNorm inputs are read as fp16, accumulation and statistics stay f32 (transformer.py:210-223,271-305 keep fp32 activations; the measured

@@ -329,6 +329,149 @@ __device__ __forceinline__ void attn_body2(const AttnArgs& a, int bx, int h, int
     }
 }
 
+// LONG-KEY form (round 6): the adapter's self-attention over 257 / 1025 keys, the CLIP towers.  attn_body fetches every key block's K and V^T fragments from L2
+// once PER WAVE: twelve 16-byte-per-lane loads per 32 keys and wave at dh = 96, and the CU's vector-memory path accepts one such instruction per 16 cycles for all
+// four SIMDs together - 768 cycles of address work per block step against 192 of MFMA (32 windows x 1024 frames: 308 us per layer, 0.13 of the MFMA peak).  Here a
+// workgroup is 4 waves x 32 query rows (two 16-row tiles per wave share a block's fragments in registers, as attn_body2) and a key block is staged in LDS ONCE per
+// workgroup by LDS-DMA - each wave moves NF / 4 of its NF fragments, already in the lane order the MFMAs consume, so every ds_read_b128 is one conflict-free 1 KiB
+// run - double-buffered: block i + 1 travels while block i is computed, one barrier per block.  No key split, no padding mask, no per-row positions, not causal.
+// Per tile the operations of attn_body in the same order: rows are BIT-identical to the short-key kernel's.
+typedef const __attribute__((address_space(1))) void* attn_gptr_t;
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+template <int DH>
+__device__ __forceinline__ void attn_body_lds(const AttnArgs& a, int bx, int h, int b, char* smem) {
+    constexpr int NC = DH / 32, ND = DH / 16, NF = 2 * NC + ND, STAGE = NF * 1024;
+    static_assert(NF % 4 == 0, "the four waves stage NF / 4 fragments each");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int q0 = bx * 128 + wave * 32;
+    const bool active = q0 < a.Lq, two = q0 + 16 < a.Lq;      // (wave-uniform) an idle wave still stages its share and keeps the barriers
+    const int kb_ = b / a.kv_div;
+    const int Lk = a.Lk;
+    op16x8 qf[2][NC];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const op16_t* qp = (const op16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + qt * 16 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const op16x8*)(qp + c * 32);
+    }
+    const op16_t* kbase = (const op16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const op16_t* vbase = (const op16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    const int krow = (fr >> 2) * 8 + (fr & 3);
+    // fragment f of a block: f < 2 NC: score tile t = f / NC, k-chunk c = f % NC of K; else V^T fragment dt = f - 2 NC.  The source address of a lane is the
+    // address attn_body loads from; the destination is lane-linear behind the fragment's base.
+    auto stage = [&](int k0, char* buf) {
+#pragma unroll
+        for (int i = 0; i < NF / 4; ++i) {
+            const int f = wave + 4 * i;
+            const op16_t* src;
+            if (f < 2 * NC) {
+                const int t = f / NC, c = f - t * NC;
+                src = kbase + (int64_t)min(k0 + krow + t * 4, Lk - 1) * a.k_rs + c * 32;
+            } else {
+                src = vbase + (int64_t)(f - 2 * NC) * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks;
+            }
+            __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(buf + f * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 o[2][ND];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int nblk = (Lk + 31) >> 5;
+    stage(0, smem);
+    for (int i = 0; i < nblk; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of block i have landed ...
+        __builtin_amdgcn_s_barrier();                         // ... and everyone's; and every wave is done reading the other buffer (block i - 1)
+        asm volatile("" ::: "memory");
+        if (i + 1 < nblk) stage((i + 1) * 32, smem + ((i + 1) & 1) * STAGE);
+        if (!active) continue;
+        const char* buf = smem + (i & 1) * STAGE + lane * 16;
+        const int k0 = i * 32;
+        op16x8 kf[2][NC];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const op16x8*)(buf + (t * NC + c) * 1024);
+        op16x8 vf[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const op16x8*)(buf + (2 * NC + dt) * 1024);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (qt == 1 && !two) continue;      // (wave-uniform)
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s[t] = rv_mfma16(kf[t][c], qf[qt][c], s[t]);
+            }
+            float mx = -INFINITY;
+            if (k0 + 32 <= Lk) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s[t][r] *= a.scale;
+                        mx = fmaxf(mx, s[t][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + g * 8 + t * 4 + r;
+                        const float v = key >= Lk ? -INFINITY : s[t][r] * a.scale;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __expf(m_run[qt] - m_use);
+            float psum = 0.f;
+            float pp[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[t][r] - m_use);
+                    pp[t * 4 + r] = e;
+                    psum += e;
+                }
+            l_run[qt] = l_run[qt] * alpha + psum;
+            m_run[qt] = m_new;
+            union { op16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf.u[j] = pack_op16x2_bounded(pp[2 * j], pp[2 * j + 1]);
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) o[qt][dt] *= alpha;
+            }
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) o[qt][dt] = rv_mfma16(vf[dt], pf.v, o[qt][dt]);
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int row = q0 + qt * 16 + fr;
+        if (row >= a.Lq) continue;
+        const float inv = 1.0f / l;
+        op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)row * a.o_rs + h * DH + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+            *(u32x2*)(op + dt * 16) = pack_op16x4(f32x4{o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv});
+    }
+}
+
 // 1-D grid, XCD-aware: workgroup id lands on XCD id % 8 (private L2), so the query tiles of one (batch, head) - which read
 // the same K / V^T - get ids that differ by multiples of 8, and an XCD only ever touches 1/8 of the (batch, head) pairs.
 __device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, int& h, int& b) {
@@ -349,6 +492,14 @@ __global__ __launch_bounds__(256, DH <= 128 ? 3 : 1) void attn_kernel(AttnArgs a
     if constexpr (QS) attn_body<DH, SPLIT, false, true>(a, bx, h, b);      // (the LLM has no key padding: checked by the launcher)
     else if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b);
     else attn_body<DH, SPLIT, false>(a, bx, h, b);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_kernel_lds(AttnArgs a, int tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (2 * (DH / 32) + DH / 16) * 1024];
+    int bx, h, b;
+    if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;      // (workgroup-uniform)
+    attn_body_lds<DH>(a, bx, h, b, smem);
 }
 
 // Two attention problems of the same head geometry in one launch (the shared-prefix prefill: the prefix rows attend among
@@ -431,6 +582,17 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
         if (split) hipLaunchKernelGGL((attn_kernel<128, true, true>), grid, dim3(256), 0, st, a, tiles);
         else hipLaunchKernelGGL((attn_kernel<128, false, true>), grid, dim3(256), 0, st, a, tiles);
         RV_CHECK_LAUNCH("attention");
+        return RV_OK;
+    }
+    // long-key problems without a mask (the adapter's self-attention, the CLIP towers): key blocks staged in LDS once per 128 query rows (attn_body_lds)
+    const bool lds = !split && !a.key_pad && !a.causal && !a.row_pos && !a.row_share && !a.out_packed && !a.out_lo && a.Lk >= 96 && a.Lq >= 48 &&
+                     (a.dh == 64 || a.dh == 96) && rv_cur_opts().attn_lds;
+    if (lds) {
+        const int t128 = (int)cdiv(a.Lq, 128);
+        const dim3 g128(attn_grid(t128, a.H * a.B));
+        if (a.dh == 64) hipLaunchKernelGGL((attn_kernel_lds<64>), g128, dim3(256), 0, st, a, t128);
+        else hipLaunchKernelGGL((attn_kernel_lds<96>), g128, dim3(256), 0, st, a, t128);
+        RV_CHECK_LAUNCH("attention (LDS-staged keys)");
         return RV_OK;
     }
     if (a.dh == 64 && !split)

@@ -250,8 +250,8 @@ ClipWs carve_clip(const rv_ctx* c, void* ws, size_t cap, int N, int T, int Nq, i
     w.a16 = (op16_t*)k.take((size_t)R1 * d * 2);
     w.h16 = (op16_t*)k.take((size_t)R1 * ff * 2);
     const int64_t RT = (int64_t)(Nq > 0 ? Nq : 1) * (Lq > 0 ? Lq : 1);
-    w.tk16 = (op16_t*)k.take((size_t)RT * d * 2);
-    w.tv16 = (op16_t*)k.take((size_t)RT * d * 2);
+    w.tk16 = (op16_t*)k.take((size_t)RT * d * 2 * 2);     // the text K and V rows side by side: [RT, 2 d] (ONE projection over the k / v rows of w_in), row stride 2 d
+    w.tv16 = w.tk16 ? w.tk16 + d : nullptr;
     w.tvt16 = (op16_t*)k.take((size_t)(Nq > 0 ? Nq : 1) * d * w.Lqpad * 2);
     w.pad = (uint8_t*)k.take((size_t)RT);
     const size_t nqf = (size_t)(Nq > 0 ? Nq : 1);
@@ -317,6 +317,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "last_block_rows") return &o.last_block_rows;
     if (k == "adapter_stream16") return &o.adapter_stream16;
     if (k == "adapter_fold_t2v") return &o.adapter_fold_t2v;
+    if (k == "attn_lds") return &o.attn_lds;
     return nullptr;
 }
 }  // namespace
@@ -434,8 +435,8 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
         for (size_t l = 0; l < c->t2v.size(); ++l) {
             const AdapterLayer& L = c->t2v[l];
             op16_t* q16 = w.qk16;
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
-            RV_TRY(rv_gemm_impl(txt, d, L.w_in + 2 * d * d, d, 1, L.b_in + 2 * d, nullptr, 0, w.tv16, d, RV_OP16, RV_ACT_NONE, RT, d, d, w.sk, w.sk_bytes, st));
+            // K and V of the text tokens in ONE launch: the k / v rows of in_proj_weight are adjacent (rows d .. 3 d - 1), the outputs land side by side (stride 2 d)
+            RV_TRY(rv_gemm_impl(txt, d, L.w_in + d * d, d, 1, L.b_in + d, nullptr, 0, w.tk16, 2 * d, RV_OP16, RV_ACT_NONE, RT, 2 * d, d, w.sk, w.sk_bytes, st));
             // Folded cross-attention (rowops.hip t2v_fold_kernel): all frame rows of a query attend to its <= 32 text tokens, so Q projection + attention +
             // output projection = x . A1^T -> softmax -> P . A2^T: two skinny GEMMs (K = 768 -> N = H * LK; K = H * LK -> N = 768) instead of two 768 x 768 ones
             // and two [rows, 768] round trips.  Per query: the rows of its N / Nq windows.
@@ -445,12 +446,21 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
             if (fold) {
                 float* S32 = (float*)w.qk16;        // [R0, NK] f32 (the q / k buffer is free in this stage)
                 op16_t* P16 = w.a16;                // [R0, NK]
-                RV_TRY(k_t2v_fold(L.w_in, L.b_in, L.w_out, w.tk16, w.tv16, Nq, Lq, LK, H, dh, scale, w.fa1, w.fc1, w.fa2, st));
-                for (int qi = 0; qi < Nq; ++qi)
+                RV_TRY(k_t2v_fold(L.w_in, L.b_in, L.w_out, w.tk16, w.tv16, 2 * d, Nq, Lq, LK, H, dh, scale, w.fa1, w.fc1, w.fa2, st));
+                // several queries: ONE grouped launch per GEMM (rows of query qi x that query's folded matrices), not a loop of Nq small ones
+                if (Nq > 1) {
+                    RV_TRY(rv_gemm_grouped_impl(vp16, d, w.fa1, NK * d, w.fc1, NK, nullptr, 0, S32, NK, RV_F32, R0, NK, d, Rq, st));
+                    RV_TRY(k_t2v_softmax(S32, w.pad, P16, R0, H, LK, Lq, Rq, st));
+                    if (s16)
+                        RV_TRY(rv_gemm_grouped_impl(P16, NK, w.fa2, NK * d, L.b_out, 0, (const float*)vres16, d, ys16, d, RV_OP16, R0, d, NK, Rq, st, 1));
+                    else
+                        RV_TRY(rv_gemm_grouped_impl(P16, NK, w.fa2, NK * d, L.b_out, 0, v32, d, w.y32, d, RV_F32, R0, d, NK, Rq, st));
+                }
+                for (int qi = 0; qi < Nq && Nq == 1; ++qi)
                     RV_TRY(rv_gemm_impl(vp16 + qi * Rq * d, d, w.fa1 + qi * NK * d, d, 1, w.fc1 + qi * NK, nullptr, 0, S32 + qi * Rq * NK, NK, RV_F32, RV_ACT_NONE, Rq, NK, d,
                                         w.sk, w.sk_bytes, st));
-                RV_TRY(k_t2v_softmax(S32, w.pad, P16, R0, H, LK, Lq, Rq, st));
-                for (int qi = 0; qi < Nq; ++qi) {
+                if (Nq == 1) RV_TRY(k_t2v_softmax(S32, w.pad, P16, R0, H, LK, Lq, Rq, st));
+                for (int qi = 0; qi < Nq && Nq == 1; ++qi) {
                     const int64_t r0 = qi * Rq;
                     if (s16)
                         RV_TRY(rv_gemm_impl(P16 + r0 * NK, NK, w.fa2 + qi * NK * d, NK, 1, L.b_out, (const float*)(vres16 + r0 * d), d, ys16 + r0 * d, d, RV_OP16, RV_ACT_NONE, Rq, d,
@@ -461,8 +471,8 @@ extern "C" int rv_clip_encoder(rv_ctx* c, const void* x, const void* txt, const 
                 }
             } else {
                 RV_TRY(rv_gemm_impl(vp16, d, L.w_in, d, 1, L.b_in, nullptr, 0, q16, d, RV_OP16, RV_ACT_NONE, R0, d, d, w.sk, w.sk_bytes, st));
-                RV_TRY(k_transpose_v(w.tv16, d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
-                AttnArgs a{q16, d, (int64_t)T * d, w.tk16, d, (int64_t)Lq * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
+                RV_TRY(k_transpose_v(w.tv16, 2 * d, w.tvt16, Nq, Lq, w.Lqpad, H, dh, st));
+                AttnArgs a{q16, d, (int64_t)T * d, w.tk16, 2 * d, (int64_t)Lq * 2 * d, dh, w.tvt16, (int64_t)d * w.Lqpad, (int64_t)dh * w.Lqpad,
                            w.Lqpad, w.a16, d, (int64_t)T * d, w.pad, N, H, dh, T, Lq, 0, 0, N / Nq, scale};
                 RV_TRY(k_attention(a, st));
             }

@@ -226,7 +226,7 @@ __device__ __forceinline__ void p4_stage_load(const op16_t* __restrict__ A, int6
 template <int OUT_BF16, int ACT, int ST, int ROPE = 0>
 __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A, int64_t lda, const op16_t* __restrict__ W,
                                                     const float* __restrict__ bias, const float* res, int64_t ldr, void* Cv,
-                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, QkvRope qr) {
+                                                    int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n, QkvRope qr, GemmGroups gg) {
     __shared__ __attribute__((aligned(16))) char smem[ST * P4_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,7 +244,18 @@ __global__ __launch_bounds__(256) void gemm_tile_p4(const op16_t* __restrict__ A
             tn = tiles_n8 + r / tiles_m;
         }
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0 = tm * BM;
+    const int n0 = tn * BN;
+    if (gg.rows) {
+        // GROUPED problem (rv_gemm_grouped_impl): rows [g * rows, (g + 1) * rows) are multiplied with the g-th weight matrix (and bias); a group owns
+        // gg.tiles row tiles of its own, so a tile never straddles two weights and the group's last tile ends at the group's last row
+        const int gi = tm / gg.tiles;
+        m0 = gi * gg.rows + (tm - gi * gg.tiles) * BM;
+        W += (int64_t)gi * gg.w_stride;
+        if (bias) bias += (int64_t)gi * gg.bias_stride;
+        const int end = (gi + 1) * gg.rows;
+        M = end < M ? end : M;
+    }
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, kg = lane >> 4;
 
@@ -729,7 +740,7 @@ void launch_tile(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, con
     const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
     if (WP && rv_cur_opts().gemm_tile_variant == 1) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
-                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
+                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{}, GemmGroups{});
         return;
     }
     if (WP && rv_cur_opts().gemm_tile_variant == 3) {
@@ -739,7 +750,7 @@ void launch_tile(const op16_t* A, int64_t lda, const op16_t* W, int64_t ldw, con
     }
     if (WP && (rv_cur_opts().gemm_tile_variant == 2 || rv_cur_opts().gemm_tile_variant >= 4)) {
         hipLaunchKernelGGL((gemm_tile_p4<OUT_BF16, ACT, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, bias, res, ldr, C,
-                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{});
+                           ldc, M, N, K, tiles_m, tiles_n, QkvRope{}, GemmGroups{});
         return;
     }
     hipLaunchKernelGGL((gemm_tile<OUT_BF16, ACT, WP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, W, ldw, bias, res, ldr,
@@ -848,6 +859,35 @@ int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_l
     return RV_OK;
 }
 
+// G problems of identical shape in ONE launch of the 128 x 128 ring kernel: rows [g * rows_per_group, ...) x Wp + g * w_stride (+ bias + g * bias_stride), fragment-packed
+// weights, no activation, f32 or 16-bit output, optional residual (f32, or 16-bit rows with res16).  The folded text -> video cross-attention of the ClipEncoder multiplies
+// the frame rows of every QUERY with that query's own folded matrices (engine.hip): with one query per window (stage-1 sparse: 32 windows in flight) the per-query loop was
+// 128 launches of 15 us for 26 GFLOP - 43 % of the adapter.
+int rv_gemm_grouped_impl(const void* A, int64_t lda, const void* Wp, int64_t w_stride, const float* bias, int64_t bias_stride, const float* residual, int64_t ldr, void* C,
+                         int64_t ldc, int out_dtype, int64_t M, int64_t N, int64_t K, int64_t rows_per_group, hipStream_t st, int res16) {
+    RV_CHECK_ARG(A && Wp && C && M > 0 && N > 0 && K > 0 && rows_per_group > 0 && M % rows_per_group == 0, "rv_gemm_grouped: bad arguments");
+    RV_CHECK_ARG(K % 64 == 0 && N % 16 == 0 && lda % 8 == 0 && ldc % 4 == 0 && M < (1ll << 31), "rv_gemm_grouped: alignment (K %% 64, N %% 16, lda %% 8, ldc %% 4)");
+    RV_CHECK_ARG(out_dtype == RV_OP16 || out_dtype == RV_F32, "rv_gemm_grouped: out dtype must be 16-bit or f32");
+    if (res16) {
+        RV_CHECK_ARG(residual && ldr > 0 && ldr % 4 == 0, "rv_gemm_grouped: a 16-bit residual needs ldr %% 4 == 0");
+        ldr = -ldr;
+    }
+    GemmGroups gg;
+    gg.rows = (int)rows_per_group;
+    gg.tiles = (int)cdiv(rows_per_group, BM);
+    gg.w_stride = w_stride;
+    gg.bias_stride = bias_stride;
+    const int tiles_m = (int)(M / rows_per_group) * gg.tiles, tiles_n = (int)cdiv(N, BN);
+    if (out_dtype == RV_OP16)
+        hipLaunchKernelGGL((gemm_tile_p4<1, RV_ACT_NONE, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const op16_t*)A, lda, (const op16_t*)Wp, bias, residual, ldr, C, ldc,
+                           (int)M, (int)N, (int)K, tiles_m, tiles_n, QkvRope{}, gg);
+    else
+        hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3>), dim3(tiles_m * tiles_n), dim3(256), 0, st, (const op16_t*)A, lda, (const op16_t*)Wp, bias, residual, ldr, C, ldc,
+                           (int)M, (int)N, (int)K, tiles_m, tiles_n, QkvRope{}, gg);
+    RV_CHECK_LAUNCH("rv_gemm_grouped");
+    return RV_OK;
+}
+
 int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t D, const QkvRope& r, const GemvNorm* norm,
                   void* ws, size_t ws_bytes, hipStream_t st, int w_layout, int64_t Kdim) {
     RV_CHECK_ARG(A && Wp && r.cs && r.q16 && r.kc && r.vtc, "gemm_qkv_rope: null argument");
@@ -882,7 +922,7 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
             return gemm_pp_qkv_rope(A, lda, Wp, M, N, K, r, ws, st);
         const int tiles_m = (int)cdiv(M, BM), tiles_n = N / BN;
         hipLaunchKernelGGL((gemm_tile_p4<0, RV_ACT_NONE, 3, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a, lda, w, nullptr, nullptr,
-                           (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, tiles_m, tiles_n, r);
+                           (int64_t)0, nullptr, (int64_t)0, (int)M, N, K, tiles_m, tiles_n, r, GemmGroups{});
     }
     RV_CHECK_LAUNCH("gemm_qkv_rope");
     return RV_OK;

@@ -25,6 +25,8 @@ struct RvOpts {
                                 // read anyway) instead of f32 + 16-bit copies; 0 = the f32 stream (always so in the bf16 build)
     int adapter_fold_t2v = 1;   // ClipEncoder text -> video layers with <= 32 text tokens: Q projection + cross-attention + output projection as two skinny GEMMs around a
                                 // softmax (rowops.hip t2v_fold_kernel); 0 = the three separate steps
+    int attn_lds = 1;           // attention with >= 96 keys, no mask, dh 64 / 96 (the adapter's self-attention, the CLIP towers): key blocks staged in LDS once per 128 query rows
+                                // (attention.hip attn_body_lds); 0 = every wave fetches its fragments from L2 (rounds 1 - 5).  Bit-identical rows.
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };
@@ -197,6 +199,13 @@ int gemm_qkv_rope(const void* A, int64_t lda, const void* Wp, int64_t M, int64_t
 int rv_gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int w_layout, const float* bias,
                  const float* residual, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act, int64_t M, int64_t N,
                  int64_t K, void* ws, size_t ws_bytes, hipStream_t st, const GemvNorm* norm = nullptr, int res16 = 0);   // res16: `residual` points at 16-bit operand rows (M > 32 only)
+// grouped form of the 128 x 128 ring kernel (gemm.hip gemm_tile_p4): rows per group, row tiles per group, element strides between the groups' weights / biases
+struct GemmGroups {
+    int rows = 0, tiles = 0;
+    int64_t w_stride = 0, bias_stride = 0;
+};
+int rv_gemm_grouped_impl(const void* A, int64_t lda, const void* Wp, int64_t w_stride, const float* bias, int64_t bias_stride, const float* residual, int64_t ldr, void* C,
+                         int64_t ldc, int out_dtype, int64_t M, int64_t N, int64_t K, int64_t rows_per_group, hipStream_t st, int res16 = 0);
 int gemv_blocks(int act, int64_t N);
 int gemm_rows(const op16_t* X, const op16_t* W, const float* bias, const float* res, int64_t ldr, void* C, int64_t ldc, int out_dtype, int act,
               int M, int N, int K, hipStream_t st, const GemvNorm& nrm, const QkvRope* qr, int w_layout = 1);   // gemm_rows.hip: 33 .. 144 fragment-packed rows
@@ -237,7 +246,7 @@ int k_qkv_rope_split(const float* qkv32, int64_t ld, const QkvRope& qr, int64_t 
 // output row i = gi * B + b of a_out (16-bit) / h_out (f32) <- input row idx[i], or gi * Mg + P0 + b * S + S - 1 with idx == nullptr
 int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t rows, int Mg, int P0, int B, int S, void* a_out, float* h_out, int D, hipStream_t st);
 // text -> video cross-attention folded into two skinny GEMMs (rowops.hip): A1p [Nq][H * LK, d] / A2p [Nq][d, H * LK] fragment-packed, c1 [Nq][H * LK]
-int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int Nq, int Lq, int LK, int H, int dh, float scale,
+int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int64_t ld, int Nq, int Lq, int LK, int H, int dh, float scale,
                void* A1p, float* c1, void* A2p, hipStream_t st);
 int k_t2v_softmax(const float* S, const uint8_t* pad, void* P16, int64_t rows, int H, int LK, int Lq, int64_t rows_per_query, hipStream_t st);
 int k_sine_pos(float* pos, int T, int d, hipStream_t st);

@@ -366,7 +366,7 @@ __device__ __forceinline__ int64_t rv_wp_index(int n, int k, int K) {      // el
 }
 // grid (ceil(d / 256), H * LK, Nq); A1p / A2p: [Nq][H * LK * d] packed, c1: [Nq][H * LK]
 __global__ __launch_bounds__(256) void t2v_fold_kernel(const op16_t* __restrict__ wq_p, const float* __restrict__ bq, const op16_t* __restrict__ wo_p,
-                                                       const op16_t* __restrict__ tk, const op16_t* __restrict__ tv, int Lq, int LK, int H, int dh, int d, float scale,
+                                                       const op16_t* __restrict__ tk, const op16_t* __restrict__ tv, int64_t ld, int Lq, int LK, int H, int dh, int d, float scale,
                                                        op16_t* __restrict__ A1p, float* __restrict__ c1, op16_t* __restrict__ A2p) {
     const int k = blockIdx.x * 256 + threadIdx.x;          // a column of Wq (A1) / a row of Wo (A2)
     const int hj = blockIdx.y, h = hj / LK, j = hj % LK, q = blockIdx.z;
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void t2v_fold_kernel(const op16_t* __restrict_
     __shared__ float kr[128], vr[128];                      // the key / value row of (query, token j), head h
     const bool valid = j < Lq;
     for (int t = threadIdx.x; t < dh; t += 256) {
-        kr[t] = valid ? op16_to_f32(tk[((int64_t)q * Lq + j) * d + h * dh + t]) : 0.f;
-        vr[t] = valid ? op16_to_f32(tv[((int64_t)q * Lq + j) * d + h * dh + t]) : 0.f;
+        kr[t] = valid ? op16_to_f32(tk[((int64_t)q * Lq + j) * ld + h * dh + t]) : 0.f;
+        vr[t] = valid ? op16_to_f32(tv[((int64_t)q * Lq + j) * ld + h * dh + t]) : 0.f;
     }
     __syncthreads();
     if (k < d) {
@@ -394,6 +394,61 @@ __global__ __launch_bounds__(256) void t2v_fold_kernel(const op16_t* __restrict_
         if (threadIdx.x == 0) c1[(int64_t)q * NK + hj] = c * scale;
     }
 }
+// The same fold with the weights held in REGISTERS (round 6).  t2v_fold_kernel re-reads its 2 x dh weight elements (2-byte loads out of the fragment-packed layout) for
+// every (query, key slot): 21 us per layer with one query, 315 us with the 32 queries of 32 stage-1 windows in flight (14 % of that adapter call).  Here a workgroup is
+// (A1 or A2, 256 columns k, head h, a few queries): a thread loads ITS dh weight elements - Wq[h dh + t, k] for A1, Wo[k, h dh + t] for A2 - ONCE, a query's LK key
+// (value) rows of head h sit in LDS as f32, and a slot is dh FMAs out of registers and LDS broadcasts.  One weight array per workgroup keeps the kernel near 128
+// registers: with both (256) every ds_read had to be waited for on the spot - 5000 cycles per slot instead of ~800.  Same sums in the same order (t ascending, f32
+// FMA): results are bit-identical to t2v_fold_kernel.
+template <int DH, int LK>
+__global__ __launch_bounds__(256) void t2v_fold_reg_kernel(const op16_t* __restrict__ wq_p, const float* __restrict__ bq, const op16_t* __restrict__ wo_p,
+                                                           const op16_t* __restrict__ tk, const op16_t* __restrict__ tv, int64_t ld, int Lq, int H, int d, float scale,
+                                                           op16_t* __restrict__ A1p, float* __restrict__ c1, op16_t* __restrict__ A2p, int Nq, int qpw) {
+    const int which = blockIdx.x & 1;                       // 0: A1 (keys, Wq), 1: A2 (values, Wo)
+    const int k = (blockIdx.x >> 1) * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    const int NK = H * LK;
+    __shared__ __attribute__((aligned(16))) float rr[LK][DH];
+    float w[DH];
+    const int kc = k < d ? k : d - 1;
+#pragma unroll
+    for (int t = 0; t < DH; ++t) w[t] = op16_to_f32(which ? wo_p[rv_wp_index(kc, h * DH + t, d)] : wq_p[rv_wp_index(h * DH + t, kc, d)]);
+    const op16_t* rows = which ? tv : tk;
+    const float mul = which ? 1.0f : scale;
+    // qpw queries per workgroup: the weights above are loaded once for all of them
+    for (int q = blockIdx.z * qpw; q < Nq && q < (blockIdx.z + 1) * qpw; ++q) {
+        __syncthreads();                                     // (the previous query's rows are no longer read)
+        for (int i = threadIdx.x; i < LK * DH; i += 256) {
+            const int j = i / DH, t = i - j * DH;
+            rr[j][t] = j < Lq ? op16_to_f32(rows[((int64_t)q * Lq + j) * ld + h * DH + t]) : 0.f;
+        }
+        __syncthreads();
+        if (k < d) {
+#pragma unroll 2
+            for (int j = 0; j < LK; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < DH; t += 4) {
+                    const f32x4 kk = *(const f32x4*)&rr[j][t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += kk[e] * w[t + e];
+                }
+                const int hj = h * LK + j;
+                if (which) A2p[(int64_t)q * NK * d + rv_wp_index(k, hj, NK)] = f32_to_op16(acc);
+                else A1p[(int64_t)q * NK * d + rv_wp_index(hj, k, d)] = f32_to_op16(acc * mul);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 64) {          // c1[(h, j)] = scale * bq_h . K[j, h]   (the A1 workgroup of the first column chunk holds the key rows)
+            for (int j = 0; j < LK; ++j) {
+                float c = 0.f;
+                for (int t = threadIdx.x; t < DH; t += 64) c += rr[j][t] * bq[h * DH + t];
+                c = wave_sum(c);
+                if (threadIdx.x == 0) c1[(int64_t)q * NK + h * LK + j] = c * scale;
+            }
+        }
+    }
+}
+
 // P[r, (h, j)] = softmax_j (S[r, (h, j)]) over the keys j < Lq that are not padded (pad[q][j] == 1: ignore); one thread per (row, head) - its LK scores are 64 / 128
 // contiguous bytes, a wave's are one contiguous 4 / 8 KiB run: 16-byte loads and 8-byte stores; the other slots get 0
 template <int LK>
@@ -622,13 +677,25 @@ int k_gather_last_rows(const void* a16, const float* h, const int* idx, int64_t 
     return RV_OK;
 }
 
-int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int Nq, int Lq, int LK, int H, int dh, float scale,
+int k_t2v_fold(const void* wq_p, const float* bq, const void* wo_p, const void* tk16, const void* tv16, int64_t ld, int Nq, int Lq, int LK, int H, int dh, float scale,
                void* A1p, float* c1, void* A2p, hipStream_t st) {
     const int d = H * dh;
-    RV_CHECK_ARG(wq_p && bq && wo_p && tk16 && tv16 && A1p && c1 && A2p && Nq > 0 && Lq > 0 && Lq <= LK && (LK == 16 || LK == 32) && dh <= 128 && d % 32 == 0,
+    RV_CHECK_ARG(wq_p && bq && wo_p && tk16 && tv16 && A1p && c1 && A2p && ld >= d && Nq > 0 && Lq > 0 && Lq <= LK && (LK == 16 || LK == 32) && dh <= 128 && d % 32 == 0,
                  "t2v_fold: bad arguments");
-    hipLaunchKernelGGL(t2v_fold_kernel, dim3((unsigned)cdiv(d, 256), (unsigned)(H * LK), (unsigned)Nq), dim3(256), 0, st, (const op16_t*)wq_p, bq, (const op16_t*)wo_p,
-                       (const op16_t*)tk16, (const op16_t*)tv16, Lq, LK, H, dh, d, scale, (op16_t*)A1p, c1, (op16_t*)A2p);
+#define RV_FOLD_REG(DH_, LK_)                                                                                                                                  \
+    hipLaunchKernelGGL((t2v_fold_reg_kernel<DH_, LK_>), dim3((unsigned)(2 * cdiv(d, 256)), (unsigned)H, (unsigned)cdiv(Nq, qpw)), dim3(256), 0, st, (const op16_t*)wq_p, bq, \
+                       (const op16_t*)wo_p, (const op16_t*)tk16, (const op16_t*)tv16, ld, Lq, H, d, scale, (op16_t*)A1p, c1, (op16_t*)A2p, Nq, qpw)
+    // measured (rocprofv3, 768-wide adapter): generic 11 + 9.5 us per query, register form 29.5 + 1.9 us per query: the register form from three queries on
+    const bool reg = Nq >= 3;
+    const int qpw = (int)cdiv((int64_t)Nq * 2 * cdiv(d, 256) * H, 1024);  // queries per workgroup: about one round of workgroups (four fit a CU)
+    if (reg && dh == 96 && LK == 16) RV_FOLD_REG(96, 16);
+    else if (reg && dh == 96 && LK == 32) RV_FOLD_REG(96, 32);
+    else if (reg && dh == 64 && LK == 16) RV_FOLD_REG(64, 16);
+    else if (reg && dh == 64 && LK == 32) RV_FOLD_REG(64, 32);
+    else     // one or two queries, other head widths: the generic kernel (weights re-read per key slot; 24 x as many workgroups)
+        hipLaunchKernelGGL(t2v_fold_kernel, dim3((unsigned)cdiv(d, 256), (unsigned)(H * LK), (unsigned)Nq), dim3(256), 0, st, (const op16_t*)wq_p, bq, (const op16_t*)wo_p,
+                           (const op16_t*)tk16, (const op16_t*)tv16, ld, Lq, LK, H, dh, d, scale, (op16_t*)A1p, c1, (op16_t*)A2p);
+#undef RV_FOLD_REG
     RV_CHECK_LAUNCH("t2v_fold");
     return RV_OK;
 }

@@ -514,6 +514,23 @@ def test_attention(dev, case):
     assert rel_err(y.float().cpu(), ref) < tol(BF16_TOL)
 
 
+@pytest.mark.parametrize("Tn,N", [(256, 5), (1024, 2), (130, 3)])
+def test_attention_with_lds_staged_keys_is_bit_identical(dev, Tn, N):
+    """The long-key attention form (attention.hip attn_body_lds: key blocks staged in LDS once per 128 query rows, option ``attn_lds``) performs the per-tile
+    operations of the per-wave form in the same order: the ClipEncoder's outputs - every frame row, through both self-attention layers over T + 1 keys - are
+    BIT-identical with the option on and off (T + 1 = 257 / 1025 / 131 keys: partial last key block, a last workgroup with one live wave)."""
+    eng = _tiny_engine(dev)
+    x = feats(f"al.x.{Tn}", (N, Tn, 768), bf16=fl())
+    q = feats("al.q", (1, 7, 768), bf16=fl())
+    m = torch.ones(1, 7)
+    outs = {}
+    for v in (1, 0):
+        eng.set_option("attn_lds", v)
+        outs[v] = eng.clip_encoder(x, q, m, "all").clone()
+    eng.set_option("attn_lds", 1)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_project_dense(dev):
     from oracle import adapter
     from revisionllm_amd import engine
