@@ -319,7 +319,7 @@ def pmc_traffic(kernel, grid_threads):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE; tools/pmc_summary.py).  None if no summary matches."""
     want = kernel.replace(" ", "")
-    for fname in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for fname in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         d = committed_profile(fname)
         if d is None:
             continue
@@ -1137,13 +1137,13 @@ def main():
                      **({"tflops": v["tflops"]} if "tflops" in v else {}), **({"rows": v["rows"]} if "rows" in v else {}),
                      **({"timing": v["timing"]} if "timing" in v else {}),
                      **({"prefills_per_launch": v["prefills_per_launch"]} if "prefills_per_launch" in v else {})} for k, v in legs.items()}
-        for fname in ("r5_pmc_mfma.json", "r4_pmc_mfma.json", "r3_pmc_mfma.json", "r2_pmc_mfma.json"):
+        for fname in ("r6_pmc_mfma.json", "r5_pmc_mfma.json", "r4_pmc_mfma.json", "r3_pmc_mfma.json", "r2_pmc_mfma.json"):
             pmc = committed_profile(fname)
             if pmc is not None:
                 other["prefill_gemm_pmc"] = dict(pmc.get("summary") or {}, source="profiles/" + fname)
                 break
         # the decode gate/up kernel INSIDE a decode step (rocprofv3 kernel trace of isolated steps, committed): the number to price it with
-        for fname in ("r5_decode_steps.json", "r4_decode_steps.json", "r3_decode_steps.json", "r2_decode_steps.json"):
+        for fname in ("r6_decode_steps.json", "r5_decode_steps.json", "r4_decode_steps.json", "r3_decode_steps.json", "r2_decode_steps.json"):
             prof = committed_profile(fname)
             ks = [] if prof is None else prof.get("rows", {}).get(str(legs["decode_gateup_gemv"]["rows"]), {}).get("kernels", [])
             want = legs["decode_gateup_gemv"]["kernel"].replace(" ", "")
@@ -1156,7 +1156,7 @@ def main():
                 break
         # the dominant kernel inside a batched prefill pass (other kernels between its launches: the clock is not pinned at the power cap
         # by one kernel), from the committed rocprofv3 summary of tools/prefill_prof.sh - next to the live back-to-back figure above
-        pf_name = next((n_ for n_ in ("r5_prefill_pass.json", "r4_prefill_pass.json") if committed_profile(n_) is not None), "r3_prefill_pass.json")
+        pf_name = next((n_ for n_ in ("r6_prefill_pass.json", "r5_prefill_pass.json", "r4_prefill_pass.json") if committed_profile(n_) is not None), "r3_prefill_pass.json")
         pf = committed_profile(pf_name)
         if pf is not None and pf.get("rows") == dom.get("rows"):
             row = next((r_ for r_ in pf.get("kernels", []) if r_["kernel"].replace(" ", "") == dom["kernel"].replace(" ", "")), None)

@@ -132,7 +132,7 @@ def test_stage2_driver_under_the_reference_names_reproduces_the_reference_eval_r
             ri, wi = r["info"], w["info"]
             assert set(ri) == set(wi)
             assert all(ri[k] == wi[k] for k in ("gt", "frames", "iou", "hierarchy_zooms"))
-            for k, bound in (("max_entropy", 2e-3), ("mean_entropy", 2e-3), ("score_cos", 2e-4)):
+            for k, bound in (("max_entropy", 1e-4), ("mean_entropy", 1e-4), ("score_cos", 2e-6)):          # measured 1.6e-5 / 8e-6 / 2e-7
                 assert len(ri[k]) == len(wi[k])
                 e = float(np.max(np.abs(np.array(ri[k]) - np.array(wi[k])) / np.abs(np.array(wi[k]))))
                 worst[mode, k] = max(worst.get((mode, k), 0.0), e)

@@ -1,13 +1,21 @@
 """Yardstick only (never on the product path): what torch.matmul (hipBLASLt / rocBLAS) reaches on the prefill GEMM shapes, next to
-rv_gemm on the same shapes.  Usage: python tools/blas_yardstick.py"""
+rv_gemm on the same shapes, in the operand type of the library build under test (fp16 by default; `python tools/blas_yardstick.py bf16`).  Both sides get a 16-bit
+output and no bias / residual: the main loops are compared, not the fused epilogues the engine runs.  Usage: python tools/blas_yardstick.py [f16|bf16]"""
+import sys
 import torch
 
 import os
 
 from revisionllm_amd import hip, ops
 
+if len(sys.argv) > 1:
+    hip.set_flavour(sys.argv[1])
+DT = hip.op_dtype()
+print(f"operands: {hip.flavour()} ({DT}); torch {torch.__version__}", flush=True)
 dev = torch.device("cuda:0")
-OPT = hip.Options(gemm_waves=int(os.environ["WAVES"])) if os.environ.get("WAVES") else None   # WAVES=4 / 8: the rv_gemm form
+OPT = hip.Options(gemm_waves=int(os.environ["WAVES"])) if os.environ.get("WAVES") else None
+if len(sys.argv) > 1 and OPT is not None:
+    OPT = hip.Options(flavour=sys.argv[1], gemm_waves=int(os.environ["WAVES"]))   # WAVES=4 / 8: the rv_gemm form
 shapes = [(4020, 22016, 4096), (4020, 4096, 4096), (4020, 4096, 11008), (4020, 12288, 4096), (2010, 22016, 4096), (4096, 4096, 4096), (8192, 8192, 8192)]
 
 
@@ -38,8 +46,8 @@ def timeit(fn, n=20, warm=5, min_ms=300.0):
 
 for M, N, K in shapes:
     copies = 6                                   # rotate weights: the 256 MB infinity cache must not serve them
-    x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
-    ws = [(torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16) for _ in range(copies)]
+    x = (torch.randn(M, K, device=dev) * 0.5).to(DT)
+    ws = [(torch.randn(N, K, device=dev) * 0.05).to(DT) for _ in range(copies)]
     i = [0]
 
     def blas():
@@ -49,7 +57,7 @@ for M, N, K in shapes:
     wps = [ops.pack_fragments(w) for w in ws]
     line = f"M={M:5d} N={N:5d} K={K:5d}  torch.matmul {t_blas * 1e3:7.1f} us  {2.0 * M * N * K / t_blas / 1e9:7.1f} TF/s"
     if wps is not None:
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(M, N, dtype=DT, device=dev)
 
         def mine():
             ops.gemm(x, wps[i[0] % copies], out=out, w_packed=True, ctx=OPT)

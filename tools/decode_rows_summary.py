@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/dr_<rows>/dr_kernel_stats.csv (tools/decode_rows_prof.sh) into gpurun_out/r5_decode_steps.json (copied to profiles/): the kernels of an
+"""Summarise gpurun_out/dr_<rows>/dr_kernel_stats.csv (tools/decode_rows_prof.sh) into gpurun_out/r6_decode_steps.json (copied to profiles/): the kernels of an
 isolated merged decode step at several row counts."""
 import csv
 import json
@@ -17,11 +17,11 @@ for R in sys.argv[1:]:
     out["rows"][R] = {"kernels": ks[:8], "projection_and_attention_us_per_layer": round(per_layer, 1)}
 import os, re
 ms = {}
-if os.path.exists("gpurun_out/r5_decode_ms.log"):
-    for line in open("gpurun_out/r5_decode_ms.log"):
+if os.path.exists("gpurun_out/r6_decode_ms.log"):
+    for line in open("gpurun_out/r6_decode_ms.log"):
         m = re.match(r"(fp8 )?rows\s+(\d+): ([\d.]+) ms/step", line)
         if m:
             ms[m.group(2) + ("f8" if m.group(1) else "")] = float(m.group(3))
 out["ms_per_step"] = ms
-json.dump(out, open("gpurun_out/r5_decode_steps.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r6_decode_steps.json", "w"), indent=1)
 print(json.dumps({k: v["projection_and_attention_us_per_layer"] for k, v in out["rows"].items()}))

@@ -25,5 +25,5 @@ for r in list(csv.DictReader(open(f)))[:12]:
         if n.startswith("gemm_pp") and "<0, 0, 0" in n:      # o (K = 4096) and down (K = 11008) launches average together
             e["tflops"] = round((2.0 * rows_ * 4096 * (4096 + 11008) / 2) / avg / 1e6, 1)
         out["kernels"].append(e)
-json.dump(out, open("gpurun_out/r5_prefill_pass.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r6_prefill_pass.json", "w"), indent=1)
 PY
