@@ -127,7 +127,8 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        rounding points (q and the attention output are never rounded to 16 bits; A1 / A2 are).  0 = the three separate steps.
  *   "attn_lds"           1 (default) = rv_attention / the ClipEncoder's and CLIP towers' self-attention with >= 96 keys and no mask (head width 64 / 96, not causal): a
  *                        workgroup of 128 query rows stages every 32-key block of K / V^T in LDS once (LDS-DMA, double-buffered) instead of each wave fetching its own
- *                        copy from L2 (transformer.py:193,210-223 at T = 256 / 1024).  0 = the per-wave form.  Rows are bit-identical either way.
+ *                        copy from L2 (transformer.py:193,210-223 at T = 256 / 1024); the LLM prefill's causal attention (rv_llm_prefill_* with > 16 rows per sequence) likewise
+ *                        shares one staged copy among the four waves of a 64-row workgroup.  0 = the per-wave form.  Rows are bit-identical either way.
  *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
  *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the
  *                        LayerNorm inputs are read as fp16, accumulation and statistics stay f32 (transformer.py:210-223,271-305 keep fp32 activations; the measured

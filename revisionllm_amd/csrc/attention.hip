@@ -472,6 +472,132 @@ __device__ __forceinline__ void attn_body_lds(const AttnArgs& a, int bx, int h, 
     }
 }
 
+// The same staging for the LLM PREFILL (causal, dh = 128, 171 keys at the headline): one 16-row tile per wave, 64 query rows per workgroup - the tiling of attn_body, so
+// a workgroup's four waves (which attn_kernel_pair lets fetch the same key blocks four times) share one staged copy.  A wave computes the blocks below its own causal
+// limit and keeps staging / the barriers for the rest of the workgroup's range.  Per tile the operations of attn_body in the same order: bit-identical rows.
+template <int DH>
+__device__ __forceinline__ void attn_body_lds1(const AttnArgs& a, int bx, int h, int b, char* smem) {
+    constexpr int NC = DH / 32, ND = DH / 16, NF = 2 * NC + ND, STAGE = NF * 1024;
+    static_assert(NF % 4 == 0, "the four waves stage NF / 4 fragments each");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int q0 = bx * 64 + wave * 16;
+    const bool active = q0 < a.Lq;
+    const int kb_ = b / a.kv_div;
+    const int Lk = a.Lk, q_pos0 = a.q_pos0;
+    const op16_t* qp = (const op16_t*)a.q + (int64_t)b * a.q_bs + (int64_t)min(q0 + fr, a.Lq - 1) * a.q_rs + h * DH + g * 8;
+    op16x8 qf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qf[c] = *(const op16x8*)(qp + c * 32);
+    const op16_t* kbase = (const op16_t*)a.k + (int64_t)kb_ * a.k_bs + (int64_t)h * a.k_hs + g * 8;
+    const op16_t* vbase = (const op16_t*)a.vt + (int64_t)kb_ * a.vt_bs + (int64_t)h * a.vt_hs + (int64_t)fr * a.vt_ds + g * a.vt_ks;
+    const int krow = (fr >> 2) * 8 + (fr & 3);
+    auto stage = [&](int k0, char* buf) {
+#pragma unroll
+        for (int i = 0; i < NF / 4; ++i) {
+            const int f = wave + 4 * i;
+            const op16_t* src;
+            if (f < 2 * NC) {
+                const int t = f / NC, c = f - t * NC;
+                src = kbase + (int64_t)min(k0 + krow + t * 4, Lk - 1) * a.k_rs + c * 32;
+            } else {
+                src = vbase + (int64_t)(f - 2 * NC) * 16 * a.vt_ds + (int64_t)(k0 >> 3) * a.vt_ks;
+            }
+            __builtin_amdgcn_global_load_lds((attn_gptr_t)src, (attn_lptr_t)(buf + f * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qpos = q_pos0 + q0 + fr;
+    const int kend = a.causal ? min(Lk, q_pos0 + q0 + 16) : Lk;                        // this wave's keys
+    const int kend_wg = a.causal ? min(Lk, q_pos0 + min(bx * 64 + 64, a.Lq)) : Lk;      // the workgroup's (its last live row's)
+    const int nblk = (kend_wg + 31) >> 5;
+    stage(0, smem);
+    for (int i = 0; i < nblk; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + 1 < nblk) stage((i + 1) * 32, smem + ((i + 1) & 1) * STAGE);
+        const int k0 = i * 32;
+        if (!active || k0 >= kend) continue;
+        const char* buf = smem + (i & 1) * STAGE + lane * 16;
+        op16x8 kf[2][NC];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[t][c] = *(const op16x8*)(buf + (t * NC + c) * 1024);
+        op16x8 vf[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) vf[dt] = *(const op16x8*)(buf + (2 * NC + dt) * 1024);
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s[t] = rv_mfma16(kf[t][c], qf[c], s[t]);
+        }
+        float mx = -INFINITY;
+        const bool interior = k0 + 32 <= Lk && (!a.causal || k0 + 31 <= q_pos0 + q0);
+        if (interior) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[t][r] *= a.scale;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + g * 8 + t * 4 + r;
+                    const bool dead = key >= Lk || (a.causal && key > qpos);
+                    const float v = dead ? -INFINITY : s[t][r] * a.scale;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        float psum = 0.f;
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[t][r] - m_use);
+                p[t * 4 + r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        union { op16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf.u[j] = pack_op16x2_bounded(p[2 * j], p[2 * j + 1]);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
+        }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) o[dt] = rv_mfma16(vf[dt], pf.v, o[dt]);
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q0 + fr >= a.Lq) return;
+    const float inv = 1.0f / l_run;
+    op16_t* op = (op16_t*)a.out + (int64_t)b * a.o_bs + (int64_t)(q0 + fr) * a.o_rs + h * DH + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+        *(u32x2*)(op + dt * 16) = pack_op16x4(f32x4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv});
+}
+
 // 1-D grid, XCD-aware: workgroup id lands on XCD id % 8 (private L2), so the query tiles of one (batch, head) - which read
 // the same K / V^T - get ids that differ by multiples of 8, and an XCD only ever touches 1/8 of the (batch, head) pairs.
 __device__ __forceinline__ bool attn_map(int tiles, int H, int pairs, int& bx, int& h, int& b) {
@@ -527,6 +653,35 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_pair(AttnArgs a, AttnArgs 
     }
 }
 
+// one problem, 64 query rows per workgroup, key blocks staged in LDS (causal or not; the classic single-generate prefill)
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_kernel_lds1(AttnArgs a, int tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (2 * (DH / 32) + DH / 16) * 1024];
+    int bx, h, b;
+    if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;      // (workgroup-uniform)
+    attn_body_lds1<DH>(a, bx, h, b, smem);
+}
+
+// attn_kernel_pair with the key blocks staged in LDS (attn_body_lds1); no split queries
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_kernel_pair_lds(AttnArgs a, AttnArgs b, int tiles, AttnGroups gr) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (2 * (DH / 32) + DH / 16) * 1024];
+    int bx, h, z;
+    const int per = a.B + b.B;
+    if (!attn_map(tiles, a.H, a.H * per * gr.G, bx, h, z)) return;
+    const int g = z / per;
+    z -= g * per;
+    AttnArgs& p = z < a.B ? a : b;
+    if (gr.G > 1) {      // (uniform per workgroup)
+        p.q = (const op16_t*)p.q + gr.q_off[g];
+        p.out = (op16_t*)p.out + gr.o_off[g];
+        p.k = (const op16_t*)p.k + gr.kv_off[g];
+        p.vt = (const op16_t*)p.vt + gr.kv_off[g];
+    }
+    if (bx * 64 >= p.Lq) return;       // (workgroup-uniform: the two problems may differ in length, tiles counts the longer one)
+    attn_body_lds1<DH>(p, bx, h, z < a.B ? z : z - a.B, smem);
+}
+
 }  // namespace
 
 static int attn_check(const AttnArgs& a) {
@@ -547,7 +702,9 @@ int k_attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t st, const
     const AttnGroups gr = groups ? *groups : AttnGroups{};
     RV_CHECK_ARG(gr.G >= 1 && gr.G <= RV_MAX_PREFILL_GROUPS, "attention pair: 1 .. %d groups", RV_MAX_PREFILL_GROUPS);
     RV_CHECK_ARG((a.q_lo != 0) == (b.q_lo != 0), "attention pair: both problems or neither carry split queries");
+    const bool lds = !a.q_lo && !ATTN_PAIR_Q32 && rv_cur_opts().attn_lds && !a.row_pos && !b.row_pos && !a.out_lo && !b.out_lo;
     if (a.q_lo) hipLaunchKernelGGL((attn_kernel_pair<128, true>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    else if (lds) hipLaunchKernelGGL((attn_kernel_pair_lds<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     else hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, a.H * (a.B + b.B) * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     RV_CHECK_LAUNCH("attention pair");
     return RV_OK;
@@ -562,7 +719,9 @@ int k_attention_groups(const AttnArgs& b, hipStream_t st, const AttnGroups& gr) 
     AttnArgs a = b;
     a.B = 0;      // every workgroup takes problem b
     const int tiles = (int)cdiv(b.Lq, (ATTN_PAIR_Q32 && !b.q_lo) ? 128 : 64);
+    const bool lds = !b.q_lo && !ATTN_PAIR_Q32 && rv_cur_opts().attn_lds && !b.out_lo;
     if (b.q_lo) hipLaunchKernelGGL((attn_kernel_pair<128, true>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
+    else if (lds) hipLaunchKernelGGL((attn_kernel_pair_lds<128>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     else hipLaunchKernelGGL((attn_kernel_pair<128>), dim3(attn_grid(tiles, b.H * b.B * gr.G)), dim3(256), 0, st, a, b, tiles, gr);
     RV_CHECK_LAUNCH("attention groups");
     return RV_OK;
@@ -593,6 +752,11 @@ int k_attention(const AttnArgs& a, hipStream_t st) {
         if (a.dh == 64) hipLaunchKernelGGL((attn_kernel_lds<64>), g128, dim3(256), 0, st, a, t128);
         else hipLaunchKernelGGL((attn_kernel_lds<96>), g128, dim3(256), 0, st, a, t128);
         RV_CHECK_LAUNCH("attention (LDS-staged keys)");
+        return RV_OK;
+    }
+    if (!split && a.dh == 128 && !a.key_pad && !a.row_pos && !a.row_share && !a.out_packed && !a.out_lo && a.Lk >= 64 && a.Lq > 16 && rv_cur_opts().attn_lds) {
+        hipLaunchKernelGGL((attn_kernel_lds1<128>), grid, dim3(256), 0, st, a, tiles);      // the LLM prefill of one generate: 64-row workgroups share a staged copy
+        RV_CHECK_LAUNCH("attention (LDS-staged keys, dh 128)");
         return RV_OK;
     }
     if (a.dh == 64 && !split)

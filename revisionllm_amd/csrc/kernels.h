@@ -25,8 +25,9 @@ struct RvOpts {
                                 // read anyway) instead of f32 + 16-bit copies; 0 = the f32 stream (always so in the bf16 build)
     int adapter_fold_t2v = 1;   // ClipEncoder text -> video layers with <= 32 text tokens: Q projection + cross-attention + output projection as two skinny GEMMs around a
                                 // softmax (rowops.hip t2v_fold_kernel); 0 = the three separate steps
-    int attn_lds = 1;           // attention with >= 96 keys, no mask, dh 64 / 96 (the adapter's self-attention, the CLIP towers): key blocks staged in LDS once per 128 query rows
-                                // (attention.hip attn_body_lds); 0 = every wave fetches its fragments from L2 (rounds 1 - 5).  Bit-identical rows.
+    int attn_lds = 1;           // attention with >= 96 keys, no mask, dh 64 / 96 (the adapter's self-attention, the CLIP towers) and the LLM prefill's attention (causal, dh 128): key
+                                // blocks staged in LDS once per workgroup (attention.hip attn_body_lds / attn_body_lds1); 0 = every wave fetches its fragments from L2 (rounds 1 - 5).
+                                // Bit-identical rows.
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };

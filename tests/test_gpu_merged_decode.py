@@ -179,6 +179,26 @@ def test_batched_prefill_groups_match_separate_prefills(G, P0):
     assert rel_err(lb[3:3 + 7 * G].cpu(), la[3:3 + 7 * G].cpu()) < 1e-2
 
 
+@pytest.mark.parametrize("G,B,P0,S", [(4, 7, 32, 139), (3, 7, 40, 96), (2, 7, 0, 96), (1, 5, 32, 171)])
+def test_prefill_attention_with_lds_staged_keys_is_bit_identical(G, B, P0, S):
+    """The prefill's causal attention with its key blocks staged in LDS once per 64-row workgroup (attention.hip attn_body_lds1, option ``attn_lds``) against the
+    per-wave form of rounds 1 - 5: logits AND every byte of the KV pool equal - shared prefix + per-call rows (the pair launch), several prefills to a pass
+    (groups), no shared prefix (the groups launch), a lone prefill."""
+    eng = _engine()
+    D, R, Smax = 4096, 64, 256
+    g = torch.Generator().manual_seed(31 + G)
+    hs = torch.randn(G * (P0 + B * S), D, generator=g).mul(0.02).cuda()
+    row0 = [3 + B * i for i in range(G)]
+    outs = []
+    for v in (1, 0):
+        eng.set_option("attn_lds", v)
+        pool, _ = eng.new_kv_pool(R, Smax)
+        lg = (eng.llm_prefill_pool_groups(hs.clone(), G, B, P0, pool, R, row0, Smax) if G > 1 else eng.llm_prefill_pool(hs.clone(), B, P0, pool, R, row0[0], Smax))
+        outs.append((lg.clone(), pool.clone()))
+    eng.set_option("attn_lds", 1)
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def _tiny_model(parity=False):
     from revisionllm_amd.model import ReVisionLlamaForCausalLM
     from revisionllm_amd.utils import synth
