@@ -78,6 +78,10 @@ def parse():
     p.add_argument("--pools", type=int, default=2,
                    help="KV pools of the DecodeServer; >= 2 switches on the gang policy: a pool is filled with generates first, then its merged "
                         "steps run with all rows while the next generates prefill into the other pool")
+    p.add_argument("--encode-batch", type=int, default=1,
+                   help="adapter calls of recursions in flight per rv_clip_encoder call (serve.DecodeServer encode_batch; 1 = every recursion encodes its own windows: the "
+                        "default - the adapter alone runs 1.55 / 1.33 / 1.25 ms per recursion at 1 / 4 / 8 to a call, but the K = 20 pipeline measured level: 6262 vs 6267 "
+                        "segments/s over four alternations at 1 / 8, DESIGN section 9)")
     p.add_argument("--prefill-batch", type=int, default=4,
                    help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
                         "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
@@ -576,7 +580,7 @@ def main():
             rows_rec = len(stage2.plan_groups(W, batch)) * args.queries
             args.pool_rows = rows_rec * max(1, min(args.streams, args.steps, 144 // rows_rec))
         server = serve.DecodeServer(model, rows=args.pool_rows, smax=192 if batch + 72 + G <= 192 else 256, gmax=max(16, G), pools=args.pools, gang=args.pools > 1,
-                                    prefill_batch=args.prefill_batch)
+                                    prefill_batch=args.prefill_batch, encode_batch=args.encode_batch)
         stages.server = server
 
     work = {"sets": input_sets(args.queries), "W": W, "batch": batch, "G": G, "group": own_group, "by_query": by_query}
@@ -909,7 +913,7 @@ def main():
             try:
                 from revisionllm_amd import serve
                 work["sets"] = input_sets(1)
-                wide = serve.DecodeServer(model, rows=140, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130)
+                wide = serve.DecodeServer(model, rows=140, smax=server.Smax, gmax=max(16, G), pools=2, gang=True, prefill_batch=args.prefill_batch, slot=130, encode_batch=args.encode_batch)
                 inter.servers.append(wide)
                 stages.server = wide
                 streams = [torch.cuda.Stream(dev) for _ in range(40)]
@@ -1003,7 +1007,7 @@ def main():
         try:
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-extras", "--no-cpu-baseline",
-                   "--op-dtype", other_fl, "--seed", str(args.seed), "--streams", str(args.streams), "--prefill-batch", str(args.prefill_batch), "--pools", str(args.pools)]
+                   "--op-dtype", other_fl, "--seed", str(args.seed), "--streams", str(args.streams), "--prefill-batch", str(args.prefill_batch), "--encode-batch", str(args.encode_batch), "--pools", str(args.pools)]
             r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, REVISION_BENCH_CHILD="1"))
             line = [l for l in r_.stdout.splitlines() if l.startswith("{")][-1]
             o_ = json.loads(line)
@@ -1061,7 +1065,7 @@ def main():
                     b_max = nc_m if pq else -(-nc_m // world)
                     rows_m = b_max * max(1, min(in_flight, 144 // b_max)) if pq else min(144, max(b_max, in_flight * nc_m // world))
                     srv = serve.DecodeServer(model, rows=rows_m, smax=server.Smax, gmax=max(16, G), pools=args.pools, gang=args.pools > 1,
-                                             prefill_batch=args.prefill_batch, slot=180 + 20 * ("queries", "segments", "strong").index(mode))
+                                             prefill_batch=args.prefill_batch, slot=180 + 20 * ("queries", "segments", "strong").index(mode), encode_batch=args.encode_batch)
                     inter.servers.append(srv)
                     stages.server = srv
             except Exception as e:  # noqa: BLE001 - set-up failed on THIS rank (e.g. no memory for the extra KV pools)
@@ -1190,6 +1194,9 @@ def main():
                        "prefill": ("batched: up to %d waiting prefills of the steps in flight ride in one pass (serve.DecodeServer; %.2f per pass in this run)"
                                    % (server.prefill_batch, server.pf_tickets / max(1, server.pf_batches)) + "; steps by pass size: %s" % dict(sorted(server.pf_hist.items()))
                                    if server is not None and server.prefill_batch > 1 else "one pass per step"),
+                       "adapter": ("batched: up to %d waiting adapter calls of the steps in flight run as one rv_clip_encoder call, a query per recursion "
+                                   "(serve.DecodeServer.submit_encode; %.2f per call in this run)" % (server.encode_batch, server.enc_tickets / max(1, server.enc_batches))
+                                   if server is not None and getattr(server, "encode_batch", 1) > 1 else "one call per recursion"),
                        "parallelism": ("single GPU" if world == 1 else
                                        f"queries x{world}: whole recursions dealt to the ranks (each rank = the 1-GPU pipeline on its own videos / queries), "
                                        "one RCCL all-gather of the per-call proposals at the end of the timed region" if by_query else

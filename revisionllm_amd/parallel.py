@@ -200,8 +200,21 @@ def launch_queries_sharded_steps(stages, tokenizer, features_local, W, queries, 
     dev = feats_of[0].device
     index = [stage2.call_row_index(plan, perms[qi], dev, W) for qi in range(nq)]   # host inputs first: no host wait between stages
     rows, prompts, cos_all = [], {}, []
+    # the adapter: through the server's batched encodes when it offers them (several recursions in flight share one rv_clip_encoder call) - every
+    # query's ticket is submitted before the first one is waited for
+    srv = getattr(stages, "server", None)
+    batched_enc = srv is not None and getattr(srv, "encode_batch", 1) > 1
+    tickets = [srv.submit_encode(feats_of[qi], qf) for qi, (qf, _, _) in enumerate(queries)] if batched_enc else None
     for qi, (qf, qc, sentence) in enumerate(queries):
-        cls_local, cos_local = stages.encode(feats_of[qi], qf), stages.cosine(feats_of[qi], qc)
+        if batched_enc:
+            while tickets[qi].ready is None:
+                yield sched.RETRY
+            torch.cuda.current_stream(dev).wait_event(tickets[qi].ready)
+            cls_local = tickets[qi].cls
+            cls_local.record_stream(torch.cuda.current_stream(dev))
+        else:
+            cls_local = stages.encode(feats_of[qi], qf)
+        cos_local = stages.cosine(feats_of[qi], qc)
         if exchange:                                                 # exchange 1: [W/R, D] CLS rows (+ [W/R] cosine scores)
             cls_local, cos_local = _gated(stages, world, lambda: (allgather_rows(cls_local, W, group),
                                                                   allgather_rows(cos_local[:, None], W, group)[:, 0]))

@@ -333,18 +333,34 @@ class PrefillTicket:
         return (id(self.job.pool), self.B, self.P0, self.h.shape[0], self.lens)
 
 
+class EncodeTicket:
+    """One recursion's adapter call handed to the server (``DecodeServer.submit_encode``): ``ready`` (event) / ``cls`` (its windows' CLS rows) are set
+    once the batch it rides in has been enqueued."""
+
+    def __init__(self, features, query_feats, event):
+        self.features, self.query_feats, self.event = features, query_feats, event
+        self.ready = self.cls = None
+
+    @property
+    def key(self):
+        return (tuple(self.features.shape), tuple(self.query_feats.shape), self.features.dtype)
+
+
 class DecodeServer:
     """The pools + the stepping policy (module docstring).  ``gang=False``: one pool, greedy steps.  What ``generate_steps``
     uses: ``fits``, ``reserve`` (-> ``Job`` with ``job.pool``; ``None``: no room - wait if ``blocking`` else decode alone), ``join``;
     what ``sched.Interleaver`` uses: ``pump`` / ``wait_one``."""
 
-    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False, prefill_batch=1, pool_factory=None):
+    def __init__(self, model, rows=32, smax=256, gmax=64, max_ahead=2, slot=97, pools=1, gang=False, prefill_batch=1, pool_factory=None, encode_batch=1):
         """``prefill_batch`` > 1: the generates' LLM prefills go through the server too - up to that many waiting prefills of identical
         geometry (rows, shared-prefix length, length) ride in ONE pass (``rv_llm_prefill_pool_groups``: the GEMMs see G x 1005 rows
         instead of 1005, which the N = 4096 projections in particular are too small for), on one prefill stream in submission order.
         A batch is enqueued as soon as ``prefill_batch`` tickets wait, or whatever waits when no earlier batch is still running (the
         stream never idles for the sake of a fuller batch); of the waiting tickets a pass takes the count that costs least per prefill
-        (``best_prefill_batch``: row-tile padding and the CU fill of the stream-K teams).  Per-row results equal the separate prefills up to GEMM summation order."""
+        (``best_prefill_batch``: row-tile padding and the CU fill of the stream-K teams).  Per-row results equal the separate prefills up to GEMM summation order.
+        ``encode_batch`` > 1 (round 6): the recursions' ADAPTER calls go through the server too - up to that many waiting encodes of identical geometry
+        (windows, frames, text tokens) run as ONE ``rv_clip_encoder`` call with one query per recursion (``submit_encode``): 1.55 ms per recursion alone,
+        1.33 four to a call, 1.25 eight (the K = 768 GEMMs fill more whole rounds, the CLS-only tail of six latency-bound launches is paid once per call)."""
         assert pools >= 1 and (pools >= 2 or not gang), "the gang policy alternates between at least two pools"
         assert 1 <= prefill_batch <= 8
         self.prefill_batch, self.pf_queue, self.pf_inflight = prefill_batch, [], []
@@ -352,6 +368,11 @@ class DecodeServer:
         self.pf_slot = slot + 16
         self.pf_batches = self.pf_tickets = 0
         self.pf_hist = {}            # groups per pass -> tickets served by passes of that size
+        assert 1 <= encode_batch <= 16
+        self.encode_batch, self.enc_queue, self.enc_inflight = encode_batch, [], []
+        self.enc_stream = torch.cuda.Stream(model.engine.device) if encode_batch > 1 else None
+        self.enc_slot = slot + 17
+        self.enc_batches = self.enc_tickets = 0
         dev_ = getattr(getattr(model, "engine", None), "device", None)      # (tests drive the policy with model = None and stand-in pools)
         self.cus_per_xcd = (max(8, torch.cuda.get_device_properties(dev_).multi_processor_count // 8)
                             if getattr(dev_, "type", "cpu") == "cuda" and torch.cuda.is_available() else 32)
@@ -482,8 +503,58 @@ class DecodeServer:
         self.pf_hist[n] = self.pf_hist.get(n, 0) + n
         return True
 
+    # ---- batched adapter calls ---------------------------------------------------------------------------------------------------
+    def submit_encode(self, features, query_feats):
+        """features [N, T, 768] (16-bit operands, ready on the caller's current stream), query_feats [Lq, 768] -> ticket; poll ``ticket.ready`` (an event),
+        then ``ticket.cls`` = f32 [N, D], the CLS row of every window for this query (``stage2.encode_windows`` of this recursion alone)."""
+        ev = torch.cuda.Event()
+        ev.record()
+        t = EncodeTicket(features, query_feats, ev)
+        self.enc_queue.append(t)
+        return t
+
+    def _pump_encode(self, partial=False, force=False):
+        """Same launch rule as the prefills: a FULL batch any time; a partial one when the host has nothing else to do and no earlier batch is
+        still running, or when forced."""
+        if not self.enc_queue:
+            return False
+        self.enc_inflight = [e for e in self.enc_inflight if not e.query()]
+        lead = self.enc_queue[0]
+        n = 1
+        while n < len(self.enc_queue) and n < self.encode_batch and self.enc_queue[n].key == lead.key:
+            n += 1
+        full = n == self.encode_batch or n < len(self.enc_queue)
+        if not full and not force and not (partial and not self.enc_inflight):
+            return False
+        batch, self.enc_queue = self.enc_queue[:n], self.enc_queue[n:]
+        eng = self.model.engine
+        prev = eng.slot
+        eng.slot = self.enc_slot
+        with torch.cuda.stream(self.enc_stream):
+            for t in batch:
+                self.enc_stream.wait_event(t.event)
+                t.features.record_stream(self.enc_stream)
+                t.query_feats.record_stream(self.enc_stream)
+            N = lead.features.shape[0]
+            x = torch.cat([t.features for t in batch]) if n > 1 else lead.features
+            txt = torch.stack([t.query_feats for t in batch])
+            cls = eng.clip_encoder(x, txt, torch.ones(n, txt.shape[1]), "cls")
+            ev = torch.cuda.Event()
+            ev.record(self.enc_stream)
+        eng.slot = prev
+        for i, t in enumerate(batch):
+            t.cls = cls[i * N:(i + 1) * N]
+            t.ready = ev
+            t.features = t.query_feats = None
+        self.enc_inflight.append(ev)
+        self.enc_batches += 1
+        self.enc_tickets += n
+        return True
+
     def pump(self):
         progressed = False
+        if self.enc_queue:
+            progressed |= self._pump_encode()
         if self.pf_queue:
             progressed |= self._pump_prefill()
         for p in self.pools:
@@ -492,7 +563,8 @@ class DecodeServer:
 
     def idle(self):
         """The scheduler made no progress and is about to block: what is waiting for a fuller batch goes now if the prefill stream is idle."""
-        return bool(self.pf_queue) and self._pump_prefill(partial=True)
+        moved = bool(self.enc_queue) and self._pump_encode(partial=True)
+        return (bool(self.pf_queue) and self._pump_prefill(partial=True)) or moved
 
     def wait_one(self):
         for p in self.pools:
@@ -503,6 +575,8 @@ class DecodeServer:
     def flush(self):
         """Nothing is in flight anywhere and no task has a device event pending (the scheduler would spin): the partly filled
         pool is run as it is (end of the workload, or fewer tasks in flight than a pool takes)."""
+        if self.enc_queue and self._pump_encode(force=True):
+            return True
         if self.pf_queue and self._pump_prefill(force=True):
             return True
         if self.gang:

@@ -213,6 +213,28 @@ def _tiny_model(parity=False):
     return m
 
 
+def test_batched_adapter_calls_equal_separate_ones():
+    """``DecodeServer(encode_batch=4)``: the adapter calls of recursions in flight ride in ONE rv_clip_encoder call (a query per recursion, grouped fold
+    GEMMs): every recursion's CLS rows equal its own call's up to the GEMM plans' summation order (at these few rows the K = 2048 FFN-2 takes a stream-K plan
+    that depends on the total row count: one 16-bit rounding moves, measured 3.9e-4 of the largest element in fp16 - with or without the folded attention,
+    i.e. a property of the engine at small row counts, not of the batching; at the bench's 100 x 256-frame recursions the rows are bit-identical) - whatever it
+    was batched with (3 tickets: a full batch is not needed, ``flush`` launches what waits)."""
+    from revisionllm_amd import serve
+    m = _tiny_model()
+    eng = m.engine
+    srv = serve.DecodeServer(m, rows=32, smax=64, gmax=8, pools=2, gang=True, prefill_batch=1, encode_batch=4)
+    feats_ = [feats(f"be.x{i}", (9, 32, 768), bf16=fl()).to(op()).cuda() for i in range(3)]
+    qfs = [feats(f"be.q{i}", (6, 768), bf16=fl()).to(op()).cuda() for i in range(3)]
+    want = [eng.clip_encoder(f, q[None], torch.ones(1, 6), "cls").clone() for f, q in zip(feats_, qfs)]
+    tickets = [srv.submit_encode(f, q) for f, q in zip(feats_, qfs)]
+    assert all(t.ready is None for t in tickets) and not srv.pump()          # a partial batch waits ...
+    assert srv.flush() and all(t.ready is not None for t in tickets)          # ... until nothing else can move
+    tickets[0].ready.synchronize()
+    assert srv.enc_batches == 1 and srv.enc_tickets == 3
+    for t, w in zip(tickets, want):
+        assert t.cls.shape == w.shape and rel_err(t.cls.cpu(), w.cpu()) < tol(8e-3)
+
+
 @pytest.mark.parametrize("n_passes,streams,pools,pbatch", [(3, 3, 1, 1), (5, 2, 1, 1), (7, 6, 2, 1), (9, 8, 3, 1), (7, 6, 2, 4)])
 def test_recursions_through_the_decode_server_equal_sequential(n_passes, streams, pools, pbatch):
     """Several stage-2 recursions in flight on their own HIP streams, their generates decoding through ONE DecodeServer (shared KV
