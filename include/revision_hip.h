@@ -129,6 +129,9 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        workgroup of 128 query rows stages every 32-key block of K / V^T in LDS once (LDS-DMA, double-buffered) instead of each wave fetching its own
  *                        copy from L2 (transformer.py:193,210-223 at T = 256 / 1024); the LLM prefill's causal attention (rv_llm_prefill_* with > 16 rows per sequence) likewise
  *                        shares one staged copy among the four waves of a 64-row workgroup.  0 = the per-wave form.  Rows are bit-identical either way.
+ *   "qkv_lds"            1 (default) = the LLM prefill's fused QKV projection (rv_llm_prefill_* / rv_llm_forward with S > 1, persistent 256-column form): a whole panel's RoPE-rotated
+ *                        Q, K-cache rows and transposed V-cache pieces are staged in LDS and stored as whole 128-byte row slabs / 16-byte pieces of 8 positions; 0 = every lane
+ *                        stores the 4 columns it holds (2-byte stores for V^T).  The same bytes land in the same places (vtimellm_llama.py:79-90 with past_key_values).
  *   "adapter_stream16"   1 (default) = rv_clip_encoder / the 768-d ClipEncoder with an output projector, fp16 build only: the encoder's residual stream is kept in HBM
  *                        as fp16 (the copies its GEMMs consume anyway) instead of f32 + fp16 copies: the residual operands of the out-projection / FFN-2 epilogues and the
  *                        LayerNorm inputs are read as fp16, accumulation and statistics stay f32 (transformer.py:210-223,271-305 keep fp32 activations; the measured

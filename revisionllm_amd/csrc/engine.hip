@@ -318,6 +318,7 @@ int* option_slot(RvOpts& o, const char* key) {
     if (k == "adapter_stream16") return &o.adapter_stream16;
     if (k == "adapter_fold_t2v") return &o.adapter_fold_t2v;
     if (k == "attn_lds") return &o.attn_lds;
+    if (k == "qkv_lds") return &o.qkv_lds;
     return nullptr;
 }
 }  // namespace

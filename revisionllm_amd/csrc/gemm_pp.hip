@@ -439,6 +439,9 @@ __device__ __forceinline__ void pp4_mainloop(f32x4 (&acc)[8][8], const Pp4Src& s
 template <int NFR>
 __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const QkvRope& qr, const QkvRow& row, int sec, int head, int slab0, int kg) {
     const int p0 = slab0 + kg * 4;
+    if constexpr ((RS_PROBE_K_ & 256) != 0) { if (sec == 2) return; }      // (timing probes, tools/qkv_store_probe.sh: no V^T / K / Q stores)
+    if constexpr ((RS_PROBE_K_ & 512) != 0) { if (sec == 1) return; }
+    if constexpr ((RS_PROBE_K_ & 1024) != 0) { if (sec == 0) return; }
     if (sec == 2) {
         for (int bb = row.b0; bb < row.b1; ++bb) {
             op16_t* dst = (op16_t*)qr.vtc + ((int64_t)bb * qr.H + head) * 128 * qr.Smax + rv_vt_index(p0, row.pos);
@@ -469,6 +472,128 @@ __device__ __forceinline__ void pp_rope_row_store(const f32x4 (&v)[NFR], const Q
         }
     }
 }
+// The fused q / k / v epilogue of a WHOLE 256 x 256 panel, staged through LDS (round 6; the "LDS-staged V^T" of VERDICT r4 / r5).  pp_rope_row_store writes what a lane
+// holds - 4 consecutive columns of one row per fragment: 8-byte pieces of Q / K rows (32 contiguous bytes per row and instruction) and, for V, sixteen 2-byte stores per row
+// 16 bytes apart (the cache keeps V transposed in blocks of 8 positions).  Probes with the stores compiled out (tools/qkv_store_probe.sh, 4 x 1005 rows): 361 us per launch,
+// 335 without the V^T stores, 341 without K, 348 without Q, 302 without any - 59 us of a 361 us launch were its stores.  Here a wave first parks its 128 x 64 sub-tile (one
+// head slab of one section; RoPE applied, packed to 16 bits: the same values) in a private LDS tile - the operand stages are free behind the main loop's last barrier - with
+// the rows' (position, cache rows) next to it, and then writes it out in the order memory wants:
+//   Q / K   a lane takes 8 consecutive columns (16 bytes) of a row: a store instruction covers 8 whole 128-byte row slabs;
+//   V^T     a lane takes ONE column d and the 8 rows of an aligned group of 8 positions of one sequence: 16 bytes, and the wave's 64 columns are 1 KiB contiguous
+//           (element (d, pos) at ((pos >> 3) * 128 + d) * 8 + (pos & 7)); rows whose group of 8 is cut by the tile's edge or a sequence's end go out as 2-byte stores.
+// Every byte lands where pp_rope_row_store puts it: caches and Q bit-identical (tests: the batched / shared-prefix / ragged prefills against their separate forms).
+template <int F8>
+__device__ __forceinline__ void pp_epilogue_rope_lds(const f32x4 (&acc)[4][8], int M, int m0, int n0, int wave, int lane, const QkvRope& qr, const PpScale& sc,
+                                                     char* smem) {
+    constexpr int RS = 144;                                 // bytes per tile row: 128 + 16 (conflict-free 8-byte writes, 16-byte and 2-byte-column reads)
+    constexpr int TILE = 128 * RS, WREG = TILE + 128 * 16;  // + one int4 per row: (pos or -1, b0, b1, mrow)
+    static_assert(8 * WREG <= PP_LDS, "eight private wave regions");
+    char* my = smem + wave * WREG;
+    int4* info = (int4*)(my + TILE);
+    const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, kg = lane >> 4;
+    const int D = qr.H * 128, nb = n0 + wc * 64;
+    const int sec = __builtin_amdgcn_readfirstlane(nb / D), hd0 = nb - sec * D, head = hd0 >> 7, slab0 = hd0 & 127;
+    const int mbase = m0 + wr * 128;
+    // ---- phase A: rotate / pack what the lane holds into the tile; lanes kg == 0 record their row ----
+    // rows first (8 per lane: two integer divisions each), then column block by column block with the NEXT block's (cos, sin) loads in flight: a row's coefficients sit
+    // behind its position, and fetched row block by row block they were 8 dependent L2 round trips per epilogue
+    // (the 128 rows' records are computed ONCE - two rows per lane, not eight per lane four times over - and read back: the epilogue is bound by its instruction count,
+    // and a row costs ~100 instructions)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int r = lane + 64 * hh, m = mbase + r;
+        const QkvRow row = qkv_rope_row(qr, m < M ? m : M - 1);
+        info[r] = (m < M && row.b1 > row.b0) ? int4{row.pos, row.b0, row.b1, row.mrow} : int4{-1, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int posv[8];
+    unsigned okm = 0;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int p_ = ((const int*)(info + mi * 16 + fr))[0];
+        okm |= (p_ >= 0 ? 1u : 0u) << mi;
+        posv[mi] = p_ >= 0 ? p_ : qr.cs_pos0;          // (a dead row reads a valid table row; nothing of it is stored)
+    }
+    if (sec == 2) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                f32x4 v = acc[ni][mi];
+                if constexpr (F8) v = pp_scaled(sc, mbase + mi * 16 + fr, nb + ni * 16 + kg * 4, v);
+                if ((okm >> mi) & 1u) *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = pack_op16x4(v);
+            }
+    } else {
+        const float* cs0 = qr.cs + (slab0 + kg * 4) - (int64_t)qr.cs_pos0 * 128;      // (row.cs = qr.cs + (pos - cs_pos0) * 128 for prefill rows)
+        f32x4 tc[8], tn[8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) tc[mi] = *(const f32x4*)(cs0 + (int64_t)posv[mi] * 128);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            if (ni < 3) {
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) tn[mi] = *(const f32x4*)(cs0 + (int64_t)posv[mi] * 128 + (ni + 1) * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                f32x4 v = acc[ni][mi];
+                if constexpr (F8) v = pp_scaled(sc, mbase + mi * 16 + fr, nb + ni * 16 + kg * 4, v);
+                const f32x4 t = tc[mi];
+                const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
+                const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
+                if ((okm >> mi) & 1u) *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = pack_op16x4(f32x4{a0, b0, a1, b1});
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) tc[mi] = tn[mi];
+        }
+    }
+    if constexpr ((RS_PROBE_K_ & 2048) != 0) return;         // (timing probe: phase A only - rows, coefficients, rotation, LDS writes; nothing leaves the CU)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-private region: the wave's own LDS writes are complete before its lanes read each other's)
+    // ---- phase B ----
+    if (sec < 2) {
+        const int rl = lane >> 3, ch = lane & 7;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 8 + rl;
+            const int4 ri = info[r];
+            if (ri.x < 0) continue;
+            const u32x4 val = *(const u32x4*)(my + r * RS + ch * 16);
+            if (sec == 0) {
+                *(u32x4*)((op16_t*)qr.q16 + (int64_t)ri.w * D + head * 128 + slab0 + ch * 8) = val;
+            } else {
+                for (int bb = ri.y; bb < ri.z; ++bb)
+                    *(u32x4*)((op16_t*)qr.kc + (((int64_t)bb * qr.H + head) * qr.Smax + ri.x) * 128 + slab0 + ch * 8) = val;
+            }
+        }
+        return;
+    }
+    const int64_t vrow = (int64_t)128 * qr.Smax;            // elements per (cache row, head) of V^T
+    for (int r = 0; r < 128;) {                             // (wave-uniform walk over the tile's rows)
+        const int4 a = info[r];
+        const int pos = __builtin_amdgcn_readfirstlane(a.x), b0 = __builtin_amdgcn_readfirstlane(a.y), b1 = __builtin_amdgcn_readfirstlane(a.z);
+        if (pos < 0) { ++r; continue; }
+        bool full = (pos & 7) == 0 && r + 7 < 128;
+        if (full) {
+            const int4 z = info[r + 7];
+            full = __builtin_amdgcn_readfirstlane(z.x) == pos + 7 && __builtin_amdgcn_readfirstlane(z.y) == b0 && __builtin_amdgcn_readfirstlane(z.z) == b1;
+        }
+        const char* col = my + r * RS + lane * 2;
+        if (full) {     // rows r .. r + 7 = positions pos .. pos + 7 of one sequence: this lane's column as one 16-byte piece
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = (uint32_t)*(const uint16_t*)(col + (2 * j) * RS) | ((uint32_t)*(const uint16_t*)(col + (2 * j + 1) * RS) << 16);
+            for (int bb = b0; bb < b1; ++bb)
+                *(u32x4*)((op16_t*)qr.vtc + ((int64_t)bb * qr.H + head) * vrow + rv_vt_index(slab0 + lane, pos)) = w;
+            r += 8;
+        } else {
+            const op16_t val = *(const op16_t*)col;
+            for (int bb = b0; bb < b1; ++bb) ((op16_t*)qr.vtc)[((int64_t)bb * qr.H + head) * vrow + rv_vt_index(slab0 + lane, pos)] = val;
+            ++r;
+        }
+    }
+}
+
 // Epilogue: lane owns row m = .. + fr, columns n = .. + kg * 4 .. + 3 of every 16 x 16 fragment.
 template <int OUT_BF16, int ACT, int ROPE, int NF, int F8 = 0>
 __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const float* __restrict__ bias, const float* res, int64_t ldr,
@@ -820,7 +945,10 @@ __device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t
 
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
             if constexpr (W4) pp4_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
-            else pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
+            else if constexpr (ROPE == 2 && NF == 4) {      // the LDS-staged form (a kernel of its own: with both forms in one kernel the accumulators spilled, 361 -> 393 us);
+                pp_epilogue_rope_lds<F8>(acc, M, m0, n0, wave, lane, qr, sc, smem);      // every wave leaves the LDS before the next main loop stages into it
+                __syncthreads();
+            } else pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
             continue;
         }
         if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
@@ -992,6 +1120,16 @@ int launch_sk(const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias,
         if (w4) {
             hipLaunchKernelGGL((gemm_pp4_sk<OUT_BF16, ACT, ROPE>), dim3(G), dim3(256), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K, tm_team, TS,
                                nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG | MHS << 8, tiles_n);
+            return RV_OK;
+        }
+    }
+    if constexpr (ROPE == 1 && NF == 4) {
+        // ROPE = 2: the same kernel with the whole-panel q / k / v epilogue staged through LDS (pp_epilogue_rope_lds; option qkv_lds; prefill rows only)
+        static std::atomic<uint64_t> attr_set2{0};
+        if (rv_cur_opts().qkv_lds && !qr.row_pos) {
+            if (int rc = reserve_lds(gemm_pp_sk<OUT_BF16, ACT, 2, NF, F8>, attr_set2)) return rc;
+            hipLaunchKernelGGL((gemm_pp_sk<OUT_BF16, ACT, 2, NF, F8>), dim3(G), dim3(512), PP_LDS, st, A, lda, Wp, bias, res, ldr, C, ldc, M, N, K,
+                               tm_team, TS, nk, dp_panels, (groups - dp_panels) * nk, partial, flags, status, epoch, qr, sc, PG | MHS << 8, tiles_n);
             return RV_OK;
         }
     }

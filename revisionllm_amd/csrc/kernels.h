@@ -28,6 +28,8 @@ struct RvOpts {
     int attn_lds = 1;           // attention with >= 96 keys, no mask, dh 64 / 96 (the adapter's self-attention, the CLIP towers) and the LLM prefill's attention (causal, dh 128): key
                                 // blocks staged in LDS once per workgroup (attention.hip attn_body_lds / attn_body_lds1); 0 = every wave fetches its fragments from L2 (rounds 1 - 5).
                                 // Bit-identical rows.
+    int qkv_lds = 1;            // prefill (persistent 256-column QKV GEMM): the fused RoPE / KV-cache epilogue of a whole panel is staged through LDS and stored as whole row slabs /
+                                // 16-byte V^T pieces (gemm_pp.hip pp_epilogue_rope_lds); 0 = every lane stores what it holds (rounds 1 - 5).  Same bytes.
     int precision = 0;          // LLM forward: 0 = bf16 GEMM operands (default); 1 = PARITY: every GEMM operand is the split pair (hi, lo) = (bf16(x), bf16(x - hi)) against
                                 // K-duplicated weights ("<name>.p2" bound), i.e. 16-bit-mantissa activations - the reference's fp32 scores to 1e-3
 };

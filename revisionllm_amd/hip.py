@@ -192,7 +192,7 @@ def check(rc, what):
         raise HipLibraryError(f"{what} failed (status {rc}): {' | '.join(mine or msgs)}")
 
 
-OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant", "rows_fill", "rows_spread", "rows_persistent", "rows_single", "gemm_waves", "gemm_mhalf", "precision", "lm_head_split", "last_block_rows", "adapter_stream16", "adapter_fold_t2v", "attn_lds")
+OPTION_KEYS = ("gemm_tile_variant", "gemm_cus", "gemm_arows", "fp8_decode", "fp8_prefill", "sample_variant", "rows_fill", "rows_spread", "rows_persistent", "rows_single", "gemm_waves", "gemm_mhalf", "precision", "lm_head_split", "last_block_rows", "adapter_stream16", "adapter_fold_t2v", "attn_lds", "qkv_lds")
 
 
 class Options:

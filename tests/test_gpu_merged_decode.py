@@ -213,6 +213,28 @@ def _tiny_model(parity=False):
     return m
 
 
+@pytest.mark.parametrize("G,B,P0,S", [(4, 7, 32, 139), (3, 7, 40, 96), (2, 7, 0, 96), (1, 5, 32, 171), (4, 1, 0, 327), (8, 7, 32, 139), (2, 3, 17, 61)])
+def test_prefill_qkv_epilogue_through_lds_writes_the_same_bytes(G, B, P0, S):
+    """The fused q / k / v epilogue of the persistent prefill GEMM staged through LDS (gemm_pp.hip pp_epilogue_rope_lds, option ``qkv_lds``: whole 128-byte row slabs
+    of Q / K, 16-byte pieces of 8 positions of V^T, 2-byte stores only where a group of 8 positions is cut by a tile edge or a sequence end) against the per-lane
+    stores of rounds 1 - 5: the logits and EVERY byte of the KV pool are equal - shared prefix, no prefix, one / several / eight prefills to a pass, one-row
+    sequences of 327 positions, short odd geometry (sequence ends inside tiles, groups of positions cut everywhere)."""
+    eng = _engine()
+    D, R, Smax = 4096, 64, 352
+    g = torch.Generator().manual_seed(41 + G + S)
+    hs = torch.randn(G * (P0 + B * S), D, generator=g).mul(0.02).cuda()
+    row0 = [1 + B * i for i in range(G)]
+    outs = []
+    for v in (1, 0):
+        eng.set_option("qkv_lds", v)
+        pool, _ = eng.new_kv_pool(R, Smax)
+        lg = (eng.llm_prefill_pool_groups(hs.clone(), G, B, P0, pool, R, row0, Smax) if G > 1 else eng.llm_prefill_pool(hs.clone(), B, P0, pool, R, row0[0], Smax))
+        outs.append((lg.clone(), pool.clone()))
+    eng.set_option("qkv_lds", 1)
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].float().abs().max()) > 0
+
+
 def test_batched_adapter_calls_equal_separate_ones():
     """``DecodeServer(encode_batch=4)``: the adapter calls of recursions in flight ride in ONE rv_clip_encoder call (a query per recursion, grouped fold
     GEMMs): every recursion's CLS rows equal its own call's up to the GEMM plans' summation order (at these few rows the K = 2048 FFN-2 takes a stream-K plan
