@@ -139,6 +139,9 @@ __device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
 }
 __device__ __forceinline__ u32x2 pack_op16x4(f32x4 v) { return u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])}; }
 __device__ __forceinline__ uint32_t pack_op16x2_bounded(float lo, float hi) { return pack_op16x2(lo, hi); }
+// (bf16 has fp32's exponent range: nothing saturates, nothing to report - the fp16 flavour's accumulate-then-report pair as no-ops)
+__device__ __forceinline__ uint32_t pack_op16x2_m(float lo, float hi, uint32_t&) { return pack_op16x2(lo, hi); }
+__device__ __forceinline__ void rv_note_saturation(uint32_t) {}
 __device__ __forceinline__ float op16x2_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float op16x2_hi_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ f32x4 rv_mfma16(op16x8 a, op16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }

@@ -506,14 +506,15 @@ __device__ __forceinline__ void pp_epilogue_rope_lds(const f32x4 (&acc)[4][8], i
         info[r] = (m < M && row.b1 > row.b0) ? int4{row.pos, row.b0, row.b1, row.mrow} : int4{-1, 0, 0, 0};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (a dead row - past M - reads a valid table row and writes its tile row like any other: phase B never looks at it.  Its accumulators are those of row M - 1,
+    // whose operand rows the main loop's clamped loads gave it: they can raise the saturation report below only together with that live row)
     int posv[8];
-    unsigned okm = 0;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int p_ = ((const int*)(info + mi * 16 + fr))[0];
-        okm |= (p_ >= 0 ? 1u : 0u) << mi;
-        posv[mi] = p_ >= 0 ? p_ : qr.cs_pos0;          // (a dead row reads a valid table row; nothing of it is stored)
+        posv[mi] = p_ >= 0 ? p_ : qr.cs_pos0;
     }
+    uint32_t sat = 0;                                   // one saturation report for the wave's whole sub-tile
     if (sec == 2) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -521,7 +522,7 @@ __device__ __forceinline__ void pp_epilogue_rope_lds(const f32x4 (&acc)[4][8], i
             for (int mi = 0; mi < 8; ++mi) {
                 f32x4 v = acc[ni][mi];
                 if constexpr (F8) v = pp_scaled(sc, mbase + mi * 16 + fr, nb + ni * 16 + kg * 4, v);
-                if ((okm >> mi) & 1u) *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = pack_op16x4(v);
+                *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_op16x2_m(v[0], v[1], sat), pack_op16x2_m(v[2], v[3], sat)};
             }
     } else {
         const float* cs0 = qr.cs + (slab0 + kg * 4) - (int64_t)qr.cs_pos0 * 128;      // (row.cs = qr.cs + (pos - cs_pos0) * 128 for prefill rows)
@@ -541,12 +542,13 @@ __device__ __forceinline__ void pp_epilogue_rope_lds(const f32x4 (&acc)[4][8], i
                 const f32x4 t = tc[mi];
                 const float a0 = __fmaf_rn(v[0], t[0], -__fmul_rn(v[1], t[1])), b0 = __fmaf_rn(v[1], t[0], __fmul_rn(v[0], t[1]));
                 const float a1 = __fmaf_rn(v[2], t[2], -__fmul_rn(v[3], t[3])), b1 = __fmaf_rn(v[3], t[2], __fmul_rn(v[2], t[3]));
-                if ((okm >> mi) & 1u) *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = pack_op16x4(f32x4{a0, b0, a1, b1});
+                *(u32x2*)(my + (mi * 16 + fr) * RS + (ni * 16 + kg * 4) * 2) = u32x2{pack_op16x2_m(a0, b0, sat), pack_op16x2_m(a1, b1, sat)};
             }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) tc[mi] = tn[mi];
         }
     }
+    rv_note_saturation(sat);
     if constexpr ((RS_PROBE_K_ & 2048) != 0) return;         // (timing probe: phase A only - rows, coefficients, rotation, LDS writes; nothing leaves the CU)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-private region: the wave's own LDS writes are complete before its lanes read each other's)
     // ---- phase B ----
