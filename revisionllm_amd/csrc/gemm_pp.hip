@@ -633,6 +633,11 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu(acc[ni][0][r]) * acc[ni + 1][0][r];
+                if constexpr ((RS_PROBE_K_ & 32768) != 0) {      // (timing probe: the gated epilogue computed, not stored)
+                    const u32x2 o_ = pack_op16x4(v);
+                    asm volatile("" ::"v"(o_[0]), "v"(o_[1]));
+                    continue;
+                }
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
