@@ -25,12 +25,19 @@ extern "C" int rv_last_error(char* buf, size_t n) {
 // ---- numeric status (common.h): every translation unit registers itself at load time; rv_numeric_status_bind points all of them at one
 // caller-owned device buffer.  The list is built by static constructors (no HIP call), walked under the caller's current device.
 static RvTuNode* g_numeric_head = nullptr;
-static unsigned int* g_numeric_ptr = nullptr;
+static unsigned int* g_numeric_ptr[64] = {};      // per device ordinal (one process per GPU is the design; several devices in one process each get their own buffer)
 void rv_numeric_register(RvTuNode* n) {
     n->next = g_numeric_head;
     g_numeric_head = n;
 }
-unsigned int* rv_numeric_bound() { return g_numeric_ptr; }
+static int numeric_device() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1;
+}
+unsigned int* rv_numeric_bound() {
+    const int d = numeric_device();
+    return d < 0 ? nullptr : g_numeric_ptr[d];
+}
 
 extern "C" int rv_numeric_status_bind(uint32_t* status_dev) {
     RV_CHECK_ARG(((uintptr_t)status_dev & 15) == 0, "rv_numeric_status_bind: the buffer must be 16-byte aligned");
@@ -39,7 +46,9 @@ extern "C" int rv_numeric_status_bind(uint32_t* status_dev) {
             rv_set_error("rv_numeric_status_bind: hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
             return RV_ERR_HIP;
         }
-    g_numeric_ptr = (unsigned int*)status_dev;
+    const int d = numeric_device();
+    RV_CHECK_ARG(d >= 0, "rv_numeric_status_bind: no current device");
+    g_numeric_ptr[d] = (unsigned int*)status_dev;
     return RV_OK;
 }
 
