@@ -1062,8 +1062,23 @@ def g15_memory(M):
     out["inference_seq"] = mo["sequences"]
     out["inference_scores"] = torch.stack(mo["scores"], 0)
     save("g15_memory", **out)
+    # ... and with a ClipEncoder adapter (missing #3): what does the reference itself do with a <memory> prompt?  Recorded, so that the build's refusal
+    # ("the reference's own failure") is a checked statement: the exception type and message of the reference's generate on a tiny hierarchy model.
+    mc = tiny_model(M, shape, ns())
+    mc.generation_config.eos_token_id = None
+    featc = T(synth.features("g15.featc", (B, 6, 16, 768), SEED))
+    qfc = (T(synth.features("g15.qc", (B, 5, 768), SEED)), torch.ones(B, 5))
+    try:
+        mc.generate(ids, images=featc, query_feats=qfc, do_sample=False, max_new_tokens=2, use_cache=True, visual_memory=vm2, prefix_memory=pm)
+        clip_err = None
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)
+        where = [f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in tb if "/reference/" in fr.filename]
+        clip_err = {"type": type(e).__name__, "message": str(e)[:300], "reference_frames": where[-4:]}
+    print("g15: <memory> with a ClipEncoder adapter through the reference:", clip_err)
     with open(os.path.join(HERE, "g15_text.json"), "w") as f:
-        json.dump({"inference_text": text}, f)
+        json.dump({"inference_text": text, "clip_encoder_with_memory": clip_err}, f, indent=1)
 
 
 

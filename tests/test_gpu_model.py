@@ -321,6 +321,10 @@ def test_memory_prompts_vs_reference_golden_and_oracle(golden, tag):
             m.generate(ids_plain, images=feat, max_new_tokens=1, visual_memory=vm, prefix_memory=pm)
         with pytest.raises(ValueError, match="come together"):
             m.generate(ids, images=feat, max_new_tokens=1, visual_memory=vm)
+        # (the reference ITSELF fails there: golden g15_text.json records its exception for this call - an AttributeError raised in transformer.py:119, reached
+        # from vtimellm_arch.py:222 - so the refusal names a checked fact)
+        ref_fail = golden.json("g15_text")["clip_encoder_with_memory"]
+        assert ref_fail["type"] == "AttributeError" and ref_fail["reference_frames"][-2:] == ["vtimellm_arch.py:222", "transformer.py:119"]
         mc = _model(shape, _args())
         with pytest.raises(NotImplementedError, match="transformer.py:119"):
             mc.generate(ids, images=feats("g15.h", (2, 4, 8, 768)), query_feats=(feats("g15.q", (2, 4, 768)), torch.ones(2, 4)), max_new_tokens=1,
