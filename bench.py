@@ -82,9 +82,10 @@ def parse():
                    help="adapter calls of recursions in flight per rv_clip_encoder call (serve.DecodeServer encode_batch; 1 = every recursion encodes its own windows: the "
                         "default - the adapter alone runs 1.55 / 1.33 / 1.25 ms per recursion at 1 / 4 / 8 to a call, but the K = 20 pipeline measured level: 6262 vs 6267 "
                         "segments/s over four alternations at 1 / 8, DESIGN section 9)")
-    p.add_argument("--prefill-batch", type=int, default=4,
+    p.add_argument("--prefill-batch", type=int, default=8,
                    help="LLM prefills of the steps in flight that may ride in ONE pass (the DecodeServer batches the waiting prefills of identical "
-                        "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own")
+                        "geometry: GEMMs of up to N x 1005 rows); 1 = every step prefills on its own.  8 since round 6 (passes of 8 + 8 + 4 at K = 20: 6476 / 6470 / 6490 "
+                        "against 6325 / 6351 / 6382 segments/s at 4, three alternations on one box; rounds 3 - 5 measured 8 level with 4)")
     p.add_argument("--pool-rows", type=int, default=0,
                    help="rows of a KV pool (<= 32: the weight-streaming decode kernel; 33 .. 144: the split-K kernel with LDS-shared activations); "
                         "0 = one gang for all the steps in flight: rows of a recursion (7) x min(streams, steps, 20) = 140 rows at --steps 20")

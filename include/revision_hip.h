@@ -99,7 +99,7 @@ void rv_ctx_destroy(rv_ctx* ctx);
  *                        in ping-pong (128 x 64 outputs each); 4 = one wave per SIMD owning 128 x 128 outputs (accumulators in the AGPR half of
  *                        the register file; 128 instead of 192 KiB of LDS fragment reads per k-tile).  Bit-identical results; measured level
  *                        with 8 up to ~4000 rows (0 .. -2.5 %) and ahead for more rows (8192^3: +30 %).  FP8 x FP8 and 192-column forms: always 8.
- *   "gemm_mhalf"         1 (default): a persistent prefill GEMM over >= 10 row tiles of 256 (batched prefills) lets one XCD's team of workgroups cover HALF the
+ *   "gemm_mhalf"         2 (default since round 6: from 32 row tiles on - 8 prefills to a pass - a QUARTER of the row tiles x four times the panels), 1: a persistent prefill GEMM over >= 10 row tiles of 256 (batched prefills) lets one XCD's team of workgroups cover HALF the
  *                        row tiles of twice as many weight panels (16 row tiles: 8 x 4 instead of 16 x 2 tiles per team) - fewer activation bytes
  *                        re-fetched per tile.  0: the round-3 teams.  The stream-K split points move with the team shape, so results may differ in the
  *                        last bit between the two settings (each is deterministic).

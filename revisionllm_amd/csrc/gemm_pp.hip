@@ -1110,6 +1110,16 @@ int launch_sk(const op16_t* A, int64_t lda, const op16_t* Wp, const float* bias,
             PG = pg2;
             MHS = 1;
         }
+        // ... and a QUARTER of the m-tiles x four times the panels when the halves are still tall (round 6: 8 prefills to a pass = 32 m-tiles: 8 x 4 tiles per team instead
+        // of 16 x 2 - the same shape the 16-tile pass has had since round 4; per 32 tiles an XCD then fetches 16.5 + 8.4 MB instead of 33 + 4.2)
+        if (MHS == 1 && rv_cur_opts().gemm_mhalf >= 2 && tm_team >= 16 && tm_team % 2 == 0) {
+            const int tm4 = tm_team / 2, pg4 = per_x / tm4;
+            if (pg4 <= 255 && tm4 * pg4 >= tm_team * PG) {
+                tm_team = tm4;
+                PG = pg4;
+                MHS = 2;
+            }
+        }
     }
     const int TS = tm_team * PG;
     const int T = (PG > 1 || MHS) ? 8 * (per_x / TS) : pp_teams(M);

@@ -13,7 +13,7 @@ struct RvOpts {
     int sample_variant = 1;     // 1 compacted-candidate top-k fast path, 0 general selection (identical outputs)
     int gemm_arows = 1;         // 1: short-K many-row GEMMs (K <= 1024, the adapter / projector family) take the A-resident kernel
     int gemm_waves = 8;         // persistent 256 x 256 x 64 prefill GEMMs (bf16, 256-column panels): 4 = one wave per SIMD with 128 x 128 outputs each, 8 = the two-wave-per-SIMD ping-pong form
-    int gemm_mhalf = 1;         // persistent prefill GEMMs with >= 10 m-tiles: a team covers half the m-tiles of twice as many panels (less activation re-fetch per tile; same results)
+    int gemm_mhalf = 2;         // (2, round 6: from 32 m-tiles on a QUARTER of them x four times the panels)  persistent prefill GEMMs with >= 10 m-tiles: a team covers half the m-tiles of twice as many panels (less activation re-fetch per tile; same results)
     int rows_single = 1;        // 81 .. 144-row decode kernel: a launch whose column groups fill >= 3/4 of the CUs runs without a K split
     int rows_persistent = 1;    // 33 .. 144-row decode kernel: launches with more items than resident workgroups run as a persistent grid with deferred hand-overs
     int rows_spread = 0;        // 33 .. 144-row decode kernel: launches with at most this many workgroups take a CU each (0: never)

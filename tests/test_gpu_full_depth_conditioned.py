@@ -239,10 +239,12 @@ def test_conditioned_batched_recursion_equals_reference(fx):
     _records_equal_reference(rec, g, meta, r.tol)
 
 
-@pytest.mark.parametrize("fixture,copies,pool_rows", [("g8c", 4, 32), ("g8c", 8, 56), ("g8c", 10, 70), ("g8c", 20, 140), ("g8d", 20, 140)])
-def test_conditioned_headline_pipeline_equals_reference(request, fixture, copies, pool_rows):
+@pytest.mark.parametrize("fixture,copies,pool_rows,pbatch", [("g8c", 4, 32, 4), ("g8c", 8, 56, 4), ("g8c", 10, 70, 4), ("g8c", 20, 140, 4), ("g8d", 20, 140, 4),
+                                                             ("g8c", 20, 140, 8), ("g8d", 20, 140, 8)])
+def test_conditioned_headline_pipeline_equals_reference(request, fixture, copies, pool_rows, pbatch):
     """The pipeline the bench runs, free-running at 32 layers: ``copies`` instances of the G8c recursion in flight on their own HIP
-    streams, prefills up to four to a pass (~4000-row GEMMs), decode steps merged into 28- / 56- / 70- / 140-row passes of gang-filled KV pools (140 rows = the bench's default: all twenty steps in flight in one pass).
+    streams, prefills up to ``pbatch`` to a pass (~4000- / ~8000-row GEMMs; 8 = the bench's default since round 6), decode steps merged into 28- / 56- / 70- / 140-row passes of
+    gang-filled KV pools (140 rows = the bench's default: all twenty steps in flight in one pass).
     EVERY instance must reproduce the reference's record."""
     from revisionllm_amd import parallel, sched, serve
     from revisionllm_amd.utils import synth
@@ -257,7 +259,7 @@ def test_conditioned_headline_pipeline_equals_reference(request, fixture, copies
     tok = synth.FakeTokenizer()
     st = parallel.HipStages(m, tok)
     u = T(g["uniforms"]).t().contiguous()                                   # [G, calls]
-    server = serve.DecodeServer(m, rows=pool_rows, smax=192, gmax=16, pools=2, gang=True, prefill_batch=4)
+    server = serve.DecodeServer(m, rows=pool_rows, smax=192, gmax=16, pools=2, gang=True, prefill_batch=pbatch)
     st.server = server
     streams = [torch.cuda.Stream("cuda:0") for _ in range(copies)]
     torch.cuda.synchronize()

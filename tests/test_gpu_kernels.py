@@ -54,7 +54,9 @@ def test_init_hash_bit_exact(dev):
                                     (7, 1024, 11008), (16, 32000, 512), (17, 768, 2048), (100, 4096, 768), (1197, 4096, 4096),
                                     (1057, 22016, 1024), (5000, 1536, 768), (129, 256, 11008),
                                     # >= 8 row tiles of 256 (batched prefills): the stream-K teams take groups of 4 / 2 adjacent panels (last group ragged)
-                                    (2010, 2560, 1024), (4020, 4352, 2048), (3000, 1280, 4096)])
+                                    (2010, 2560, 1024), (4020, 4352, 2048), (3000, 1280, 4096),
+                                    # 32 row tiles (8 prefills to a pass): teams of a QUARTER of the m-tiles x 4 panels
+                                    (8040, 4352, 2048)])
 @pytest.mark.parametrize("out", ["bf16", "f32"])
 def test_gemm(dev, M, N, K, out):
     from revisionllm_amd import hip, ops

@@ -18,8 +18,8 @@ for d in r6_fetch r6_write r6_sq r6_grbm; do find gpurun_out/$d -name '*.csv' -s
 python3 tools/decode_rows_time.py 7 14 28 56 70 112 140 > gpurun_out/r6_decode_ms.log 2>&1
 python3 tools/decode_rows_time.py 56 70 112 140 --fp8 >> gpurun_out/r6_decode_ms.log 2>&1
 python3 tools/decode_rows_summary.py 14 28 56 70 112 140 70f8 112f8 140f8
-# one batched prefill pass at the headline's row count (4 x 1005 rows), per-kernel averages -> gpurun_out/r6_prefill_pass.json
-bash tools/prefill_prof.sh 4 > gpurun_out/r6_prefill_prof.log 2>&1
+# one batched prefill pass at the headline's row count (8 x 1005 rows since the bench batches up to 8 prefills), per-kernel averages -> gpurun_out/r6_prefill_pass.json
+bash tools/prefill_prof.sh 8 > gpurun_out/r6_prefill_prof.log 2>&1
 # the stage-2 adapter alone (one recursion's 100 windows x 256 frames, 30 runs): per-kernel times when nothing else runs
 rm -rf gpurun_out/r6_adapter
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r6_adapter -o adp -- python3 tools/adapter_prof.py 30 > gpurun_out/r6_adapter.log 2>&1
