@@ -17,6 +17,8 @@ OPT = hip.Options(gemm_waves=int(os.environ["WAVES"])) if os.environ.get("WAVES"
 if len(sys.argv) > 1 and OPT is not None:
     OPT = hip.Options(flavour=sys.argv[1], gemm_waves=int(os.environ["WAVES"]))   # WAVES=4 / 8: the rv_gemm form
 shapes = [(4020, 22016, 4096), (4020, 4096, 4096), (4020, 4096, 11008), (4020, 12288, 4096), (2010, 22016, 4096), (4096, 4096, 4096), (8192, 8192, 8192)]
+if os.environ.get("ROWS"):                       # ROWS=8040: the four projection shapes of a pass of that many rows only
+    shapes = [(int(os.environ["ROWS"]), n, k) for n, k in ((22016, 4096), (4096, 4096), (4096, 11008), (12288, 4096))]
 
 
 def timeit(fn, n=20, warm=5, min_ms=300.0):

@@ -61,11 +61,11 @@ def sq_summary(sq_dir, grbm_dir, out_prefix, n_xcd=8, simds=1024):
     if pp:
         busy = sum(r["SQ_VALU_MFMA_BUSY_CYCLES"] * r["launches"] for r in pp)
         cyc = sum(r["kernel_cycles"] * r["launches"] for r in pp)
-        summary = {"kernels": "gemm_pp_sk<...> (the prefill projections of the recursion: passes of 4 x 1005 rows)", "mfma_util": round(busy / (cyc * simds), 4),
+        summary = {"kernels": "gemm_pp_sk<...> (the prefill projections of the recursion: passes of up to 8 x 1005 rows)", "mfma_util": round(busy / (cyc * simds), 4),
                    "lds_bank_conflict_cycles": sum(r.get("SQ_LDS_BANK_CONFLICT", 0) for r in pp),
                    "by_kernel": {r["kernel"]: {"mfma_util": r["mfma_util"], "launches": r["launches"], "parked": r.get("frac_waves_parked_at_waitcnt_or_barrier"),
                                                "issue_stalled": r.get("frac_waves_issue_stalled")} for r in pp}}
-    json.dump({"note": "rocprofv3 --pmc, two passes (SQ set / GRBM set) of `bench.py --steps 2 --warmup 1 --settle 0 --streams 1 --no-cpu-baseline --no-extras`; "
+    json.dump({"note": "rocprofv3 --pmc, two passes (SQ set / GRBM set) of `bench.py --steps 16 --warmup 0 --settle 0 --no-cpu-baseline --no-extras` (tools/profile_r6.sh); "
                        "averages per launch; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
                "summary": summary, "kernels": rows[:30]}, open(out_prefix + "_pmc_mfma.json", "w"), indent=1)
     print("wrote", out_prefix + "_pmc_mfma.json", summary)
