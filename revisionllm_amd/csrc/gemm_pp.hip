@@ -28,6 +28,19 @@
 
 #include "kernels.h"
 
+// PP_ABL (compile-time ablation probe, tools/pp_probe.sh; results are garbage, only the time means anything): 1 = the steady state issues no LDS-DMA,
+// 2 = no fragment reads, 4 = no barriers, 8 = no MFMAs, 16 = every panel reads the weights of panel 0 (W stays in L2; lda = 0 does the same for A).
+#ifndef PP_ABL
+#define PP_ABL 0
+#endif
+#if PP_ABL & 32
+// 32 = cycle stamps (s_memtime) behind each of the 8 barriers of a k-tile, summed per slot over the steady-state tiles of workgroup 0 .. 255, waves 0 and 4:
+// pp_stamp_buf[(workgroup * 2 + group) * 9 + slot], [.. + 8] = k-tiles counted; read with rv_pp_stamps (probe builds are linked without the export map).
+__device__ __attribute__((visibility("default"))) unsigned long long pp_stamp_buf[256 * 2 * 9];
+// pp_stamp_ext[workgroup * 4 + i]: 0 = prologue (entry of the k-split loop -> behind its second barrier), 1 = the whole loop, 2 = the whole-panel epilogue, 3 = panels
+__device__ __attribute__((visibility("default"))) unsigned long long pp_stamp_ext[3 * 256 * 4];   // [kind: 0 gated, 1 plain, 2 q/k/v][workgroup][i]
+#endif
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -83,7 +96,7 @@ __device__ __forceinline__ void pp_sources(PpSrc& s, const op16_t* __restrict__ 
     // W unit n1, NF = 4: the same two fragments further on; NF = 3: one fragment per wave column -> piece wcol * 2 + ks,
     // one piece per wave: wcol = wave >> 1, ks = wave & 1 (kept in w1[0]).
     const int kfr = K >> 5;
-    const int nb0 = (n0 >> 4) + (wave >> 1) * NF + (wave & 1);
+    const int nb0 = ((PP_ABL & 16) ? 0 : (n0 >> 4)) + (wave >> 1) * NF + (wave & 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         s.w0[ks] = (unsigned)(((((int64_t)nb0 * kfr + ks) * 64 + lane) * 8) * 2);
@@ -121,8 +134,10 @@ __device__ __forceinline__ void issue_unit(const PpSrc& s, int k0, char* dst0, i
 
 template <int N_>
 __device__ __forceinline__ void wait_vm() {
-    static_assert(N_ >= 0 && N_ <= 12, "extend the table");
-    if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    static_assert(N_ >= 0 && N_ <= 14, "extend the table");
+    if constexpr (N_ == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N_ == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N_ == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     else if constexpr (N_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N_ == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -175,8 +190,196 @@ __device__ __forceinline__ pp_i32x8 pp_cat(op16x8 lo, op16x8 hi) {
     const i32x4_ a = __builtin_bit_cast(i32x4_, lo), b = __builtin_bit_cast(i32x4_, hi);
     return pp_i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-template <int NF, int F8 = 0>
-__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane) {
+// ---- round 6: the k-split form of the same tile (16-bit operands, 256-column panels) ---------------------------------------------------
+// What the cycle stamps (PP_ABL & 32, tools/pp_stamps.py) showed in the loop above: a k-tile takes ~2560 cycles against 2048 of MFMA issue, and 350 of the
+// 510 lost cycles sit in the two slots around a group's phase-0 memory part - its 12 ds_read_b128 are consumed by the compute part right behind the next
+// barrier, so their LDS latency (4 waves x 12 KiB through the LDS + the LDS-DMA issues in front of the barrier) is exposed twice per k-tile and SIMD.  With
+// the quadrant order all 64 operand registers are live, so nothing can be read ahead.  Here a phase is (M-half, k32-half) instead of a quadrant:
+//     phase 0 (m0, k0)   phase 1 (m0, k1)   phase 2 (m1, k0)   phase 3 (m1, k1)      16 MFMAs each: 4 W fragments x 4 A fragments of ONE k32 half
+// so a phase needs 4 + 4 operand fragments (32 registers) and the other 32 hold what the NEXT compute part needs: the memory part of phase p reads the
+// operands of compute part p + 1 (8 / 4 / 4 / 8 ds_read_b128: 24 per k-tile as before), a whole compute part and two barriers before they are used.
+// Every accumulator still sees k ascending (k0 of a tile, then k1): the results are bit-identical to the quadrant loop's.
+// LDS: ONE ring of ten 16 KiB units (all 160 KiB), a unit per phase in the order its data is needed:
+//     phase 0 issues UA0(c+2) (A rows of the m0 halves) | phase 1 UW1(c+2) (the k1 pieces of the 16 W fragments) | phase 2 UA1(c+2) | phase 3 UW0(c+3)
+// and the unit issued in phase t (counted over all tiles) lands in slot t mod 10, i.e. on the unit issued 10 phases earlier.  First / last read (memory
+// part of phase, tile): UW0(c) ph3(c-1); UA0(c) ph3(c-1), ph0(c); UW1(c) ph0(c); UA1(c) ph1(c), ph2(c) - every unit is overwritten >= 2 phases (>= 3 barriers)
+// after its last read, and travels 7 phases (1.75 k-tiles; UW0: 8) between issue and first read - the quadrant loop gave A 1.5 and W 2 k-tiles.
+// Counted waits (a wave's loads retire in order, the issue order is the order of first use; placed as above: group 1 at the end of its memory part, group 0
+// at the end of its compute part, before the barrier in front of the first read):  end of ph0: UA1(c) | end of ph2: UW0, UA0 (c+1) | end of ph3: UW1(c+1),
+// each with 6 younger units in flight = vmcnt(12) in the steady state; the last three tiles are peeled (e1 / e2 / e3 = tile c+1 / c+2 / c+3 exists).
+#ifndef PP_KSPLIT
+#define PP_KSPLIT 1
+#endif
+// LDS-DMA as inline asm in the SGPR-base + 32-bit-VGPR-offset form: the builtin makes the compiler (a) rebuild a 64-bit VGPR address per load (v_lshl_add_u64) and
+// (b) treat every later wait as "flat pending" - each s_waitcnt it inserts for a ds_read result becomes lgkmcnt(0), which here would wait for the reads of the NEXT
+// compute part as well.  The compiler knows nothing about these loads: the counted vmcnt waits and the barriers below are the only ordering.
+__device__ __forceinline__ void glds16_sv(const char* sbase, unsigned voff, char* lds_dst) {
+    const unsigned l = (unsigned)(uintptr_t)(lptr_t)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(l) : "memory");   // (M0 is reserved, never allocated: nothing else in a kernel that runs this loop uses it)
+}
+template <int KIND>   // 0 = UA0, 1 = UA1, 2 = UW0, 3 = UW1 of k-tile kt (absolute) into the 16 KiB unit at dst0
+__device__ __forceinline__ void issue_ks(const PpSrc& s, int kt, char* dst0, int wave) {
+    char* dst = dst0 + wave * 2048;
+    const char* ab = s.A + (int64_t)kt * (PBK * 2);
+    const char* wb = s.W + (int64_t)kt * (PBK * 32);
+    if constexpr (KIND == 0) {
+        glds16_sv(ab, s.a0[0], dst);
+        glds16_sv(ab, s.a0[1], dst + 1024);
+    } else if constexpr (KIND == 1) {
+        glds16_sv(ab, s.a1[0], dst);
+        glds16_sv(ab, s.a1[1], dst + 1024);
+    } else {   // piece wave * 2 + i = fragment (wave & 1) + 2 i of wave column wave >> 1, k32 half KIND - 2
+        glds16_sv(wb, s.w0[KIND - 2], dst);
+        glds16_sv(wb, s.w1[KIND - 2], dst + 1024);
+    }
+}
+template <int DUMMY = 0>
+__device__ __forceinline__ void pp_mainloop_ks(f32x4 (&acc)[4][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1) {
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, kg = lane >> 4;
+    const int a_rd = (wr * 64 + fr) * 128;                    // A fragment f (rows wr * 64 + f * 16 + fr) of a unit: + f * 2048 + chunk
+    const int a_c0 = ((kg ^ (fr & 7)) << 4), a_c1 = (((4 + kg) ^ (fr & 7)) << 4);
+    const int w_rd = wc * 4096 + lane * 16;                   // W fragment j of this wave column: piece (wc * 2 + (j & 1)) * 2 + (j >> 1)
+    auto slot = [&](int ib, int k) { const int x = ib + k; return smem + (x >= 10 ? x - 10 : x) * UNIT; };
+    op16x8 A0[4], A1[4], W0[4], W1[4];
+    [[maybe_unused]] uint32_t st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] uint64_t st_prev = 0;
+#if PP_ABL & 32
+#define PP_STAMP(i) { const uint64_t t_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(t_ - st_prev); st_prev = t_; }
+#else
+#define PP_STAMP(i)
+#endif
+#define KS_READ_A(DST, BASE, CH)                                                                            \
+    if constexpr (!(PP_ABL & 2)) _Pragma("unroll") for (int f = 0; f < 4; ++f) DST[f] = *(const op16x8*)((BASE) + a_rd + f * 2048 + (CH));
+#define KS_READ_W(DST, BASE)                                                                                \
+    if constexpr (!(PP_ABL & 2)) _Pragma("unroll") for (int j = 0; j < 4; ++j) DST[j] = *(const op16x8*)((BASE) + w_rd + (j & 1) * 2048 + (j >> 1) * 1024);
+#define KS_MFMA(WB, AB, MI0)                                                                                \
+    if constexpr (!(PP_ABL & 8)) _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
+        acc[j][(MI0) + f] = rv_mfma16(WB[j], AB[f], acc[j][(MI0) + f]);
+#define KS_SYNC_M(WAITN)                                   \
+    if constexpr (grp == 1) { WAITN; }                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if constexpr (!(PP_ABL & 4)) __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_sched_barrier(0);
+#define KS_SYNC_C(WAITN)                                   \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if constexpr (grp == 0) { WAITN; }                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if constexpr (!(PP_ABL & 4)) __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PP_ABL & 2) {   // (the probe computes on whatever these hold)
+        asm volatile("" : "=v"(A0[0]), "=v"(A0[1]), "=v"(A0[2]), "=v"(A0[3]), "=v"(A1[0]), "=v"(A1[1]), "=v"(A1[2]), "=v"(A1[3]));
+        asm volatile("" : "=v"(W0[0]), "=v"(W0[1]), "=v"(W0[2]), "=v"(W0[3]), "=v"(W1[0]), "=v"(W1[1]), "=v"(W1[2]), "=v"(W1[3]));
+    }
+
+#if PP_ABL & 32
+    const uint64_t t_in = __builtin_readcyclecounter();
+#endif
+    // prologue: what tiles -3 .. -1 of the steady state would have issued, in its order (slots 1 .. 9), then what the memory part of phase 3 of tile -1 does
+    issue_ks<2>(src, kt0, smem + 1 * UNIT, wave);
+    issue_ks<0>(src, kt0, smem + 2 * UNIT, wave);
+    issue_ks<3>(src, kt0, smem + 3 * UNIT, wave);
+    issue_ks<1>(src, kt0, smem + 4 * UNIT, wave);
+    if (nks > 1) {
+        issue_ks<2>(src, kt0 + 1, smem + 5 * UNIT, wave);
+        issue_ks<0>(src, kt0 + 1, smem + 6 * UNIT, wave);
+        issue_ks<3>(src, kt0 + 1, smem + 7 * UNIT, wave);
+        issue_ks<1>(src, kt0 + 1, smem + 8 * UNIT, wave);
+        if (nks > 2) issue_ks<2>(src, kt0 + 2, smem + 9 * UNIT, wave);
+    }
+    if (nks > 2) wait_vm<14>();                  // UW0(0), UA0(0) landed
+    else if (nks > 1) wait_vm<12>();
+    else wait_vm<4>();
+    __builtin_amdgcn_s_barrier();
+    KS_READ_A(A0, smem + 2 * UNIT, a_c0)
+    KS_READ_W(W0, smem + 1 * UNIT)
+    if (nks > 2) wait_vm<12>();                  // UW1(0)
+    else if (nks > 1) wait_vm<10>();
+    else wait_vm<2>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
+
+    auto tile = [&](auto e1_c, auto e2_c, auto e3_c, auto group_c, int c, int ib) {   // ib = 4 c mod 10: the ring slot phase 0 of this tile issues into
+        constexpr bool e1 = decltype(e1_c)::value, e2 = decltype(e2_c)::value, e3 = decltype(e3_c)::value;
+        constexpr int grp = decltype(group_c)::value;
+        const int kt = kt0 + c;
+        // ---- phase 0: (m0, k0) on A0 W0; reads (m0, k1) ----
+        KS_READ_A(A1, slot(ib, 2), a_c1)
+        KS_READ_W(W1, slot(ib, 3))
+        if constexpr (e2 && !(PP_ABL & 1)) issue_ks<0>(src, kt + 2, slot(ib, 0), wave);
+        KS_SYNC_M(wait_vm<e2 ? 12 : e1 ? 8 : 0>())          // UA1 of this tile
+        PP_STAMP(0)
+        KS_MFMA(W0, A0, 0)
+        KS_SYNC_C(wait_vm<e2 ? 12 : e1 ? 8 : 0>())
+        PP_STAMP(1)
+        // ---- phase 1: (m0, k1) on A1 W1; reads (m1, k0) ----
+        KS_READ_A(A0, slot(ib, 4), a_c0)
+        if constexpr (e2 && !(PP_ABL & 1)) issue_ks<3>(src, kt + 2, slot(ib, 1), wave);
+        KS_SYNC_M((void)0)
+        PP_STAMP(2)
+        KS_MFMA(W1, A1, 0)
+        KS_SYNC_C((void)0)
+        PP_STAMP(3)
+        // ---- phase 2: (m1, k0) on A0 W0; reads (m1, k1) ----
+        KS_READ_A(A1, slot(ib, 4), a_c1)
+        if constexpr (e2 && !(PP_ABL & 1)) issue_ks<1>(src, kt + 2, slot(ib, 2), wave);
+        KS_SYNC_M(if constexpr (e1) wait_vm<e2 ? 12 : 4>())  // UW0, UA0 of the next tile
+        PP_STAMP(4)
+        KS_MFMA(W0, A0, 4)
+        KS_SYNC_C(if constexpr (e1) wait_vm<e2 ? 12 : 4>())
+        PP_STAMP(5)
+        // ---- phase 3: (m1, k1) on A1 W1; reads (m0, k0) of the next tile ----
+        if constexpr (e1) {
+            KS_READ_A(A0, slot(ib, 6), a_c0)
+            KS_READ_W(W0, slot(ib, 5))
+        }
+        if constexpr (e3 && !(PP_ABL & 1)) issue_ks<2>(src, kt + 3, slot(ib, 3), wave);
+        KS_SYNC_M(if constexpr (e1) wait_vm<e3 ? 12 : e2 ? 10 : 2>())   // UW1 of the next tile
+        PP_STAMP(6)
+        KS_MFMA(W1, A1, 4)
+        KS_SYNC_C(if constexpr (e1) wait_vm<e3 ? 12 : e2 ? 10 : 2>())
+        PP_STAMP(7)
+    };
+    auto run = [&](auto group_c) {
+        int c = 0, ib = 0;
+        auto next = [&]() { ++c; ib = ib >= 6 ? ib - 6 : ib + 4; };
+        while (c + 3 < nks) { tile(std::true_type{}, std::true_type{}, std::true_type{}, group_c, c, ib); next(); }
+        if (c + 2 < nks) { tile(std::true_type{}, std::true_type{}, std::false_type{}, group_c, c, ib); next(); }
+        if (c + 1 < nks) { tile(std::true_type{}, std::false_type{}, std::false_type{}, group_c, c, ib); next(); }
+        tile(std::false_type{}, std::false_type{}, std::false_type{}, group_c, c, ib);
+    };
+#if PP_ABL & 32
+    st_prev = __builtin_readcyclecounter();
+    const uint64_t t_pro = st_prev;
+#endif
+    if (wr == 1) __builtin_amdgcn_s_setprio(1);   // (PP_PRIO_MODE 1 of the quadrant loop: static priority for the second-dispatched half)
+    if (wr == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    if (wr == 1) __builtin_amdgcn_s_setprio(0);
+#if PP_ABL & 32
+    if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&pp_stamp_buf[(blockIdx.x * 2 + wr) * 9 + i], (unsigned long long)st_sum[i]);
+        atomicAdd(&pp_stamp_buf[(blockIdx.x * 2 + wr) * 9 + 8], (unsigned long long)nks);
+        if (wr == 0) {
+            atomicAdd(&pp_stamp_ext[(kind * 256 + blockIdx.x) * 4 + 0], (unsigned long long)(t_pro - t_in));
+        }
+    }
+#endif
+#undef KS_READ_A
+#undef KS_READ_W
+#undef KS_MFMA
+#undef KS_SYNC_M
+#undef KS_SYNC_C
+#undef PP_STAMP
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+}
+
+template <int NF, int F8 = 0, int KS = 1>
+__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1) {
+    if constexpr (NF == 4 && !F8 && KS && PP_KSPLIT) {   // the k-split loop (above): same operands, same LDS budget, same results
+        pp_mainloop_ks(acc, src, kt0, nks, smem, wave, lane, kind);
+        return;
+    } else {
     constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant = loads per wave of unit U2
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kg = lane >> 4;
@@ -204,6 +407,17 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
 
     op16x8 af[4][2], b0[2][2], b1[2][2];
+    [[maybe_unused]] uint32_t st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] uint64_t st_prev = 0;
+#if PP_ABL & 32
+#define PP_STAMP(i) { const uint64_t t_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(t_ - st_prev); st_prev = t_; }
+#else
+#define PP_STAMP(i)
+#endif
+    if constexpr (PP_ABL & 2) {   // (the probe computes on whatever these hold)
+        asm volatile("" : "=v"(af[0][0]), "=v"(af[0][1]), "=v"(af[1][0]), "=v"(af[1][1]), "=v"(af[2][0]), "=v"(af[2][1]), "=v"(af[3][0]), "=v"(af[3][1]));
+        asm volatile("" : "=v"(b0[0][0]), "=v"(b0[0][1]), "=v"(b0[1][0]), "=v"(b0[1][1]), "=v"(b1[0][0]), "=v"(b1[0][1]), "=v"(b1[1][0]), "=v"(b1[1][1]));
+    }
     // One k-tile.  m1 / m2 (tile c+1 / c+2 exists: their units are issued here) and the wave's M-group are compile-time
     // constants: the steady-state loop carries no branches - the last two tiles are peeled, the two groups run separate copies.
     auto tile = [&](auto m1_c, auto m2_c, auto group_c, int c, int ws) {   // ws = c % 3
@@ -231,7 +445,7 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         }                                                                                                           \
     } while (0)
 #define PP_MFMA(B, NI, MI0, NJ, MID_ISSUE)                                                                          \
-    do {                                                                                                            \
+    if constexpr (!(PP_ABL & 8)) do {                                                                               \
         if constexpr (PP_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);                                             \
         PP_MFMA_PART(B, NI, MI0, NJ, 0);                                                                            \
         if constexpr (PP_ISSUE_MID) {                                                                               \
@@ -243,24 +457,24 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         if constexpr (PP_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);                                             \
     } while (0)
 #define PP_READ_A(BASE)                                                                                             \
-    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                 \
+    if constexpr (!(PP_ABL & 2)) _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                 \
         af[f][0] = *(const op16x8*)((BASE) + a_rd + f * 2048 + a_c0);                                               \
         af[f][1] = *(const op16x8*)((BASE) + a_rd + f * 2048 + a_c1);                                               \
     }
 #define PP_READ_W(B, BASE, RD, NJ)                                                                                  \
-    _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                \
+    if constexpr (!(PP_ABL & 2)) _Pragma("unroll") for (int j = 0; j < (NJ); ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                \
         B[j][ks] = *(const op16x8*)((BASE) + (RD) + j * 2048 + ks * 1024);
         // The memory part of a phase ends at its first barrier, the compute part at its second.  Group 1 waits for its
         // loads at the end of its memory part, group 0 at the end of its compute part: the same slot.
 #define PP_SYNC_M(WAITN)                                   \
     if constexpr (grp == 1) { WAITN; }                     \
     __builtin_amdgcn_sched_barrier(0);                     \
-    __builtin_amdgcn_s_barrier();                          \
+    if constexpr (!(PP_ABL & 4)) __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
 #define PP_SYNC_C(WAITN)                                   \
     if constexpr (grp == 0) { WAITN; }                     \
     __builtin_amdgcn_sched_barrier(0);                     \
-    __builtin_amdgcn_s_barrier();                          \
+    if constexpr (!(PP_ABL & 4)) __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
 
         // PP_ISSUE_MID = 1: the unit of a phase is issued in the MIDDLE of its compute part (between the two halves of its MFMAs, which run on
@@ -270,27 +484,35 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
         // ---- phase 0: quadrant (m0, n0) ----
         PP_READ_W(b0, wcur, w_rd, 2)
         PP_READ_A(acur)
-        if constexpr (!MID && m1) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
+        if constexpr (!MID && m1 && !(PP_ABL & 1)) issue_unit<3, NF>(src, k1, anxt + UNIT, wave);
         PP_SYNC_M(wait_vm<m1 ? 8 + NJ1 - 2 * MID : 2>())          // U2 of this tile
+        PP_STAMP(0)
         PP_MFMA(b0, 0, 0, 2, if constexpr (m1) issue_unit<3 _PP_C NF>(src, k1, anxt + UNIT, wave));
         PP_SYNC_C(wait_vm<m1 ? 8 + NJ1 : 2>())
+        PP_STAMP(1)
         // ---- phase 1: quadrant (m0, n1) ----
         PP_READ_W(b1, wcur + UNIT, w_rd1, NJ1)
-        if constexpr (!MID && m2) issue_unit<1, NF>(src, k2, wnn, wave);
+        if constexpr (!MID && m2 && !(PP_ABL & 1)) issue_unit<1, NF>(src, k2, wnn, wave);
         PP_SYNC_M(wait_vm<m2 ? 8 + NJ1 - 2 * MID : m1 ? 6 + NJ1 : 0>())     // U3 of this tile
+        PP_STAMP(2)
         PP_MFMA(b1, 2, 0, NJ1, if constexpr (m2) issue_unit<1 _PP_C NF>(src, k2, wnn, wave));
         PP_SYNC_C(wait_vm<m2 ? 8 + NJ1 : m1 ? 6 + NJ1 : 0>())
+        PP_STAMP(3)
         // ---- phase 2: quadrant (m1, n1) ----
         PP_READ_A(acur + UNIT)
-        if constexpr (!MID && m2) issue_unit<0, NF>(src, k2, acur, wave);   // U0(c+2) into the slot U0(c) left in phase 0
+        if constexpr (!MID && m2 && !(PP_ABL & 1)) issue_unit<0, NF>(src, k2, acur, wave);   // U0(c+2) into the slot U0(c) left in phase 0
         PP_SYNC_M((void)0)
+        PP_STAMP(4)
         PP_MFMA(b1, 2, 4, NJ1, if constexpr (m2) issue_unit<0 _PP_C NF>(src, k2, acur, wave));
         PP_SYNC_C((void)0)
+        PP_STAMP(5)
         // ---- phase 3: quadrant (m1, n0) ----
-        if constexpr (!MID && m2) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
+        if constexpr (!MID && m2 && !(PP_ABL & 1)) issue_unit<2, NF>(src, k2, wnn + UNIT, wave);
         PP_SYNC_M(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 - NJ1 * MID : 2 + NJ1>())  // U0 (and the older U1) of the next tile
+        PP_STAMP(6)
         PP_MFMA(b0, 0, 4, 2, if constexpr (m2) issue_unit<2 _PP_C NF>(src, k2, wnn + UNIT, wave));
         PP_SYNC_C(if constexpr (m1) wait_vm<m2 ? 6 + 2 * NJ1 : 2 + NJ1>())
+        PP_STAMP(7)
     };
     auto run = [&](auto group_c) {
         int c = 0, ws = 0;
@@ -310,8 +532,17 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
     // Measured at 4020 rows, alternating builds on one box: gate/up 610.3 / 611.4 (mode 0) vs 606.8 / 605.5 (1) vs 606.8 (2) us,
     // o / down 218.1 / 218.6 vs 217.2 / 216.2, QKV 380.1 / 380.8 vs 380.4 / 378.5: priorities are worth half a percent at most.
     if constexpr (PP_PRIO_MODE == 1) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
+#if PP_ABL & 32
+    st_prev = __builtin_readcyclecounter();
+#endif
     if (wr == 0) run(std::integral_constant<int, 0>{});   // the two groups run separate copies of the loop
     else run(std::integral_constant<int, 1>{});
+#if PP_ABL & 32
+    if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&pp_stamp_buf[(blockIdx.x * 2 + wr) * 9 + i], (unsigned long long)st_sum[i]);
+        atomicAdd(&pp_stamp_buf[(blockIdx.x * 2 + wr) * 9 + 8], (unsigned long long)nks);
+    }
+#endif
     if constexpr (PP_PRIO_MODE == 1) { if (wr == 1) __builtin_amdgcn_s_setprio(0); }
 #undef PP_MFMA
 #undef PP_MFMA_PART
@@ -319,7 +550,9 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& sr
 #undef PP_READ_W
 #undef PP_SYNC_M
 #undef PP_SYNC_C
+#undef PP_STAMP
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+    }
 }
 
 // ---- the FOUR-wave form of the 256 x 256 x 64 tile (bf16 operands, 256-column panels) --------------------------------------------
@@ -940,6 +1173,9 @@ __device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t
         for (int i = 0; i < NFW; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if PP_ABL & 32
+        const uint64_t t_ml = __builtin_readcyclecounter();
+#endif
         if constexpr (W4) {
             Pp4Src src;
             pp4_sources(src, A, lda, Wp, M, K, m0, n0, wave, lane);
@@ -947,15 +1183,25 @@ __device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t
         } else {
             PpSrc src;
             pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
-            pp_mainloop<NF, F8>(acc, src, ks0, nks, smem, wave, lane);
+            pp_mainloop<NF, F8, (PP_KSPLIT & (ROPE ? 2 : 1)) != 0>(acc, src, ks0, nks, smem, wave, lane, ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1);
         }
+#if PP_ABL & 32
+        if (tid == 0 && blockIdx.x < 256) atomicAdd(&pp_stamp_ext[((ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1) * 256 + blockIdx.x) * 4 + 1], (unsigned long long)(__builtin_readcyclecounter() - t_ml));
+#endif
 
+#if PP_ABL & 32
+        const uint64_t t_ep = __builtin_readcyclecounter();
+#define PP_EP_STAMP if (tid == 0 && blockIdx.x < 256) { atomicAdd(&pp_stamp_ext[((ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1) * 256 + blockIdx.x) * 4 + 2], (unsigned long long)(__builtin_readcyclecounter() - t_ep)); atomicAdd(&pp_stamp_ext[((ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1) * 256 + blockIdx.x) * 4 + 3], 1ull); }
+#else
+#define PP_EP_STAMP
+#endif
         if (ks0 == 0 && nks == nk) {   // whole panel: finish it from the registers
             if constexpr (W4) pp4_epilogue<OUT_BF16, ACT, ROPE>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr);
             else if constexpr (ROPE == 2 && NF == 4) {      // the LDS-staged form (a kernel of its own: with both forms in one kernel the accumulators spilled, 361 -> 393 us);
                 pp_epilogue_rope_lds<F8>(acc, M, m0, n0, wave, lane, qr, sc, smem);      // every wave leaves the LDS before the next main loop stages into it
                 __syncthreads();
             } else pp_epilogue<OUT_BF16, ACT, ROPE, NF, F8>(acc, bias, res, ldr, Cv, ldc, M, m0, n0, wave, lane, qr, sc);
+            PP_EP_STAMP
             continue;
         }
         if constexpr (NF == 4) {   // (192-column panels are launched without a stream-K tail: whole panels only)
@@ -1314,3 +1560,16 @@ int gemm_pp_fp8(const void* A8, int64_t lda, const float* sa, const void* W8p, c
     RV_CHECK_LAUNCH("gemm_pp_fp8");
     return RV_OK;
 }
+
+#if PP_ABL & 32
+extern "C" __attribute__((visibility("default"))) int rv_pp_stamps(unsigned long long* host_out, int reset) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp_stamp_buf), sizeof(pp_stamp_buf)) != hipSuccess) return -1;
+    if (host_out && hipMemcpyFromSymbol(host_out + 256 * 2 * 9, HIP_SYMBOL(pp_stamp_ext), sizeof(pp_stamp_ext)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[256 * 2 * 9];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pp_stamp_buf), zeros, sizeof(zeros)) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pp_stamp_ext), zeros, sizeof(pp_stamp_ext)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

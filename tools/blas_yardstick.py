@@ -19,6 +19,26 @@ if len(sys.argv) > 1 and OPT is not None:
 shapes = [(4020, 22016, 4096), (4020, 4096, 4096), (4020, 4096, 11008), (4020, 12288, 4096), (2010, 22016, 4096), (4096, 4096, 4096), (8192, 8192, 8192)]
 if os.environ.get("ROWS"):                       # ROWS=8040: the four projection shapes of a pass of that many rows only
     shapes = [(int(os.environ["ROWS"]), n, k) for n, k in ((22016, 4096), (4096, 4096), (4096, 11008), (12288, 4096))]
+if os.environ.get("KSWEEP"):                     # KSWEEP=1: N = 4096 at growing K - a line fit separates the per-k-tile time from the per-tile fixed cost
+    shapes = [(int(os.environ.get("ROWS", 8040)), 4096, k) for k in (512, 1024, 2048, 4096, 8192, 16384)]
+
+
+def clocks_of(fn, seconds=1.5):
+    """CLOCKS=1: mean shader clock / socket power over `seconds` of back-to-back launches (bench.ClockSampler: sysfs, no GPU call)."""
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import ClockSampler
+    for _ in range(200):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with ClockSampler(dev, period=0.02) as cs:
+        while time.time() - t0 < seconds:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+    s = cs.summary()
+    return f"[{s['sclk_mhz_mean']:.0f} MHz {s['power_w_mean']:.0f} W]" if s.get("available") else "[clocks n/a]"
 
 
 def timeit(fn, n=20, warm=5, min_ms=300.0):
@@ -58,6 +78,8 @@ for M, N, K in shapes:
     t_blas = timeit(blas)
     wps = [ops.pack_fragments(w) for w in ws]
     line = f"M={M:5d} N={N:5d} K={K:5d}  torch.matmul {t_blas * 1e3:7.1f} us  {2.0 * M * N * K / t_blas / 1e9:7.1f} TF/s"
+    if os.environ.get("CLOCKS"):
+        line += " " + clocks_of(blas)
     if wps is not None:
         out = torch.empty(M, N, dtype=DT, device=dev)
 
@@ -67,6 +89,8 @@ for M, N, K in shapes:
         try:
             t = timeit(mine)
             line += f"   rv_gemm {t * 1e3:7.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TF/s"
+            if os.environ.get("CLOCKS"):
+                line += " " + clocks_of(mine)
         except Exception as e:  # noqa: BLE001
             line += f"   rv_gemm failed: {e}"
     print(line, flush=True)
