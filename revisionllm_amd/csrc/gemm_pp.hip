@@ -208,7 +208,12 @@ __device__ __forceinline__ pp_i32x8 pp_cat(op16x8 lo, op16x8 hi) {
 // at the end of its compute part, before the barrier in front of the first read):  end of ph0: UA1(c) | end of ph2: UW0, UA0 (c+1) | end of ph3: UW1(c+1),
 // each with 6 younger units in flight = vmcnt(12) in the steady state; the last three tiles are peeled (e1 / e2 / e3 = tile c+1 / c+2 / c+3 exists).
 #ifndef PP_KSPLIT
-#define PP_KSPLIT 1
+#define PP_KSPLIT 1      // bit 0: the kernels without a q / k / v epilogue run this loop, bit 1: those too (measured slower inside a pass: 642 -> 672 us)
+#endif
+#ifndef PP_EARLY
+#define PP_EARLY 0       // 1 (probe): the next work item's first loads are issued before the current item's whole-panel epilogue (pp_sk_body) - measured SLOWER
+                         // inside a pass of 8040 rows (gate/up 1069 -> 1098 us, o / down 395 -> 430): a wave's vmcnt retires in order, so the epilogue's stores queue
+                         // behind the cold loads and the loop's first counted wait then waits for ALL nine units and the stores
 #endif
 // LDS-DMA as inline asm in the SGPR-base + 32-bit-VGPR-offset form: the builtin makes the compiler (a) rebuild a 64-bit VGPR address per load (v_lshl_add_u64) and
 // (b) treat every later wait as "flat pending" - each s_waitcnt it inserts for a ds_read result becomes lgkmcnt(0), which here would wait for the reads of the NEXT
@@ -233,8 +238,27 @@ __device__ __forceinline__ void issue_ks(const PpSrc& s, int kt, char* dst0, int
         glds16_sv(wb, s.w1[KIND - 2], dst + 1024);
     }
 }
+// The first nine units of a work item in the steady state's order (ring slots 1 .. 9): 18 loads per wave (fewer for items of one or two k-tiles).  A caller may
+// issue them BEFORE the previous item's epilogue (PP_EARLY, a probe: nothing reads the LDS then; any wave is past the loop's last barrier) to run the panel's cold
+// start - every workgroup of the chip asking HBM for new weights at the same moment, 5 - 8 thousand cycles per item on the stamps - under the epilogue's stores.
+// The counted waits stay valid with the epilogue's younger loads / stores in flight (a younger operation only makes vmcnt(n) wait longer) - which is also why it
+// does not pay: see PP_EARLY.
+__device__ __forceinline__ void ks_issue_prologue(const PpSrc& src, int kt0, int nks, char* smem, int wave) {
+    issue_ks<2>(src, kt0, smem + 1 * UNIT, wave);
+    issue_ks<0>(src, kt0, smem + 2 * UNIT, wave);
+    issue_ks<3>(src, kt0, smem + 3 * UNIT, wave);
+    issue_ks<1>(src, kt0, smem + 4 * UNIT, wave);
+    if (nks > 1) {
+        issue_ks<2>(src, kt0 + 1, smem + 5 * UNIT, wave);
+        issue_ks<0>(src, kt0 + 1, smem + 6 * UNIT, wave);
+        issue_ks<3>(src, kt0 + 1, smem + 7 * UNIT, wave);
+        issue_ks<1>(src, kt0 + 1, smem + 8 * UNIT, wave);
+        if (nks > 2) issue_ks<2>(src, kt0 + 2, smem + 9 * UNIT, wave);
+    }
+}
 template <int DUMMY = 0>
-__device__ __forceinline__ void pp_mainloop_ks(f32x4 (&acc)[4][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1) {
+__device__ __forceinline__ void pp_mainloop_ks(f32x4 (&acc)[4][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1,
+                                               bool pre = false) {
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kg = lane >> 4;
     const int a_rd = (wr * 64 + fr) * 128;                    // A fragment f (rows wr * 64 + f * 16 + fr) of a unit: + f * 2048 + chunk
@@ -275,18 +299,9 @@ __device__ __forceinline__ void pp_mainloop_ks(f32x4 (&acc)[4][8], const PpSrc& 
 #if PP_ABL & 32
     const uint64_t t_in = __builtin_readcyclecounter();
 #endif
-    // prologue: what tiles -3 .. -1 of the steady state would have issued, in its order (slots 1 .. 9), then what the memory part of phase 3 of tile -1 does
-    issue_ks<2>(src, kt0, smem + 1 * UNIT, wave);
-    issue_ks<0>(src, kt0, smem + 2 * UNIT, wave);
-    issue_ks<3>(src, kt0, smem + 3 * UNIT, wave);
-    issue_ks<1>(src, kt0, smem + 4 * UNIT, wave);
-    if (nks > 1) {
-        issue_ks<2>(src, kt0 + 1, smem + 5 * UNIT, wave);
-        issue_ks<0>(src, kt0 + 1, smem + 6 * UNIT, wave);
-        issue_ks<3>(src, kt0 + 1, smem + 7 * UNIT, wave);
-        issue_ks<1>(src, kt0 + 1, smem + 8 * UNIT, wave);
-        if (nks > 2) issue_ks<2>(src, kt0 + 2, smem + 9 * UNIT, wave);
-    }
+    // prologue: what tiles -3 .. -1 of the steady state would have issued (ks_issue_prologue; `pre`: the caller issued it already, under the previous work
+    // item's epilogue), then what the memory part of phase 3 of tile -1 does
+    if (!pre) ks_issue_prologue(src, kt0, nks, smem, wave);
     if (nks > 2) wait_vm<14>();                  // UW0(0), UA0(0) landed
     else if (nks > 1) wait_vm<12>();
     else wait_vm<4>();
@@ -375,9 +390,10 @@ __device__ __forceinline__ void pp_mainloop_ks(f32x4 (&acc)[4][8], const PpSrc& 
 }
 
 template <int NF, int F8 = 0, int KS = 1>
-__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1) {
+__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[NF][8], const PpSrc& src, int kt0, int nks, char* smem, int wave, int lane, [[maybe_unused]] int kind = 1,
+                                            [[maybe_unused]] bool pre = false) {
     if constexpr (NF == 4 && !F8 && KS && PP_KSPLIT) {   // the k-split loop (above): same operands, same LDS budget, same results
-        pp_mainloop_ks(acc, src, kt0, nks, smem, wave, lane, kind);
+        pp_mainloop_ks(acc, src, kt0, nks, smem, wave, lane, kind, pre);
         return;
     } else {
     constexpr int NJ1 = NF - 2;      // fragments of the n1 quadrant = loads per wave of unit U2
@@ -1144,28 +1160,48 @@ __device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t
     // Work list: first this team's range of the stream-K unit space (the last `panels % T` panels, cut evenly: always
     // partial pieces), then its whole panels (panel r * T + team) - the pieces are published long before they are needed.
     const int whole_rounds = dp_panels / T;
-    for (int u = u_begin, r = 0;;) {
-        int panel, ks0, nks, sk_panel = -1;
-        if (u < u_end) {
-            sk_panel = u / nk;
-            ks0 = u - sk_panel * nk;
-            nks = min(nk - ks0, u_end - u);
-            panel = dp_panels + sk_panel;
-            u += nks;
-        } else if (r < whole_rounds) {
-            panel = r * T + team;
-            ks0 = 0;
-            nks = nk;
-            ++r;
-        } else {
-            break;
+    // (round 6) the loop looks one work item ahead: the k-split main loop's first loads of item i + 1 are issued before the whole-panel epilogue of item i
+    struct Item {
+        int panel, ks0, nks, sk_panel, n0, m0;
+        bool ok;
+    };
+    int u_ = u_begin, r_ = 0;
+    auto next_item = [&]() {
+        Item it{0, 0, 0, -1, 0, 0, false};
+        for (;;) {
+            it.sk_panel = -1;
+            if (u_ < u_end) {
+                it.sk_panel = u_ / nk;
+                it.ks0 = u_ - it.sk_panel * nk;
+                it.nks = min(nk - it.ks0, u_end - u_);
+                it.panel = dp_panels + it.sk_panel;
+                u_ += it.nks;
+            } else if (r_ < whole_rounds) {
+                it.panel = r_ * T + team;
+                it.ks0 = 0;
+                it.nks = nk;
+                ++r_;
+            } else {
+                return it;
+            }
+            const int tpanel = unit_panel(it.panel);     // this workgroup's panel of the group
+            if (tpanel >= tiles_n) continue;
+            it.n0 = tpanel * (NF * 64);
+            it.m0 = unit_m0(it.panel);
+            it.ok = true;
+            return it;
         }
-        const int tpanel = unit_panel(panel);     // this workgroup's panel of the group
-        if (tpanel >= tiles_n) continue;
-        const int n0 = tpanel * (NF * 64);
+    };
+    constexpr bool KS_LOOP = !W4 && NF == 4 && !F8 && (PP_KSPLIT & (ROPE ? 2 : 1)) != 0;
+    constexpr bool EARLY = KS_LOOP && ROPE != 2 && PP_EARLY;   // (the LDS-staged q / k / v epilogue needs the LDS itself)
+    [[maybe_unused]] PpSrc src_pre;
+    [[maybe_unused]] bool pre = false;
+    for (Item it = next_item(); it.ok;) {
+        [[maybe_unused]] const int panel = it.panel;
+        const int ks0 = it.ks0, nks = it.nks, sk_panel = it.sk_panel, n0 = it.n0;
         // launder m0 so that the row-dependent address math of the epilogue is not hoisted out of this loop (it would stay live across
         // the main loop and push the accumulators into scratch)
-        int m0 = unit_m0(panel);
+        int m0 = it.m0;
         asm volatile("" : "+s"(m0));
         constexpr int NFW = W4 ? 8 : NF;   // fragments per wave along N
         f32x4 acc[NFW][8];
@@ -1182,8 +1218,18 @@ __device__ __forceinline__ void pp_sk_body(const op16_t* __restrict__ A, int64_t
             pp4_mainloop(acc, src, ks0, nks, smem, wave, lane);
         } else {
             PpSrc src;
-            pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
-            pp_mainloop<NF, F8, (PP_KSPLIT & (ROPE ? 2 : 1)) != 0>(acc, src, ks0, nks, smem, wave, lane, ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1);
+            if (EARLY && pre) src = src_pre;
+            else pp_sources<NF>(src, A, lda, Wp, M, K, m0, n0, wave, lane);
+            pp_mainloop<NF, F8, (PP_KSPLIT & (ROPE ? 2 : 1)) != 0>(acc, src, ks0, nks, smem, wave, lane, ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1, EARLY && pre);
+        }
+        it = next_item();
+        pre = false;
+        if constexpr (EARLY) {
+            if (ks0 == 0 && nks == nk && it.ok) {   // the next item's first loads travel under this item's epilogue
+                pp_sources<NF>(src_pre, A, lda, Wp, M, K, it.m0, it.n0, wave, lane);
+                ks_issue_prologue(src_pre, it.ks0, it.nks, smem, wave);
+                pre = true;
+            }
         }
 #if PP_ABL & 32
         if (tid == 0 && blockIdx.x < 256) atomicAdd(&pp_stamp_ext[((ROPE ? 2 : ACT == RV_ACT_SILU_MUL ? 0 : 1) * 256 + blockIdx.x) * 4 + 1], (unsigned long long)(__builtin_readcyclecounter() - t_ml));
