@@ -104,6 +104,56 @@ def test_gemm(dev, M, N, K, out):
                 assert rel_err(ys.float().cpu(), torch.relu(ref0 + bias.double()) + res.double()) < tol_
 
 
+def _stream_k_piece_lengths(M, N, K, cus, mhalf=2):
+    """Host mirror of launch_sk's work division (csrc/gemm_pp.hip): the set of k-tile counts of the stream-K pieces of a launch on ``cus`` CUs."""
+    cdiv = lambda a, b: -(-a // b)      # noqa: E731
+    tiles_m, tiles_n, nk, per_x = cdiv(M, 256), N // 256, K // 64, (cus & ~7) >> 3
+    pg = per_x // tiles_m if (tiles_m >= 8 and per_x // tiles_m >= 2) else 1
+    tm, mhs = tiles_m, 0
+    if mhalf and tiles_m >= 10 and tiles_m % 2 == 0 and tiles_m <= per_x:
+        tm2, pg2 = tiles_m // 2, per_x // (tiles_m // 2)
+        if tm2 * pg2 > tiles_m * pg or (tm2 * pg2 == tiles_m * pg and tm2 + pg2 < tiles_m + pg):
+            tm, pg, mhs = tm2, pg2, 1
+        if mhs == 1 and mhalf >= 2 and tm >= 16 and tm % 2 == 0 and (tm // 2) * (per_x // (tm // 2)) >= tm * pg:
+            tm, pg, mhs = tm // 2, per_x // (tm // 2), 2
+    ts = tm * pg
+    teams = 8 * (per_x // ts) if (pg > 1 or mhs) else (8 * (per_x // tiles_m) if tiles_m <= per_x else 0)
+    groups = cdiv(tiles_n, pg) << mhs
+    total = (groups - groups // teams * teams) * nk
+    out = set()
+    for t in range(teams):
+        u, e = t * total // teams, (t + 1) * total // teams
+        while u < e:
+            n = min(nk - u % nk, e - u)
+            out.add(n)
+            u += n
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,cus,short", [(1005, 22016, 2048, 256, {1, 2, 3}), (1005, 22016, 4096, 248, {2, 3}), (1005, 22016, 4096, 176, {3}),
+                                             (1190, 22016, 4096, 216, {3}), (1005, 2560, 4096, 256, {2})])
+def test_stream_k_pieces_of_one_two_and_three_k_tiles(dev, M, N, K, cus, short):
+    """The k-split main loop of the persistent prefill GEMM (round 6) peels its last three k-tiles and shortens its prologue for work items of one or two
+    k-tiles: launches whose stream-K tail is cut into pieces that short (found with the host mirror above; ``gemm_cus`` moves the cuts) against float64, plain
+    and gated epilogues, and bit-stable over repeats."""
+    from revisionllm_amd import hip, ops
+    assert short <= _stream_k_piece_lengths(M, N, K, cus), "the work division changed: pick shapes that still cut pieces this short"
+    a = feats(f"gemm.a.{M}.{K}", (M, K), bf16=fl())
+    w = bf(feats(f"gemm.w.{N}.{K}", (N, K), bf16=fl()) * (1.0 / math.sqrt(K))).float()
+    ad, wpk = bf(a).to(dev), ops.pack_fragments(bf(w).to(dev))
+    ref0 = a.double() @ w.double().t()
+    opt = hip.Options(gemm_tile_variant=5, gemm_cus=cus)
+    y = ops.gemm(ad, wpk, out_dtype=op(), w_packed=True, stream_k=True, ctx=opt)
+    assert rel_err(y.float().cpu(), ref0) < tol(BF16_TOL)
+    for _ in range(3):
+        assert torch.equal(y, ops.gemm(ad, wpk, out_dtype=op(), w_packed=True, stream_k=True, ctx=opt))
+    if N % 512 == 0:
+        yg = ops.gemm(ad, wpk, out_dtype=op(), act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=True, ctx=opt)
+        r3 = ref0.view(M, N // 32, 2, 16)
+        assert rel_err(yg.float().cpu(), (torch.nn.functional.silu(r3[:, :, 0]) * r3[:, :, 1]).reshape(M, N // 2)) < tol(BF16_TOL)
+        assert torch.equal(yg, ops.gemm(ad, wpk, out_dtype=op(), act=hip.RV_ACT_SILU_MUL, w_packed=True, stream_k=True, ctx=opt))
+
+
 @pytest.mark.parametrize("M,N,K,act,out,res", [
     (25600, 4096, 768, 0, "bf16", False),      # dense projector, 100 windows x 256 frames (the "feature scan")
     (25700, 1536, 768, 0, "bf16", False),      # adapter Q/K projection (100 x 257 rows)
