@@ -202,3 +202,12 @@ __device__ __forceinline__ float rv_act_apply(float x) {
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// silu(x) = x * sigmoid(x) for the gated MLP epilogues of every GEMM family (one definition: the kernels' gated outputs are compared bit for bit).  The reciprocal is
+// v_rcp_f32 (1 ulp), not the IEEE division sequence (v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup: 10 of the 14 VALU instructions per output the epilogue
+// of the prefill gate/up GEMM spent - its stamps read 5.8 k cycles per 256 x 256 tile with the stores compiled out).  x -> -inf: exp = inf, rcp = 0, x * 0 = -0 as before.
+#ifdef RV_SILU_DIV      // (A/B probe: the division form of rounds 1 - 5)
+__device__ __forceinline__ float rv_silu(float x) { return x / (1.0f + __expf(-x)); }
+#else
+__device__ __forceinline__ float rv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif

@@ -29,7 +29,8 @@
 #include "kernels.h"
 
 // PP_ABL (compile-time ablation probe, tools/pp_probe.sh; results are garbage, only the time means anything): 1 = the steady state issues no LDS-DMA,
-// 2 = no fragment reads, 4 = no barriers, 8 = no MFMAs, 16 = every panel reads the weights of panel 0 (W stays in L2; lda = 0 does the same for A).
+// 2 = no fragment reads, 4 = no barriers, 8 = no MFMAs, 16 = every panel reads the weights of panel 0 (W stays in L2; lda = 0 does the same for A),
+// 64 = the plain / gated whole-panel epilogues of the eight-wave form compute but do not store.
 #ifndef PP_ABL
 #define PP_ABL 0
 #endif
@@ -46,7 +47,7 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return rv_silu(x); }
 
 constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int UNIT = 128 * 128;      // bytes: 128 rows (or W columns) x 64 k x bf16
@@ -887,6 +888,10 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                     asm volatile("" ::"v"(o_[0]), "v"(o_[1]));
                     continue;
                 }
+                if constexpr ((PP_ABL & 64) != 0) {      // (probe: computed, not stored)
+                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                    continue;
+                }
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + no) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + no) = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -901,6 +906,10 @@ __device__ __forceinline__ void pp_epilogue(const f32x4 (&acc_in)[NF][8], const 
                     for (int r = 0; r < 4; ++r) v[r] = rv_act_apply<ACT>(v[r]);
                 }
                 if (res) v += rv_residual4(res, ldr, m, n);
+                if constexpr ((PP_ABL & 64) != 0) {      // (probe: computed, not stored)
+                    asm volatile("" ::"v"(v));
+                    continue;
+                }
                 if (OUT_BF16) *(u32x2*)((op16_t*)Cv + (int64_t)m * ldc + n) = pack_op16x4(v);
                 else *(f32x4*)((float*)Cv + (int64_t)m * ldc + n) = v;
             }

@@ -11,7 +11,7 @@
 
 namespace {
 
-__device__ __forceinline__ float gemv_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gemv_silu(float x) { return rv_silu(x); }
 
 // The 8 virtual k-waves' partial sums of an output element are added as a balanced tree.  Every kernel of the decode family
 // (gemv_stream with 8 or 4 physical waves, the split-K kernel for 33 .. 144 rows whose workgroups carry 1, 2 or 4 adjacent virtual
