@@ -458,6 +458,11 @@ def main():
         return 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args)
+    # The contract is ONE JSON line on rank 0's stdout.  Libraries write there too (RCCL's version banner sits in a stdio buffer and comes out at process exit,
+    # i.e. BEHIND the line): from here on descriptor 1 is stderr, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); start it as "
@@ -1233,7 +1238,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, len(stage2.plan_groups(100, 100)), int(P))
             except Exception as e:  # noqa: BLE001 - the reported baseline must never cost the line
                 out["cpu_baseline"] = {"value": None, "unit": "segments/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
