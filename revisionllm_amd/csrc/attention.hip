@@ -27,7 +27,7 @@ namespace {
 // PAD: a key-padding mask is present (the text cross-attention of the adapter); without it the per-key byte loads and their
 // branches are compiled out.
 template <int DH, bool SPLIT, bool PAD, bool QS = false>
-__device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int b) {
+__device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int b, [[maybe_unused]] float* merge = nullptr) {
     constexpr int NC = DH / 32, ND = DH / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -156,8 +156,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bx, int h, int 
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if constexpr (SPLIT) {
-        __shared__ float sm_m[4][16], sm_l[4][16];
-        __shared__ __attribute__((aligned(16))) float sm_o[4][16][DH + 4];
+        // (the merge area belongs to the KERNEL: as function-local __shared__ arrays every instantiation of this body a kernel dispatches between - with and
+        // without a padding mask - got its own copy, 68.6 KB per workgroup for the decode attention instead of 34.3: two workgroups per CU instead of three)
+        float (*sm_o)[16][DH + 4] = (float (*)[16][DH + 4])merge;
+        float (*sm_m)[16] = (float (*)[16])(merge + 4 * 16 * (DH + 4));
+        float (*sm_l)[16] = sm_m + 4;
         if (g == 0) {
             sm_m[wave][fr] = m_run;
             sm_l[wave][fr] = l_run;
@@ -615,9 +618,10 @@ template <int DH, bool SPLIT, bool QS = false>
 __global__ __launch_bounds__(256, DH <= 128 ? 3 : 1) void attn_kernel(AttnArgs a, int tiles) {
     int bx, h, b;
     if (!attn_map(tiles, a.H, a.H * a.B, bx, h, b)) return;
-    if constexpr (QS) attn_body<DH, SPLIT, false, true>(a, bx, h, b);      // (the LLM has no key padding: checked by the launcher)
-    else if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b);
-    else attn_body<DH, SPLIT, false>(a, bx, h, b);
+    __shared__ __attribute__((aligned(16))) float merge[SPLIT ? 4 * 16 * (DH + 4) + 2 * 4 * 16 : 4];   // partial (m, l, O) of the four key-split waves
+    if constexpr (QS) attn_body<DH, SPLIT, false, true>(a, bx, h, b, merge);      // (the LLM has no key padding: checked by the launcher)
+    else if (a.key_pad) attn_body<DH, SPLIT, true>(a, bx, h, b, merge);
+    else attn_body<DH, SPLIT, false>(a, bx, h, b, merge);
 }
 
 template <int DH>
